@@ -1,0 +1,71 @@
+"""Pin the CPU oracle against fixtures produced by real scikit-image 0.18.3 and by the imported
+reference functions (generators: tests/golden/make_*.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import f1_ref, label_contract_ref, normalize_ref
+from oracle import postprocess_ref as P
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _cases(npz):
+    return sorted({k.split("/")[0] for k in npz.files})
+
+
+def _unpack(g, n, key):
+    h, w = g[n + "/shape"]
+    return np.unpackbits(g[n + "/" + key])[: h * w].reshape(h, w).astype(bool)
+
+
+POST = np.load(os.path.join(G, "postprocess_golden.npz"))
+
+
+@pytest.mark.parametrize("name", _cases(POST))
+@pytest.mark.parametrize("impl", ["scipy", "c"])
+def test_postprocess_matches_skimage(name, impl):
+    m = _unpack(POST, name, "mask")
+    lab = (lambda m, c: P.label_scipy(m, c)) if impl == "scipy" else (lambda m, c: P.label_c(m, c))
+    post = P.mask_postprocess_scipy if impl == "scipy" else P.mask_postprocess_c
+    assert np.array_equal(lab(m, 1), POST[name + "/label4_raw"])
+    assert np.array_equal(lab(m, 2), POST[name + "/label8_raw"])
+    assert np.array_equal(post(m), POST[name + "/labels"])       # bit-exact incl. raster-order ids
+    assert np.array_equal(P.remove_small_holes_ref(m), _unpack(POST, name, "holes"))
+    assert np.array_equal(P.remove_small_objects_ref(_unpack(POST, name, "holes"), 16), _unpack(POST, name, "objs"))
+
+
+def test_threshold_is_strict():
+    prob = np.array([[0.5, 0.50001, 0.49999]], np.float32).repeat(20, 0)
+    assert (P.postprocess_scipy(prob, hole_area=0, min_size=0) > 0).sum() == 20
+
+
+F1 = np.load(os.path.join(G, "f1_golden.npz"))
+
+
+@pytest.mark.parametrize("name", _cases(F1))
+def test_f1_matches_reference(name):
+    gt, seg = F1[name + "/gt"], F1[name + "/seg"]
+    assert tuple(f1_ref.eval_tp_fp_fn_ref(gt, seg)) == tuple(F1[name + "/tpfpfn"])
+    gt_rb, seg_rb = f1_ref.remove_boundary_cells_ref(gt), f1_ref.remove_boundary_cells_ref(seg)
+    assert np.array_equal(gt_rb, F1[name + "/gt_rb"]) and np.array_equal(seg_rb, F1[name + "/seg_rb"])
+    assert tuple(f1_ref.eval_tp_fp_fn_ref(gt_rb, seg_rb)) == tuple(F1[name + "/tpfpfn_rb"])
+    assert f1_ref.dice_ref(gt, seg) == pytest.approx(float(F1[name + "/dice"]), abs=0)
+
+
+NORM = np.load(os.path.join(G, "normalize_golden.npz"))
+
+
+@pytest.mark.parametrize("name", _cases(NORM))
+def test_normalize_matches_reference(name):
+    out = normalize_ref.normalize_channel_ref(NORM[name + "/in"])
+    assert out.dtype == np.uint8 and np.array_equal(out, NORM[name + "/out"])
+
+
+LC = np.load(os.path.join(G, "label_contract_golden.npz"))
+
+
+@pytest.mark.parametrize("name", _cases(LC))
+def test_label_contract_matches_reference(name):
+    assert np.array_equal(label_contract_ref.create_interior_map_ref(LC[name + "/inst"]), LC[name + "/interior"])

@@ -1,0 +1,142 @@
+/* cellseg_hip.h - C-ABI of the MI355X (gfx950) engine for the NeurIPS-CellSeg 3-class U-Net hot path.
+ *
+ * The reference (JunMa11/NeurIPS-CellSeg) has no FFI layer: its hot path is three Python call sites that
+ * dispatch into MONAI / PyTorch / scikit-image.  Each entry point below names the reference interface it
+ * replaces (file:line under the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the name ends in `_host`
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls return without synchronising
+ *     unless documented otherwise
+ *   - return 0 on success, a negative cs_status otherwise; cs_last_error() gives a message (thread-local)
+ *   - activations are NHWC fp32 inside the engine; images cross the boundary with explicit element strides,
+ *     so the reference's `[1,3,H,W]` tensor (physically NHWC after its .permute, predict.py:108) and a
+ *     contiguous NCHW tensor are both accepted without a copy
+ *   - thread-compatible, not thread-safe: one host thread per handle (one process per GPU under data parallel)
+ */
+#ifndef CELLSEG_HIP_H
+#define CELLSEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cs_status {
+    CS_OK = 0,
+    CS_ERR_INVALID = -1,      /* bad argument / unsupported shape            */
+    CS_ERR_HIP = -2,          /* a HIP runtime call failed                   */
+    CS_ERR_WORKSPACE = -3,    /* caller workspace too small                  */
+    CS_ERR_NOT_LOADED = -4,   /* a parameter was never loaded                */
+    CS_ERR_UNKNOWN_KEY = -5   /* state-dict key does not exist in this net   */
+} cs_status;
+
+enum { CS_NORM_INSTANCE = 0, CS_NORM_BATCH = 1 };
+enum { CS_ACT_PRELU = 0, CS_ACT_RELU = 1 };
+
+const char* cs_last_error(void);
+int cs_version(void);
+/* Number of visible HIP devices (>=1) or a negative cs_status: lets a host fail loudly without torch. */
+int cs_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * U-Net engine  -  replaces monai.networks.nets.UNet(spatial_dims=2, ...) as instantiated at
+ *   baseline/model_training_3class.py:201-208 and baseline/predict.py:45-52
+ * Topology: MONAI residual U-Net, kernel 3, every stride 2, `num_res_units` >= 1, ADN order "NDA".
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cs_unet cs_unet;
+
+/* channels[n_channels], strides are all 2 (n_channels-1 of them).  Allocates the packed-weight arena on the
+ * current device (the only allocation the engine ever makes; it happens here, never on the launch path). */
+int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* channels_host, int n_channels,
+                   int num_res_units, int norm_kind, int act_kind);
+int cs_unet_destroy(cs_unet* net);
+
+/* State-dict surface (replaces model.load_state_dict / model.state_dict, predict.py:80-81,
+ * model_training_3class.py:269-274).  Keys are MONAI's: "model.0.conv.unit0.conv.weight", ... */
+int cs_unet_num_params(const cs_unet* net);
+/* key_out must hold >= 160 bytes; shape_out[4]; returns rank (1..4) or negative status. */
+int cs_unet_param_info(const cs_unet* net, int index, char* key_out_host, int64_t* shape_out_host);
+/* Copy + repack one tensor given in PyTorch layout (conv [Cout,Cin,k,k], transposed conv [Cin,Cout,k,k],
+ * bias [C], PReLU slope [1], BatchNorm weight/bias/running_mean/running_var [C]) from device memory. */
+int cs_unet_load_param(cs_unet* net, const char* key_host, const float* data, int64_t numel, void* stream);
+
+/* Bytes of caller workspace needed for a forward over `n` windows of h x w (multiples of 2^(levels)). */
+size_t cs_unet_workspace_bytes(const cs_unet* net, int n, int h, int w);
+
+/* forward: replaces `model(inputs)` (model_training_3class.py:255) in eval/no-grad use.
+ * x: n images of in_channels x h x w addressed as x[i*sn + c*sc + y*sh + xx*sw] (element strides).
+ * logits_nhwc: [n,h,w,out_channels] fp32 contiguous. */
+int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                    int n, int h, int w, float* logits_nhwc, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sliding-window inference  -  replaces monai.inferers.sliding_window_inference(x, roi, sw_batch, model)
+ *   (baseline/predict.py:109, baseline/model_training_3class.py:291-293; constant blending, zero padding)
+ * fused with softmax(dim=1)[0,1] (predict.py:110-111) and `> 0.5` (predict.py:113).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cs_swi_plan {
+    int img_h, img_w;          /* unpadded image                                 */
+    int roi_h, roi_w;
+    int pad_top, pad_left;     /* symmetric padding when the image < roi        */
+    int pad_h, pad_w;          /* padded size = max(img, roi)                    */
+    int interval_h, interval_w;
+    int n_h, n_w;              /* windows per dimension; total = n_h * n_w       */
+} cs_swi_plan;
+
+int cs_swi_make_plan(int img_h, int img_w, int roi_h, int roi_w, double overlap, cs_swi_plan* plan_host);
+/* start offset (in padded coordinates) of window i along a dimension */
+int cs_swi_window_start(int i, int interval, int padded_size, int roi);
+
+size_t cs_swi_workspace_bytes(const cs_unet* net, const cs_swi_plan* plan_host, int engine_batch);
+
+/* image: in_channels x img_h x img_w with element strides (sc, sh, sw).  Outputs (any may be NULL):
+ *   logits_nchw [out_channels, img_h, img_w] fp32  - the tensor the reference's call returns
+ *   prob1       [img_h, img_w] fp32                - softmax(dim=1)[0,1]
+ *   mask        [img_h, img_w] uint8               - prob1 > 0.5
+ * Windows owned by this rank: indices k with first_window <= k < first_window + n_windows in the row-major
+ * window list, and output rows [row_begin, row_end): a rank that owns a strip of rows runs every window that
+ * intersects it (multi-GPU tiled inference); single GPU: 0, n_h*n_w, 0, img_h. */
+int cs_swi_infer(cs_unet* net, const cs_swi_plan* plan_host, const float* image, int64_t sc, int64_t sh, int64_t sw,
+                 int engine_batch, int row_begin, int row_end,
+                 float* logits_nchw, float* prob1, uint8_t* mask,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Finalize step alone (average overlapping windows in window-index order, softmax, threshold) for window
+ * predictions produced by any predictor: win_logits [(#window rows from ih_base) * n_w][roi_h][roi_w][classes]. */
+int cs_swi_finalize(const cs_swi_plan* plan_host, const float* win_logits, int classes, int ih_base,
+                    int row_begin, int row_end, float* logits_nchw, float* prob1, uint8_t* mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Connected-component post-process  -  replaces
+ *   measure.label(morphology.remove_small_objects(morphology.remove_small_holes(mask), 16))
+ *   (baseline/predict.py:113): 4-connected holes < 64 filled, 4-connected objects < 16 removed,
+ *   8-connected labels numbered 1..K in raster order of each component's first pixel (int32).
+ * ---------------------------------------------------------------------------------------------- */
+size_t cs_ccl_workspace_bytes(int h, int w);
+/* mask: uint8 [h,w] (non-zero = foreground); labels: int32 [h,w]; n_labels: device int (may be NULL). */
+int cs_ccl_postprocess(const uint8_t* mask, int h, int w, int hole_area, int min_size,
+                       int32_t* labels, int32_t* n_labels, void* workspace, size_t workspace_bytes, void* stream);
+/* Plain labelling of a mask: connectivity 4 or 8, same numbering rule (scipy.ndimage.label semantics). */
+int cs_ccl_label(const uint8_t* mask, int h, int w, int connectivity,
+                 int32_t* labels, int32_t* n_labels, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.
+ * cs_prof_enable(1) brackets every kernel launch with events; cs_prof_collect synchronises and
+ * returns per-kernel-id totals.  Disabled (default) costs nothing.
+ * ---------------------------------------------------------------------------------------------- */
+enum { CS_PROF_MAX_KERNELS = 32 };
+int cs_prof_enable(int on);
+int cs_prof_reset(void);
+/* names_out: CS_PROF_MAX_KERNELS x 48 chars; ms_out / launches_out / flops_out / bytes_out: CS_PROF_MAX_KERNELS.
+ * flops/bytes are ALGORITHMIC figures accumulated per launch (DESIGN.md "Roofline accounting"). Returns #ids. */
+int cs_prof_collect(char* names_out_host, double* ms_out_host, int64_t* launches_out_host,
+                    double* flops_out_host, double* bytes_out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CELLSEG_HIP_H */

@@ -1,0 +1,15 @@
+"""cellseg_amd - MI355X (gfx950) engine behind the NeurIPS-CellSeg 3-class U-Net inference/training path.
+
+Host-side mirror of the reference's interfaces (same names, arguments and error behaviour):
+  UNet                       <- monai.networks.nets.UNet            (baseline/predict.py:45-52)
+  sliding_window_inference   <- monai.inferers.sliding_window_inference (baseline/predict.py:109)
+  label / mask_to_instances  <- skimage.measure.label / morphology.remove_small_* (baseline/predict.py:113)
+All arithmetic runs in libcellseg_hip.so; importing this package without the built library raises.
+"""
+from ._lib import CellSegHipError, LIB_PATH, lib  # noqa: F401
+from .unet import UNet  # noqa: F401
+from .inferers import make_plan, rank_rows, sliding_window_inference, swi_infer_image, window_starts  # noqa: F401
+from .postprocess import label, mask_to_instances, prob_to_instances  # noqa: F401
+
+__all__ = ["UNet", "sliding_window_inference", "swi_infer_image", "make_plan", "window_starts", "rank_rows",
+           "label", "mask_to_instances", "prob_to_instances", "CellSegHipError", "lib", "LIB_PATH"]

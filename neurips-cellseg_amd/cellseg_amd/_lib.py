@@ -1,0 +1,100 @@
+"""ctypes binding of libcellseg_hip.so (the C-ABI declared in include/cellseg_hip.h).
+
+The library is the product: there is NO fallback.  A missing or unloadable library raises at import
+time, and every call site raises ``CellSegHipError`` when the C side reports a failure.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcellseg_hip.so")
+
+
+class CellSegHipError(RuntimeError):
+    pass
+
+
+class SwiPlan(C.Structure):
+    """Mirror of ``cs_swi_plan``."""
+    _fields_ = [(n, C.c_int) for n in ("img_h", "img_w", "roi_h", "roi_w", "pad_top", "pad_left", "pad_h", "pad_w",
+                                       "interval_h", "interval_w", "n_h", "n_w")]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C neurips-cellseg_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, sz, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double
+    sig = {
+        "cs_last_error": (C.c_char_p, []),
+        "cs_version": (i32, []),
+        "cs_device_count": (i32, []),
+        "cs_unet_create": (i32, [C.POINTER(vp), i32, i32, C.POINTER(i32), i32, i32, i32, i32]),
+        "cs_unet_destroy": (i32, [vp]),
+        "cs_unet_num_params": (i32, [vp]),
+        "cs_unet_param_info": (i32, [vp, i32, C.c_char_p, C.POINTER(i64)]),
+        "cs_unet_load_param": (i32, [vp, C.c_char_p, vp, i64, vp]),
+        "cs_unet_workspace_bytes": (sz, [vp, i32, i32, i32]),
+        "cs_unet_forward": (i32, [vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, vp, sz, vp]),
+        "cs_swi_make_plan": (i32, [i32, i32, i32, i32, f64, C.POINTER(SwiPlan)]),
+        "cs_swi_window_start": (i32, [i32, i32, i32, i32]),
+        "cs_swi_workspace_bytes": (sz, [vp, C.POINTER(SwiPlan), i32]),
+        "cs_swi_infer": (i32, [vp, C.POINTER(SwiPlan), vp, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
+        "cs_swi_finalize": (i32, [C.POINTER(SwiPlan), vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "cs_ccl_workspace_bytes": (sz, [i32, i32]),
+        "cs_ccl_postprocess": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+        "cs_ccl_label": (i32, [vp, i32, i32, i32, vp, vp, vp, sz, vp]),
+        "cs_prof_enable": (i32, [i32]),
+        "cs_prof_reset": (i32, []),
+        "cs_prof_collect": (i32, [C.c_char_p, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch: fail loudly
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_destroy cs_unet_num_params "
+            "cs_unet_param_info cs_unet_load_param cs_unet_workspace_bytes cs_unet_forward cs_swi_make_plan "
+            "cs_swi_window_start cs_swi_workspace_bytes cs_swi_infer cs_swi_finalize cs_ccl_workspace_bytes "
+            "cs_ccl_postprocess cs_ccl_label cs_prof_enable cs_prof_reset cs_prof_collect").split()
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        raise CellSegHipError(f"{what or 'cellseg_hip'} failed ({rc}): {lib.cs_last_error().decode(errors='replace')}")
+    return rc
+
+
+def require_gpu(tensor=None) -> None:
+    """Fail loudly when the hot path is asked to run without a HIP device (no CPU fallback exists)."""
+    import torch
+    if tensor is not None and tensor.device.type != "cuda":
+        raise CellSegHipError(f"cellseg_amd runs on MI355X only: got a tensor on '{tensor.device}'. There is no CPU path.")
+    if not torch.cuda.is_available():
+        raise CellSegHipError("cellseg_amd needs a HIP device (torch.cuda.is_available() is False). There is no CPU path.")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def prof_collect():
+    """-> {kernel_name: dict(ms, launches, flops, bytes)} accumulated since the last cs_prof_reset."""
+    n = 32
+    names = C.create_string_buffer(48 * n)
+    ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    la = (C.c_int64 * n)()
+    k = check(lib.cs_prof_collect(names, ms, la, fl, by), "cs_prof_collect")
+    out = {}
+    for i in range(k):
+        nm = names.raw[48 * i:48 * (i + 1)].split(b"\0", 1)[0].decode()
+        if la[i]:
+            out[nm] = dict(ms=ms[i], launches=la[i], flops=fl[i], bytes=by[i])
+    return out

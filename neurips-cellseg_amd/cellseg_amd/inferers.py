@@ -1,0 +1,124 @@
+"""``sliding_window_inference`` - drop-in for ``monai.inferers.sliding_window_inference`` as the reference uses it.
+
+Reference call sites: /root/reference/baseline/predict.py:83-84,109 and
+/root/reference/baseline/model_training_3class.py:289-293 (roi 256x256, sw_batch_size 4, MONAI defaults
+overlap=0.25, mode="constant", padding_mode="constant", cval=0).
+
+When ``predictor`` is a :class:`cellseg_amd.UNet` the whole call is one C-ABI entry (``cs_swi_infer``): window
+gather fused into the first convolution, all windows batched through the HIP U-Net, overlap averaging done in
+window-index order (bit-identical accumulation order to the reference's ``out[slice] += pred``).  For any other
+predictor the windows are gathered with torch indexing, the predictor is called as MONAI would call it, and
+the HIP finalize kernel (``cs_swi_finalize``) does the averaging.  No CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from ._lib import SwiPlan, check, lib
+from .unet import UNet
+
+DEFAULT_ENGINE_BATCH = 64
+
+
+def make_plan(img_h: int, img_w: int, roi_size: Sequence[int], overlap: float = 0.25) -> SwiPlan:
+    plan = SwiPlan()
+    check(lib.cs_swi_make_plan(int(img_h), int(img_w), int(roi_size[0]), int(roi_size[1]), float(overlap), C.byref(plan)),
+          "cs_swi_make_plan")
+    return plan
+
+
+def window_starts(plan: SwiPlan) -> Tuple[list, list]:
+    hs = [lib.cs_swi_window_start(i, plan.interval_h, plan.pad_h, plan.roi_h) for i in range(plan.n_h)]
+    ws = [lib.cs_swi_window_start(i, plan.interval_w, plan.pad_w, plan.roi_w) for i in range(plan.n_w)]
+    return hs, ws
+
+
+def rank_rows(img_h: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous strip of output rows owned by `rank` (multi-GPU tiled inference)."""
+    base, rem = divmod(img_h, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def swi_infer_image(model: UNet, image: torch.Tensor, roi_size, overlap: float = 0.25, *, engine_batch: int = DEFAULT_ENGINE_BATCH,
+                    rows: Optional[Tuple[int, int]] = None, want_logits: bool = True, want_prob: bool = False,
+                    want_mask: bool = False):
+    """image [3,H,W] (any strides) on the GPU -> (logits [3,H,W] | None, prob1 [H,W] | None, mask uint8 [H,W] | None)."""
+    _lib.require_gpu(image)
+    if image.dim() != 3:
+        raise ValueError("image must be [C,H,W]")
+    if image.dtype != torch.float32:
+        image = image.float()
+    _, h, w = image.shape
+    plan = make_plan(h, w, roi_size, overlap)
+    eng = model.engine()
+    dev = image.device
+    with torch.cuda.device(dev):
+        nbytes = lib.cs_swi_workspace_bytes(eng.handle, C.byref(plan), int(engine_batch))
+        if nbytes == 0:
+            raise _lib.CellSegHipError(f"cs_swi_workspace_bytes: {lib.cs_last_error().decode()}")
+        ws = model.workspace(("swi", h, w, plan.roi_h, plan.roi_w, plan.n_h, plan.n_w, int(engine_batch)), nbytes, dev)
+        logits = torch.empty((model.out_channels, h, w), dtype=torch.float32, device=dev) if want_logits else None
+        prob = torch.empty((h, w), dtype=torch.float32, device=dev) if want_prob else None
+        mask = torch.empty((h, w), dtype=torch.uint8, device=dev) if want_mask else None
+        r0, r1 = rows if rows is not None else (0, h)
+        sc, sh, sw = image.stride()
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()   # noqa: E731
+        check(lib.cs_swi_infer(eng.handle, C.byref(plan), ptr(image), sc, sh, sw, int(engine_batch), int(r0), int(r1),
+                               ptr(logits), ptr(prob), ptr(mask), ptr(ws), ws.numel(), _lib.stream_ptr()), "cs_swi_infer")
+    return logits, prob, mask
+
+
+def sliding_window_inference(inputs: torch.Tensor, roi_size: Union[Sequence[int], int], sw_batch_size: int,
+                             predictor: Callable[[torch.Tensor], torch.Tensor], overlap: float = 0.25,
+                             mode: str = "constant", sigma_scale: float = 0.125, padding_mode: str = "constant",
+                             cval: float = 0.0, sw_device=None, device=None, *args, **kwargs) -> torch.Tensor:
+    """inputs [B,C,H,W] -> [B,Cout,H,W] fp32 logits (the reference always passes B == 1)."""
+    if str(getattr(mode, "value", mode)).lower() != "constant" or str(getattr(padding_mode, "value", padding_mode)).lower() != "constant" or cval != 0.0:
+        raise NotImplementedError("only the reference's settings are implemented: mode='constant', padding_mode='constant', cval=0")
+    if args or kwargs:
+        raise NotImplementedError("extra predictor arguments are not supported")
+    _lib.require_gpu(inputs)
+    if isinstance(roi_size, int):
+        roi_size = (roi_size, roi_size)
+    if inputs.dim() != 4:
+        raise ValueError("inputs must be [B,C,H,W]")
+    outs = []
+    for b in range(inputs.shape[0]):
+        if isinstance(predictor, UNet):
+            # sw_batch_size only groups windows per predictor call in MONAI; results do not depend on it, so the
+            # engine batches DEFAULT_ENGINE_BATCH windows per launch instead of 4.
+            logits, _, _ = swi_infer_image(predictor, inputs[b], roi_size, overlap,
+                                           engine_batch=max(int(sw_batch_size), DEFAULT_ENGINE_BATCH))
+        else:
+            logits = _generic(inputs[b], roi_size, int(sw_batch_size), predictor, overlap)
+        outs.append(logits)
+    return torch.stack(outs, 0)
+
+
+def _generic(image: torch.Tensor, roi_size, sw_batch_size: int, predictor, overlap: float) -> torch.Tensor:
+    """Arbitrary predictor: torch gathers the windows (plumbing), the HIP kernel finalizes."""
+    image = image.float()
+    c, h, w = image.shape
+    plan = make_plan(h, w, roi_size, overlap)
+    x = torch.zeros((c, plan.pad_h, plan.pad_w), dtype=torch.float32, device=image.device)
+    x[:, plan.pad_top:plan.pad_top + h, plan.pad_left:plan.pad_left + w] = image
+    hs, ws = window_starts(plan)
+    wins = [(a, b) for a in hs for b in ws]
+    preds = []
+    for g in range(0, len(wins), sw_batch_size):
+        batch = torch.stack([x[:, a:a + plan.roi_h, b:b + plan.roi_w] for a, b in wins[g:g + sw_batch_size]], 0)
+        preds.append(predictor(batch).float())
+    pred = torch.cat(preds, 0)                                     # [nwin, Cout, roi, roi]
+    if pred.shape[1] != 3:
+        raise NotImplementedError("the finalize kernel implements the 3-class contract")
+    win_logits = pred.permute(0, 2, 3, 1).contiguous()             # NHWC, as the engine stores window predictions
+    out = torch.empty((3, h, w), dtype=torch.float32, device=image.device)
+    with torch.cuda.device(image.device):
+        check(lib.cs_swi_finalize(C.byref(plan), C.c_void_p(win_logits.data_ptr()), 3, 0, 0, h, C.c_void_p(out.data_ptr()),
+                                  C.c_void_p(), C.c_void_p(), _lib.stream_ptr()), "cs_swi_finalize")
+    return out

@@ -1,0 +1,252 @@
+"""``UNet`` - drop-in for ``monai.networks.nets.UNet`` as the reference instantiates it.
+
+Reference call sites: /root/reference/baseline/predict.py:45-52, :80-81, :85, :109 and
+/root/reference/baseline/model_training_3class.py:201-208, :236, :248, :255, :271.
+
+Same constructor arguments, same ``forward`` contract ([N,3,H,W] float -> [N,3,H,W] logits), same
+``state_dict`` key names (``model.0.conv.unit0.conv.weight`` ...), so a MONAI checkpoint loads with
+``model.load_state_dict(ckpt['model_state_dict'])``.  PyTorch only stores the parameters; all arithmetic
+runs in libcellseg_hip.so (hand-written gfx950 kernels).  There is no CPU path: calling the model on a
+CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, lib
+
+_NORMS = {"instance": 0, "batch": 1}
+_ACTS = {"prelu": 0, "relu": 1}
+
+
+def _norm_name(v) -> str:
+    name = (v[0] if isinstance(v, (tuple, list)) else v)
+    name = str(getattr(name, "value", name)).lower()
+    if name not in _NORMS:
+        raise ValueError(f"norm '{v}' is not supported (instance | batch)")
+    return name
+
+
+def _act_name(v) -> str:
+    name = (v[0] if isinstance(v, (tuple, list)) else v)
+    name = str(getattr(name, "value", name)).lower()
+    if name not in _ACTS:
+        raise ValueError(f"act '{v}' is not supported (prelu | relu)")
+    return name
+
+
+class _Engine:
+    """Owns one ``cs_unet`` handle (packed weights live on the device that was current at creation)."""
+
+    def __init__(self, channels, num_res_units, norm, act, in_channels, out_channels):
+        arr = (C.c_int * len(channels))(*channels)
+        h = C.c_void_p()
+        check(lib.cs_unet_create(C.byref(h), in_channels, out_channels, arr, len(channels), num_res_units,
+                                 _NORMS[norm], _ACTS[act]), "cs_unet_create")
+        self.handle = h
+
+    def param_table(self):
+        out = []
+        key = C.create_string_buffer(160)
+        shape = (C.c_int64 * 4)()
+        for i in range(check(lib.cs_unet_num_params(self.handle))):
+            rank = check(lib.cs_unet_param_info(self.handle, i, key, shape), "cs_unet_param_info")
+            out.append((key.value.decode(), tuple(int(shape[k]) for k in range(rank))))
+        return out
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.cs_unet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def param_table(channels=(16, 32, 64, 128, 256), num_res_units=2, norm="instance", act="prelu"):
+    """(key, shape) of every tensor the C engine expects.  Host-only metadata: usable without a GPU? No -
+    the engine allocates its weight arena at creation, so this needs a HIP device; the CPU-side table is
+    built by ``_host_param_table`` and the two are compared in the GPU tests."""
+    return _Engine(tuple(channels), num_res_units, norm, act, 3, 3).param_table()
+
+
+def _host_param_table(in_ch, out_ch, channels, nru, norm, act):
+    """MONAI state-dict layout computed on the host (mirrors engine.hip build_net)."""
+    tab = []
+
+    def adn(prefix, c):
+        if norm == "batch":
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                tab.append((f"{prefix}.N.{k}", (c,)))
+            tab.append((f"{prefix}.N.num_batches_tracked", ()))
+        if act == "prelu":
+            tab.append((f"{prefix}.A.weight", (1,)))
+
+    def down(prefix, cin, c, stride):
+        for su in range(nru):
+            tab.append((f"{prefix}.conv.unit{su}.conv.weight", (c, cin if su == 0 else c, 3, 3)))
+            tab.append((f"{prefix}.conv.unit{su}.conv.bias", (c,)))
+            adn(f"{prefix}.conv.unit{su}.adn", c)
+        if stride != 1 or cin != c:
+            k = 3 if stride != 1 else 1
+            tab.append((f"{prefix}.residual.weight", (c, cin, k, k)))
+            tab.append((f"{prefix}.residual.bias", (c,)))
+
+    def up(prefix, cin, cout, top):
+        tab.append((f"{prefix}.0.conv.weight", (cin, cout, 3, 3)))
+        tab.append((f"{prefix}.0.conv.bias", (cout,)))
+        adn(f"{prefix}.0.adn", cout)
+        tab.append((f"{prefix}.1.conv.unit0.conv.weight", (cout, cout, 3, 3)))
+        tab.append((f"{prefix}.1.conv.unit0.conv.bias", (cout,)))
+        if not top:
+            adn(f"{prefix}.1.conv.unit0.adn", cout)
+
+    def block(prefix, inc, outc, chs, top):
+        c = chs[0]
+        down(f"{prefix}.0", inc, c, 2)
+        if len(chs) > 2:
+            block(f"{prefix}.1.submodule", c, c, chs[1:], False)
+            upc = 2 * c
+        else:
+            down(f"{prefix}.1.submodule", c, chs[1], 1)
+            upc = c + chs[1]
+        up(f"{prefix}.2", upc, outc, top)
+
+    block("model", in_ch, out_ch, tuple(channels), True)
+    return tab
+
+
+class UNet(nn.Module):
+    def __init__(self, spatial_dims: int = 2, in_channels: int = 3, out_channels: int = 3,
+                 channels: Sequence[int] = (16, 32, 64, 128, 256), strides: Sequence[int] = (2, 2, 2, 2),
+                 kernel_size: int = 3, up_kernel_size: int = 3, num_res_units: int = 2, act="PRELU", norm="INSTANCE",
+                 dropout: float = 0.0, bias: bool = True, adn_ordering: str = "NDA"):
+        super().__init__()
+        if spatial_dims != 2:
+            raise ValueError("cellseg_amd.UNet is the reference's 2-D network (spatial_dims=2)")
+        if in_channels != 3 or out_channels != 3:
+            raise ValueError("cellseg_amd.UNet implements the reference's 3-channel -> 3-class contract")
+        if tuple(strides) != (2,) * (len(channels) - 1):
+            raise ValueError("every stride must be 2 and len(strides) == len(channels) - 1")
+        if kernel_size != 3 or up_kernel_size != 3 or not bias or adn_ordering != "NDA" or dropout not in (0, 0.0, None):
+            raise ValueError("only MONAI's defaults (kernel 3, bias, dropout 0, ordering 'NDA') are implemented")
+        if not (1 <= num_res_units <= 4):
+            raise ValueError("num_res_units must be in 1..4")
+        if any(c % 16 or c < 16 for c in channels):
+            raise ValueError("channels must be multiples of 16 (MFMA tile width)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.channels, self.strides, self.num_res_units = tuple(channels), tuple(strides), num_res_units
+        self.norm_name, self.act_name = _norm_name(norm), _act_name(act)
+        self._keys = []
+        for key, shape in _host_param_table(in_channels, out_channels, self.channels, num_res_units,
+                                            self.norm_name, self.act_name):
+            self._register(key, shape)
+        self._engine = None
+        self._engine_device = None
+        self._uploaded: Dict[str, Tuple[int, int]] = {}
+        self._ws: Dict[Tuple, torch.Tensor] = {}
+
+    # ---- parameter registration under MONAI's dotted names -------------------------------------------
+    def _register(self, key: str, shape) -> None:
+        parts = key.split(".")
+        mod: nn.Module = self
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        leaf = parts[-1]
+        if leaf in ("running_mean", "running_var", "num_batches_tracked"):
+            init = {"running_mean": torch.zeros(shape), "running_var": torch.ones(shape),
+                    "num_batches_tracked": torch.tensor(0, dtype=torch.long)}[leaf]
+            mod.register_buffer(leaf, init)
+        else:
+            mod.register_parameter(leaf, nn.Parameter(self._init(key, shape)))
+        self._keys.append(key)
+
+    @staticmethod
+    def _init(key: str, shape) -> torch.Tensor:
+        """torch's default initialisers for Conv2d / ConvTranspose2d / PReLU / BatchNorm2d."""
+        if key.endswith(".A.weight"):
+            return torch.full(shape, 0.25)
+        if ".N." in key:
+            return torch.ones(shape) if key.endswith("weight") else torch.zeros(shape)
+        if len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            bound = 1.0 / math.sqrt(fan_in)          # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+            w = torch.empty(shape).uniform_(-bound, bound)
+            UNet._last_fan_in = fan_in
+            return w
+        bound = 1.0 / math.sqrt(getattr(UNet, "_last_fan_in", 1))
+        return torch.empty(shape).uniform_(-bound, bound)
+
+    # ---- engine plumbing ------------------------------------------------------------------------------
+    def _tensor(self, key: str) -> torch.Tensor:
+        obj = self
+        for p in key.split("."):
+            obj = getattr(obj, p)
+        return obj
+
+    def engine(self) -> _Engine:
+        """Create (once per device) the C engine and upload every tensor whose storage/version changed."""
+        p0 = next(self.parameters())
+        _lib.require_gpu(p0)
+        if self._engine is None or self._engine_device != p0.device:
+            with torch.cuda.device(p0.device):
+                self._engine = _Engine(self.channels, self.num_res_units, self.norm_name, self.act_name,
+                                       self.in_channels, self.out_channels)
+            self._engine_device = p0.device
+            self._uploaded.clear()
+            self._ws.clear()
+        stream = _lib.stream_ptr()
+        for key in self._keys:
+            if key.endswith("num_batches_tracked"):
+                continue
+            t = self._tensor(key)
+            tag = (t.data_ptr(), t._version)
+            if self._uploaded.get(key) != tag:
+                src = t.detach()
+                if src.dtype != torch.float32 or not src.is_contiguous():
+                    src = src.float().contiguous()
+                check(lib.cs_unet_load_param(self._engine.handle, key.encode(), C.c_void_p(src.data_ptr()), src.numel(),
+                                             stream), f"cs_unet_load_param({key})")
+                self._uploaded[key] = tag
+        return self._engine
+
+    def workspace(self, tag, nbytes: int, device) -> torch.Tensor:
+        ws = self._ws.get(tag)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            self._ws = {k: v for k, v in self._ws.items() if k[0] != tag[0]}    # one buffer per kind
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws[tag] = ws
+        return ws
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _lib.require_gpu(x)
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected [N,{self.in_channels},H,W], got {tuple(x.shape)}")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
+            raise _lib.CellSegHipError("training through cellseg_amd.UNet is not built yet (inference engine only); "
+                                       "call under torch.no_grad() / model.eval()")
+        if self.norm_name == "batch" and self.training:
+            raise _lib.CellSegHipError("BatchNorm variant: only eval mode (running statistics) is implemented")
+        if x.dtype != torch.float32:
+            x = x.float()
+        n, _, h, w = x.shape
+        eng = self.engine()
+        with torch.cuda.device(x.device):
+            nbytes = lib.cs_unet_workspace_bytes(eng.handle, n, h, w)
+            if nbytes == 0:
+                raise _lib.CellSegHipError(f"cs_unet_workspace_bytes: {lib.cs_last_error().decode()}")
+            ws = self.workspace(("fwd", n, h, w), nbytes, x.device)
+            out = torch.empty((n, h, w, self.out_channels), dtype=torch.float32, device=x.device)
+            sn, sc, sh, sw = x.stride()
+            check(lib.cs_unet_forward(eng.handle, C.c_void_p(x.data_ptr()), sn, sc, sh, sw, n, h, w,
+                                      C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                      _lib.stream_ptr()), "cs_unet_forward")
+        return out.permute(0, 3, 1, 2)        # NCHW view of the NHWC result, like a channels_last tensor

@@ -1,0 +1,754 @@
+// Host-side engine + C-ABI (include/cellseg_hip.h) for the MI355X 3-class U-Net hot path.
+//
+// cs_unet mirrors monai.networks.nets.UNet as the reference instantiates it
+// (baseline/predict.py:45-52, baseline/model_training_3class.py:201-208): same topology, same state-dict
+// key names, weights re-packed once into MFMA fragment order.  The forward schedule fuses each
+// ResidualUnit's strided unit0 conv with its residual conv (one pass over the input), keeps every
+// InstanceNorm + PReLU lazy (applied by the consumer) and materialises only ResidualUnit outputs.
+#include <stdarg.h>
+#include <string.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace cs {
+
+// ---------------------------------------------------------------------------------------------------
+// error + profiling plumbing
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static const char* kNames[K_NUM_IDS] = {
+    "conv3x3_s1_mfma", "conv3x3_s2_mfma", "conv1x1_mfma", "conv_first_mfma", "convT3x3s2_mfma", "convT_top_valu",
+    "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
+    "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset"};
+const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
+
+struct ProfRecord {
+    int id;
+    hipEvent_t start, stop;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRecord> g_prof_records;
+static std::vector<hipEvent_t> g_event_pool;
+static double g_prof_flops[K_NUM_IDS], g_prof_bytes[K_NUM_IDS], g_prof_ms[K_NUM_IDS];
+static int64_t g_prof_launches[K_NUM_IDS];
+
+static hipEvent_t get_event() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(int id, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    ProfRecord r{id, get_event(), get_event()};
+    (void)hipEventRecord(r.start, s);
+    g_prof_records.push_back(r);
+    slot = (int)g_prof_records.size() - 1;
+    g_prof_flops[id] += flops;
+    g_prof_bytes[id] += bytes;
+    g_prof_launches[id] += 1;
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof_records[slot].stop, stream);
+}
+
+static void prof_drain() {
+    for (auto& r : g_prof_records) {
+        (void)hipEventSynchronize(r.stop);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) g_prof_ms[r.id] += ms;
+        g_event_pool.push_back(r.start);
+        g_event_pool.push_back(r.stop);
+    }
+    g_prof_records.clear();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bump allocator over the caller's workspace; base == nullptr measures only
+// ---------------------------------------------------------------------------------------------------
+struct Bump {
+    char* base;
+    size_t off = 0, cap;
+    Bump(void* b, size_t c) : base((char*)b), cap(c) {}
+    template <typename T>
+    T* take(size_t count) {
+        const size_t bytes = (count * sizeof(T) + 255) / 256 * 256;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+    bool dry() const { return base == nullptr; }
+    bool ok() const { return dry() || off <= cap; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// network description
+// ---------------------------------------------------------------------------------------------------
+struct NormSite {          // one ADN: InstanceNorm (stats at run time) or eval BatchNorm (running stats) + PReLU/ReLU
+    int c = 0;
+    float* slope = nullptr;                 // PReLU weight (device) or nullptr for ReLU
+    float *bn_w = nullptr, *bn_b = nullptr, *bn_m = nullptr, *bn_v = nullptr;
+};
+
+struct ConvW {             // packed weights + bias of one (possibly fused) conv launch
+    float* w = nullptr;    // packed (MFMA kernels) or PyTorch layout (small VALU kernels)
+    float* bias = nullptr;
+    int cin = 0, cout = 0; // cout = total (fused) output channels
+};
+
+struct DownUnit {          // ResidualUnit in the encoder / bottom
+    int cin = 0, c = 0, stride = 2, subunits = 2;
+    bool first = false;            // cin == in_channels (3): first-layer kernel
+    bool res_conv = true;          // false: identity residual
+    bool fused_res = true;         // residual conv fused into unit0 (strided 3x3 residual)
+    ConvW unit0;                   // fused [unit0 || residual] when fused_res
+    ConvW res1x1;                  // bottom layer: separate 1x1 residual
+    std::vector<ConvW> units;      // subunits 1..
+    std::vector<NormSite> norms;   // one per subunit
+};
+
+struct UpUnit {
+    int cin_skip = 0, cin_sub = 0, cout = 0;
+    bool top = false;
+    ConvW convt;
+    NormSite norm_t;
+    ConvW unit0;
+    NormSite norm_u;   // unused at top (conv only)
+};
+
+struct ParamEntry {
+    std::string key;
+    int rank = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+    std::function<int(const float*, hipStream_t)> load;
+    bool loaded = false;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (int i = 0; i < rank; ++i) n *= shape[i];
+        return n;
+    }
+};
+
+}  // namespace cs
+
+using namespace cs;
+
+struct cs_unet {
+    int in_ch = 3, out_ch = 3, nl = 0, nru = 2, norm = CS_NORM_INSTANCE, act = CS_ACT_PRELU;
+    std::vector<int> ch;
+    std::vector<DownUnit> down;   // nl encoder units
+    DownUnit bottom;
+    std::vector<UpUnit> up;       // up[i] pairs with down[i]
+    std::vector<ParamEntry> params;
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+};
+
+namespace cs {
+
+static int copy_param(float* dst, const float* src, size_t n, hipStream_t s) {
+    CS_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return CS_OK;
+}
+
+struct ArenaPlan {   // two passes: count floats, then hand out pointers
+    float* base = nullptr;
+    size_t off = 0;
+    float* take(size_t n) {
+        n = (n + 63) / 64 * 64;
+        float* p = base ? base + off : nullptr;
+        off += n;
+        return p;
+    }
+};
+
+static void add_param(cs_unet* net, const std::string& key, std::initializer_list<int64_t> shape,
+                      std::function<int(const float*, hipStream_t)> fn) {
+    ParamEntry e;
+    e.key = key;
+    e.rank = (int)shape.size();
+    int i = 0;
+    for (auto v : shape) e.shape[i++] = v;
+    e.load = std::move(fn);
+    net->params.push_back(std::move(e));
+}
+
+static void add_norm_params(cs_unet* net, ArenaPlan& ar, const std::string& adn, NormSite& ns, int c) {
+    ns.c = c;
+    if (net->norm == CS_NORM_BATCH) {
+        ns.bn_w = ar.take(c); ns.bn_b = ar.take(c); ns.bn_m = ar.take(c); ns.bn_v = ar.take(c);
+        float *w = ns.bn_w, *b = ns.bn_b, *m = ns.bn_m, *v = ns.bn_v;
+        add_param(net, adn + ".N.weight", {c}, [=](const float* d, hipStream_t s) { return copy_param(w, d, c, s); });
+        add_param(net, adn + ".N.bias", {c}, [=](const float* d, hipStream_t s) { return copy_param(b, d, c, s); });
+        add_param(net, adn + ".N.running_mean", {c}, [=](const float* d, hipStream_t s) { return copy_param(m, d, c, s); });
+        add_param(net, adn + ".N.running_var", {c}, [=](const float* d, hipStream_t s) { return copy_param(v, d, c, s); });
+    }
+    if (net->act == CS_ACT_PRELU) {
+        ns.slope = ar.take(1);
+        float* sl = ns.slope;
+        add_param(net, adn + ".A.weight", {1}, [=](const float* d, hipStream_t s) { return copy_param(sl, d, 1, s); });
+    }
+}
+
+// conv weight + bias of a conv that writes channels [cout_off, cout_off + cout) of a fused launch
+static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, int cout, int cin, int ksize, int cout_off,
+                            bool transposed, int mode /*0 mfma, 1 first, 2 raw*/) {
+    float* wdst = cw.w;
+    float* bdst = cw.bias + cout_off;
+    const int cout_total = cw.cout;
+    if (transposed) {
+        add_param(net, conv + ".weight", {cin, cout, ksize, ksize}, [=](const float* d, hipStream_t s) {
+            if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
+            return pack_conv_weights(s, d, true, cout, cin, ksize, wdst, cout_off, cout_total);
+        });
+    } else {
+        add_param(net, conv + ".weight", {cout, cin, ksize, ksize}, [=](const float* d, hipStream_t s) {
+            if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
+            if (mode == 1) return pack_first_weights(s, d, cout, cin, wdst, cout_off, cout_total);
+            return pack_conv_weights(s, d, false, cout, cin, ksize, wdst, cout_off, cout_total);
+        });
+    }
+    add_param(net, conv + ".bias", {cout}, [=](const float* d, hipStream_t s) { return copy_param(bdst, d, cout, s); });
+}
+
+static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::string& pfx, int cin, int c, int stride) {
+    u.cin = cin; u.c = c; u.stride = stride; u.subunits = net->nru;
+    u.first = (cin == net->in_ch) && stride == 2 && cin < 16;
+    u.res_conv = (stride != 1) || (cin != c);
+    u.fused_res = u.res_conv && stride != 1;
+    u.norms.resize(u.subunits);
+    u.units.resize(u.subunits > 1 ? u.subunits - 1 : 0);
+    // unit0 (+ fused residual)
+    u.unit0.cin = cin;
+    u.unit0.cout = u.fused_res ? 2 * c : c;
+    u.unit0.w = ar.take(u.first ? packed_first_floats(u.unit0.cout, cin) : packed_conv_floats(u.unit0.cout, cin, 3));
+    u.unit0.bias = ar.take(u.unit0.cout);
+    add_conv_params(net, pfx + ".conv.unit0.conv", u.unit0, c, cin, 3, 0, false, u.first ? 1 : 0);
+    add_norm_params(net, ar, pfx + ".conv.unit0.adn", u.norms[0], c);
+    for (int su = 1; su < u.subunits; ++su) {
+        ConvW& cw = u.units[su - 1];
+        cw.cin = c; cw.cout = c;
+        cw.w = ar.take(packed_conv_floats(c, c, 3));
+        cw.bias = ar.take(c);
+        const std::string un = pfx + ".conv.unit" + std::to_string(su);
+        add_conv_params(net, un + ".conv", cw, c, c, 3, 0, false, 0);
+        add_norm_params(net, ar, un + ".adn", u.norms[su], c);
+    }
+    if (u.fused_res) {
+        add_conv_params(net, pfx + ".residual", u.unit0, c, cin, 3, c, false, u.first ? 1 : 0);
+    } else if (u.res_conv) {
+        u.res1x1.cin = cin; u.res1x1.cout = c;
+        u.res1x1.w = ar.take(packed_conv_floats(c, cin, 1));
+        u.res1x1.bias = ar.take(c);
+        add_conv_params(net, pfx + ".residual", u.res1x1, c, cin, 1, 0, false, 0);
+    }
+}
+
+static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& pfx, int cin_skip, int cin_sub, int cout, bool top) {
+    u.cin_skip = cin_skip; u.cin_sub = cin_sub; u.cout = cout; u.top = top;
+    const int cin = cin_skip + cin_sub;
+    const bool small = (cout % 16) != 0;
+    u.convt.cin = cin; u.convt.cout = cout;
+    u.convt.w = ar.take(small ? (size_t)cin * cout * 9 : packed_conv_floats(cout, cin, 3));
+    u.convt.bias = ar.take(cout);
+    add_conv_params(net, pfx + ".0.conv", u.convt, cout, cin, 3, 0, true, small ? 2 : 0);
+    add_norm_params(net, ar, pfx + ".0.adn", u.norm_t, cout);
+    u.unit0.cin = cout; u.unit0.cout = cout;
+    u.unit0.w = ar.take(small ? (size_t)cout * cout * 9 : packed_conv_floats(cout, cout, 3));
+    u.unit0.bias = ar.take(cout);
+    add_conv_params(net, pfx + ".1.conv.unit0.conv", u.unit0, cout, cout, 3, 0, false, small ? 2 : 0);
+    if (!top) add_norm_params(net, ar, pfx + ".1.conv.unit0.adn", u.norm_u, cout);
+}
+
+static void build_net(cs_unet* net, ArenaPlan& ar) {
+    net->params.clear();
+    net->down.assign(net->nl, DownUnit());
+    net->up.assign(net->nl, UpUnit());
+    std::string pfx = "model";
+    // registration order follows PyTorch: down (".0"), inner block (".1.submodule"), up (".2")
+    std::vector<std::string> prefixes(net->nl);
+    for (int d = 0; d < net->nl; ++d) {
+        prefixes[d] = pfx;
+        build_down(net, ar, net->down[d], pfx + ".0", d == 0 ? net->in_ch : net->ch[d - 1], net->ch[d], 2);
+        pfx += ".1.submodule";
+    }
+    build_down(net, ar, net->bottom, pfx, net->ch[net->nl - 1], net->ch[net->nl], 1);
+    for (int d = net->nl - 1; d >= 0; --d) {
+        const int cin_sub = (d == net->nl - 1) ? net->ch[d + 1] : net->ch[d];
+        build_up(net, ar, net->up[d], prefixes[d] + ".2", net->ch[d], cin_sub, d == 0 ? net->out_ch : net->ch[d - 1], d == 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward over n windows (roi_h x roi_w); `src` says where the pixels come from
+// ---------------------------------------------------------------------------------------------------
+struct NormRt {   // run-time state of one norm site for the current forward
+    double* stats = nullptr;
+    float2* tab = nullptr;
+};
+
+static int finish_norm(hipStream_t s, const cs_unet* net, const NormSite& ns, NormRt& rt, int n, int c_total, int count, bool dry) {
+    if (dry) return CS_OK;
+    if (net->norm == CS_NORM_BATCH) return launch_bn_table(s, ns.bn_w, ns.bn_b, ns.bn_m, ns.bn_v, rt.tab, n, ns.c, c_total, 1e-5f);
+    return launch_norm_finalize(s, rt.stats, rt.tab, n, c_total, count, 1e-5f);
+}
+
+static ConvSrc lazy_src(const float* ptr, int c, int pitch, const NormRt& rt, const NormSite& ns, int tab_c) {
+    ConvSrc s;
+    s.ptr = ptr; s.c = c; s.pitch = pitch; s.tab = rt.tab; s.slope = ns.slope; s.tab_c = tab_c; s.tab_off = 0;
+    return s;
+}
+static ConvSrc raw_src(const float* ptr, int c, int pitch) {
+    ConvSrc s;
+    s.ptr = ptr; s.c = c; s.pitch = pitch;
+    return s;
+}
+
+#define CS_TRY(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_ != CS_OK) return rc_; \
+    } while (0)
+
+// Runs (or, with a dry Bump, only sizes) the forward.  Output: logits NHWC [n, h, w, out_ch].
+static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, int h, int w, float* logits, Bump& ws, hipStream_t s) {
+    const bool dry = ws.dry();
+    const int nl = net->nl;
+    CS_REQUIRE(h % (1 << nl) == 0 && w % (1 << nl) == 0 && h > 0 && w > 0, "unet: window %d x %d must be a multiple of %d", h, w,
+               1 << nl);
+    const bool inst = net->norm == CS_NORM_INSTANCE;
+    // all statistics of one forward live in one arena so a single memset clears them
+    const size_t stats_mark = ws.off;
+    std::vector<std::pair<NormRt*, int>> pending;   // (site, channels in its stats/tab)
+    auto new_norm = [&](NormRt& rt, int c_total) {
+        rt.stats = inst ? ws.take<double>((size_t)n * c_total * 2) : nullptr;
+        (void)pending;
+    };
+    // pre-allocate statistics: walk the net once
+    std::vector<std::vector<NormRt>> rt_down(nl);
+    std::vector<NormRt> rt_bottom(net->bottom.subunits);
+    std::vector<NormRt> rt_upt(nl), rt_upu(nl);
+    for (int d = 0; d < nl; ++d) {
+        rt_down[d].resize(net->down[d].subunits);
+        for (int su = 0; su < net->down[d].subunits; ++su) new_norm(rt_down[d][su], su == 0 ? net->down[d].unit0.cout : net->down[d].c);
+    }
+    for (int su = 0; su < net->bottom.subunits; ++su) new_norm(rt_bottom[su], net->bottom.c);
+    for (int d = 0; d < nl; ++d) {
+        new_norm(rt_upt[d], net->up[d].cout);
+        if (!net->up[d].top) new_norm(rt_upu[d], net->up[d].cout);
+    }
+    const size_t stats_bytes = ws.off - stats_mark;
+    if (!dry && inst) {
+        if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
+        ProfScope prof(K_MEMSET, s, 0, (double)stats_bytes);
+        CS_HIP(hipMemsetAsync(ws.base + stats_mark, 0, stats_bytes, s));
+    }
+    auto new_tab = [&](NormRt& rt, int c_total) { rt.tab = ws.take<float2>((size_t)n * c_total); };
+
+    // ---- encoder ----
+    std::vector<float*> X(nl);   // materialised ResidualUnit outputs (skip connections)
+    const float* prev = nullptr;
+    int ph = h, pw = w, pc = net->in_ch;
+    for (int d = 0; d < nl; ++d) {
+        const DownUnit& u = net->down[d];
+        const int oh = ph / 2, ow = pw / 2, c = u.c, c0 = u.unit0.cout;
+        float* E = ws.take<float>((size_t)n * oh * ow * c0);          // [y0 || r]
+        std::vector<float*> Y(u.subunits, nullptr);
+        for (int su = 1; su < u.subunits; ++su) Y[su] = ws.take<float>((size_t)n * oh * ow * c);
+        X[d] = ws.take<float>((size_t)n * oh * ow * c);
+        for (int su = 0; su < u.subunits; ++su) new_tab(rt_down[d][su], su == 0 ? c0 : c);
+        if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
+        if (!dry) {
+            if (u.first) {
+                CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n));
+            } else {
+                CS_TRY(launch_conv_mfma(s, 3, 2, raw_src(prev, pc, pc), ConvSrc(), u.unit0.w, u.unit0.bias, E, c0, c0,
+                                        rt_down[d][0].stats, n, ph, pw));
+            }
+            CS_TRY(finish_norm(s, net, u.norms[0], rt_down[d][0], n, c0, oh * ow, dry));
+            const float* cur = E;
+            int cur_pitch = c0, cur_tabc = c0;
+            for (int su = 1; su < u.subunits; ++su) {
+                CS_TRY(launch_conv_mfma(s, 3, 1, lazy_src(cur, c, cur_pitch, rt_down[d][su - 1], u.norms[su - 1], cur_tabc), ConvSrc(),
+                                        u.units[su - 1].w, u.units[su - 1].bias, Y[su], c, c, rt_down[d][su].stats, n, oh, ow));
+                CS_TRY(finish_norm(s, net, u.norms[su], rt_down[d][su], n, c, oh * ow, dry));
+                cur = Y[su];
+                cur_pitch = c;
+                cur_tabc = c;
+            }
+            const int last = u.subunits - 1;
+            CS_TRY(launch_norm_act_add(s, lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc),
+                                       raw_src(E + c, c, c0), X[d], c, (int64_t)oh * ow, n));
+        }
+        prev = X[d];
+        ph = oh; pw = ow; pc = c;
+    }
+    // ---- bottom ----
+    float* S = nullptr;   // "sub" input of the next up layer
+    {
+        const DownUnit& u = net->bottom;
+        const int c = u.c;
+        std::vector<float*> Y(u.subunits);
+        for (int su = 0; su < u.subunits; ++su) Y[su] = ws.take<float>((size_t)n * ph * pw * c);
+        float* R = u.res_conv ? ws.take<float>((size_t)n * ph * pw * c) : nullptr;
+        S = ws.take<float>((size_t)n * ph * pw * c);
+        for (int su = 0; su < u.subunits; ++su) new_tab(rt_bottom[su], c);
+        if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
+        if (!dry) {
+            CS_TRY(launch_conv_mfma(s, 3, 1, raw_src(prev, pc, pc), ConvSrc(), u.unit0.w, u.unit0.bias, Y[0], c, c, rt_bottom[0].stats,
+                                    n, ph, pw));
+            CS_TRY(finish_norm(s, net, u.norms[0], rt_bottom[0], n, c, ph * pw, dry));
+            if (u.res_conv)
+                CS_TRY(launch_conv_mfma(s, 1, 1, raw_src(prev, pc, pc), ConvSrc(), u.res1x1.w, u.res1x1.bias, R, c, c, nullptr, n, ph, pw));
+            for (int su = 1; su < u.subunits; ++su) {
+                CS_TRY(launch_conv_mfma(s, 3, 1, lazy_src(Y[su - 1], c, c, rt_bottom[su - 1], u.norms[su - 1], c), ConvSrc(),
+                                        u.units[su - 1].w, u.units[su - 1].bias, Y[su], c, c, rt_bottom[su].stats, n, ph, pw));
+                CS_TRY(finish_norm(s, net, u.norms[su], rt_bottom[su], n, c, ph * pw, dry));
+            }
+            const int last = u.subunits - 1;
+            CS_TRY(launch_norm_act_add(s, lazy_src(Y[last], c, c, rt_bottom[last], u.norms[last], c),
+                                       u.res_conv ? raw_src(R, c, c) : raw_src(prev, c, pc), S, c, (int64_t)ph * pw, n));
+        }
+    }
+    // ---- decoder ----
+    int sc = net->bottom.c;
+    for (int d = nl - 1; d >= 0; --d) {
+        const UpUnit& u = net->up[d];
+        const int oh = ph * 2, ow = pw * 2, c = u.cout;
+        float* U = ws.take<float>((size_t)n * oh * ow * c);
+        new_tab(rt_upt[d], c);
+        float *V = nullptr, *D = nullptr;
+        if (!u.top) {
+            V = ws.take<float>((size_t)n * oh * ow * c);
+            D = ws.take<float>((size_t)n * oh * ow * c);
+            new_tab(rt_upu[d], c);
+        }
+        if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
+        if (!dry) {
+            const ConvSrc a = raw_src(X[d], u.cin_skip, u.cin_skip), b = raw_src(S, sc, sc);
+            if (c % 16 == 0) {
+                CS_TRY(launch_convt_mfma(s, a, b, u.convt.w, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
+            } else {
+                CS_TRY(launch_convt_small(s, a, b, u.convt.w, u.convt.bias, U, c, rt_upt[d].stats, n, ph, pw));
+            }
+            CS_TRY(finish_norm(s, net, u.norm_t, rt_upt[d], n, c, oh * ow, dry));
+            const ConvSrc lu = lazy_src(U, c, c, rt_upt[d], u.norm_t, c);
+            if (u.top) {
+                CS_TRY(launch_conv_last(s, lu, u.unit0.w, u.unit0.bias, logits, c, n, oh, ow));
+            } else {
+                CS_TRY(launch_conv_mfma(s, 3, 1, lu, ConvSrc(), u.unit0.w, u.unit0.bias, V, c, c, rt_upu[d].stats, n, oh, ow));
+                CS_TRY(finish_norm(s, net, u.norm_u, rt_upu[d], n, c, oh * ow, dry));
+                CS_TRY(launch_norm_act_add(s, lazy_src(V, c, c, rt_upu[d], u.norm_u, c), lu, D, c, (int64_t)oh * ow, n));
+            }
+        }
+        S = D;
+        sc = c;
+        ph = oh; pw = ow;
+    }
+    return CS_OK;
+}
+
+static int check_loaded(const cs_unet* net) {
+    for (const auto& p : net->params)
+        if (!p.loaded) {
+            set_error("parameter '%s' was never loaded", p.key.c_str());
+            return CS_ERR_NOT_LOADED;
+        }
+    return CS_OK;
+}
+
+__global__ void swi_origins_kernel(cs_swi_plan pl, int ih_lo, int count, int2* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int ih = ih_lo + k / pl.n_w, iw = k % pl.n_w;
+    int hs = ih * pl.interval_h, wsx = iw * pl.interval_w;
+    hs = hs < pl.pad_h - pl.roi_h ? hs : pl.pad_h - pl.roi_h;
+    wsx = wsx < pl.pad_w - pl.roi_w ? wsx : pl.pad_w - pl.roi_w;
+    out[k] = make_int2(hs - pl.pad_top, wsx - pl.pad_left);   // image coordinates (negative inside the zero padding)
+}
+
+}  // namespace cs
+
+// ===================================================================================================
+// C-ABI
+// ===================================================================================================
+extern "C" {
+
+const char* cs_last_error(void) { return cs::g_err; }
+int cs_version(void) { return 100; }
+
+int cs_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        cs::set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return CS_ERR_HIP;
+    }
+    return n;
+}
+
+int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* channels_host, int n_channels, int num_res_units,
+                   int norm_kind, int act_kind) {
+    CS_REQUIRE(out && channels_host, "unet_create: null argument");
+    CS_REQUIRE(in_channels == 3 && out_channels == 3, "unet_create: only the reference's 3 -> 3 channel contract is supported");
+    CS_REQUIRE(n_channels >= 2 && n_channels <= 8, "unet_create: n_channels %d out of range", n_channels);
+    CS_REQUIRE(num_res_units >= 1 && num_res_units <= 4, "unet_create: num_res_units %d out of range", num_res_units);
+    CS_REQUIRE(norm_kind == CS_NORM_INSTANCE || norm_kind == CS_NORM_BATCH, "unet_create: bad norm kind");
+    CS_REQUIRE(act_kind == CS_ACT_PRELU || act_kind == CS_ACT_RELU, "unet_create: bad act kind");
+    for (int i = 0; i < n_channels; ++i)
+        CS_REQUIRE(channels_host[i] % 16 == 0 && channels_host[i] >= 16 && channels_host[i] <= 4096,
+                   "unet_create: channels[%d]=%d must be a multiple of 16", i, channels_host[i]);
+    CS_REQUIRE(2 * channels_host[0] <= 128, "unet_create: channels[0]=%d too wide for the first-layer kernel", channels_host[0]);
+    cs_unet* net = new cs_unet();
+    net->in_ch = in_channels; net->out_ch = out_channels; net->nl = n_channels - 1; net->nru = num_res_units;
+    net->norm = norm_kind; net->act = act_kind;
+    net->ch.assign(channels_host, channels_host + n_channels);
+    ArenaPlan count;
+    build_net(net, count);
+    net->arena_floats = count.off;
+    hipError_t e = hipMalloc((void**)&net->arena, net->arena_floats * sizeof(float));
+    if (e != hipSuccess) {
+        cs::set_error("hipMalloc(%zu) for the weight arena failed: %s", net->arena_floats * sizeof(float), hipGetErrorString(e));
+        delete net;
+        return CS_ERR_HIP;
+    }
+    (void)hipMemset(net->arena, 0, net->arena_floats * sizeof(float));
+    ArenaPlan real;
+    real.base = net->arena;
+    build_net(net, real);
+    *out = net;
+    return CS_OK;
+}
+
+int cs_unet_destroy(cs_unet* net) {
+    if (!net) return CS_OK;
+    if (net->arena) (void)hipFree(net->arena);
+    delete net;
+    return CS_OK;
+}
+
+int cs_unet_num_params(const cs_unet* net) { return net ? (int)net->params.size() : CS_ERR_INVALID; }
+
+int cs_unet_param_info(const cs_unet* net, int index, char* key_out_host, int64_t* shape_out_host) {
+    CS_REQUIRE(net && index >= 0 && index < (int)net->params.size(), "param_info: index %d out of range", index);
+    const ParamEntry& p = net->params[index];
+    if (key_out_host) {
+        strncpy(key_out_host, p.key.c_str(), 159);
+        key_out_host[159] = 0;
+    }
+    if (shape_out_host)
+        for (int i = 0; i < 4; ++i) shape_out_host[i] = p.shape[i];
+    return p.rank;
+}
+
+int cs_unet_load_param(cs_unet* net, const char* key_host, const float* data, int64_t numel, void* stream) {
+    CS_REQUIRE(net && key_host && data, "load_param: null argument");
+    for (auto& p : net->params) {
+        if (p.key == key_host) {
+            CS_REQUIRE(numel == p.numel(), "load_param: '%s' expects %lld elements, got %lld", key_host, (long long)p.numel(),
+                       (long long)numel);
+            int rc = p.load(data, (hipStream_t)stream);
+            if (rc == CS_OK) p.loaded = true;
+            return rc;
+        }
+    }
+    cs::set_error("load_param: unknown key '%s'", key_host);
+    return CS_ERR_UNKNOWN_KEY;
+}
+
+size_t cs_unet_workspace_bytes(const cs_unet* net, int n, int h, int w) {
+    if (!net || n <= 0) return 0;
+    Bump b(nullptr, 0);
+    WindowSrc src;
+    if (unet_forward_impl(net, src, n, h, w, nullptr, b, nullptr) != CS_OK) return 0;
+    return b.off + 256;
+}
+
+int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n, int h, int w,
+                    float* logits_nhwc, void* workspace, size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(net && x && logits_nhwc && workspace, "unet_forward: null argument");
+    CS_REQUIRE(n > 0, "unet_forward: n = %d", n);
+    int rc = check_loaded(net);
+    if (rc) return rc;
+    WindowSrc src;
+    src.image = x; src.sn = sn; src.sc = sc; src.sh = sh; src.sw = sw;
+    src.origins = nullptr; src.img_h = h; src.img_w = w; src.roi_h = h; src.roi_w = w;
+    Bump b(workspace, workspace_bytes);
+    return unet_forward_impl(net, src, n, h, w, logits_nhwc, b, (hipStream_t)stream);
+}
+
+int cs_swi_window_start(int i, int interval, int padded_size, int roi) {
+    const int s = i * interval;
+    return s < padded_size - roi ? s : padded_size - roi;
+}
+
+int cs_swi_make_plan(int img_h, int img_w, int roi_h, int roi_w, double overlap, cs_swi_plan* pl) {
+    CS_REQUIRE(pl && img_h > 0 && img_w > 0 && roi_h > 0 && roi_w > 0, "swi plan: bad sizes");
+    CS_REQUIRE(overlap >= 0.0 && overlap < 1.0, "swi plan: overlap %.3f out of range", overlap);
+    pl->img_h = img_h; pl->img_w = img_w; pl->roi_h = roi_h; pl->roi_w = roi_w;
+    pl->pad_h = img_h > roi_h ? img_h : roi_h;
+    pl->pad_w = img_w > roi_w ? img_w : roi_w;
+    pl->pad_top = (pl->pad_h - img_h) / 2;
+    pl->pad_left = (pl->pad_w - img_w) / 2;
+    auto interval = [&](int size, int roi) {
+        int iv = size == roi ? roi : (int)(roi * (1.0 - overlap));
+        return iv > 0 ? iv : 1;
+    };
+    pl->interval_h = interval(pl->pad_h, roi_h);
+    pl->interval_w = interval(pl->pad_w, roi_w);
+    auto count = [](int size, int roi, int iv) {
+        int n = 0;
+        while ((long long)n * iv + roi < size) ++n;
+        return n + 1;
+    };
+    pl->n_h = count(pl->pad_h, roi_h, pl->interval_h);
+    pl->n_w = count(pl->pad_w, roi_w, pl->interval_w);
+    return CS_OK;
+}
+
+static void swi_row_windows(const cs_swi_plan* pl, int row_begin, int row_end, int* ih_lo, int* ih_hi) {
+    // window rows whose padded extent [hs, hs + roi) intersects padded rows [row_begin + pad_top, row_end + pad_top)
+    const int p0 = row_begin + pl->pad_top, p1 = row_end + pl->pad_top;
+    int lo = pl->n_h, hi = -1;
+    for (int ih = 0; ih < pl->n_h; ++ih) {
+        const int hs = cs_swi_window_start(ih, pl->interval_h, pl->pad_h, pl->roi_h);
+        if (hs < p1 && hs + pl->roi_h > p0) {
+            if (ih < lo) lo = ih;
+            if (ih > hi) hi = ih;
+        }
+    }
+    *ih_lo = lo;
+    *ih_hi = hi;
+}
+
+size_t cs_swi_workspace_bytes(const cs_unet* net, const cs_swi_plan* pl, int engine_batch) {
+    if (!net || !pl || engine_batch <= 0) return 0;
+    const size_t nwin = (size_t)pl->n_h * pl->n_w;
+    const size_t eb = (size_t)engine_batch < nwin ? (size_t)engine_batch : nwin;
+    const size_t unet = cs_unet_workspace_bytes(net, (int)eb, pl->roi_h, pl->roi_w);
+    if (unet == 0) return 0;
+    return unet + (nwin * 8 + 255) / 256 * 256 + (nwin * pl->roi_h * pl->roi_w * net->out_ch * 4 + 255) / 256 * 256 + 512;
+}
+
+int cs_swi_infer(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_t sc, int64_t sh, int64_t sw, int engine_batch,
+                 int row_begin, int row_end, float* logits_nchw, float* prob1, uint8_t* mask, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(net && pl && image && workspace, "swi_infer: null argument");
+    CS_REQUIRE(engine_batch > 0, "swi_infer: engine_batch %d", engine_batch);
+    CS_REQUIRE(row_begin >= 0 && row_end <= pl->img_h && row_begin < row_end, "swi_infer: bad row range [%d, %d)", row_begin, row_end);
+    int rc = check_loaded(net);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    int ih_lo, ih_hi;
+    swi_row_windows(pl, row_begin, row_end, &ih_lo, &ih_hi);
+    CS_REQUIRE(ih_hi >= ih_lo, "swi_infer: no window intersects rows [%d, %d)", row_begin, row_end);
+    const int nwin = (ih_hi - ih_lo + 1) * pl->n_w;
+    Bump b(workspace, workspace_bytes);
+    int2* origins = b.take<int2>((size_t)nwin);
+    const size_t win_floats = (size_t)pl->roi_h * pl->roi_w * net->out_ch;
+    float* win_logits = b.take<float>((size_t)nwin * win_floats);
+    if (!b.ok()) { cs::set_error("swi_infer: workspace too small"); return CS_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(cs::swi_origins_kernel, dim3((unsigned)cs::ceil_div(nwin, 256)), dim3(256), 0, s, *pl, ih_lo, nwin, origins);
+    CS_HIP(hipGetLastError());
+    WindowSrc src;
+    src.image = image; src.sn = 0; src.sc = sc; src.sh = sh; src.sw = sw;
+    src.img_h = pl->img_h; src.img_w = pl->img_w; src.roi_h = pl->roi_h; src.roi_w = pl->roi_w;
+    const size_t mark = b.off;
+    for (int k0 = 0; k0 < nwin; k0 += engine_batch) {
+        const int nb = nwin - k0 < engine_batch ? nwin - k0 : engine_batch;
+        src.origins = origins + k0;
+        b.off = mark;   // every chunk reuses the same activation workspace (stream order serialises them)
+        rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, b, s);
+        if (rc) return rc;
+    }
+    SwiFinalizeArgs fa{};
+    fa.win_logits = win_logits;
+    fa.plan = *pl;
+    fa.c = net->out_ch;
+    fa.ih_base = ih_lo;
+    fa.row_begin = row_begin;
+    fa.row_end = row_end;
+    fa.logits_nchw = logits_nchw;
+    fa.prob1 = prob1;
+    fa.mask = mask;
+    return launch_swi_finalize(s, fa);
+}
+
+int cs_swi_finalize(const cs_swi_plan* pl, const float* win_logits, int classes, int ih_base, int row_begin, int row_end,
+                    float* logits_nchw, float* prob1, uint8_t* mask, void* stream) {
+    CS_REQUIRE(pl && win_logits, "swi_finalize: null argument");
+    SwiFinalizeArgs fa{};
+    fa.win_logits = win_logits;
+    fa.plan = *pl;
+    fa.c = classes;
+    fa.ih_base = ih_base;
+    fa.row_begin = row_begin;
+    fa.row_end = row_end;
+    fa.logits_nchw = logits_nchw;
+    fa.prob1 = prob1;
+    fa.mask = mask;
+    return launch_swi_finalize((hipStream_t)stream, fa);
+}
+
+size_t cs_ccl_workspace_bytes(int h, int w) { return cs::ccl_workspace_bytes(h, w); }
+
+int cs_ccl_postprocess(const uint8_t* mask, int h, int w, int hole_area, int min_size, int32_t* labels, int32_t* n_labels,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(mask && labels && workspace, "ccl_postprocess: null argument");
+    return cs::ccl_postprocess((hipStream_t)stream, mask, h, w, hole_area, min_size, labels, n_labels, workspace, workspace_bytes);
+}
+
+int cs_ccl_label(const uint8_t* mask, int h, int w, int connectivity, int32_t* labels, int32_t* n_labels, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(mask && labels && workspace, "ccl_label: null argument");
+    return cs::ccl_label((hipStream_t)stream, mask, h, w, connectivity, labels, n_labels, workspace, workspace_bytes);
+}
+
+int cs_prof_enable(int on) {
+    cs::g_prof_on = on != 0;
+    return CS_OK;
+}
+
+int cs_prof_reset(void) {
+    cs::prof_drain();
+    for (int i = 0; i < K_NUM_IDS; ++i) {
+        cs::g_prof_flops[i] = cs::g_prof_bytes[i] = cs::g_prof_ms[i] = 0.0;
+        cs::g_prof_launches[i] = 0;
+    }
+    return CS_OK;
+}
+
+int cs_prof_collect(char* names_out_host, double* ms_out_host, int64_t* launches_out_host, double* flops_out_host,
+                    double* bytes_out_host) {
+    cs::prof_drain();
+    for (int i = 0; i < K_NUM_IDS; ++i) {
+        if (names_out_host) {
+            strncpy(names_out_host + 48 * i, cs::kernel_name(i), 47);
+            names_out_host[48 * i + 47] = 0;
+        }
+        if (ms_out_host) ms_out_host[i] = cs::g_prof_ms[i];
+        if (launches_out_host) launches_out_host[i] = cs::g_prof_launches[i];
+        if (flops_out_host) flops_out_host[i] = cs::g_prof_flops[i];
+        if (bytes_out_host) bytes_out_host[i] = cs::g_prof_bytes[i];
+    }
+    return K_NUM_IDS;
+}
+
+}  // extern "C"

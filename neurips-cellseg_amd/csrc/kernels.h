@@ -1,0 +1,90 @@
+// Internal launcher API of the gfx950 kernels (host side).  Not part of the C-ABI.
+#pragma once
+#include "cs_common.h"
+
+namespace cs {
+
+// One input source of a convolution: raw NHWC tensor + optional lazy norm/act (see Lazy).
+struct ConvSrc {
+    const float* ptr = nullptr;
+    int c = 0;          // channels taken from this source (multiple of 16 for the MFMA kernels)
+    int pitch = 0;      // floats between pixels
+    const float2* tab = nullptr;   // lazy norm table [n][tab_c] (scale, shift) or nullptr (raw)
+    const float* slope = nullptr;  // PReLU slope (device scalar); nullptr with tab set = ReLU
+    int tab_c = 0;                 // channels per image in `tab` (>= c when this source is a channel sub-range)
+    int tab_off = 0;               // channel offset of this source inside `tab`
+};
+
+// ---- weight packing (PyTorch layout -> MFMA fragment order) -----------------------------------
+// conv  W[cout][cin][k][k]  (transposed == false)   /   conv-transpose W[cin][cout][k][k] (transposed == true)
+// packed[chunk][tap][ntile_total][64 lanes][4] with cout = ntile*16 + (lane & 15), cin = chunk*16 + 4*(lane>>4) + j.
+// `cout_off`/`cout_total` let two convs (unit0 || residual) share one packed tensor; `cin_total` is the
+// concatenated input width.
+int pack_conv_weights(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
+                      float* packed, int cout_off, int cout_total);
+// first layer (cin < 16): packed[kstep][ntile_total][64], k = 4*kstep + (lane>>4) = tap*cin + c, zero padded
+int pack_first_weights(hipStream_t s, const float* w, int cout, int cin, float* packed, int cout_off, int cout_total);
+size_t packed_conv_floats(int cout_total, int cin_total, int ksize);
+size_t packed_first_floats(int cout_total, int cin);
+
+// ---- convolutions ------------------------------------------------------------------------------
+// 3x3 (pad 1) or 1x1 (pad 0) convolution, stride 1 or 2, fp32 MFMA 16x16x4.  Input = concat(a, b) along C.
+// out: raw conv + bias (NHWC, pitch floats/pixel).  stats: [n][cout][2] doubles (sum, sum of squares) or null.
+int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, const ConvSrc& b, const float* wpack,
+                     const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
+
+// first layer: cin < 16 (3), 3x3 pad 1, reads windows straight out of the image (tiler gather fused).
+// image element strides (sc, sh, sw); per-window origins (y0, x0) in image coordinates (may be negative when the
+// image is smaller than the roi); pixels outside the window or the image read as 0.
+struct WindowSrc {
+    const float* image = nullptr;
+    int64_t sn = 0, sc = 0, sh = 0, sw = 0;   // sn used when origins == nullptr (plain batched forward)
+    const int2* origins = nullptr;           // [n] (y0, x0) or nullptr
+    int img_h = 0, img_w = 0;                // bounds of the image (or of each batch item)
+    int roi_h = 0, roi_w = 0;                // window size = conv input size
+};
+int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
+                      float* out, int pitch_out, int cout, double* stats, int n);
+
+// transposed 3x3 stride 2 pad 1 output_padding 1 (MFMA), input = concat(a, b); out is [n, 2h, 2w, cout]
+int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* wpack, const float* bias,
+                      float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
+
+// small-cout (<= 4) VALU kernels for the top of the decoder
+// transposed conv cin -> cout(<=4); weights in PyTorch layout W[cin][cout][3][3] (no packing)
+int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* w_torch, const float* bias,
+                       float* out, int cout, double* stats, int n, int hin, int win);
+// final conv c -> c (c <= 4) on lazy input + identity residual of the same lazy input: out = conv(T(u)) + b + T(u)
+int launch_conv_last(hipStream_t s, const ConvSrc& u, const float* w_torch, const float* bias, float* out, int c,
+                     int n, int h, int w);
+
+// ---- normalisation ------------------------------------------------------------------------------
+// stats [n][c][2] (double) -> tab [n][c] (rstd, -mean*rstd); count = h*w; eps = 1e-5
+int launch_norm_finalize(hipStream_t s, const double* stats, float2* tab, int n, int c, int count, float eps);
+// eval-mode BatchNorm: tab[n][c] from running stats and affine parameters
+int launch_bn_table(hipStream_t s, const float* weight, const float* bias, const float* mean, const float* var,
+                    float2* tab, int n, int c, int c_total, float eps);
+// out = T_y(y) + T_r(r)   (T = lazy norm/act or identity), all NHWC with channel count c
+int launch_norm_act_add(hipStream_t s, const ConvSrc& y, const ConvSrc& r, float* out, int pitch_out, int64_t npix_per_image, int n);
+
+// ---- tiler finalize -------------------------------------------------------------------------------
+struct SwiFinalizeArgs {
+    const float* win_logits;    // [n_h*n_w][roi_h][roi_w][c] NHWC
+    cs_swi_plan plan;
+    int c;                      // classes (<= 4)
+    int ih_base;                // window-row index of win_logits[0] (a rank holds only the window rows it ran)
+    int row_begin, row_end;     // image rows finalised by this call
+    float* logits_nchw;         // [c][img_h][img_w] or null
+    float* prob1;               // [img_h][img_w] or null
+    uint8_t* mask;              // [img_h][img_w] or null
+};
+int launch_swi_finalize(hipStream_t s, const SwiFinalizeArgs& a);
+
+// ---- connected components ----------------------------------------------------------------------
+size_t ccl_workspace_bytes(int h, int w);
+int ccl_postprocess(hipStream_t s, const uint8_t* mask, int h, int w, int hole_area, int min_size, int32_t* labels,
+                    int32_t* n_labels, void* ws, size_t ws_bytes);
+int ccl_label(hipStream_t s, const uint8_t* mask, int h, int w, int conn, int32_t* labels, int32_t* n_labels, void* ws,
+              size_t ws_bytes);
+
+}  // namespace cs

@@ -1,0 +1,569 @@
+// gfx950 (MI355X) fp32 convolution kernels for the 3-class U-Net hot path.
+//
+// Replaces the implicit torch conv2d / conv_transpose2d / instance_norm / prelu dispatches behind
+// monai.networks.nets.UNet.forward (reference call sites baseline/predict.py:109 -> :45-52,
+// baseline/model_training_3class.py:255).
+//
+// Design (DESIGN.md "Kernels"):
+//   * NHWC fp32 activations; implicit GEMM with M = 16 output pixels of one image row, N = 16 output
+//     channels, K = taps x input channels, on v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 64-lane wave).
+//   * the K loop walks 16-channel chunks: the halo'd input patch of the chunk is staged through LDS with the
+//     PRODUCER's InstanceNorm + PReLU applied on the fly (lazy normalisation: normalised tensors are never
+//     written to HBM), weights arrive pre-packed in MFMA fragment order so a B fragment is one ds_read_b128.
+//   * epilogue adds the bias, stores the raw conv output and accumulates per-(image, channel) sum / sum of
+//     squares in fp64 (wavefront shuffle reduction + one fp64 atomic per wave and channel) for the next norm.
+#include "kernels.h"
+
+namespace cs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SrcDev {
+    const float* ptr;
+    const float2* tab;
+    const float* slope;
+    int c, pitch, tab_c, tab_off;
+};
+
+struct ConvParams {
+    SrcDev a, b;
+    const float* wpack;
+    const float* bias;
+    float* out;
+    double* stats;
+    int pitch_out, cout, ntile_total;
+    int n, hin, win, hout, wout, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float prelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// lazy norm + activation on 4 consecutive channels
+struct Lazy4 {
+    f32x4 scale, shift;
+    float slope;
+    bool on;
+    __device__ __forceinline__ void load(const SrcDev& s, int img, int ch) {
+        on = s.tab != nullptr;
+        if (on) {
+            const f32x4* t = reinterpret_cast<const f32x4*>(s.tab + (size_t)img * s.tab_c + s.tab_off + ch);
+            f32x4 t0 = t[0], t1 = t[1];
+            scale = f32x4{t0.x, t0.z, t1.x, t1.z};
+            shift = f32x4{t0.y, t0.w, t1.y, t1.w};
+            slope = s.slope ? *s.slope : 0.f;
+        }
+    }
+    __device__ __forceinline__ f32x4 apply(f32x4 v) const {
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = prelu(v[j] * scale[j] + shift[j], slope);
+        }
+        return v;
+    }
+};
+
+// fp64 sum / sum-of-squares of one output channel held by the 4 lane groups of a wave -> atomics by group 0
+__device__ __forceinline__ void stats_commit(double s, double q, double* dst, int lane) {
+    s += __shfl_xor(s, 16);
+    q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (lane < 16) {
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, q);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic conv: KS in {3,1}, stride S in {1,2}, NT output-channel tiles of 16 per block, MT pixel rows per wave.
+// block = 256 threads = 4 waves; block tile = (4*MT) rows x 16 columns of output pixels x 16*NT channels.
+// ------------------------------------------------------------------------------------------------
+template <int S, int KS, int NT, int MT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+    constexpr int TH = 4 * MT, TW = 16;
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int CS = (S == 1) ? 24 : 20;   // floats per staged pixel: 16 channels + pad (bank-conflict-free A reads)
+    constexpr int PAD = KS / 2;
+    constexpr int TAPS = KS * KS;
+    __shared__ __attribute__((aligned(16))) float in_s[IH * IW * CS];
+    __shared__ __attribute__((aligned(16))) float w_s[TAPS * NT * 256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int nt0 = blockIdx.y * NT;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int chunks_a = p.a.c >> 4, chunks = (p.a.c + p.b.c) >> 4;
+    const int q = tid & 3;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool from_a = ch < chunks_a;
+        const SrcDev& src = from_a ? p.a : p.b;
+        const int c0 = (from_a ? ch : ch - chunks_a) << 4;
+        Lazy4 lz;
+        lz.load(src, img, c0 + 4 * q);
+        const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + c0 + 4 * q;
+        // ---- stage the halo'd input patch of this 16-channel chunk (4 threads per pixel) ----
+        for (int pix = tid >> 2; pix < IH * IW; pix += 64) {
+            const int iy = pix / IW, ix = pix - iy * IW;
+            const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win) {
+                v = *reinterpret_cast<const f32x4*>(base + ((size_t)gy * p.win + gx) * src.pitch);
+                v = lz.apply(v);
+            }
+            *reinterpret_cast<f32x4*>(&in_s[pix * CS + 4 * q]) = v;
+        }
+        // ---- stage this chunk's packed weights: TAPS x NT KiB, lane-linear ----
+        {
+            const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + ((size_t)ch * TAPS * p.ntile_total + nt0) * 64;
+            f32x4* wdst = reinterpret_cast<f32x4*>(w_s);
+            for (int i = tid; i < TAPS * NT * 64; i += 256) {
+                const int tap = i / (NT * 64), r = i - tap * (NT * 64);
+                wdst[i] = wsrc[(size_t)tap * p.ntile_total * 64 + r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            f32x4 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = reinterpret_cast<const f32x4*>(w_s)[(tap * NT + nt) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int row = wave * MT + m;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&in_s[((row * S + ky) * IW + pl * S + kx) * CS + 4 * g]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[m][nt] = mfma4(a.x, b[nt].x, acc[m][nt]);
+                    acc[m][nt] = mfma4(a.y, b[nt].y, acc[m][nt]);
+                    acc[m][nt] = mfma4(a.z, b[nt].z, acc[m][nt]);
+                    acc[m][nt] = mfma4(a.w, b[nt].w, acc[m][nt]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, store, statistics.  C layout: channel = lane & 15, pixel = 4 * (lane >> 4) + r ----
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = (nt0 + nt) * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        double s = 0.0, qq = 0.0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = oy0 + wave * MT + m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + g * 4 + r;
+                if (oy < p.hout && ox < p.wout) {
+                    const float v = acc[m][nt][r] + bias;
+                    p.out[(((size_t)img * p.hout + oy) * p.wout + ox) * p.pitch_out + co] = v;
+                    s += (double)v;
+                    qq += (double)v * (double)v;
+                }
+            }
+        }
+        if (p.stats) stats_commit(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+}
+
+template <int S, int KS, int NT, int MT>
+static int launch_conv_t(hipStream_t s, const ConvParams& p0) {
+    ConvParams p = p0;
+    constexpr int TH = 4 * MT;
+    p.tiles_x = ceil_div(p.wout, 16);
+    p.tiles_y = ceil_div(p.hout, TH);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.n), (unsigned)(p.ntile_total / NT));
+    hipLaunchKernelGGL((conv_mfma_kernel<S, KS, NT, MT>), grid, dim3(256), 0, s, p);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+static SrcDev to_dev(const ConvSrc& s) { return SrcDev{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
+
+int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, const ConvSrc& b, const float* wpack,
+                     const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
+    CS_REQUIRE(ksize == 3 || ksize == 1, "conv: ksize %d unsupported", ksize);
+    CS_REQUIRE(stride == 1 || stride == 2, "conv: stride %d unsupported", stride);
+    CS_REQUIRE(!(ksize == 1 && stride != 1), "conv: 1x1 stride 2 unsupported");
+    CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0, "conv: input channels (%d,%d) must be multiples of 16", a.c, b.c);
+    CS_REQUIRE(cout % 16 == 0, "conv: cout %d must be a multiple of 16", cout);
+    CS_REQUIRE((a.pitch % 4) == 0 && (b.c == 0 || (b.pitch % 4) == 0), "conv: pixel pitch must be a multiple of 4 floats");
+    ConvParams p{};
+    p.a = to_dev(a);
+    p.b = to_dev(b);
+    p.wpack = wpack;
+    p.bias = bias;
+    p.out = out;
+    p.stats = stats;
+    p.pitch_out = pitch_out;
+    p.cout = cout;
+    p.ntile_total = cout / 16;
+    p.n = n;
+    p.hin = hin;
+    p.win = win;
+    const int pad = ksize / 2;
+    p.hout = (hin + 2 * pad - ksize) / stride + 1;
+    p.wout = (win + 2 * pad - ksize) / stride + 1;
+    const int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
+    const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
+    ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
+#define CS_DISPATCH_NT(S_, KS_, MT_)                                           \
+    switch (nt) {                                                              \
+        case 4: return launch_conv_t<S_, KS_, 4, MT_>(s, p);                   \
+        case 2: return launch_conv_t<S_, KS_, 2, MT_>(s, p);                   \
+        default: return launch_conv_t<S_, KS_, 1, MT_>(s, p);                  \
+    }
+    if (ksize == 1) { CS_DISPATCH_NT(1, 1, 2) }
+    if (stride == 1) { CS_DISPATCH_NT(1, 3, 2) }
+    CS_DISPATCH_NT(2, 3, 1)
+#undef CS_DISPATCH_NT
+}
+
+// ------------------------------------------------------------------------------------------------
+// first layer: CIN (3) input channels, 3x3 pad 1, K = 9*CIN flattened as k = tap*CIN + c (padded to 4).
+// Reads its windows straight from the image (sliding-window gather fused, row T step 5 "cat slices").
+// ------------------------------------------------------------------------------------------------
+struct FirstParams {
+    const float* image;
+    int64_t sn, sc, sh, sw;
+    const int2* origins;
+    int img_h, img_w, roi_h, roi_w;
+    const float* wpack;
+    const float* bias;
+    float* out;
+    double* stats;
+    int pitch_out, cout, ntile_total, n, hout, wout, tiles_x, tiles_y;
+};
+
+template <int S, int CIN, int NT, int MT>
+__global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
+    constexpr int TH = 4 * MT, TW = 16;
+    constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+    constexpr int KSTEPS = (9 * CIN + 3) / 4;
+    __shared__ float in_s[IH * IW * CIN + 4];
+    __shared__ float w_s[KSTEPS * NT * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    int y0 = 0, x0 = 0;
+    const float* image = p.image;
+    if (p.origins) {
+        const int2 o = p.origins[img];
+        y0 = o.x;
+        x0 = o.y;
+    } else {
+        image += (size_t)img * p.sn;
+    }
+    for (int i = tid; i < IH * IW * CIN; i += 256) {
+        const int c = i % CIN, pix = i / CIN;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int wy = oy0 * S - 1 + iy, wx = ox0 * S - 1 + ix;       // window-local coordinates
+        const int gy = y0 + wy, gx = x0 + wx;                         // image coordinates
+        float v = 0.f;
+        if (wy >= 0 && wy < p.roi_h && wx >= 0 && wx < p.roi_w && gy >= 0 && gy < p.img_h && gx >= 0 && gx < p.img_w)
+            v = image[c * p.sc + gy * p.sh + gx * p.sw];
+        in_s[i] = v;
+    }
+    if (tid < 4) in_s[IH * IW * CIN + tid] = 0.f;
+    for (int i = tid; i < KSTEPS * NT * 64; i += 256) w_s[i] = p.wpack[i];
+    __syncthreads();
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int k = 4 * ks + g;
+        const int tap = (k < 9 * CIN) ? k / CIN : 0, c = (k < 9 * CIN) ? k - (k / CIN) * CIN : 0;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int koff = (ky * IW + kx) * CIN + c;
+        float b[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = w_s[(ks * NT + nt) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = wave * MT + m;
+            const float a = in_s[((row * S) * IW + pl * S) * CIN + koff];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma4(a, b[nt], acc[m][nt]);
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        double s = 0.0, qq = 0.0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = oy0 + wave * MT + m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + g * 4 + r;
+                if (oy < p.hout && ox < p.wout) {
+                    const float v = acc[m][nt][r] + bias;
+                    p.out[(((size_t)img * p.hout + oy) * p.wout + ox) * p.pitch_out + co] = v;
+                    s += (double)v;
+                    qq += (double)v * (double)v;
+                }
+            }
+        }
+        if (p.stats) stats_commit(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+}
+
+int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
+                      float* out, int pitch_out, int cout, double* stats, int n) {
+    CS_REQUIRE(cin == 3, "first conv: in_channels %d unsupported (the reference always feeds 3)", cin);
+    CS_REQUIRE(stride == 2, "first conv: stride %d unsupported", stride);
+    CS_REQUIRE(cout == 16 || cout == 32 || cout == 64 || cout == 128, "first conv: fused cout %d unsupported", cout);
+    FirstParams p{};
+    p.image = src.image;
+    p.sn = src.sn; p.sc = src.sc; p.sh = src.sh; p.sw = src.sw;
+    p.origins = src.origins;
+    p.img_h = src.img_h; p.img_w = src.img_w; p.roi_h = src.roi_h; p.roi_w = src.roi_w;
+    p.wpack = wpack; p.bias = bias; p.out = out; p.stats = stats;
+    p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16; p.n = n;
+    p.hout = (src.roi_h + 2 - 3) / 2 + 1;
+    p.wout = (src.roi_w + 2 - 3) / 2 + 1;
+    constexpr int MT = 2;
+    p.tiles_x = ceil_div(p.wout, 16);
+    p.tiles_y = ceil_div(p.hout, 4 * MT);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * n));
+    const double flops = 2.0 * n * p.hout * p.wout * (double)cout * cin * 9;
+    const double bytes = 4.0 * n * ((double)src.roi_h * src.roi_w * cin + (double)p.hout * p.wout * cout);
+    ProfScope prof(K_CONV_FIRST, s, flops, bytes);
+    switch (cout / 16) {
+        case 1: hipLaunchKernelGGL((conv_first_kernel<2, 3, 1, MT>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_first_kernel<2, 3, 2, MT>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((conv_first_kernel<2, 3, 4, MT>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv_first_kernel<2, 3, 8, MT>), grid, dim3(256), 0, s, p); break;
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// transposed conv k3 s2 p1 op1 as 4 output phases over a 2x2 input neighbourhood:
+//   out[2i+a][2j+b] += in[i+di][j+dj] * W[ky][kx],  ky: 0->(a=1,di=1) 1->(a=0,di=0) 2->(a=1,di=0); same for kx.
+// M tile = 16 input pixels of one row; each wave owns one input row of the block's 4-row tile.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
+    constexpr int TH = 4, TW = 16, IH = TH + 1, IW = TW + 1, CS = 24;
+    __shared__ __attribute__((aligned(16))) float in_s[IH * IW * CS];
+    __shared__ __attribute__((aligned(16))) float w_s[9 * NT * 256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int iy0 = ty * TH, ix0 = tx * TW;
+    const int nt0 = blockIdx.y * NT;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ph][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int chunks_a = p.a.c >> 4, chunks = (p.a.c + p.b.c) >> 4;
+    const int q = tid & 3;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool from_a = ch < chunks_a;
+        const SrcDev& src = from_a ? p.a : p.b;
+        const int c0 = (from_a ? ch : ch - chunks_a) << 4;
+        Lazy4 lz;
+        lz.load(src, img, c0 + 4 * q);
+        const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + c0 + 4 * q;
+        for (int pix = tid >> 2; pix < IH * IW; pix += 64) {
+            const int iy = pix / IW, ix = pix - iy * IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gy < p.hin && gx < p.win) {
+                v = *reinterpret_cast<const f32x4*>(base + ((size_t)gy * p.win + gx) * src.pitch);
+                v = lz.apply(v);
+            }
+            *reinterpret_cast<f32x4*>(&in_s[pix * CS + 4 * q]) = v;
+        }
+        {
+            const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + ((size_t)ch * 9 * p.ntile_total + nt0) * 64;
+            f32x4* wdst = reinterpret_cast<f32x4*>(w_s);
+            for (int i = tid; i < 9 * NT * 64; i += 256) {
+                const int tap = i / (NT * 64), r = i - tap * (NT * 64);
+                wdst[i] = wsrc[(size_t)tap * p.ntile_total * 64 + r];
+            }
+        }
+        __syncthreads();
+        f32x4 a[2][2];
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj)
+                a[di][dj] = *reinterpret_cast<const f32x4*>(&in_s[((wave + di) * IW + pl + dj) * CS + 4 * g]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int pa = (ky == 1) ? 0 : 1, di = (ky == 0) ? 1 : 0;
+            const int pb = (kx == 1) ? 0 : 1, dj = (kx == 0) ? 1 : 0;
+            const int ph = pa * 2 + pb;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 b = reinterpret_cast<const f32x4*>(w_s)[(tap * NT + nt) * 64 + lane];
+                acc[ph][nt] = mfma4(a[di][dj].x, b.x, acc[ph][nt]);
+                acc[ph][nt] = mfma4(a[di][dj].y, b.y, acc[ph][nt]);
+                acc[ph][nt] = mfma4(a[di][dj].z, b.z, acc[ph][nt]);
+                acc[ph][nt] = mfma4(a[di][dj].w, b.w, acc[ph][nt]);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int iy = iy0 + wave;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = (nt0 + nt) * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        double s = 0.0, qq = 0.0;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int oy = 2 * iy + (ph >> 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ix = ix0 + g * 4 + r;
+                const int ox = 2 * ix + (ph & 1);
+                if (iy < p.hin && ix < p.win) {
+                    const float v = acc[ph][nt][r] + bias;
+                    p.out[(((size_t)img * p.hout + oy) * p.wout + ox) * p.pitch_out + co] = v;
+                    s += (double)v;
+                    qq += (double)v * (double)v;
+                }
+            }
+        }
+        if (p.stats) stats_commit(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+}
+
+int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* wpack, const float* bias,
+                      float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
+    CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0, "convT: input channels (%d,%d) must be multiples of 16", a.c, b.c);
+    CS_REQUIRE(cout % 16 == 0, "convT: cout %d must be a multiple of 16", cout);
+    ConvParams p{};
+    p.a = to_dev(a);
+    p.b = to_dev(b);
+    p.wpack = wpack; p.bias = bias; p.out = out; p.stats = stats;
+    p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16;
+    p.n = n; p.hin = hin; p.win = win; p.hout = 2 * hin; p.wout = 2 * win;
+    p.tiles_x = ceil_div(win, 16);
+    p.tiles_y = ceil_div(hin, 4);
+    const int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * n), (unsigned)(p.ntile_total / nt));
+    const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
+    const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
+    ProfScope prof(K_CONVT, s, flops, bytes);
+    switch (nt) {
+        case 4: hipLaunchKernelGGL((convt_mfma_kernel<4>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((convt_mfma_kernel<2>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((convt_mfma_kernel<1>), grid, dim3(256), 0, s, p); break;
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_conv_kernel(const float* w, int transposed, int cout, int cin, int taps, float* packed, int cout_off,
+                                 int ntile_total) {
+    // one thread per packed element of this conv's slice: (chunk, tap, ntile_local, lane, j)
+    const int64_t total = (int64_t)(cin / 16) * taps * (cout / 16) * 256;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int j = e & 3, lane = (e >> 2) & 63;
+    int64_t r = e >> 8;
+    const int ntl = r % (cout / 16);
+    r /= (cout / 16);
+    const int tap = r % taps;
+    const int chunk = r / taps;
+    const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
+    const float v = transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap];
+    const int nt = cout_off / 16 + ntl;
+    packed[(((size_t)chunk * taps + tap) * ntile_total + nt) * 256 + lane * 4 + j] = v;
+}
+
+int pack_conv_weights(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, float* packed,
+                      int cout_off, int cout_total) {
+    CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack: bad channel counts");
+    const int taps = ksize * ksize;
+    const int64_t total = (int64_t)(cin / 16) * taps * (cout / 16) * 256;
+    ProfScope prof(K_PACK, s, 0, 8.0 * total);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, transposed ? 1 : 0, cout,
+                       cin, taps, packed, cout_off, cout_total / 16);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+__global__ void pack_first_kernel(const float* w, int cout, int cin, float* packed, int cout_off, int ntile_total, int ksteps) {
+    const int total = ksteps * (cout / 16) * 64;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int lane = e & 63;
+    int r = e >> 6;
+    const int ntl = r % (cout / 16);
+    const int ks = r / (cout / 16);
+    const int k = 4 * ks + (lane >> 4);
+    float v = 0.f;
+    if (k < 9 * cin) {
+        const int tap = k / cin, c = k - tap * cin, co = ntl * 16 + (lane & 15);
+        v = w[((size_t)co * cin + c) * 9 + tap];
+    }
+    packed[((size_t)ks * ntile_total + cout_off / 16 + ntl) * 64 + lane] = v;
+}
+
+int pack_first_weights(hipStream_t s, const float* w, int cout, int cin, float* packed, int cout_off, int cout_total) {
+    const int ksteps = (9 * cin + 3) / 4;
+    const int total = ksteps * (cout / 16) * 64;
+    ProfScope prof(K_PACK, s, 0, 8.0 * total);
+    hipLaunchKernelGGL(pack_first_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, cout, cin, packed, cout_off,
+                       cout_total / 16, ksteps);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+size_t packed_conv_floats(int cout_total, int cin_total, int ksize) {
+    return (size_t)(cin_total / 16) * ksize * ksize * (cout_total / 16) * 256;
+}
+size_t packed_first_floats(int cout_total, int cin) { return (size_t)((9 * cin + 3) / 4) * (cout_total / 16) * 64; }
+
+}  // namespace cs

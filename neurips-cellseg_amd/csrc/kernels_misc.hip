@@ -1,0 +1,355 @@
+// gfx950 kernels around the convolutions: normalisation tables, residual add, the two 3-channel layers at the
+// top of the decoder (VALU: N = 3 is too narrow for MFMA tiles) and the sliding-window finalize.
+//
+// Reference rows: M (instance_norm / prelu / residual add inside monai UNet),
+// T step 6 (out / count map, crop), S (softmax(dim=1)[0,1], predict.py:110-111), P1 (> 0.5, predict.py:113).
+#include "kernels.h"
+
+namespace cs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float prelu1(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm statistics -> (scale, shift) table.  biased variance, eps inside the sqrt (torch semantics).
+// ------------------------------------------------------------------------------------------------
+__global__ void norm_finalize_kernel(const double* stats, float2* tab, int total, double inv_count, double eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double mean = stats[2 * i] * inv_count;
+    double var = stats[2 * i + 1] * inv_count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + eps);
+    tab[i] = make_float2((float)rstd, (float)(-mean * rstd));
+}
+
+int launch_norm_finalize(hipStream_t s, const double* stats, float2* tab, int n, int c, int count, float eps) {
+    const int total = n * c;
+    ProfScope prof(K_NORM_FINALIZE, s, 0, 24.0 * total);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, stats, tab, total,
+                       1.0 / (double)count, (double)eps);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+__global__ void bn_table_kernel(const float* weight, const float* bias, const float* mean, const float* var, float2* tab,
+                                int n, int c, int c_total, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const int ch = i % c, img = i / c;
+    const float rstd = 1.0f / sqrtf(var[ch] + eps);
+    const float alpha = rstd * (weight ? weight[ch] : 1.f);
+    tab[(size_t)img * c_total + ch] = make_float2(alpha, (bias ? bias[ch] : 0.f) - mean[ch] * alpha);
+}
+
+int launch_bn_table(hipStream_t s, const float* weight, const float* bias, const float* mean, const float* var, float2* tab,
+                    int n, int c, int c_total, float eps) {
+    ProfScope prof(K_NORM_FINALIZE, s, 0, 8.0 * n * c);
+    hipLaunchKernelGGL(bn_table_kernel, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, s, weight, bias, mean, var, tab, n,
+                       c, c_total, eps);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = T_y(y) + T_r(r): materialises a ResidualUnit output (cx + res).  float4 per thread.
+// ------------------------------------------------------------------------------------------------
+struct AddSrc {
+    const float* ptr;
+    const float2* tab;
+    const float* slope;
+    int pitch, tab_c, tab_off;
+};
+
+__device__ __forceinline__ f32x4 load_lazy4(const AddSrc& s, int img, int64_t pix, int c4) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(s.ptr + pix * s.pitch + 4 * c4);
+    if (s.tab) {
+        const f32x4* t = reinterpret_cast<const f32x4*>(s.tab + (size_t)img * s.tab_c + s.tab_off + 4 * c4);
+        const f32x4 t0 = t[0], t1 = t[1];
+        const float slope = s.slope ? *s.slope : 0.f;
+        v.x = prelu1(v.x * t0.x + t0.y, slope);
+        v.y = prelu1(v.y * t0.z + t0.w, slope);
+        v.z = prelu1(v.z * t1.x + t1.y, slope);
+        v.w = prelu1(v.w * t1.z + t1.w, slope);
+    }
+    return v;
+}
+
+__global__ void norm_act_add_kernel(AddSrc y, AddSrc r, float* out, int pitch_out, int c4n, int64_t npix, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / c4n;
+        const int c4 = (int)(i - pix * c4n);
+        const int img = (int)(pix / npix);
+        const f32x4 a = load_lazy4(y, img, pix, c4);
+        const f32x4 b = load_lazy4(r, img, pix, c4);
+        *reinterpret_cast<f32x4*>(out + pix * pitch_out + 4 * c4) = a + b;
+    }
+}
+
+static AddSrc to_add(const ConvSrc& s) { return AddSrc{s.ptr, s.tab, s.slope, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
+
+int launch_norm_act_add(hipStream_t s, const ConvSrc& y, const ConvSrc& r, float* out, int pitch_out, int64_t npix_per_image,
+                        int n) {
+    CS_REQUIRE(y.c == r.c && y.c % 4 == 0, "norm_act_add: channel mismatch %d vs %d", y.c, r.c);
+    const int c4n = y.c / 4;
+    const int64_t total = (int64_t)n * npix_per_image * c4n;
+    const int64_t blocks = (total + 255) / 256;
+    ProfScope prof(K_NORM_ACT_ADD, s, 0, 48.0 * total);
+    hipLaunchKernelGGL(norm_act_add_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, to_add(y),
+                       to_add(r), out, pitch_out, c4n, npix_per_image, total);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// top transposed conv: cin -> COUT (3) k3 s2 p1 op1, VALU.  One thread per INPUT pixel computes the 2x2 output
+// quad.  Weights W[cin][COUT][3][3] are re-laid in LDS as [cin][COUT*9 (+pad to 28)] and read as broadcasts.
+// ------------------------------------------------------------------------------------------------
+struct SmallSrc {
+    const float* ptr;
+    int c, pitch;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256) void convt_small_kernel(SmallSrc a, SmallSrc b, const float* w, const float* bias, float* out,
+                                                          double* stats, int hin, int win) {
+    constexpr int WROW = ((COUT * 9 + 3) / 4) * 4;
+    extern __shared__ __attribute__((aligned(16))) float w_s[];   // [cin][WROW]
+    const int cin = a.c + b.c;
+    for (int i = threadIdx.x; i < cin * WROW; i += blockDim.x) {
+        const int ci = i / WROW, r = i - ci * WROW;
+        w_s[i] = r < COUT * 9 ? w[(size_t)ci * COUT * 9 + r] : 0.f;
+    }
+    __syncthreads();
+    const int img = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = pix < hin * win;
+    const int iy = valid ? pix / win : 0, ix = valid ? pix - iy * win : 0;
+    float acc[4][COUT];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[ph][co] = 0.f;
+
+    const bool has_r = ix + 1 < win, has_d = iy + 1 < hin;
+    for (int part = 0; part < 2; ++part) {
+        const SmallSrc& s = part == 0 ? a : b;
+        if (s.c == 0) continue;
+        const int cbase = part == 0 ? 0 : a.c;
+        const float* p00 = s.ptr + (((size_t)img * hin + iy) * win + ix) * s.pitch;
+        const float* p01 = p00 + s.pitch;
+        const float* p10 = p00 + (size_t)win * s.pitch;
+        const float* p11 = p10 + s.pitch;
+        for (int c = 0; c < s.c; c += 4) {
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 x00 = *reinterpret_cast<const f32x4*>(p00 + c);
+            const f32x4 x01 = has_r ? *reinterpret_cast<const f32x4*>(p01 + c) : z;
+            const f32x4 x10 = has_d ? *reinterpret_cast<const f32x4*>(p10 + c) : z;
+            const f32x4 x11 = (has_r && has_d) ? *reinterpret_cast<const f32x4*>(p11 + c) : z;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* wr = &w_s[(cbase + c + j) * WROW];
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const float* wk = wr + co * 9;   // [ky][kx]
+                    acc[0][co] += x00[j] * wk[4];                                                      // (even, even)
+                    acc[1][co] += x01[j] * wk[3] + x00[j] * wk[5];                                     // (even, odd)
+                    acc[2][co] += x10[j] * wk[1] + x00[j] * wk[7];                                     // (odd, even)
+                    acc[3][co] += x11[j] * wk[0] + x10[j] * wk[2] + x01[j] * wk[6] + x00[j] * wk[8];   // (odd, odd)
+                }
+            }
+        }
+    }
+    const int hout = 2 * hin, wout = 2 * win;
+    double s[COUT], q[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        s[co] = 0.0;
+        q[co] = 0.0;
+    }
+    if (valid) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            float* o = out + (((size_t)img * hout + 2 * iy + (ph >> 1)) * wout + 2 * ix + (ph & 1)) * COUT;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float v = acc[ph][co] + (bias ? bias[co] : 0.f);
+                o[co] = v;
+                s[co] += (double)v;
+                q[co] += (double)v * (double)v;
+            }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                s[co] += __shfl_xor(s[co], off);
+                q[co] += __shfl_xor(q[co], off);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(stats + ((size_t)img * COUT + co) * 2, s[co]);
+                atomicAdd(stats + ((size_t)img * COUT + co) * 2 + 1, q[co]);
+            }
+        }
+    }
+}
+
+int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* w_torch, const float* bias, float* out,
+                       int cout, double* stats, int n, int hin, int win) {
+    CS_REQUIRE(cout == 3, "convT(small): cout %d unsupported (3-class contract)", cout);
+    CS_REQUIRE(a.tab == nullptr && b.tab == nullptr, "convT(small): lazy inputs unsupported");
+    CS_REQUIRE(a.c % 4 == 0 && b.c % 4 == 0, "convT(small): channels must be multiples of 4");
+    const int cin = a.c + b.c;
+    const size_t lds = (size_t)cin * 28 * sizeof(float);
+    const double flops = 2.0 * n * hin * win * (double)cout * cin * 9;
+    const double bytes = 4.0 * n * ((double)hin * win * cin + 4.0 * hin * win * cout);
+    ProfScope prof(K_CONVT_TOP, s, flops, bytes);
+    dim3 grid((unsigned)ceil_div(hin * win, 256), (unsigned)n);
+    hipLaunchKernelGGL((convt_small_kernel<3>), grid, dim3(256), lds, s, SmallSrc{a.ptr, a.c, a.pitch},
+                       SmallSrc{b.ptr, b.c, b.pitch}, w_torch, bias, out, stats, hin, win);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// last layer: logits = conv3x3(T(u)) + bias + T(u)   (ResidualUnit(3->3, subunits=1, last_conv_only) with an
+// identity residual).  T = InstanceNorm + PReLU of the top transposed conv, applied lazily.  One thread per pixel.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void conv_last_kernel(const float* u, const float2* tab, const float* slope_p, const float* w,
+                                                        const float* bias, float* out, int h, int wd) {
+    __shared__ float w_s[C * C * 9];
+    __shared__ float b_s[C];
+    for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) w_s[i] = w[i];
+    if (threadIdx.x < C) b_s[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int img = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= h * wd) return;
+    const int y = pix / wd, x = pix - y * wd;
+    float sc[C], sh[C];
+    const float slope = (tab && slope_p) ? *slope_p : 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float2 t = tab ? tab[img * C + c] : make_float2(1.f, 0.f);
+        sc[c] = t.x;
+        sh[c] = t.y;
+    }
+    float acc[C], centre[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = b_s[c];
+    const float* base = u + (size_t)img * h * wd * C;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            if (yy < 0 || yy >= h || xx < 0 || xx >= wd) continue;
+            const float* pxl = base + ((size_t)yy * wd + xx) * C;
+#pragma unroll
+            for (int ci = 0; ci < C; ++ci) {
+                float v = pxl[ci];
+                if (tab) v = prelu1(v * sc[ci] + sh[ci], slope);
+                if (ky == 1 && kx == 1) centre[ci] = v;
+#pragma unroll
+                for (int co = 0; co < C; ++co) acc[co] += v * w_s[(co * C + ci) * 9 + ky * 3 + kx];
+            }
+        }
+    }
+    float* o = out + ((size_t)img * h * wd + pix) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = acc[c] + centre[c];
+}
+
+int launch_conv_last(hipStream_t s, const ConvSrc& u, const float* w_torch, const float* bias, float* out, int c, int n, int h,
+                     int w) {
+    CS_REQUIRE(c == 3 && u.pitch == 3, "conv(last): %d channels unsupported (3-class contract)", c);
+    const double flops = 2.0 * n * h * w * 81.0;
+    const double bytes = 4.0 * n * (double)h * w * 6;
+    ProfScope prof(K_CONV_LAST, s, flops, bytes);
+    dim3 grid((unsigned)ceil_div(h * w, 256), (unsigned)n);
+    hipLaunchKernelGGL((conv_last_kernel<3>), grid, dim3(256), 0, s, u.ptr, u.tab, u.slope, w_torch, bias, out, h, w);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sliding-window finalize: for each image pixel sum the (<= 2 x 2) window predictions that cover it IN WINDOW
+// INDEX ORDER (the reference's `out[slice] += pred` order, so the fp32 sum is bit-identical), divide by the
+// count, then softmax over classes, class-1 probability and the strict > 0.5 threshold.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int win_start(int i, int interval, int size, int roi) {
+    const int s = i * interval;
+    return s < size - roi ? s : size - roi;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void swi_finalize_kernel(SwiFinalizeArgs a) {
+    const cs_swi_plan& pl = a.plan;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = a.row_begin + blockIdx.y;
+    if (x >= pl.img_w || y >= a.row_end) return;
+    const int py = y + pl.pad_top, px = x + pl.pad_left;   // padded coordinates
+    float sum[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sum[c] = 0.f;
+    float cnt = 0.f;
+    int ih_lo = (py - pl.roi_h) / pl.interval_h;
+    ih_lo = ih_lo < 0 ? 0 : ih_lo;
+    int iw_lo = (px - pl.roi_w) / pl.interval_w;
+    iw_lo = iw_lo < 0 ? 0 : iw_lo;
+    for (int ih = ih_lo; ih < pl.n_h; ++ih) {
+        const int hs = win_start(ih, pl.interval_h, pl.pad_h, pl.roi_h);
+        if (hs > py) break;
+        if (py >= hs + pl.roi_h) continue;
+        for (int iw = iw_lo; iw < pl.n_w; ++iw) {
+            const int ws = win_start(iw, pl.interval_w, pl.pad_w, pl.roi_w);
+            if (ws > px) break;
+            if (px >= ws + pl.roi_w) continue;
+            const float* p = a.win_logits + ((((size_t)(ih - a.ih_base) * pl.n_w + iw) * pl.roi_h + (py - hs)) * pl.roi_w + (px - ws)) * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) sum[c] += p[c];
+            cnt += 1.f;
+        }
+    }
+    float l[C], m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        l[c] = sum[c] / cnt;
+        m = fmaxf(m, l[c]);
+    }
+    const size_t o = (size_t)y * pl.img_w + x;
+    if (a.logits_nchw) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) a.logits_nchw[(size_t)c * pl.img_h * pl.img_w + o] = l[c];
+    }
+    if (a.prob1 || a.mask) {
+        float den = 0.f, e1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float e = expf(l[c] - m);
+            den += e;
+            if (c == 1) e1 = e;
+        }
+        const float p1 = e1 / den;
+        if (a.prob1) a.prob1[o] = p1;
+        if (a.mask) a.mask[o] = p1 > 0.5f ? 1 : 0;
+    }
+}
+
+int launch_swi_finalize(hipStream_t s, const SwiFinalizeArgs& a) {
+    CS_REQUIRE(a.c == 3, "swi finalize: %d classes unsupported (3-class contract)", a.c);
+    CS_REQUIRE(a.row_begin >= 0 && a.row_end <= a.plan.img_h && a.row_begin <= a.row_end, "swi finalize: bad row range");
+    if (a.row_end == a.row_begin) return CS_OK;
+    const double px = (double)(a.row_end - a.row_begin) * a.plan.img_w;
+    ProfScope prof(K_SWI_FINALIZE, s, 0, px * (12.0 * 4 + 17.0));
+    dim3 grid((unsigned)ceil_div(a.plan.img_w, 256), (unsigned)(a.row_end - a.row_begin));
+    hipLaunchKernelGGL((swi_finalize_kernel<3>), grid, dim3(256), 0, s, a);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

@@ -1,0 +1,227 @@
+"""GPU parity tests: the HIP path (through the C-ABI in libcellseg_hip.so) against the CPU oracle.
+
+Run on the MI355X box with ``pytest -m gpu``.  Tolerances: logits <= 1e-4 max-abs in fp32 (north_star);
+connected-component labels bit-exact (including ids, which follow scipy's raster order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+LOGIT_TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _pair(channels=(16, 32, 64, 128, 256), nru=2, norm="instance", act="prelu", seed=2022):
+    import cellseg_amd as ca
+    from oracle.unet_ref import UNetRef
+    torch.manual_seed(seed)
+    ref = UNetRef(channels=channels, strides=(2,) * (len(channels) - 1), num_res_units=nru, norm=norm, act=act).eval()
+    if norm == "batch":      # non-trivial running statistics / affine
+        g = torch.Generator().manual_seed(seed + 1)
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    for n, p in ref.named_parameters():          # distinct PReLU slopes so a mixed-up slope shows
+        if n.endswith("A.weight"):
+            p.data.fill_(0.05 + 0.4 * torch.rand(1, generator=torch.Generator().manual_seed(hash(n) % 1000)).item())
+    hip = ca.UNet(channels=channels, strides=(2,) * (len(channels) - 1), num_res_units=nru, norm=norm, act=act)
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip.to(_dev()).eval()
+
+
+@pytest.mark.parametrize("channels,nru,shape", [
+    ((16, 32), 2, (2, 3, 32, 48)),
+    ((16, 32, 64), 2, (2, 3, 64, 64)),
+    ((16, 32, 64, 128, 256), 2, (2, 3, 64, 64)),
+    ((16, 32, 64, 128, 256), 2, (4, 3, 256, 256)),
+    ((16, 32, 64, 128, 256), 1, (1, 3, 96, 64)),
+    ((16, 32, 64, 128, 256), 3, (1, 3, 64, 64)),
+    ((32, 64, 128, 256, 512), 2, (2, 3, 128, 128)),
+])
+def test_unet_forward_matches_oracle(channels, nru, shape):
+    ref, hip = _pair(channels, nru)
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        want = ref(x)
+        got = hip(x.to(_dev())).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= LOGIT_TOL
+
+
+def test_unet_forward_accepts_nhwc_strides():
+    ref, hip = _pair()
+    x = torch.rand(2, 64, 64, 3, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        want = ref(x.permute(0, 3, 1, 2))
+        got = hip(x.to(_dev()).permute(0, 3, 1, 2)).cpu()      # the reference's physically-NHWC tensor (predict.py:108)
+    assert (got - want).abs().max().item() <= LOGIT_TOL
+
+
+def test_unet_batchnorm_relu_variant():
+    ref, hip = _pair((32, 64, 128, 256, 512), 2, "batch", "relu")
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        want = ref(x)
+        got = hip(x.to(_dev())).cpu()
+    assert (got - want).abs().max().item() <= LOGIT_TOL
+
+
+def test_weights_reupload_after_update():
+    ref, hip = _pair((16, 32, 64), 2)
+    x = torch.rand(1, 3, 32, 32)
+    with torch.no_grad():
+        hip(x.to(_dev()))
+        for p in ref.parameters():
+            p.mul_(1.1)
+        hip.load_state_dict(ref.state_dict())
+        assert (hip(x.to(_dev())).cpu() - ref(x)).abs().max().item() <= LOGIT_TOL
+
+
+def test_cpu_tensor_fails_loudly():
+    import cellseg_amd as ca
+    m = ca.UNet()
+    with pytest.raises(ca.CellSegHipError):
+        m(torch.rand(1, 3, 64, 64))
+
+
+@pytest.mark.parametrize("hw,overlap", [((200, 200), 0.25), ((256, 256), 0.25), ((300, 520), 0.25), ((520, 300), 0.5),
+                                        ((1024, 1000), 0.25)])
+def test_sliding_window_matches_oracle(hw, overlap):
+    import cellseg_amd as ca
+    from oracle.sliding_window_ref import sliding_window_inference_ref
+    ref, hip = _pair()
+    x = torch.rand(1, 3, *hw, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = sliding_window_inference_ref(x, (256, 256), 4, ref, overlap=overlap)
+        got = ca.sliding_window_inference(x.to(_dev()), (256, 256), 4, hip, overlap=overlap).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= LOGIT_TOL
+
+
+def test_sliding_window_generic_predictor_and_outputs():
+    import cellseg_amd as ca
+    from oracle.postprocess_ref import softmax_interior_ref
+    from oracle.sliding_window_ref import sliding_window_inference_ref
+    conv = torch.nn.Conv2d(3, 3, 3, padding=1)
+    torch.manual_seed(1)
+    torch.nn.init.normal_(conv.weight, std=0.5)
+    x = torch.rand(1, 3, 300, 600)
+    with torch.no_grad():
+        want = sliding_window_inference_ref(x, (256, 256), 4, conv)
+        got = ca.sliding_window_inference(x.to(_dev()), (256, 256), 4, conv.to(_dev())).cpu()
+    assert (got - want).abs().max().item() <= 1e-5
+    ref, hip = _pair()
+    with torch.no_grad():
+        lg, prob, mask = ca.swi_infer_image(hip, x[0].to(_dev()), (256, 256), 0.25, want_prob=True, want_mask=True)
+    p_ref = softmax_interior_ref(lg.cpu().numpy())
+    assert np.abs(prob.cpu().numpy() - p_ref).max() <= 1e-6
+    sure = np.abs(p_ref - 0.5) > 1e-6
+    assert np.array_equal(mask.cpu().numpy()[sure] != 0, (p_ref > 0.5)[sure])
+
+
+def test_sliding_window_row_strips_equal_full():
+    """Multi-GPU partition: finalising row strips separately reproduces the single-GPU result bit for bit."""
+    import cellseg_amd as ca
+    ref, hip = _pair()
+    x = torch.rand(3, 700, 520, generator=torch.Generator().manual_seed(3)).to(_dev())
+    with torch.no_grad():
+        full, _, mfull = ca.swi_infer_image(hip, x, (256, 256), 0.5, want_mask=True)
+        full, mfull = full.clone(), mfull.clone()
+        for world in (2, 3):
+            for rank in range(world):
+                r0, r1 = ca.rank_rows(700, rank, world)
+                part, _, mpart = ca.swi_infer_image(hip, x, (256, 256), 0.5, rows=(r0, r1), want_mask=True)
+                assert torch.equal(part[:, r0:r1], full[:, r0:r1]) and torch.equal(mpart[r0:r1], mfull[r0:r1])
+
+
+# ------------------------------------------------------------------------------------------- connected components
+POST = np.load(os.path.join(G, "postprocess_golden.npz"))
+CASES = sorted({k.split("/")[0] for k in POST.files})
+
+
+def _unpack(n, key):
+    h, w = POST[n + "/shape"]
+    return np.unpackbits(POST[n + "/" + key])[: h * w].reshape(h, w).astype(bool)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_ccl_matches_skimage_golden(name):
+    import cellseg_amd as ca
+    m = torch.from_numpy(_unpack(name, "mask")).to(_dev())
+    assert np.array_equal(ca.label(m, 1).cpu().numpy(), POST[name + "/label4_raw"])
+    assert np.array_equal(ca.label(m, 2).cpu().numpy(), POST[name + "/label8_raw"])
+    lab, num = ca.mask_to_instances(m, return_num=True)
+    assert np.array_equal(lab.cpu().numpy(), POST[name + "/labels"])
+    assert int(num.item()) == int(POST[name + "/labels"].max())
+
+
+def _blob_prob(n, seed=2022):
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    g = gaussian_filter(rng.random((n, n), dtype=np.float32), 6)
+    return np.clip(0.5 + (g - np.quantile(g, 0.6)) * 8 / (g.max() - g.min()), 0, 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_ccl_large_matches_c_oracle(n):
+    import cellseg_amd as ca
+    from oracle.postprocess_ref import postprocess_c
+    prob = _blob_prob(n)
+    want = postprocess_c(prob)
+    got = ca.prob_to_instances(torch.from_numpy(prob).to(_dev())).cpu().numpy()
+    assert got.dtype == np.int32 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("kind", ["noise", "ones", "checker", "serpentine", "zeros"])
+def test_ccl_stress_masks(kind):
+    import cellseg_amd as ca
+    from oracle.postprocess_ref import label_c, mask_postprocess_c
+    n = 1536
+    rng = np.random.default_rng(1)
+    if kind == "noise":
+        m = rng.random((n, n)) > 0.45
+    elif kind == "ones":
+        m = np.ones((n, n), bool)
+    elif kind == "zeros":
+        m = np.zeros((n, n), bool)
+    elif kind == "checker":
+        m = (np.indices((n, n)).sum(0) % 2).astype(bool)
+    else:
+        m = np.zeros((n, n), bool)
+        m[::2] = True
+        m[1::4, -1] = True
+        m[3::4, 0] = True
+    t = torch.from_numpy(m).to(_dev())
+    assert np.array_equal(ca.label(t, 1).cpu().numpy(), label_c(m, 1))
+    assert np.array_equal(ca.label(t, 2).cpu().numpy(), label_c(m, 2))
+    assert np.array_equal(ca.mask_to_instances(t).cpu().numpy(), mask_postprocess_c(m))
+
+
+def test_ccl_idempotent_and_deterministic():
+    import cellseg_amd as ca
+    prob = torch.from_numpy(_blob_prob(2048, 7)).to(_dev())
+    a = ca.prob_to_instances(prob)
+    b = ca.prob_to_instances(prob)
+    assert torch.equal(a, b)
+    again = ca.mask_to_instances(a > 0)          # relabelling the cleaned mask changes nothing
+    assert torch.equal(again, a)
+
+
+def test_ccl_empty_and_ragged():
+    import cellseg_amd as ca
+    assert ca.label(torch.zeros((0, 5), dtype=torch.bool, device=_dev())).shape == (0, 5)
+    m = torch.ones((3, 1), dtype=torch.bool, device=_dev())
+    assert ca.label(m).cpu().tolist() == [[1], [1], [1]]
+    m = torch.tensor([[1, 0, 1, 0, 1]], dtype=torch.uint8, device=_dev())
+    assert ca.label(m).cpu().tolist() == [[1, 0, 2, 0, 3]]

@@ -13,8 +13,9 @@
 //   merge    one union per (run, run-above) adjacency (first pixel of each overlap only): atomicMin hooking of
 //            the larger root under the smaller, so a component's root is its first raster pixel.
 //   compress every pixel points at its root.
-//   sizes    one atomicAdd per non-root run; runs >= threshold just set a byte flag at the root with a plain
-//            store (every writer stores the same 1), so the giant background component sees no contended atomics.
+//   sizes    runs >= threshold set a byte flag at their root (plain store, same value from every writer); in a second
+//            launch only runs of un-flagged roots add their length atomically, so the giant background component
+//            sees no contended atomics.
 //   filter   flip pixels of small components.
 //   rank     roots are counted per 1024-pixel chunk, chunk counts are scanned, every root gets
 //            1 + (number of roots before it) - exactly scipy's numbering - and pixels read their root's rank.
@@ -123,6 +124,11 @@ __global__ __launch_bounds__(256) void ccl_compress_kernel(int64_t n, int* L) {
 }
 
 // -------- component sizes (saturating at thr) ---------------------------------------------------------
+// Two launches so that the kernel boundary makes the `big` flags visible: (1) every run of length >= thr marks
+// its root big with a plain store (all writers store the same 1); (2) only runs whose root is NOT big add their
+// length with an atomic.  The giant background component is flagged by its first long run, so its thousands of
+// short runs never touch the contended counter.
+template <int PHASE>
 __global__ __launch_bounds__(256) void ccl_sizes_kernel(const uint8_t* mask, int want, int h, int w, const int* L, int* size,
                                                         uint8_t* big, int thr) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,8 +139,11 @@ __global__ __launch_bounds__(256) void ccl_sizes_kernel(const uint8_t* mask, int
     if (x > 0 && is_fg(mask, i - 1, want)) return;   // not a run start
     const int r = L[i];
     const int len = size[i];
-    if (len >= thr) big[r] = 1;                      // same value from every writer: no atomic needed
-    else if (r != (int)i) atomicAdd(&size[r], len);  // the root run already holds its own length
+    if (PHASE == 0) {
+        if (len >= thr) big[r] = 1;
+    } else {
+        if (len < thr && r != (int)i && !big[r]) atomicAdd(&size[r], len);   // the root run already holds its own length
+    }
 }
 
 // flip pixels of components smaller than thr: `want` pixels become !want
@@ -290,8 +299,10 @@ int flip_small(hipStream_t s, uint8_t* m, int want, int h, int w, int thr, const
     {
         ProfScope prof(K_CCL_SIZES, s, 0, 6.0 * n);
         CS_HIP(hipMemsetAsync(ws.big, 0, (size_t)n, s));
-        hipLaunchKernelGGL(ccl_sizes_kernel, dim3((unsigned)ceil_div(w, 256), (unsigned)h), dim3(256), 0, s, m, want, h, w, ws.L,
-                           ws.size, ws.big, thr);
+        hipLaunchKernelGGL((ccl_sizes_kernel<0>), dim3((unsigned)ceil_div(w, 256), (unsigned)h), dim3(256), 0, s, m, want, h, w,
+                           ws.L, ws.size, ws.big, thr);
+        hipLaunchKernelGGL((ccl_sizes_kernel<1>), dim3((unsigned)ceil_div(w, 256), (unsigned)h), dim3(256), 0, s, m, want, h, w,
+                           ws.L, ws.size, ws.big, thr);
     }
     {
         ProfScope prof(K_CCL_FILTER, s, 0, 6.0 * n);

@@ -11,3 +11,21 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _effective_cpus():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+try:   # the GPU box shows 256 logical CPUs under a 16-CPU cgroup quota: keep the torch-CPU oracle off 256 threads
+    import torch
+    torch.set_num_threads(min(_effective_cpus(), 16))
+except ImportError:
+    pass

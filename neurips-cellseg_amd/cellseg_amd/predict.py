@@ -1,0 +1,82 @@
+"""``predict`` - command-line drop-in for /root/reference/baseline/predict.py (same flags, same outputs).
+
+    python -m cellseg_amd.predict -i ./inputs -o ./outputs --model_path ./work_dir/unet_3class --model_name unet
+
+Per image: read -> per-channel percentile normalisation (host) -> H2D -> sliding-window U-Net inference, softmax,
+> 0.5, remove_small_holes, remove_small_objects, 8-connected labelling (all on the MI355X) -> D2H -> int32 zlib
+TIFF ``<stem>_label.tiff``.  Only ``--model_name unet`` is accelerated (unetr / swinunetr are out of scope and
+refused).  Under ``torchrun`` the images are dealt to the ranks (one process per GPU, no collective).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+join = os.path.join
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser("Baseline for Microscopy image segmentation (MI355X engine)", add_help=True)
+    parser.add_argument("-i", "--input_path", default="./inputs", type=str, help="input images")
+    parser.add_argument("-o", "--output_path", default="./outputs", type=str, help="output path")
+    parser.add_argument("--model_path", default="./work_dir/unet_3class", help="directory holding best_Dice_model.pth")
+    parser.add_argument("--show_overlay", required=False, default=False, action="store_true", help="save segmentation overlay")
+    parser.add_argument("--model_name", default="unet", help="only 'unet' runs on the MI355X engine")
+    parser.add_argument("--num_class", default=3, type=int, help="segmentation classes")
+    parser.add_argument("--input_size", default=256, type=int, help="sliding-window size")
+    parser.add_argument("--overlap", default=0.25, type=float, help="window overlap (MONAI default 0.25)")
+    parser.add_argument("--random_init", action="store_true", help="no checkpoint: random weights (smoke runs)")
+    args = parser.parse_args(argv)
+
+    if args.model_name.lower() != "unet":
+        raise SystemExit(f"--model_name {args.model_name}: only 'unet' is implemented by the MI355X engine")
+    if args.num_class != 3:
+        raise SystemExit("--num_class: the engine implements the reference's 3-class contract")
+
+    import cellseg_amd as ca
+    from cellseg_amd import parallel, preprocess
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("predict needs an MI355X: there is no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    os.makedirs(args.output_path, exist_ok=True)
+    img_names = preprocess.list_images(args.input_path)
+    model = ca.UNet(spatial_dims=2, in_channels=3, out_channels=args.num_class, channels=(16, 32, 64, 128, 256),
+                    strides=(2, 2, 2, 2), num_res_units=2)
+    if not args.random_init:
+        checkpoint = torch.load(join(args.model_path, "best_Dice_model.pth"), map_location="cpu")
+        model.load_state_dict(checkpoint["model_state_dict"])
+    model = model.to(device).eval()
+    roi_size = (args.input_size, args.input_size)
+
+    with torch.no_grad():
+        for k in parallel.shard_items(len(img_names), rank, world):
+            img_name = img_names[k]
+            img_data = preprocess.read_image(join(args.input_path, img_name))
+            pre_img_data = preprocess.prepare_image(img_data)
+            t0 = time.time()
+            x = torch.from_numpy(preprocess.to_unit_float(pre_img_data)).to(device)          # [H,W,3]: NHWC, no copy needed
+            _, _, mask = ca.swi_infer_image(model, x.permute(2, 0, 1), roi_size, args.overlap, want_logits=False, want_mask=True)
+            labels = ca.mask_to_instances(mask).cpu().numpy()
+            preprocess.write_label_tiff(join(args.output_path, preprocess.label_name(img_name)), labels)
+            t1 = time.time()
+            print(f"Prediction finished: {img_name}; img size = {pre_img_data.shape}; costing: {t1 - t0:.2f}s")
+            if args.show_overlay:
+                b = labels > 0
+                edge = b & ~(np.roll(b, 1, 0) & np.roll(b, -1, 0) & np.roll(b, 1, 1) & np.roll(b, -1, 1))
+                over = img_data.copy() if img_data.ndim == 3 else np.repeat(img_data[:, :, None], 3, -1)
+                over[edge] = np.iinfo(over.dtype).max if np.issubdtype(over.dtype, np.integer) else 1.0
+                from PIL import Image
+                Image.fromarray(over[:, :, :3].astype(np.uint8)).save(join(args.output_path, "overlay_" + img_name.split(".")[0] + ".png"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,113 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/cellseg_hip.h declares,
+the window plan matches the oracle tiler, MONAI state-dict compatibility, loud failure without a GPU, host
+pre/post-processing against the reference-generated goldens.  No GPU compute is called."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    import cellseg_amd as ca
+    header = open(os.path.join(ROOT, "include", "cellseg_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(ca.lib, name), f"{name} declared in include/cellseg_hip.h but not exported"
+    assert declared == set(ca._lib.EXPORTED)
+    assert ca.lib.cs_version() >= 100
+
+
+@pytest.mark.parametrize("hw", [(4096, 4096), (1024, 1000), (512, 512), (200, 200), (256, 300), (257, 255), (2000, 333)])
+@pytest.mark.parametrize("overlap", [0.25, 0.5, 0.0])
+def test_plan_matches_oracle_tiler(hw, overlap):
+    import cellseg_amd as ca
+    from oracle.sliding_window_ref import scan_starts
+    plan = ca.make_plan(hw[0], hw[1], (256, 256), overlap)
+    hs, ws = ca.window_starts(plan)
+    assert hs == scan_starts(max(hw[0], 256), 256, overlap) and ws == scan_starts(max(hw[1], 256), 256, overlap)
+    assert plan.pad_top == max(256 - hw[0], 0) // 2 and plan.pad_left == max(256 - hw[1], 0) // 2
+    assert (plan.n_h, plan.n_w) == (len(hs), len(ws))
+
+
+def test_plan_window_counts_of_the_configs():
+    import cellseg_amd as ca
+    assert (lambda p: p.n_h * p.n_w)(ca.make_plan(4096, 4096, (256, 256), 0.25)) == 441
+    assert (lambda p: p.n_h * p.n_w)(ca.make_plan(4096, 4096, (256, 256), 0.5)) == 961
+    assert (lambda p: p.n_h * p.n_w)(ca.make_plan(8192, 8192, (512, 512), 0.5)) == 961
+
+
+def test_state_dict_is_monai_compatible_both_ways():
+    import cellseg_amd as ca
+    from oracle.unet_ref import UNetRef
+    for kw in (dict(), dict(channels=(32, 64, 128, 256, 512)), dict(num_res_units=1), dict(norm="batch", act="relu")):
+        ref = UNetRef(**kw)
+        hip = ca.UNet(**{**kw, "strides": (2,) * (len(kw.get("channels", (16, 32, 64, 128, 256))) - 1)})
+        a, b = hip.state_dict(), ref.state_dict()
+        assert set(a) == set(b) and all(a[k].shape == b[k].shape for k in a)
+        hip.load_state_dict(b)
+        ref.load_state_dict(hip.state_dict())
+    assert sum(p.numel() for p in ca.UNet().parameters()) == 1_626_072
+
+
+def test_no_cpu_fallback():
+    import cellseg_amd as ca
+    m = ca.UNet()
+    with pytest.raises(ca.CellSegHipError):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(ca.CellSegHipError):
+        ca.sliding_window_inference(torch.zeros(1, 3, 300, 300), (256, 256), 4, m)
+    with pytest.raises(ca.CellSegHipError):
+        ca.mask_to_instances(torch.zeros(8, 8, dtype=torch.bool))
+    with pytest.raises(ca.CellSegHipError):
+        ca.label(torch.zeros(8, 8, dtype=torch.bool))
+
+
+def test_unsupported_arguments_are_refused():
+    import cellseg_amd as ca
+    with pytest.raises(ValueError):
+        ca.UNet(spatial_dims=3)
+    with pytest.raises(ValueError):
+        ca.UNet(channels=(16, 32, 64), strides=(2, 1))
+    with pytest.raises(ValueError):
+        ca.UNet(channels=(10, 20, 40), strides=(2, 2))
+    with pytest.raises(NotImplementedError):
+        ca.sliding_window_inference(torch.zeros(1, 3, 8, 8), (256, 256), 4, ca.UNet(), mode="gaussian")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "neurips-cellseg_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(d, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f
+
+
+def test_preprocess_matches_reference_golden():
+    from cellseg_amd import preprocess
+    from oracle import normalize_ref
+    g = np.load(os.path.join(G, "normalize_golden.npz"))
+    for n in sorted({k.split("/")[0] for k in g.files}):
+        assert np.array_equal(preprocess.normalize_channel(g[n + "/in"]), g[n + "/out"])
+    rng = np.random.default_rng(0)
+    for img in (rng.integers(0, 4000, (50, 60), dtype=np.uint16), rng.integers(0, 255, (40, 30, 4), dtype=np.uint8)):
+        pre = preprocess.prepare_image(img)
+        assert np.array_equal(pre, normalize_ref.preprocess_image_ref(img))
+        assert np.array_equal(preprocess.to_unit_float(pre).transpose(2, 0, 1)[None], normalize_ref.to_network_input_ref(pre))
+
+
+def test_label_tiff_round_trip(tmp_path):
+    from cellseg_amd import preprocess
+    lab = (np.arange(300 * 200).reshape(300, 200) % 70001).astype(np.int32)
+    p = str(tmp_path / preprocess.label_name("cell_001.png"))
+    assert p.endswith("cell_001_label.tiff")
+    preprocess.write_label_tiff(p, lab)
+    back = preprocess.read_image(p)
+    assert back.dtype == np.int32 and np.array_equal(back, lab)

@@ -41,27 +41,29 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 
 __device__ __forceinline__ float prelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
-// lazy norm + activation on 4 consecutive channels
+// lazy norm + activation on 4 consecutive channels.  Branch-free on purpose: a conditional load makes hipcc wait
+// vmcnt(0) at the join, which would serialise the table fetch in front of the chunk's input loads.
 struct Lazy4 {
-    f32x4 scale, shift;
+    f32x4 t0, t1;      // (scale0, shift0, scale1, shift1), (scale2, shift2, scale3, shift3)
     float slope;
     bool on;
-    __device__ __forceinline__ void load(const SrcDev& s, int img, int ch) {
+    __device__ __forceinline__ void load(const SrcDev& s, int img, int ch, const float* dummy) {
         on = s.tab != nullptr;
-        if (on) {
-            const f32x4* t = reinterpret_cast<const f32x4*>(s.tab + (size_t)img * s.tab_c + s.tab_off + ch);
-            f32x4 t0 = t[0], t1 = t[1];
-            scale = f32x4{t0.x, t0.z, t1.x, t1.z};
-            shift = f32x4{t0.y, t0.w, t1.y, t1.w};
-            slope = s.slope ? *s.slope : 0.f;
-        }
+        const f32x4* t = on ? reinterpret_cast<const f32x4*>(s.tab + (size_t)img * s.tab_c + s.tab_off + ch)
+                            : reinterpret_cast<const f32x4*>(dummy);
+        t0 = t[0];
+        t1 = t[1];
+        const float* sp = (on && s.slope) ? s.slope : dummy;
+        slope = *sp;
+        if (!(on && s.slope)) slope = 0.f;
     }
     __device__ __forceinline__ f32x4 apply(f32x4 v) const {
-        if (on) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = prelu(v[j] * scale[j] + shift[j], slope);
-        }
-        return v;
+        f32x4 r;
+        r.x = prelu(v.x * t0.x + t0.y, slope);
+        r.y = prelu(v.y * t0.z + t0.w, slope);
+        r.z = prelu(v.z * t1.x + t1.y, slope);
+        r.w = prelu(v.w * t1.z + t1.w, slope);
+        return on ? r : v;
     }
 };
 
@@ -88,6 +90,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     constexpr int CS = (S == 1) ? 24 : 20;   // floats per staged pixel: 16 channels + pad (bank-conflict-free A reads)
     constexpr int PAD = KS / 2;
     constexpr int TAPS = KS * KS;
+    constexpr int IN_ITERS = (IH * IW + 63) / 64;          // staged pixels per thread (4 threads per pixel)
+    constexpr int W_ITERS = (TAPS * NT * 64 + 255) / 256;  // packed-weight float4s per thread
     __shared__ __attribute__((aligned(16))) float in_s[IH * IW * CS];
     __shared__ __attribute__((aligned(16))) float w_s[TAPS * NT * 256];
 
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int img = bid / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int nt0 = blockIdx.y * NT;
+    const int q = tid & 3;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -107,36 +112,64 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // per-thread staging geometry (the same for every chunk): pixel offset inside the image, or -1 for padding
+    int goff[IN_ITERS];
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (tid >> 2) + 64 * it;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
+        goff[it] = (pix < IH * IW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win) ? gy * p.win + gx : -1;
+    }
+
     const int chunks_a = p.a.c >> 4, chunks = (p.a.c + p.b.c) >> 4;
-    const int q = tid & 3;
-    for (int ch = 0; ch < chunks; ++ch) {
+    f32x4 rin[IN_ITERS], rw[W_ITERS];
+    Lazy4 lz;
+
+    // global -> registers for chunk `ch` (raw values; the lazy norm/act is applied when they are written to LDS)
+    auto load_chunk = [&](int ch) {
         const bool from_a = ch < chunks_a;
         const SrcDev& src = from_a ? p.a : p.b;
         const int c0 = (from_a ? ch : ch - chunks_a) << 4;
-        Lazy4 lz;
-        lz.load(src, img, c0 + 4 * q);
+        lz.load(src, img, c0 + 4 * q, p.wpack);
         const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + c0 + 4 * q;
-        // ---- stage the halo'd input patch of this 16-channel chunk (4 threads per pixel) ----
-        for (int pix = tid >> 2; pix < IH * IW; pix += 64) {
-            const int iy = pix / IW, ix = pix - iy * IW;
-            const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win) {
-                v = *reinterpret_cast<const f32x4*>(base + ((size_t)gy * p.win + gx) * src.pitch);
-                v = lz.apply(v);
-            }
-            *reinterpret_cast<f32x4*>(&in_s[pix * CS + 4 * q]) = v;
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {   // unconditional (clamped) loads; padding is zeroed at store time
+            const int o = goff[it] >= 0 ? goff[it] : 0;
+            rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * src.pitch);
         }
-        // ---- stage this chunk's packed weights: TAPS x NT KiB, lane-linear ----
-        {
-            const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + ((size_t)ch * TAPS * p.ntile_total + nt0) * 64;
-            f32x4* wdst = reinterpret_cast<f32x4*>(w_s);
-            for (int i = tid; i < TAPS * NT * 64; i += 256) {
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + ((size_t)ch * TAPS * p.ntile_total + nt0) * 64;
+#pragma unroll
+        for (int it = 0; it < W_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            if ((TAPS * NT * 64) % 256 == 0 || i < TAPS * NT * 64) {
                 const int tap = i / (NT * 64), r = i - tap * (NT * 64);
-                wdst[i] = wsrc[(size_t)tap * p.ntile_total * 64 + r];
+                rw[it] = wsrc[(size_t)tap * p.ntile_total * 64 + r];
             }
         }
-        __syncthreads();
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int pix = (tid >> 2) + 64 * it;
+            if (IH * IW % 64 == 0 || pix < IH * IW) {
+                const f32x4 v = goff[it] >= 0 ? lz.apply(rin[it]) : f32x4{0.f, 0.f, 0.f, 0.f};   // padding stays 0 after the activation
+                *reinterpret_cast<f32x4*>(&in_s[pix * CS + 4 * q]) = v;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < W_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            if ((TAPS * NT * 64) % 256 == 0 || i < TAPS * NT * 64) reinterpret_cast<f32x4*>(w_s)[i] = rw[it];
+        }
+    };
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        if (more) load_chunk(ch + 1);   // next chunk's global loads stay in flight under this chunk's MFMAs
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int ky = tap / KS, kx = tap - ky * KS;
@@ -157,6 +190,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             }
         }
         __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias, store, statistics.  C layout: channel = lane & 15, pixel = 4 * (lane >> 4) + r ----
@@ -379,6 +416,8 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
 template <int NT>
 __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
     constexpr int TH = 4, TW = 16, IH = TH + 1, IW = TW + 1, CS = 24;
+    constexpr int IN_ITERS = (IH * IW + 63) / 64;
+    constexpr int W_ITERS = (9 * NT * 64 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float in_s[IH * IW * CS];
     __shared__ __attribute__((aligned(16))) float w_s[9 * NT * 256];
 
@@ -391,6 +430,7 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
     const int img = bid / p.tiles_y;
     const int iy0 = ty * TH, ix0 = tx * TW;
     const int nt0 = blockIdx.y * NT;
+    const int q = tid & 3;
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -398,34 +438,61 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[ph][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    int goff[IN_ITERS];
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (tid >> 2) + 64 * it;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        goff[it] = (pix < IH * IW && gy < p.hin && gx < p.win) ? gy * p.win + gx : -1;
+    }
+
     const int chunks_a = p.a.c >> 4, chunks = (p.a.c + p.b.c) >> 4;
-    const int q = tid & 3;
-    for (int ch = 0; ch < chunks; ++ch) {
+    f32x4 rin[IN_ITERS], rw[W_ITERS];
+    Lazy4 lz;
+    auto load_chunk = [&](int ch) {
         const bool from_a = ch < chunks_a;
         const SrcDev& src = from_a ? p.a : p.b;
         const int c0 = (from_a ? ch : ch - chunks_a) << 4;
-        Lazy4 lz;
-        lz.load(src, img, c0 + 4 * q);
+        lz.load(src, img, c0 + 4 * q, p.wpack);
         const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + c0 + 4 * q;
-        for (int pix = tid >> 2; pix < IH * IW; pix += 64) {
-            const int iy = pix / IW, ix = pix - iy * IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gy < p.hin && gx < p.win) {
-                v = *reinterpret_cast<const f32x4*>(base + ((size_t)gy * p.win + gx) * src.pitch);
-                v = lz.apply(v);
-            }
-            *reinterpret_cast<f32x4*>(&in_s[pix * CS + 4 * q]) = v;
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int o = goff[it] >= 0 ? goff[it] : 0;
+            rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * src.pitch);
         }
-        {
-            const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + ((size_t)ch * 9 * p.ntile_total + nt0) * 64;
-            f32x4* wdst = reinterpret_cast<f32x4*>(w_s);
-            for (int i = tid; i < 9 * NT * 64; i += 256) {
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + ((size_t)ch * 9 * p.ntile_total + nt0) * 64;
+#pragma unroll
+        for (int it = 0; it < W_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            if ((9 * NT * 64) % 256 == 0 || i < 9 * NT * 64) {
                 const int tap = i / (NT * 64), r = i - tap * (NT * 64);
-                wdst[i] = wsrc[(size_t)tap * p.ntile_total * 64 + r];
+                rw[it] = wsrc[(size_t)tap * p.ntile_total * 64 + r];
             }
         }
-        __syncthreads();
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int pix = (tid >> 2) + 64 * it;
+            if (pix < IH * IW) {
+                const f32x4 v = goff[it] >= 0 ? lz.apply(rin[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&in_s[pix * CS + 4 * q]) = v;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < W_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            if ((9 * NT * 64) % 256 == 0 || i < 9 * NT * 64) reinterpret_cast<f32x4*>(w_s)[i] = rw[it];
+        }
+    };
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        if (more) load_chunk(ch + 1);
         f32x4 a[2][2];
 #pragma unroll
         for (int di = 0; di < 2; ++di)
@@ -448,6 +515,10 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
             }
         }
         __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
     }
 
     const int iy = iy0 + wave;

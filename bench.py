@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--roi", type=int, default=256)
     ap.add_argument("--overlap", type=float, default=0.5, help="0.5 = stride 128 (BASELINE configs[2]); reference default 0.25")
     ap.add_argument("--width", choices=sorted(WIDTHS), default="baseline32")
-    ap.add_argument("--engine-batch", type=int, default=64)
+    ap.add_argument("--engine-batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the reference-width (16..256) secondary measurement")
     args = ap.parse_args()

@@ -21,7 +21,7 @@ from . import _lib
 from ._lib import SwiPlan, check, lib
 from .unet import UNet
 
-DEFAULT_ENGINE_BATCH = 64
+DEFAULT_ENGINE_BATCH = 256
 
 
 def make_plan(img_h: int, img_w: int, roi_size: Sequence[int], overlap: float = 0.25) -> SwiPlan:

@@ -79,6 +79,36 @@ __device__ __forceinline__ void stats_commit(double s, double q, double* dst, in
     }
 }
 
+
+// Epilogue shared by the MFMA kernels: the wave's accumulators (C layout: channel = lane & 15, pixel = 4*(lane>>4)+r)
+// go through a wave-private LDS slab so that the global stores are 16 B per lane with consecutive lanes on
+// consecutive channels of one pixel (whole 64*NT-byte pixel records, full cache lines) instead of 64-byte fragments.
+// `ep` points at this wave's slab of ROWS*16 pixels x (16*NT + 4) floats.  Returns nothing; stats are separate.
+template <int NT, int ROWS>
+__device__ __forceinline__ void epilogue_store(float* ep, const f32x4 (&vals)[ROWS][NT], int lane, float* out_row0, int64_t row_stride,
+                                               int pitch, int n_rows_valid, int n_cols_valid) {
+    constexpr int EPS = 16 * NT + 4;
+    const int pl = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ep[(m * 16 + g * 4 + r) * EPS + nt * 16 + pl] = vals[m][nt][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the slab is wave-private, no barrier needed
+    __builtin_amdgcn_wave_barrier();
+    constexpr int F4_PER_PIX = NT * 4;
+#pragma unroll
+    for (int i = lane; i < ROWS * 16 * F4_PER_PIX; i += 64) {
+        const int pix = i / F4_PER_PIX, c4 = i - pix * F4_PER_PIX;
+        const int m = pix >> 4, x = pix & 15;
+        if (m < n_rows_valid && x < n_cols_valid) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+            *reinterpret_cast<f32x4*>(out_row0 + m * row_stride + (int64_t)x * pitch + c4 * 4) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic conv: KS in {3,1}, stride S in {1,2}, NT output-channel tiles of 16 per block, MT pixel rows per wave.
 // block = 256 threads = 4 waves; block tile = (4*MT) rows x 16 columns of output pixels x 16*NT channels.
@@ -92,8 +122,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     constexpr int TAPS = KS * KS;
     constexpr int IN_ITERS = (IH * IW + 63) / 64;          // staged pixels per thread (4 threads per pixel)
     constexpr int W_ITERS = (TAPS * NT * 64 + 255) / 256;  // packed-weight float4s per thread
-    __shared__ __attribute__((aligned(16))) float in_s[IH * IW * CS];
-    __shared__ __attribute__((aligned(16))) float w_s[TAPS * NT * 256];
+    constexpr int IN_FLOATS = (IH * IW * CS + 3) / 4 * 4;
+    constexpr int EP_FLOATS = 4 * MT * 16 * (16 * NT + 4);     // epilogue slabs reuse the staging memory
+    constexpr int SM_FLOATS = (IN_FLOATS + TAPS * NT * 256) > EP_FLOATS ? (IN_FLOATS + TAPS * NT * 256) : EP_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    float* const in_s = smem;
+    float* const w_s = smem + IN_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
@@ -196,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         }
     }
 
-    // ---- epilogue: bias, store, statistics.  C layout: channel = lane & 15, pixel = 4 * (lane >> 4) + r ----
+    // ---- epilogue: bias, statistics (fp64), then full-line stores through a wave-private LDS slab ----
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (nt0 + nt) * 16 + pl;
@@ -208,15 +242,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ox = ox0 + g * 4 + r;
+                const float v = acc[m][nt][r] + bias;
+                acc[m][nt][r] = v;
                 if (oy < p.hout && ox < p.wout) {
-                    const float v = acc[m][nt][r] + bias;
-                    p.out[(((size_t)img * p.hout + oy) * p.wout + ox) * p.pitch_out + co] = v;
                     s += (double)v;
                     qq += (double)v * (double)v;
                 }
             }
         }
         if (p.stats) stats_commit(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+    {
+        const int oy = oy0 + wave * MT;
+        float* out_row0 = p.out + (((size_t)img * p.hout + oy) * p.wout + ox0) * p.pitch_out + nt0 * 16;
+        epilogue_store<NT, MT>(smem + wave * (MT * 16 * (16 * NT + 4)), acc, lane, out_row0, (int64_t)p.wout * p.pitch_out, p.pitch_out,
+                               p.hout - oy, p.wout - ox0);
     }
 }
 
@@ -295,8 +335,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
     constexpr int TH = 4 * MT, TW = 16;
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int KSTEPS = (9 * CIN + 3) / 4;
-    __shared__ float in_s[IH * IW * CIN + 4];
-    __shared__ float w_s[KSTEPS * NT * 64];
+    constexpr int IN_FLOATS = (IH * IW * CIN + 4 + 3) / 4 * 4;
+    constexpr int EP_FLOATS = 4 * MT * 16 * (16 * NT + 4);
+    constexpr int SM_FLOATS = (IN_FLOATS + KSTEPS * NT * 64) > EP_FLOATS ? (IN_FLOATS + KSTEPS * NT * 64) : EP_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    float* const in_s = smem;
+    float* const w_s = smem + IN_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
@@ -365,15 +409,22 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ox = ox0 + g * 4 + r;
+                const float v = acc[m][nt][r] + bias;
+                acc[m][nt][r] = v;
                 if (oy < p.hout && ox < p.wout) {
-                    const float v = acc[m][nt][r] + bias;
-                    p.out[(((size_t)img * p.hout + oy) * p.wout + ox) * p.pitch_out + co] = v;
                     s += (double)v;
                     qq += (double)v * (double)v;
                 }
             }
         }
         if (p.stats) stats_commit(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+    __syncthreads();   // every wave has finished reading the staged tile before the slabs overwrite it
+    {
+        const int oy = oy0 + wave * MT;
+        float* out_row0 = p.out + (((size_t)img * p.hout + oy) * p.wout + ox0) * p.pitch_out;
+        epilogue_store<NT, MT>(smem + wave * (MT * 16 * (16 * NT + 4)), acc, lane, out_row0, (int64_t)p.wout * p.pitch_out, p.pitch_out,
+                               p.hout - oy, p.wout - ox0);
     }
 }
 
@@ -418,8 +469,13 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
     constexpr int TH = 4, TW = 16, IH = TH + 1, IW = TW + 1, CS = 24;
     constexpr int IN_ITERS = (IH * IW + 63) / 64;
     constexpr int W_ITERS = (9 * NT * 64 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float in_s[IH * IW * CS];
-    __shared__ __attribute__((aligned(16))) float w_s[9 * NT * 256];
+    constexpr int IN_FLOATS = (IH * IW * CS + 3) / 4 * 4;
+    constexpr int EPS = 16 * NT + 4;
+    constexpr int EP_FLOATS = 4 * 64 * EPS;                    // per wave: 2 output rows x 32 output pixels
+    constexpr int SM_FLOATS = (IN_FLOATS + 9 * NT * 256) > EP_FLOATS ? (IN_FLOATS + 9 * NT * 256) : EP_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    float* const in_s = smem;
+    float* const w_s = smem + IN_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
@@ -522,6 +578,7 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
     }
 
     const int iy = iy0 + wave;
+    float* ep = smem + wave * 64 * EPS;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (nt0 + nt) * 16 + pl;
@@ -529,20 +586,34 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
         double s = 0.0, qq = 0.0;
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
-            const int oy = 2 * iy + (ph >> 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ix = ix0 + g * 4 + r;
-                const int ox = 2 * ix + (ph & 1);
+                const float v = acc[ph][nt][r] + bias;
+                ep[((ph >> 1) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + nt * 16 + pl] = v;
                 if (iy < p.hin && ix < p.win) {
-                    const float v = acc[ph][nt][r] + bias;
-                    p.out[(((size_t)img * p.hout + oy) * p.wout + ox) * p.pitch_out + co] = v;
                     s += (double)v;
                     qq += (double)v * (double)v;
                 }
             }
         }
         if (p.stats) stats_commit(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (iy < p.hin) {
+        constexpr int F4_PER_PIX = NT * 4;
+        float* out0 = p.out + (((size_t)img * p.hout + 2 * iy) * p.wout + 2 * ix0) * p.pitch_out + nt0 * 16;
+        const int cols_valid = 2 * (p.win - ix0);
+#pragma unroll
+        for (int i = lane; i < 64 * F4_PER_PIX; i += 64) {
+            const int pix = i / F4_PER_PIX, c4 = i - pix * F4_PER_PIX;
+            const int row = pix >> 5, x = pix & 31;
+            if (x < cols_valid) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                *reinterpret_cast<f32x4*>(out0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) = v;
+            }
+        }
     }
 }
 

@@ -203,6 +203,16 @@ def main():
             achieved = k["bytes"] / sec / 1e9
             rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                   "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
+        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # gfx950 correction applied; tools/pmc_summary.py).  bench.py cannot read PMCs itself, so it quotes the summary.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name, {})
+            if res is main_res and args.engine_batch == 256 and args.size == 4096 and args.width == "baseline32":
+                rl["traffic"] = pmc.get("hbm_bytes_per_launch")
+                rl["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 PMC passes of the default command)"
+                rl["algorithmic_bytes_per_launch"] = round(k["bytes"] / k["launches"])
+        except (OSError, ValueError, KeyError):
+            pass
         rl.update({"kernel": name, "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 5),
                    "algorithmic_per_launch": (k["flops"] if mfma else k["bytes"]) / k["launches"],
                    "share_of_gpu_time": round(k["ms"] / sum(v["ms"] for v in prof.values()), 4)})

@@ -72,6 +72,17 @@ size_t cs_unet_workspace_bytes(const cs_unet* net, int n, int h, int w);
 int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                     int n, int h, int w, float* logits_nhwc, void* workspace, size_t workspace_bytes, void* stream);
 
+/* backward: replaces `loss.backward()` through the network (model_training_3class.py:260).  Uses the activations the
+ * LAST cs_unet_forward left in its workspace (which must still be intact) and the input it read.  Writes every
+ * parameter gradient, in PyTorch layout, into one flat fp32 buffer of cs_unet_grad_numel() floats at
+ * cs_unet_grad_offset(param_index) - the flat buffer is the single bucket a data-parallel host all-reduces.
+ * InstanceNorm networks only. */
+int64_t cs_unet_grad_numel(const cs_unet* net);
+int64_t cs_unet_grad_offset(const cs_unet* net, int param_index);
+size_t cs_unet_backward_workspace_bytes(const cs_unet* net, int n, int h, int w);
+int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspace, size_t workspace_bytes,
+                     float* flat_grad, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Sliding-window inference  -  replaces monai.inferers.sliding_window_inference(x, roi, sw_batch, model)
  *   (baseline/predict.py:109, baseline/model_training_3class.py:291-293; constant blending, zero padding)

@@ -40,6 +40,10 @@ def _load() -> C.CDLL:
         "cs_unet_load_param": (i32, [vp, C.c_char_p, vp, i64, vp]),
         "cs_unet_workspace_bytes": (sz, [vp, i32, i32, i32]),
         "cs_unet_forward": (i32, [vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, vp, sz, vp]),
+        "cs_unet_grad_numel": (i64, [vp]),
+        "cs_unet_grad_offset": (i64, [vp, i32]),
+        "cs_unet_backward_workspace_bytes": (sz, [vp, i32, i32, i32]),
+        "cs_unet_backward": (i32, [vp, vp, vp, sz, vp, vp]),
         "cs_swi_make_plan": (i32, [i32, i32, i32, i32, f64, C.POINTER(SwiPlan)]),
         "cs_swi_window_start": (i32, [i32, i32, i32, i32]),
         "cs_swi_workspace_bytes": (sz, [vp, C.POINTER(SwiPlan), i32]),
@@ -60,7 +64,8 @@ def _load() -> C.CDLL:
 
 lib = _load()
 EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_destroy cs_unet_num_params "
-            "cs_unet_param_info cs_unet_load_param cs_unet_workspace_bytes cs_unet_forward cs_swi_make_plan "
+            "cs_unet_param_info cs_unet_load_param cs_unet_workspace_bytes cs_unet_forward cs_unet_grad_numel "
+            "cs_unet_grad_offset cs_unet_backward_workspace_bytes cs_unet_backward cs_swi_make_plan "
             "cs_swi_window_start cs_swi_workspace_bytes cs_swi_infer cs_swi_finalize cs_ccl_workspace_bytes "
             "cs_ccl_postprocess cs_ccl_label cs_prof_enable cs_prof_reset cs_prof_collect").split()
 

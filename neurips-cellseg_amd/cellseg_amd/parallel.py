@@ -36,3 +36,21 @@ def gather_row_strips(strip: torch.Tensor, img_h: int, group=None) -> torch.Tens
     dist.all_gather(parts, padded, group=group)
     rows = [rank_rows(img_h, r, world) for r in range(world)]
     return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(rows)], 0)
+
+
+def sync_gradients(model, group=None) -> None:
+    """Data-parallel gradient exchange: ONE RCCL all-reduce over the engine's flat fp32
+    gradient bucket (6.5 MB at the reference width), then the mean.  `loss.backward()` leaves every parameter
+    gradient as a view of ``model.flat_grad``; this re-binds the views after the in-place reduction so the optimiser
+    reads the averaged values whatever autograd did with the originals."""
+    import torch.distributed as dist
+    flat = model.flat_grad
+    if flat is None:
+        raise RuntimeError("sync_gradients: run backward first")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / world)
+    for key, p in model.named_parameters():
+        off, numel, shape = model._grad_slots[key]
+        p.grad = flat[off:off + numel].view(shape)

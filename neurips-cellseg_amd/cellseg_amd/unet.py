@@ -122,6 +122,29 @@ def _host_param_table(in_ch, out_ch, channels, nru, norm, act):
     return tab
 
 
+class _UNetFunction(torch.autograd.Function):
+    """Autograd bookkeeping only: forward and backward both run in libcellseg_hip.so.
+
+    forward keeps the engine's activation workspace alive (ctx) until backward; backward fills ONE flat fp32 gradient
+    buffer (the data-parallel bucket) and hands PyTorch per-parameter views of it."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        out, ws = module._forward_engine(x, tag="train")
+        ctx.module, ctx.ws, ctx.x, ctx.shape = module, ws, x, tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        module = ctx.module
+        flat = module._backward_engine(grad_out, ctx.shape)
+        grads = []
+        for key in module._param_keys:
+            off, numel, shape = module._grad_slots[key]
+            grads.append(flat[off:off + numel].view(shape))
+        return (None, None, *grads)
+
+
 class UNet(nn.Module):
     def __init__(self, spatial_dims: int = 2, in_channels: int = 3, out_channels: int = 3,
                  channels: Sequence[int] = (16, 32, 64, 128, 256), strides: Sequence[int] = (2, 2, 2, 2),
@@ -151,6 +174,9 @@ class UNet(nn.Module):
         self._engine_device = None
         self._uploaded: Dict[str, Tuple[int, int]] = {}
         self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._param_keys = [k for k, _ in self.named_parameters()]
+        self._grad_slots: Dict[str, Tuple[int, int, Tuple[int, ...]]] = {}
+        self.flat_grad = None          # the flat gradient bucket of the last backward (what data parallel all-reduces)
 
     # ---- parameter registration under MONAI's dotted names -------------------------------------------
     def _register(self, key: str, shape) -> None:
@@ -203,6 +229,13 @@ class UNet(nn.Module):
             self._engine_device = p0.device
             self._uploaded.clear()
             self._ws.clear()
+            self._grad_slots = {}
+            for i, (key, shape) in enumerate(self._engine.param_table()):
+                off = lib.cs_unet_grad_offset(self._engine.handle, i)
+                numel = 1
+                for d in shape:
+                    numel *= d
+                self._grad_slots[key] = (int(off), numel, tuple(shape))
         stream = _lib.stream_ptr()
         for key in self._keys:
             if key.endswith("num_batches_tracked"):
@@ -226,27 +259,48 @@ class UNet(nn.Module):
             self._ws[tag] = ws
         return ws
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _lib.require_gpu(x)
-        if x.dim() != 4 or x.shape[1] != self.in_channels:
-            raise ValueError(f"expected [N,{self.in_channels},H,W], got {tuple(x.shape)}")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
-            raise _lib.CellSegHipError("training through cellseg_amd.UNet is not built yet (inference engine only); "
-                                       "call under torch.no_grad() / model.eval()")
-        if self.norm_name == "batch" and self.training:
-            raise _lib.CellSegHipError("BatchNorm variant: only eval mode (running statistics) is implemented")
-        if x.dtype != torch.float32:
-            x = x.float()
+    def _forward_engine(self, x: torch.Tensor, tag: str = "fwd"):
         n, _, h, w = x.shape
         eng = self.engine()
         with torch.cuda.device(x.device):
             nbytes = lib.cs_unet_workspace_bytes(eng.handle, n, h, w)
             if nbytes == 0:
                 raise _lib.CellSegHipError(f"cs_unet_workspace_bytes: {lib.cs_last_error().decode()}")
-            ws = self.workspace(("fwd", n, h, w), nbytes, x.device)
+            ws = self.workspace((tag, n, h, w), nbytes, x.device)
             out = torch.empty((n, h, w, self.out_channels), dtype=torch.float32, device=x.device)
             sn, sc, sh, sw = x.stride()
             check(lib.cs_unet_forward(eng.handle, C.c_void_p(x.data_ptr()), sn, sc, sh, sw, n, h, w,
                                       C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
                                       _lib.stream_ptr()), "cs_unet_forward")
-        return out.permute(0, 3, 1, 2)        # NCHW view of the NHWC result, like a channels_last tensor
+        return out.permute(0, 3, 1, 2), ws        # NCHW view of the NHWC result, like a channels_last tensor
+
+    def _backward_engine(self, grad_out: torch.Tensor, shape) -> torch.Tensor:
+        n, _, h, w = shape
+        eng = self._engine
+        g = grad_out.permute(0, 2, 3, 1).contiguous().float()             # NHWC, as the engine wrote the logits
+        with torch.cuda.device(g.device):
+            nbytes = lib.cs_unet_backward_workspace_bytes(eng.handle, n, h, w)
+            if nbytes == 0:
+                raise _lib.CellSegHipError(f"cs_unet_backward_workspace_bytes: {lib.cs_last_error().decode()}")
+            ws = self.workspace(("bwd", n, h, w), nbytes, g.device)
+            flat = torch.empty(int(lib.cs_unet_grad_numel(eng.handle)), dtype=torch.float32, device=g.device)
+            check(lib.cs_unet_backward(eng.handle, C.c_void_p(g.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                       C.c_void_p(flat.data_ptr()), _lib.stream_ptr()), "cs_unet_backward")
+        self.flat_grad = flat
+        return flat
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _lib.require_gpu(x)
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected [N,{self.in_channels},H,W], got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            x = x.float()
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            if self.norm_name != "instance":
+                raise _lib.CellSegHipError("training is implemented for the reference's InstanceNorm network only")
+            params = [p for _, p in self.named_parameters()]
+            return _UNetFunction.apply(self, x, *params)
+        if self.norm_name == "batch" and self.training:
+            raise _lib.CellSegHipError("BatchNorm variant: only eval mode (running statistics) is implemented")
+        return self._forward_engine(x)[0]

@@ -32,7 +32,8 @@ void set_error(const char* fmt, ...);
 enum KernelId {
     K_CONV3_S1 = 0, K_CONV3_S2, K_CONV1, K_CONV_FIRST, K_CONVT, K_CONVT_TOP, K_CONV_LAST,
     K_NORM_FINALIZE, K_NORM_ACT_ADD, K_SWI_FINALIZE, K_PACK, K_CCL_INIT, K_CCL_MERGE, K_CCL_COMPRESS,
-    K_CCL_SIZES, K_CCL_FILTER, K_CCL_COUNT, K_CCL_SCAN, K_CCL_RANK, K_CCL_RELABEL, K_MEMSET, K_NUM_IDS
+    K_CCL_SIZES, K_CCL_FILTER, K_CCL_COUNT, K_CCL_SCAN, K_CCL_RANK, K_CCL_RELABEL, K_MEMSET, K_NORM_BWD, K_COLSUM,
+    K_WGRAD, K_TOP_BWD, K_NUM_IDS
 };
 const char* kernel_name(int id);
 struct ProfScope {   // records start event on construction and stop event on destruction when profiling is on
@@ -47,14 +48,6 @@ struct ProfScope {   // records start event on construction and stop event on de
 struct View {
     float* ptr = nullptr;
     int c = 0, pitch = 0;
-};
-
-// lazy InstanceNorm/BatchNorm + PReLU applied by the CONSUMER while it stages its input:
-// v = x * tab[n][ch].x + tab[n][ch].y ; v = v >= 0 ? v : v * slope[0]
-struct Lazy {
-    const float2* tab = nullptr;   // [n][c] (scale, shift); nullptr = identity
-    const float* slope = nullptr;  // device scalar (PReLU weight) or nullptr (slope 0 = ReLU when tab != nullptr)
-    int relu = 0;
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

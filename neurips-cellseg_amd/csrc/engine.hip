@@ -31,7 +31,8 @@ void set_error(const char* fmt, ...) {
 static const char* kNames[K_NUM_IDS] = {
     "conv3x3_s1_mfma", "conv3x3_s2_mfma", "conv1x1_mfma", "conv_first_mfma", "convT3x3s2_mfma", "convT_top_valu",
     "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
-    "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset"};
+    "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset", "norm_bwd",
+    "colsum", "wgrad_mfma", "top_bwd_valu"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
 
 struct ProfRecord {
@@ -103,15 +104,20 @@ struct Bump {
 // ---------------------------------------------------------------------------------------------------
 struct NormSite {          // one ADN: InstanceNorm (stats at run time) or eval BatchNorm (running stats) + PReLU/ReLU
     int c = 0;
+    int p_slope = -1;                       // parameter index of the PReLU weight
     float* slope = nullptr;                 // PReLU weight (device) or nullptr for ReLU
     float *bn_w = nullptr, *bn_b = nullptr, *bn_m = nullptr, *bn_v = nullptr;
 };
 
 struct ConvW {             // packed weights + bias of one (possibly fused) conv launch
     float* w = nullptr;    // packed (MFMA kernels) or PyTorch layout (small VALU kernels)
+    float* wd = nullptr;   // the same weights packed for the DATA-GRADIENT launch (see kernels_bwd.hip header)
     float* bias = nullptr;
     int cin = 0, cout = 0; // cout = total (fused) output channels
+    int p_w[2] = {-1, -1}, p_b[2] = {-1, -1};   // parameter indices (slot 1 = fused residual conv)
 };
+
+enum DgradKind { DG_NONE = 0, DG_S1, DG_S2_AS_CONVT, DG_CONVT_AS_S2, DG_1X1 };
 
 struct DownUnit {          // ResidualUnit in the encoder / bottom
     int cin = 0, c = 0, stride = 2, subunits = 2;
@@ -139,11 +145,34 @@ struct ParamEntry {
     int64_t shape[4] = {0, 0, 0, 0};
     std::function<int(const float*, hipStream_t)> load;
     bool loaded = false;
+    int64_t grad_off = 0;      // float offset of this parameter's gradient in the flat gradient buffer
     int64_t numel() const {
         int64_t n = 1;
         for (int i = 0; i < rank; ++i) n *= shape[i];
         return n;
     }
+};
+
+struct NormRt {   // run-time state of one norm site for the current forward
+    double* stats = nullptr;
+    float2* tab = nullptr;
+};
+
+// Pointers into the forward workspace recorded by the last forward; the backward pass replays them.
+struct Tape {
+    bool valid = false;
+    int n = 0, h = 0, w = 0;
+    WindowSrc src;
+    std::vector<float*> E, X;                 // per encoder level: fused conv output, ResidualUnit output
+    std::vector<std::vector<float*>> Y;       // per encoder level: subunit outputs (index 0 unused: unit0 lives in E)
+    std::vector<std::vector<NormRt>> rt_down;
+    std::vector<float*> Yb;                   // bottom subunit outputs
+    float* Rb = nullptr;
+    float* Sb = nullptr;                      // bottom ResidualUnit output
+    std::vector<NormRt> rt_bottom;
+    std::vector<float*> U, V, D;              // per decoder level: transposed-conv output, unit0 output, ResidualUnit output
+    std::vector<NormRt> rt_upt, rt_upu;
+    const float* logits = nullptr;
 };
 
 }  // namespace cs
@@ -159,6 +188,8 @@ struct cs_unet {
     std::vector<ParamEntry> params;
     float* arena = nullptr;
     size_t arena_floats = 0;
+    int64_t grad_floats = 0;
+    Tape tape;
 };
 
 namespace cs {
@@ -179,8 +210,8 @@ struct ArenaPlan {   // two passes: count floats, then hand out pointers
     }
 };
 
-static void add_param(cs_unet* net, const std::string& key, std::initializer_list<int64_t> shape,
-                      std::function<int(const float*, hipStream_t)> fn) {
+static int add_param(cs_unet* net, const std::string& key, std::initializer_list<int64_t> shape,
+                     std::function<int(const float*, hipStream_t)> fn) {
     ParamEntry e;
     e.key = key;
     e.rank = (int)shape.size();
@@ -188,6 +219,7 @@ static void add_param(cs_unet* net, const std::string& key, std::initializer_lis
     for (auto v : shape) e.shape[i++] = v;
     e.load = std::move(fn);
     net->params.push_back(std::move(e));
+    return (int)net->params.size() - 1;
 }
 
 static void add_norm_params(cs_unet* net, ArenaPlan& ar, const std::string& adn, NormSite& ns, int c) {
@@ -203,29 +235,42 @@ static void add_norm_params(cs_unet* net, ArenaPlan& ar, const std::string& adn,
     if (net->act == CS_ACT_PRELU) {
         ns.slope = ar.take(1);
         float* sl = ns.slope;
-        add_param(net, adn + ".A.weight", {1}, [=](const float* d, hipStream_t s) { return copy_param(sl, d, 1, s); });
+        ns.p_slope = add_param(net, adn + ".A.weight", {1}, [=](const float* d, hipStream_t s) { return copy_param(sl, d, 1, s); });
     }
 }
 
-// conv weight + bias of a conv that writes channels [cout_off, cout_off + cout) of a fused launch
+// conv weight + bias of a conv that writes channels [cout_off, cout_off + cout) of a fused launch.
+// `dg` says how the same tensor is packed a second time (into cw.wd) for the data-gradient launch.
 static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, int cout, int cin, int ksize, int cout_off,
-                            bool transposed, int mode /*0 mfma, 1 first, 2 raw*/) {
+                            bool transposed, int mode /*0 mfma, 1 first, 2 raw*/, int dg = DG_NONE, int slot = 0) {
     float* wdst = cw.w;
+    float* wd = cw.wd;
     float* bdst = cw.bias + cout_off;
     const int cout_total = cw.cout;
+    auto pack_dgrad = [=](const float* d, hipStream_t s) -> int {
+        switch (dg) {
+            case DG_S1: return pack_conv_weights(s, d, true, cin, cout, 3, wd, 0, cin, true, 0);
+            case DG_1X1: return pack_conv_weights(s, d, true, cin, cout, 1, wd, 0, cin, false, 0);
+            case DG_S2_AS_CONVT: return pack_conv_weights(s, d, true, cin, cout, 3, wd, 0, cin, false, cout_off);
+            case DG_CONVT_AS_S2: return pack_conv_weights(s, d, false, cin, cout, 3, wd, 0, cin, false, 0);
+            default: return CS_OK;
+        }
+    };
     if (transposed) {
-        add_param(net, conv + ".weight", {cin, cout, ksize, ksize}, [=](const float* d, hipStream_t s) {
+        cw.p_w[slot] = add_param(net, conv + ".weight", {cin, cout, ksize, ksize}, [=](const float* d, hipStream_t s) {
+            if (int rc = pack_dgrad(d, s)) return rc;
             if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
             return pack_conv_weights(s, d, true, cout, cin, ksize, wdst, cout_off, cout_total);
         });
     } else {
-        add_param(net, conv + ".weight", {cout, cin, ksize, ksize}, [=](const float* d, hipStream_t s) {
+        cw.p_w[slot] = add_param(net, conv + ".weight", {cout, cin, ksize, ksize}, [=](const float* d, hipStream_t s) {
+            if (int rc = pack_dgrad(d, s)) return rc;
             if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
             if (mode == 1) return pack_first_weights(s, d, cout, cin, wdst, cout_off, cout_total);
             return pack_conv_weights(s, d, false, cout, cin, ksize, wdst, cout_off, cout_total);
         });
     }
-    add_param(net, conv + ".bias", {cout}, [=](const float* d, hipStream_t s) { return copy_param(bdst, d, cout, s); });
+    cw.p_b[slot] = add_param(net, conv + ".bias", {cout}, [=](const float* d, hipStream_t s) { return copy_param(bdst, d, cout, s); });
 }
 
 static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::string& pfx, int cin, int c, int stride) {
@@ -240,24 +285,30 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     u.unit0.cout = u.fused_res ? 2 * c : c;
     u.unit0.w = ar.take(u.first ? packed_first_floats(u.unit0.cout, cin) : packed_conv_floats(u.unit0.cout, cin, 3));
     u.unit0.bias = ar.take(u.unit0.cout);
-    add_conv_params(net, pfx + ".conv.unit0.conv", u.unit0, c, cin, 3, 0, false, u.first ? 1 : 0);
+    // data gradient of unit0 (+ fused residual): a transposed conv over [dy0 || dr] for the strided units, a flipped
+    // stride-1 conv for the bottom unit; the first layer needs none (the image has no gradient)
+    const int dg0 = u.first ? DG_NONE : (stride == 2 ? DG_S2_AS_CONVT : DG_S1);
+    if (dg0 != DG_NONE) u.unit0.wd = ar.take(packed_conv_floats(cin, u.unit0.cout, 3));
+    add_conv_params(net, pfx + ".conv.unit0.conv", u.unit0, c, cin, 3, 0, false, u.first ? 1 : 0, dg0, 0);
     add_norm_params(net, ar, pfx + ".conv.unit0.adn", u.norms[0], c);
     for (int su = 1; su < u.subunits; ++su) {
         ConvW& cw = u.units[su - 1];
         cw.cin = c; cw.cout = c;
         cw.w = ar.take(packed_conv_floats(c, c, 3));
         cw.bias = ar.take(c);
+        cw.wd = ar.take(packed_conv_floats(c, c, 3));
         const std::string un = pfx + ".conv.unit" + std::to_string(su);
-        add_conv_params(net, un + ".conv", cw, c, c, 3, 0, false, 0);
+        add_conv_params(net, un + ".conv", cw, c, c, 3, 0, false, 0, DG_S1, 0);
         add_norm_params(net, ar, un + ".adn", u.norms[su], c);
     }
     if (u.fused_res) {
-        add_conv_params(net, pfx + ".residual", u.unit0, c, cin, 3, c, false, u.first ? 1 : 0);
+        add_conv_params(net, pfx + ".residual", u.unit0, c, cin, 3, c, false, u.first ? 1 : 0, dg0, 1);
     } else if (u.res_conv) {
         u.res1x1.cin = cin; u.res1x1.cout = c;
         u.res1x1.w = ar.take(packed_conv_floats(c, cin, 1));
+        u.res1x1.wd = ar.take(packed_conv_floats(cin, c, 1));
         u.res1x1.bias = ar.take(c);
-        add_conv_params(net, pfx + ".residual", u.res1x1, c, cin, 1, 0, false, 0);
+        add_conv_params(net, pfx + ".residual", u.res1x1, c, cin, 1, 0, false, 0, DG_1X1, 0);
     }
 }
 
@@ -268,12 +319,14 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     u.convt.cin = cin; u.convt.cout = cout;
     u.convt.w = ar.take(small ? (size_t)cin * cout * 9 : packed_conv_floats(cout, cin, 3));
     u.convt.bias = ar.take(cout);
-    add_conv_params(net, pfx + ".0.conv", u.convt, cout, cin, 3, 0, true, small ? 2 : 0);
+    if (!small) u.convt.wd = ar.take(packed_conv_floats(cin, cout, 3));
+    add_conv_params(net, pfx + ".0.conv", u.convt, cout, cin, 3, 0, true, small ? 2 : 0, small ? DG_NONE : DG_CONVT_AS_S2, 0);
     add_norm_params(net, ar, pfx + ".0.adn", u.norm_t, cout);
     u.unit0.cin = cout; u.unit0.cout = cout;
     u.unit0.w = ar.take(small ? (size_t)cout * cout * 9 : packed_conv_floats(cout, cout, 3));
     u.unit0.bias = ar.take(cout);
-    add_conv_params(net, pfx + ".1.conv.unit0.conv", u.unit0, cout, cout, 3, 0, false, small ? 2 : 0);
+    if (!small) u.unit0.wd = ar.take(packed_conv_floats(cout, cout, 3));
+    add_conv_params(net, pfx + ".1.conv.unit0.conv", u.unit0, cout, cout, 3, 0, false, small ? 2 : 0, small ? DG_NONE : DG_S1, 0);
     if (!top) add_norm_params(net, ar, pfx + ".1.conv.unit0.adn", u.norm_u, cout);
 }
 
@@ -299,11 +352,6 @@ static void build_net(cs_unet* net, ArenaPlan& ar) {
 // ---------------------------------------------------------------------------------------------------
 // forward over n windows (roi_h x roi_w); `src` says where the pixels come from
 // ---------------------------------------------------------------------------------------------------
-struct NormRt {   // run-time state of one norm site for the current forward
-    double* stats = nullptr;
-    float2* tab = nullptr;
-};
-
 static int finish_norm(hipStream_t s, const cs_unet* net, const NormSite& ns, NormRt& rt, int n, int c_total, int count, bool dry) {
     if (dry) return CS_OK;
     if (net->norm == CS_NORM_BATCH) return launch_bn_table(s, ns.bn_w, ns.bn_b, ns.bn_m, ns.bn_v, rt.tab, n, ns.c, c_total, 1e-5f);
@@ -328,12 +376,18 @@ static ConvSrc raw_src(const float* ptr, int c, int pitch) {
     } while (0)
 
 // Runs (or, with a dry Bump, only sizes) the forward.  Output: logits NHWC [n, h, w, out_ch].
-static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, int h, int w, float* logits, Bump& ws, hipStream_t s) {
+static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, int h, int w, float* logits, Bump& ws, hipStream_t s,
+                             Tape* tape = nullptr) {
     const bool dry = ws.dry();
     const int nl = net->nl;
     CS_REQUIRE(h % (1 << nl) == 0 && w % (1 << nl) == 0 && h > 0 && w > 0, "unet: window %d x %d must be a multiple of %d", h, w,
                1 << nl);
     const bool inst = net->norm == CS_NORM_INSTANCE;
+    if (tape) {
+        tape->valid = false;
+        tape->E.assign(nl, nullptr); tape->Y.assign(nl, {}); tape->U.assign(nl, nullptr); tape->V.assign(nl, nullptr);
+        tape->D.assign(nl, nullptr);
+    }
     // all statistics of one forward live in one arena so a single memset clears them
     const size_t stats_mark = ws.off;
     std::vector<std::pair<NormRt*, int>> pending;   // (site, channels in its stats/tab)
@@ -399,6 +453,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         }
         prev = X[d];
         ph = oh; pw = ow; pc = c;
+        if (tape) { tape->E[d] = E; tape->Y[d] = Y; }
     }
     // ---- bottom ----
     float* S = nullptr;   // "sub" input of the next up layer
@@ -426,6 +481,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             CS_TRY(launch_norm_act_add(s, lazy_src(Y[last], c, c, rt_bottom[last], u.norms[last], c),
                                        u.res_conv ? raw_src(R, c, c) : raw_src(prev, c, pc), S, c, (int64_t)ph * pw, n));
         }
+        if (tape) { tape->Yb = Y; tape->Rb = R; tape->Sb = S; }
     }
     // ---- decoder ----
     int sc = net->bottom.c;
@@ -461,6 +517,206 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         S = D;
         sc = c;
         ph = oh; pw = ow;
+        if (tape) { tape->U[d] = U; tape->V[d] = V; tape->D[d] = D; }
+    }
+    if (tape) {
+        tape->valid = !dry;
+        tape->n = n; tape->h = h; tape->w = w; tape->src = src;
+        tape->X = X;
+        tape->rt_down = rt_down; tape->rt_bottom = rt_bottom; tape->rt_upt = rt_upt; tape->rt_upu = rt_upu;
+        tape->logits = logits;
+    }
+    return CS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward over the batch recorded in net->tape.  `acc` = fp64 / fp32 accumulators (zeroed by the caller's memset),
+// `buf` = gradient activations.  Gradients land in `flat` at params[i].grad_off, in PyTorch layouts.
+// ---------------------------------------------------------------------------------------------------
+static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& acc, Bump& buf, float* flat, hipStream_t s) {
+    const bool dry = buf.dry();
+    const Tape& T = net->tape;
+    const int nl = net->nl, n = T.n, h = T.h, w = T.w;
+    CS_REQUIRE(net->norm == CS_NORM_INSTANCE, "backward: BatchNorm training is not implemented (InstanceNorm only)");
+    CS_REQUIRE(dry || T.src.origins == nullptr, "backward: the recorded forward must be a plain batched forward");
+    auto gptr = [&](int pidx) { return flat + net->params[pidx].grad_off; };
+    auto oom = [&]() { set_error("backward: workspace too small"); return CS_ERR_WORKSPACE; };
+
+    // helpers -------------------------------------------------------------------------------------------
+    auto bias_grad = [&](const float* dy, int pitch, int c, int64_t npix_total, int pidx) -> int {
+        double* d = acc.take<double>(c);
+        if (dry) return CS_OK;
+        CS_TRY(launch_colsum(s, dy, pitch, c, npix_total, d));
+        return launch_f64_to_f32(s, d, gptr(pidx), c);
+    };
+    auto norm_bwd = [&](const NormSite& ns, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch,
+                        int64_t npix) -> int {
+        double* red = acc.take<double>((size_t)n * y.c * 2);
+        double* dsl = acc.take<double>(1);
+        if (dry) return CS_OK;
+        CS_TRY(launch_norm_bwd(s, y, da, da_pitch, dy, dy_pitch, red, dsl, npix, n));
+        if (ns.p_slope >= 0) return launch_f64_to_f32(s, dsl, gptr(ns.p_slope), 1);
+        return CS_OK;
+    };
+    auto rsrc = [&](const float* p, int c, int pitch) { return raw_src(p, c, pitch); };
+
+    std::vector<float*> dX(nl, nullptr);
+    float* dS = nullptr;       // gradient w.r.t. the "sub" input of the level above (D[d+1] or the bottom output)
+
+    // ---- decoder, top level first ----
+    for (int d = 0; d < nl; ++d) {
+        const UpUnit& u = net->up[d];
+        const int c = u.cout, cs = u.cin_skip, cb = u.cin_sub, cin_t = cs + cb;
+        const int oh = h >> d, ow = w >> d, ph = oh / 2, pw = ow / 2;
+        const float* Ssub = (d == nl - 1) ? T.Sb : T.D[d + 1];
+        const ConvSrc lu = lazy_src(T.U[d], c, c, T.rt_upt[d], u.norm_t, c);
+        float* d_au = buf.take<float>((size_t)n * oh * ow * c);
+        float* dU = buf.take<float>((size_t)n * oh * ow * c);
+        dX[d] = buf.take<float>((size_t)n * ph * pw * cs);
+        float* dSn = buf.take<float>((size_t)n * ph * pw * cb);
+        float* dwt = acc.take<float>((size_t)9 * cin_t * c);
+        if (!buf.ok()) return oom();
+        if (u.top) {
+            double* dw_last = acc.take<double>(81);
+            double* db_last = acc.take<double>(3);
+            if (!dry) {
+                CS_TRY(launch_conv_last_bwd(s, dlogits, lu, u.unit0.w, d_au, dw_last, db_last, n, oh, ow));
+                CS_TRY(launch_f64_to_f32(s, dw_last, gptr(u.unit0.p_w[0]), c * c * 9));
+                CS_TRY(launch_f64_to_f32(s, db_last, gptr(u.unit0.p_b[0]), c));
+            }
+        } else {
+            float* dV = buf.take<float>((size_t)n * oh * ow * c);
+            float* dwu = acc.take<float>((size_t)9 * c * c);
+            if (!buf.ok()) return oom();
+            CS_TRY(norm_bwd(u.norm_u, lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow));
+            CS_TRY(bias_grad(dV, c, c, (int64_t)n * oh * ow, u.unit0.p_b[0]));
+            if (!dry) {
+                CS_TRY(launch_wgrad(s, 3, 1, dV, c, c, lu, nullptr, dwu, c, c, 0, 0, n, oh, ow, oh, ow));
+                CS_TRY(launch_unpack_wgrad(s, dwu, c, c, 0, 0, c, c, 9, gptr(u.unit0.p_w[0])));
+                ConvOutExtra ex;
+                ex.addend = dS; ex.pitch_add = c;          // identity residual of the up ResidualUnit
+                CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dV, c, c), ConvSrc(), u.unit0.wd, nullptr, d_au, c, c, nullptr, n, oh, ow, &ex));
+            }
+        }
+        CS_TRY(norm_bwd(u.norm_t, lu, d_au, c, dU, c, (int64_t)oh * ow));
+        CS_TRY(bias_grad(dU, c, c, (int64_t)n * oh * ow, u.convt.p_b[0]));
+        if (!dry) {
+            if (u.top) {
+                CS_TRY(launch_convt_small_bwd_data(s, dU, u.convt.w, cin_t, 0, cs, dX[d], cs, false, n, ph, pw));
+                CS_TRY(launch_convt_small_bwd_data(s, dU, u.convt.w, cin_t, cs, cb, dSn, cb, false, n, ph, pw));
+                WgradNarrow nb;
+                nb.ptr = dU; nb.c = c; nb.sn = (int64_t)oh * ow * c; nb.sc = 1; nb.sh = (int64_t)ow * c; nb.sw = c;
+                CS_TRY(launch_wgrad(s, 3, 2, T.X[d], cs, cs, ConvSrc(), &nb, dwt, cin_t, c, 0, 0, n, ph, pw, oh, ow));
+                CS_TRY(launch_wgrad(s, 3, 2, Ssub, cb, cb, ConvSrc(), &nb, dwt, cin_t, c, cs, 0, n, ph, pw, oh, ow));
+            } else {
+                ConvOutExtra ex;
+                ex.out2 = dSn; ex.pitch_out2 = cb; ex.split = cs;
+                CS_TRY(launch_conv_mfma(s, 3, 2, rsrc(dU, c, c), ConvSrc(), u.convt.wd, nullptr, dX[d], cs, cin_t, nullptr, n, oh, ow, &ex));
+                CS_TRY(launch_wgrad(s, 3, 2, T.X[d], cs, cs, rsrc(dU, c, c), nullptr, dwt, cin_t, c, 0, 0, n, ph, pw, oh, ow));
+                CS_TRY(launch_wgrad(s, 3, 2, Ssub, cb, cb, rsrc(dU, c, c), nullptr, dwt, cin_t, c, cs, 0, n, ph, pw, oh, ow));
+            }
+            CS_TRY(launch_unpack_wgrad(s, dwt, cin_t, c, 0, 0, cin_t, c, 9, gptr(u.convt.p_w[0])));
+        }
+        dS = dSn;
+    }
+
+    // ---- bottom ----
+    {
+        const DownUnit& u = net->bottom;
+        const int c = u.c, cin = u.cin, ph = h >> nl, pw = w >> nl;
+        const int64_t npix = (int64_t)ph * pw;
+        const float* Xin = T.X[nl - 1];
+        float* dXin = dX[nl - 1];
+        if (u.res_conv) {
+            float* dwr = acc.take<float>((size_t)c * cin);
+            CS_TRY(bias_grad(dS, c, c, n * npix, u.res1x1.p_b[0]));
+            if (!dry) {
+                CS_TRY(launch_wgrad(s, 1, 1, dS, c, c, rsrc(Xin, cin, cin), nullptr, dwr, c, cin, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_unpack_wgrad(s, dwr, c, cin, 0, 0, c, cin, 1, gptr(u.res1x1.p_w[0])));
+            }
+        }
+        const float* da = dS;
+        for (int su = u.subunits - 1; su >= 0; --su) {
+            const ConvW& cw = su == 0 ? u.unit0 : u.units[su - 1];
+            float* dY = buf.take<float>((size_t)n * npix * c);
+            float* dwa = acc.take<float>((size_t)9 * c * (su == 0 ? cin : c));
+            float* da_new = su > 0 ? buf.take<float>((size_t)n * npix * c) : nullptr;
+            if (!buf.ok()) return oom();
+            CS_TRY(norm_bwd(u.norms[su], lazy_src(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c), da, c, dY, c, npix));
+            CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0]));
+            if (dry) { da = da_new; continue; }
+            if (su > 0) {
+                const ConvSrc prev = lazy_src(T.Yb[su - 1], c, c, T.rt_bottom[su - 1], u.norms[su - 1], c);
+                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, dwa, c, c, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_unpack_wgrad(s, dwa, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
+                CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dY, c, c), ConvSrc(), cw.wd, nullptr, da_new, c, c, nullptr, n, ph, pw));
+                da = da_new;
+            } else {
+                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, rsrc(Xin, cin, cin), nullptr, dwa, c, cin, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_unpack_wgrad(s, dwa, c, cin, 0, 0, c, cin, 9, gptr(cw.p_w[0])));
+                ConvOutExtra ex;
+                ex.addend = dXin; ex.pitch_add = cin;
+                CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dY, c, c), ConvSrc(), cw.wd, nullptr, dXin, cin, cin, nullptr, n, ph, pw, &ex));
+            }
+        }
+        if (!dry) {
+            if (u.res_conv) {
+                ConvOutExtra ex;
+                ex.addend = dXin; ex.pitch_add = cin;
+                CS_TRY(launch_conv_mfma(s, 1, 1, rsrc(dS, c, c), ConvSrc(), u.res1x1.wd, nullptr, dXin, cin, cin, nullptr, n, ph, pw, &ex));
+            } else {
+                CS_TRY(launch_norm_act_add(s, rsrc(dXin, cin, cin), rsrc(dS, c, c), dXin, cin, npix, n));
+            }
+        }
+    }
+
+    // ---- encoder, deepest level first ----
+    for (int d = nl - 1; d >= 0; --d) {
+        const DownUnit& u = net->down[d];
+        const int c = u.c, c0 = u.unit0.cout, cin = u.cin;
+        const int oh = h >> (d + 1), ow = w >> (d + 1), ph = oh * 2, pw = ow * 2;
+        const int64_t npix = (int64_t)oh * ow;
+        const float* dXd = dX[d];
+        CS_TRY(bias_grad(dXd, c, c, n * npix, u.unit0.p_b[1]));      // residual conv bias (the residual branch is raw)
+        const float* da = dXd;
+        for (int su = u.subunits - 1; su >= 1; --su) {
+            const ConvW& cw = u.units[su - 1];
+            float* dY = buf.take<float>((size_t)n * npix * c);
+            float* da_new = buf.take<float>((size_t)n * npix * c);
+            float* dwa = acc.take<float>((size_t)9 * c * c);
+            if (!buf.ok()) return oom();
+            CS_TRY(norm_bwd(u.norms[su], lazy_src(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c), da, c, dY, c, npix));
+            CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0]));
+            if (!dry) {
+                const ConvSrc prev = su - 1 == 0 ? lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0)
+                                                 : lazy_src(T.Y[d][su - 1], c, c, T.rt_down[d][su - 1], u.norms[su - 1], c);
+                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, dwa, c, c, 0, 0, n, oh, ow, oh, ow));
+                CS_TRY(launch_unpack_wgrad(s, dwa, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
+                CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dY, c, c), ConvSrc(), cw.wd, nullptr, da_new, c, c, nullptr, n, oh, ow));
+            }
+            da = da_new;
+        }
+        float* dY0 = buf.take<float>((size_t)n * npix * c);
+        float* dwf = acc.take<float>((size_t)9 * c0 * cin);
+        if (!buf.ok()) return oom();
+        CS_TRY(norm_bwd(u.norms[0], lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0), da, c, dY0, c, npix));
+        CS_TRY(bias_grad(dY0, c, c, n * npix, u.unit0.p_b[0]));
+        if (dry) continue;
+        if (!u.first) {
+            const ConvSrc xin = rsrc(T.X[d - 1], cin, cin);
+            CS_TRY(launch_wgrad(s, 3, 2, dY0, c, c, xin, nullptr, dwf, c0, cin, 0, 0, n, oh, ow, ph, pw));
+            CS_TRY(launch_wgrad(s, 3, 2, dXd, c, c, xin, nullptr, dwf, c0, cin, c, 0, n, oh, ow, ph, pw));
+            ConvOutExtra ex;
+            ex.addend = dX[d - 1]; ex.pitch_add = cin;
+            CS_TRY(launch_convt_mfma(s, rsrc(dY0, c, c), rsrc(dXd, c, c), u.unit0.wd, nullptr, dX[d - 1], cin, cin, nullptr, n, oh, ow, &ex));
+        } else {
+            WgradNarrow nb;
+            nb.ptr = T.src.image; nb.c = cin; nb.sn = T.src.sn; nb.sc = T.src.sc; nb.sh = T.src.sh; nb.sw = T.src.sw;
+            CS_TRY(launch_wgrad(s, 3, 2, dY0, c, c, ConvSrc(), &nb, dwf, c0, cin, 0, 0, n, oh, ow, ph, pw));
+            CS_TRY(launch_wgrad(s, 3, 2, dXd, c, c, ConvSrc(), &nb, dwf, c0, cin, c, 0, n, oh, ow, ph, pw));
+        }
+        CS_TRY(launch_unpack_wgrad(s, dwf, c0, cin, 0, 0, c, cin, 9, gptr(u.unit0.p_w[0])));
+        CS_TRY(launch_unpack_wgrad(s, dwf, c0, cin, c, 0, c, cin, 9, gptr(u.unit0.p_w[1])));
     }
     return CS_OK;
 }
@@ -533,6 +789,12 @@ int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* 
     ArenaPlan real;
     real.base = net->arena;
     build_net(net, real);
+    int64_t off = 0;
+    for (auto& p : net->params) {
+        p.grad_off = off;
+        off += (p.numel() + 3) / 4 * 4;          // keep every gradient 16-byte aligned inside the flat bucket
+    }
+    net->grad_floats = off;
     *out = net;
     return CS_OK;
 }
@@ -591,7 +853,57 @@ int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_
     src.image = x; src.sn = sn; src.sc = sc; src.sh = sh; src.sw = sw;
     src.origins = nullptr; src.img_h = h; src.img_w = w; src.roi_h = h; src.roi_w = w;
     Bump b(workspace, workspace_bytes);
-    return unet_forward_impl(net, src, n, h, w, logits_nhwc, b, (hipStream_t)stream);
+    return unet_forward_impl(net, src, n, h, w, logits_nhwc, b, (hipStream_t)stream, &net->tape);
+}
+
+int64_t cs_unet_grad_numel(const cs_unet* net) { return net ? net->grad_floats : CS_ERR_INVALID; }
+
+int64_t cs_unet_grad_offset(const cs_unet* net, int index) {
+    if (!net || index < 0 || index >= (int)net->params.size()) return CS_ERR_INVALID;
+    return net->params[index].grad_off;
+}
+
+static int backward_sizes(const cs_unet* net, size_t* acc_bytes, size_t* buf_bytes) {
+    Bump acc(nullptr, 0), buf(nullptr, 0);
+    int rc = unet_backward_impl(net, nullptr, acc, buf, nullptr, nullptr);
+    *acc_bytes = acc.off;
+    *buf_bytes = buf.off;
+    return rc;
+}
+
+size_t cs_unet_backward_workspace_bytes(const cs_unet* net, int n, int h, int w) {
+    if (!net || n <= 0) return 0;
+    // sizes depend only on (n, h, w): run the planner on a scratch tape
+    cs_unet* m = const_cast<cs_unet*>(net);
+    Tape saved = m->tape;
+    Bump fb(nullptr, 0);
+    WindowSrc src;
+    size_t a = 0, b = 0;
+    int rc = unet_forward_impl(net, src, n, h, w, nullptr, fb, nullptr, &m->tape);
+    if (rc == CS_OK) rc = backward_sizes(net, &a, &b);
+    m->tape = saved;
+    return rc == CS_OK ? a + b + 512 : 0;
+}
+
+int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspace, size_t workspace_bytes, float* flat_grad,
+                     void* stream) {
+    CS_REQUIRE(net && grad_logits_nhwc && workspace && flat_grad, "unet_backward: null argument");
+    CS_REQUIRE(net->tape.valid, "unet_backward: no forward has been recorded (call cs_unet_forward first and keep its workspace intact)");
+    hipStream_t s = (hipStream_t)stream;
+    size_t acc_bytes = 0, buf_bytes = 0;
+    int rc = backward_sizes(net, &acc_bytes, &buf_bytes);
+    if (rc) return rc;
+    acc_bytes = (acc_bytes + 255) / 256 * 256;
+    if (acc_bytes + buf_bytes > workspace_bytes) {
+        cs::set_error("unet_backward: workspace %zu < %zu bytes", workspace_bytes, acc_bytes + buf_bytes);
+        return CS_ERR_WORKSPACE;
+    }
+    CS_HIP(hipMemsetAsync(workspace, 0, acc_bytes, s));
+    CS_HIP(hipMemsetAsync(flat_grad, 0, (size_t)net->grad_floats * sizeof(float), s));
+    Bump acc(workspace, acc_bytes), buf((char*)workspace + acc_bytes, workspace_bytes - acc_bytes);
+    rc = unet_backward_impl(net, grad_logits_nhwc, acc, buf, flat_grad, s);
+    net->tape.valid = false;      // the gradient buffers reused nothing of the tape, but one backward per forward
+    return rc;
 }
 
 int cs_swi_window_start(int i, int interval, int padded_size, int roi) {

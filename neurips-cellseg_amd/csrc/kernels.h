@@ -20,18 +20,33 @@ struct ConvSrc {
 // packed[chunk][tap][ntile_total][64 lanes][4] with cout = ntile*16 + (lane & 15), cin = chunk*16 + 4*(lane>>4) + j.
 // `cout_off`/`cout_total` let two convs (unit0 || residual) share one packed tensor; `cin_total` is the
 // concatenated input width.
+// `flip` reverses the taps (data gradient of a stride-1 conv); `cin_off` places this tensor's chunks at input-channel
+// offset cin_off of a wider packed conv (data gradient of the fused [unit0 || residual] conv).
 int pack_conv_weights(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
-                      float* packed, int cout_off, int cout_total);
+                      float* packed, int cout_off, int cout_total, bool flip = false, int cin_off = 0);
 // first layer (cin < 16): packed[kstep][ntile_total][64], k = 4*kstep + (lane>>4) = tap*cin + c, zero padded
 int pack_first_weights(hipStream_t s, const float* w, int cout, int cin, float* packed, int cout_off, int cout_total);
 size_t packed_conv_floats(int cout_total, int cin_total, int ksize);
 size_t packed_first_floats(int cout_total, int cin);
 
+// Extras used by the backward pass when a forward kernel computes a data gradient:
+//   out = conv(...) + bias + addend ; output channels >= `split` are written to out2 (+ addend2) instead.
+struct ConvOutExtra {
+    const float* addend = nullptr;
+    int pitch_add = 0;
+    float* out2 = nullptr;
+    int pitch_out2 = 0;
+    int split = 0;
+    const float* addend2 = nullptr;
+    int pitch_add2 = 0;
+};
+
 // ---- convolutions ------------------------------------------------------------------------------
 // 3x3 (pad 1) or 1x1 (pad 0) convolution, stride 1 or 2, fp32 MFMA 16x16x4.  Input = concat(a, b) along C.
 // out: raw conv + bias (NHWC, pitch floats/pixel).  stats: [n][cout][2] doubles (sum, sum of squares) or null.
 int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, const ConvSrc& b, const float* wpack,
-                     const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
+                     const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win,
+                     const ConvOutExtra* ex = nullptr);
 
 // first layer: cin < 16 (3), 3x3 pad 1, reads windows straight out of the image (tiler gather fused).
 // image element strides (sc, sh, sw); per-window origins (y0, x0) in image coordinates (may be negative when the
@@ -48,7 +63,8 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
 
 // transposed 3x3 stride 2 pad 1 output_padding 1 (MFMA), input = concat(a, b); out is [n, 2h, 2w, cout]
 int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* wpack, const float* bias,
-                      float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
+                      float* out, int pitch_out, int cout, double* stats, int n, int hin, int win,
+                      const ConvOutExtra* ex = nullptr);
 
 // small-cout (<= 4) VALU kernels for the top of the decoder
 // transposed conv cin -> cout(<=4); weights in PyTorch layout W[cin][cout][3][3] (no packing)
@@ -66,6 +82,29 @@ int launch_bn_table(hipStream_t s, const float* weight, const float* bias, const
                     float2* tab, int n, int c, int c_total, float eps);
 // out = T_y(y) + T_r(r)   (T = lazy norm/act or identity), all NHWC with channel count c
 int launch_norm_act_add(hipStream_t s, const ConvSrc& y, const ConvSrc& r, float* out, int pitch_out, int64_t npix_per_image, int n);
+
+// ---- backward pass (kernels_bwd.hip) -----------------------------------------------------------
+// InstanceNorm + PReLU backward of `y` (raw conv output + forward table/slope): da -> dy; red [n][c][2] and dslope
+// are fp64 accumulators that must be zero on entry.
+int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch, double* red,
+                    double* dslope, int64_t npix, int n);
+// dst[c] += sum over pixels (fp64 accumulators)
+int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npix_total, double* dst);
+struct WgradNarrow {          // "x-like" operand with <= 4 channels addressed by element strides
+    const float* ptr = nullptr;
+    int c = 0;
+    int64_t sn = 0, sc = 0, sh = 0, sw = 0;
+};
+// dw[tap][co_off + i][ci_off + j] += sum_pixels a[pix][i] * b[pix*stride + tap - pad][j]   (float atomics; dw zeroed by caller)
+int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pitch, int a_c, const ConvSrc& b, const WgradNarrow* nb,
+                 float* dw, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi);
+int launch_unpack_wgrad(hipStream_t s, const float* dwacc, int rows_total, int cols_total, int row_off, int col_off, int rows,
+                        int cols, int taps, float* dst);
+int launch_f64_to_f32(hipStream_t s, const double* src, float* dst, int n);
+int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw,
+                         double* db, int n, int h, int w);
+int launch_convt_small_bwd_data(hipStream_t s, const float* du, const float* w_torch, int cin_total, int c_begin, int c_count,
+                                float* dst, int dst_pitch, bool accumulate, int n, int hin, int win);
 
 // ---- tiler finalize -------------------------------------------------------------------------------
 struct SwiFinalizeArgs {

@@ -1,0 +1,636 @@
+// gfx950 backward-pass kernels for the 3-class U-Net (row M-bwd of SURVEY.md 8(a): what `loss.backward()` at
+// baseline/model_training_3class.py:260 dispatches through autograd for conv2d / conv_transpose2d /
+// instance_norm / prelu / add / cat).
+//
+// Data gradients reuse the forward MFMA kernels (kernels_conv.hip) with re-packed weights:
+//   dgrad(conv 3x3 s1)  = conv 3x3 s1 with W'[ci][co][8-tap]           (pack: transposed + flipped)
+//   dgrad(conv 3x3 s2)  = transposed conv k3 s2 p1 op1 with Wt = W      (pack: transposed)
+//   dgrad(convT k3 s2)  = conv 3x3 s2 with W' = Wt                      (pack: plain)
+// This file adds what has no forward counterpart:
+//   * weight gradients: MFMA GEMM with M = 16 "dy" channels, N = 16 "x" channels, K = pixels (4 per MFMA),
+//     9 taps x MT accumulator tiles per wave, split-K over images / row bands, wave partials merged with LDS
+//     float atomics and committed with one global float atomic per element and block
+//   * InstanceNorm + PReLU backward: per-(image, channel) reductions sum(dz), sum(dz*z) and the PReLU slope gradient
+//     in one pass, then dy = rstd * (dz - mean(dz) - z * mean(dz*z)) in a second pass
+//   * per-channel column sums (bias gradients) and the VALU kernels for the two 3-channel layers at the top.
+#include "kernels.h"
+
+namespace cs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4b(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float prelu_b(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm + PReLU backward
+//   z = y*scale + shift ; a = prelu(z) ; dz = da * (z >= 0 ? 1 : slope) ; dslope += sum(da * z [z < 0])
+//   red[n][c] = (sum dz, sum dz*z) ;  dy = scale * (dz - red0/m - z * red1/m)
+// ------------------------------------------------------------------------------------------------
+struct NormBwdParams {
+    const float* da;   int da_pitch;
+    const float* y;    int y_pitch;
+    const float2* tab; int tab_c, tab_off;
+    const float* slope;
+    double* red;       // [n][c][2]
+    double* dslope;    // scalar accumulator (or null for ReLU)
+    float* dy;         int dy_pitch;
+    int c, npix;       // channels, pixels per image
+    int pix_per_block;
+};
+
+// wide: c % 4 == 0 and 256 % (c/4) == 0
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
+    __shared__ float sh[256 * 9];
+    const int c4n = p.c >> 2, lanes = 256 / c4n;
+    const int quad = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+    const int img = blockIdx.y;
+    const int64_t pix0 = (int64_t)blockIdx.x * p.pix_per_block;
+    const int64_t pix1 = pix0 + p.pix_per_block < p.npix ? pix0 + p.pix_per_block : p.npix;
+    const f32x4* t = reinterpret_cast<const f32x4*>(p.tab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
+    const f32x4 t0 = t[0], t1 = t[1];
+    const float sc[4] = {t0.x, t0.z, t1.x, t1.z}, sf[4] = {t0.y, t0.w, t1.y, t1.w};
+    const float slope = p.slope ? *p.slope : 0.f;
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, ds = 0.f;
+    for (int64_t px = pix0 + pl; px < pix1; px += lanes) {
+        const int64_t g = (int64_t)img * p.npix + px;
+        const f32x4 da = *reinterpret_cast<const f32x4*>(p.da + g * p.da_pitch + 4 * quad);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(p.y + g * p.y_pitch + 4 * quad);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = y[j] * sc[j] + sf[j];
+            const float dz = z >= 0.f ? da[j] : da[j] * slope;
+            if (z < 0.f) ds += da[j] * z;
+            s1[j] += dz;
+            s2[j] += dz * z;
+        }
+    }
+    // reduce over the `lanes` threads that share a channel quad
+    float* mine = sh + threadIdx.x * 9;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mine[j] = s1[j];
+        mine[4 + j] = s2[j];
+    }
+    mine[8] = ds;
+    __syncthreads();
+    if (threadIdx.x < c4n) {
+        float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
+        for (int l = 0; l < lanes; ++l) {
+            const float* o = sh + (l * c4n + threadIdx.x) * 9;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r1[j] += o[j];
+                r2[j] += o[4 + j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double* d = p.red + ((size_t)img * p.c + 4 * threadIdx.x + j) * 2;
+            atomicAdd(d, (double)r1[j]);
+            atomicAdd(d + 1, (double)r2[j]);
+        }
+    }
+    if (p.dslope) {
+        float tot = 0.f;
+        if (threadIdx.x < 64) {
+            for (int l = threadIdx.x; l < 256; l += 64) tot += sh[l * 9 + 8];
+            for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
+            if (threadIdx.x == 0) atomicAdd(p.dslope, (double)tot);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p, int64_t total) {
+    const int c4n = p.c >> 2;
+    const double inv_m = 1.0 / (double)p.npix;
+    const float slope = p.slope ? *p.slope : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = i / c4n;
+        const int quad = (int)(i - g * c4n);
+        const int img = (int)(g / p.npix);
+        const f32x4* t = reinterpret_cast<const f32x4*>(p.tab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
+        const f32x4 t0 = t[0], t1 = t[1];
+        const float sc[4] = {t0.x, t0.z, t1.x, t1.z}, sf[4] = {t0.y, t0.w, t1.y, t1.w};
+        const double* red = p.red + ((size_t)img * p.c + 4 * quad) * 2;
+        const f32x4 da = *reinterpret_cast<const f32x4*>(p.da + g * p.da_pitch + 4 * quad);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(p.y + g * p.y_pitch + 4 * quad);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = y[j] * sc[j] + sf[j];
+            const float dz = z >= 0.f ? da[j] : da[j] * slope;
+            const float m1 = (float)(red[2 * j] * inv_m), m2 = (float)(red[2 * j + 1] * inv_m);
+            o[j] = sc[j] * (dz - m1 - z * m2);
+        }
+        *reinterpret_cast<f32x4*>(p.dy + g * p.dy_pitch + 4 * quad) = o;
+    }
+}
+
+// narrow (c <= 4, any pitch): one thread per pixel
+template <int C>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_small_kernel(NormBwdParams p) {
+    const int img = blockIdx.y;
+    const float slope = p.slope ? *p.slope : 0.f;
+    float s1[C], s2[C], ds = 0.f, sc[C], sf[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float2 t = p.tab[(size_t)img * p.tab_c + p.tab_off + c];
+        sc[c] = t.x; sf[c] = t.y; s1[c] = 0.f; s2[c] = 0.f;
+    }
+    for (int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; px < p.npix; px += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = (int64_t)img * p.npix + px;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float da = p.da[g * p.da_pitch + c];
+            const float z = p.y[g * p.y_pitch + c] * sc[c] + sf[c];
+            const float dz = z >= 0.f ? da : da * slope;
+            if (z < 0.f) ds += da * z;
+            s1[c] += dz;
+            s2[c] += dz * z;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            s1[c] += __shfl_xor(s1[c], off);
+            s2[c] += __shfl_xor(s2[c], off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(p.red + ((size_t)img * C + c) * 2, (double)s1[c]);
+            atomicAdd(p.red + ((size_t)img * C + c) * 2 + 1, (double)s2[c]);
+        }
+    }
+    if (p.dslope) {
+        for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(p.dslope, (double)ds);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void norm_bwd_apply_small_kernel(NormBwdParams p) {
+    const int img = blockIdx.y;
+    const int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= p.npix) return;
+    const float slope = p.slope ? *p.slope : 0.f;
+    const double inv_m = 1.0 / (double)p.npix;
+    const int64_t g = (int64_t)img * p.npix + px;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float2 t = p.tab[(size_t)img * p.tab_c + p.tab_off + c];
+        const float da = p.da[g * p.da_pitch + c];
+        const float z = p.y[g * p.y_pitch + c] * t.x + t.y;
+        const float dz = z >= 0.f ? da : da * slope;
+        const double* red = p.red + ((size_t)img * C + c) * 2;
+        p.dy[g * p.dy_pitch + c] = t.x * (dz - (float)(red[0] * inv_m) - z * (float)(red[1] * inv_m));
+    }
+}
+
+int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch, double* red,
+                    double* dslope, int64_t npix, int n) {
+    CS_REQUIRE(y.tab != nullptr, "norm_bwd: the forward table is required");
+    NormBwdParams p{};
+    p.da = da; p.da_pitch = da_pitch; p.y = y.ptr; p.y_pitch = y.pitch;
+    p.tab = y.tab; p.tab_c = y.tab_c ? y.tab_c : y.c; p.tab_off = y.tab_off; p.slope = y.slope;
+    p.red = red; p.dslope = y.slope ? dslope : nullptr; p.dy = dy; p.dy_pitch = dy_pitch; p.c = y.c; p.npix = (int)npix;
+    ProfScope prof(K_NORM_BWD, s, 0, 4.0 * n * npix * y.c * 5);
+    if (y.c == 3) {
+        dim3 grid((unsigned)(ceil_div((int)npix, 256) < 64 ? ceil_div((int)npix, 256) : 64), (unsigned)n);
+        hipLaunchKernelGGL((norm_bwd_reduce_small_kernel<3>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((norm_bwd_apply_small_kernel<3>), dim3((unsigned)ceil_div((int)npix, 256), (unsigned)n), dim3(256), 0, s, p);
+    } else {
+        const int c4n = y.c / 4;
+        CS_REQUIRE(y.c % 4 == 0 && c4n <= 256 && 256 % c4n == 0, "norm_bwd: %d channels unsupported (need a power of two in 16..1024)", y.c);
+        p.pix_per_block = npix >= 4096 ? 1024 : (npix >= 256 ? 256 : (int)npix);
+        dim3 grid((unsigned)ceil_div((int)npix, p.pix_per_block), (unsigned)n);
+        hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(256), 0, s, p);
+        const int64_t total = (int64_t)n * npix * c4n;
+        const int64_t blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, p, total);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums: dst[c] += sum over pixels of src[pix][c]   (bias gradients); fp64 atomics
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* src, int pitch, int c, int64_t npix, int64_t pix_per_block,
+                                                     double* dst) {
+    __shared__ float sh[256];
+    const int lanes = 256 / c > 0 ? 256 / c : 1;
+    const int ch = threadIdx.x % c, pl = threadIdx.x / c;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+    for (int cb = 0; cb < c; cb += 256) {          // channels handled 256 at a time when c > 256
+        const int cc = c > 256 ? cb + threadIdx.x : ch;
+        float acc = 0.f;
+        if (cc < c && (c > 256 || pl < lanes))
+            for (int64_t px = p0 + (c > 256 ? 0 : pl); px < p1; px += (c > 256 ? 1 : lanes)) acc += src[px * pitch + cc];
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        if (c > 256) {
+            if (cc < c) atomicAdd(dst + cc, (double)acc);
+        } else if (threadIdx.x < c) {
+            float t = 0.f;
+            for (int l = 0; l < lanes; ++l) t += sh[l * c + threadIdx.x];
+            atomicAdd(dst + threadIdx.x, (double)t);
+        }
+        __syncthreads();
+        if (c <= 256) break;
+    }
+}
+
+int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npix_total, double* dst) {
+    const int64_t ppb = npix_total >= 65536 ? 2048 : 256;
+    ProfScope prof(K_COLSUM, s, 0, 4.0 * npix_total * c);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((npix_total + ppb - 1) / ppb)), dim3(256), 0, s, src, pitch, c, npix_total, ppb, dst);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient (MFMA).  dw[tap][co_off + i][ci_off + j] += sum_pixels A[pix][i] * B[pix*S + tap - pad][j]
+//   A ("dy-like"): NHWC raw, 16*MT channels per block.  B ("x-like"): one 16-channel chunk (lazy norm/act applied
+//   while staging) or a narrow / strided source with <= 4 channels (first layer input, 3-channel tensors).
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const float* a;
+    int a_pitch;
+    // B, mode 0: NHWC 16-channel chunks
+    const float* b_ptr;
+    const float2* b_tab;
+    const float* b_slope;
+    int b_pitch, b_tab_c, b_tab_off;
+    // B, mode 1: narrow / strided (element strides), b_c <= 4 channels
+    int b_mode, b_c;
+    int64_t b_sn, b_sc, b_sh, b_sw;
+    const float* dummy;          // valid readable memory for the branch-free table loads
+    float* dw;
+    int co_total, ci_total, co_off, ci_off;
+    int n, ho, wo, hi, wi;
+    int tiles_x, tiles_y, tiles_per_block, blocks_per_image;
+};
+
+template <int S, int KS, int MT>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
+    constexpr int TH = 4, TW = 16;
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int PAD = KS / 2, TAPS = KS * KS;
+    constexpr int COP = (MT & 1) ? 16 * MT : 16 * MT + 16;   // dy pixel pitch: == 16 (mod 32) -> conflict-free A reads
+    constexpr int CSX = (S == 1) ? 16 : 24;                   // x pixel pitch: S*CSX == 16 (mod 32)
+    constexpr int A_ITERS = (TH * TW * 4 * MT + 255) / 256;   // float4 per thread for the dy tile
+    constexpr int B_ITERS = (IH * IW + 63) / 64;
+    constexpr int A_FLOATS = TH * TW * COP, B_FLOATS = (IH * IW * CSX + 3) / 4 * 4;
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS + TAPS * MT * 256];
+    float* const a_s = smem;
+    float* const b_s = smem + A_FLOATS;
+    float* const slab = smem + A_FLOATS + B_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int img = blockIdx.x / p.blocks_per_image, blk = blockIdx.x % p.blocks_per_image;
+    const int co0 = blockIdx.y * 16 * MT;       // A channel base of this block
+    const int cb0 = blockIdx.z * 16;            // B channel chunk
+    const int q = tid & 3;
+
+    f32x4 acc[TAPS][MT];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < TAPS * MT * 256; i += 256) slab[i] = 0.f;
+
+    // lazy table for this thread's B channel quad (mode 0)
+    f32x4 t0 = f32x4{1.f, 0.f, 1.f, 0.f}, t1 = t0;
+    float slope = 0.f;
+    const bool lazy = p.b_mode == 0 && p.b_tab != nullptr;
+    {
+        const f32x4* t = lazy ? reinterpret_cast<const f32x4*>(p.b_tab + (size_t)img * p.b_tab_c + p.b_tab_off + cb0 + 4 * q)
+                              : reinterpret_cast<const f32x4*>(p.dummy);
+        t0 = t[0];
+        t1 = t[1];
+        const float* sp = (lazy && p.b_slope) ? p.b_slope : p.dummy;
+        slope = *sp;
+        if (!(lazy && p.b_slope)) slope = 0.f;
+    }
+
+    f32x4 ra[A_ITERS], rb[B_ITERS];
+    int tile_y = 0, tile_x = 0;
+    auto load_tile = [&](int tile) {
+        tile_y = tile / p.tiles_x;
+        tile_x = tile - tile_y * p.tiles_x;
+        const int oy0 = tile_y * TH, ox0 = tile_x * TW;
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            const int px = i / (4 * MT), c4 = i - px * (4 * MT);
+            const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+            const bool ok = (A_ITERS * 256 == TH * TW * 4 * MT || px < TH * TW) && oy < p.ho && ox < p.wo;
+            const size_t off = ok ? (((size_t)img * p.ho + oy) * p.wo + ox) * p.a_pitch + co0 + 4 * c4 : 0;
+            ra[it] = *reinterpret_cast<const f32x4*>(p.a + off);
+            if (!ok) ra[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) {
+            const int pix = (tid >> 2) + 64 * it;
+            const int iy = pix / IW, ix = pix - iy * IW;
+            const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
+            const bool ok = pix < IH * IW && gy >= 0 && gy < p.hi && gx >= 0 && gx < p.wi;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.b_mode == 0) {
+                const size_t off = ok ? (((size_t)img * p.hi + gy) * p.wi + gx) * p.b_pitch + cb0 + 4 * q : 0;
+                v = *reinterpret_cast<const f32x4*>(p.b_ptr + off);
+                if (lazy) {
+                    v.x = prelu_b(v.x * t0.x + t0.y, slope);
+                    v.y = prelu_b(v.y * t0.z + t0.w, slope);
+                    v.z = prelu_b(v.z * t1.x + t1.y, slope);
+                    v.w = prelu_b(v.w * t1.z + t1.w, slope);
+                }
+            } else if (q == 0 && ok) {
+                const float* b = p.b_ptr + img * p.b_sn + gy * p.b_sh + gx * p.b_sw;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.b_c) v[c] = b[c * p.b_sc];
+            }
+            rb[it] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            const int px = i / (4 * MT), c4 = i - px * (4 * MT);
+            if (A_ITERS * 256 == TH * TW * 4 * MT || px < TH * TW) *reinterpret_cast<f32x4*>(&a_s[px * COP + 4 * c4]) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) {
+            const int pix = (tid >> 2) + 64 * it;
+            if (pix < IH * IW) *reinterpret_cast<f32x4*>(&b_s[pix * CSX + 4 * q]) = rb[it];
+        }
+    };
+
+    const int n_tiles = p.tiles_x * p.tiles_y;
+    const int t_begin = blk * p.tiles_per_block;
+    const int t_end = t_begin + p.tiles_per_block < n_tiles ? t_begin + p.tiles_per_block : n_tiles;
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile();
+    }
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool more = tile + 1 < t_end;
+        if (more) load_tile(tile + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float a[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = a_s[(wave * 16 + 4 * ks + kk) * COP + m * 16 + li];
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int ky = tap / KS, kx = tap - ky * KS;
+                const float b = b_s[((wave * S + ky) * IW + (4 * ks + kk) * S + kx) * CSX + li];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[tap][m] = mfma4b(a[m], b, acc[tap][m]);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+    // merge the four waves' partial tiles in LDS, then one global atomic per element
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&slab[((tap * MT + m) * 16 + kk * 4 + r) * 16 + li], acc[tap][m][r]);
+    __syncthreads();
+    const int ci_valid = p.b_mode == 0 ? 16 : p.b_c;
+    for (int i = tid; i < TAPS * MT * 256; i += 256) {
+        const int j = i & 15, row = (i >> 4) & 15, tm = i >> 8;
+        const int m = tm % MT, tap = tm / MT;
+        if (j < ci_valid) {
+            const size_t dst = ((size_t)tap * p.co_total + p.co_off + co0 + m * 16 + row) * p.ci_total + p.ci_off + cb0 + j;
+            atomicAdd(p.dw + dst, slab[i]);
+        }
+    }
+}
+
+int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pitch, int a_c, const ConvSrc& b, const WgradNarrow* nb,
+                 float* dw, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi) {
+    CS_REQUIRE(a_c % 16 == 0 && a_c > 0, "wgrad: %d dy channels (must be a multiple of 16)", a_c);
+    CS_REQUIRE((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1), "wgrad: k%d s%d unsupported", ksize, stride);
+    WgradParams p{};
+    p.a = a; p.a_pitch = a_pitch;
+    int b_chunks;
+    if (nb) {
+        CS_REQUIRE(nb->c >= 1 && nb->c <= 4, "wgrad: narrow source with %d channels", nb->c);
+        p.b_mode = 1; p.b_c = nb->c; p.b_ptr = nb->ptr; p.b_sn = nb->sn; p.b_sc = nb->sc; p.b_sh = nb->sh; p.b_sw = nb->sw;
+        b_chunks = 1;
+    } else {
+        CS_REQUIRE(b.c % 16 == 0 && b.c > 0, "wgrad: %d x channels (must be a multiple of 16)", b.c);
+        p.b_mode = 0; p.b_ptr = b.ptr; p.b_tab = b.tab; p.b_slope = b.slope; p.b_pitch = b.pitch;
+        p.b_tab_c = b.tab_c ? b.tab_c : b.c; p.b_tab_off = b.tab_off;
+        b_chunks = b.c / 16;
+    }
+    p.dummy = a;
+    p.dw = dw; p.co_total = co_total; p.ci_total = ci_total; p.co_off = co_off; p.ci_off = ci_off;
+    p.n = n; p.ho = ho; p.wo = wo; p.hi = hi; p.wi = wi;
+    p.tiles_x = ceil_div(wo, 16);
+    p.tiles_y = ceil_div(ho, 4);
+    const int mt = (a_c % 64 == 0) ? 4 : (a_c % 32 == 0) ? 2 : 1;
+    const int n_tiles = p.tiles_x * p.tiles_y;
+    const int others = n * (a_c / (16 * mt)) * b_chunks;
+    int tpb = n_tiles;                                  // as few partial sums as possible while still filling the chip
+    while (tpb > 1 && (long)others * ceil_div(n_tiles, tpb) < 1024) tpb = (tpb + 1) / 2;
+    p.tiles_per_block = tpb;
+    p.blocks_per_image = ceil_div(n_tiles, tpb);
+    dim3 grid((unsigned)(n * p.blocks_per_image), (unsigned)(a_c / (16 * mt)), (unsigned)b_chunks);
+    const double flops = 2.0 * n * ho * wo * (double)a_c * (nb ? nb->c : b.c) * ksize * ksize;
+    ProfScope prof(K_WGRAD, s, flops, 4.0 * n * ((double)ho * wo * a_c + (double)hi * wi * (nb ? nb->c : b.c)));
+#define CS_WG(S_, KS_)                                                                                       \
+    switch (mt) {                                                                                            \
+        case 4: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 4>), grid, dim3(256), 0, s, p); break;        \
+        case 2: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 2>), grid, dim3(256), 0, s, p); break;        \
+        default: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 1>), grid, dim3(256), 0, s, p); break;       \
+    }
+    if (ksize == 1) { CS_WG(1, 1) } else if (stride == 1) { CS_WG(1, 3) } else { CS_WG(2, 3) }
+#undef CS_WG
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// dwacc [taps][rows_total][cols_total] (rows row_off.., cols col_off..) -> PyTorch layout dst[row][col][tap]
+__global__ void unpack_wgrad_kernel(const float* dwacc, int rows_total, int cols_total, int row_off, int col_off, int rows, int cols,
+                                    int taps, float* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols * taps) return;
+    const int tap = i % taps, col = (i / taps) % cols, row = i / (taps * cols);
+    dst[i] = dwacc[((size_t)tap * rows_total + row_off + row) * cols_total + col_off + col];
+}
+
+int launch_unpack_wgrad(hipStream_t s, const float* dwacc, int rows_total, int cols_total, int row_off, int col_off, int rows,
+                        int cols, int taps, float* dst) {
+    const int total = rows * cols * taps;
+    ProfScope prof(K_PACK, s, 0, 8.0 * total);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, dwacc, rows_total, cols_total,
+                       row_off, col_off, rows, cols, taps, dst);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+__global__ void f64_to_f32_kernel(const double* src, float* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+int launch_f64_to_f32(hipStream_t s, const double* src, float* dst, int n) {
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, src, dst, n);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// top of the decoder (3 channels), VALU
+// ------------------------------------------------------------------------------------------------
+// last layer backward: logits = conv3x3(T(u); W) + b + T(u)
+//   d_au[p][ci] = dl[p][ci] + sum_{co,k} dl[p - (k - 1)][co] * W[co][ci][k]
+//   dW[co][ci][k] = sum_p dl[p][co] * T(u)[p + k - 1][ci] ;  db[co] = sum_p dl[p][co]
+template <int C>
+__global__ __launch_bounds__(256) void conv_last_bwd_kernel(const float* dl, const float* u, const float2* tab, const float* slope_p,
+                                                            const float* w, float* d_au, double* dw, double* db, int h, int wd) {
+    __shared__ float w_s[C * C * 9];
+    for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) w_s[i] = w[i];
+    __syncthreads();
+    const int img = blockIdx.y;
+    const float slope = slope_p ? *slope_p : 0.f;
+    float sc[C], sf[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float2 t = tab[img * C + c];
+        sc[c] = t.x; sf[c] = t.y;
+    }
+    float gw[C * C * 9], gb[C];
+#pragma unroll
+    for (int i = 0; i < C * C * 9; ++i) gw[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) gb[c] = 0.f;
+    const float* dlb = dl + (size_t)img * h * wd * C;
+    const float* ub = u + (size_t)img * h * wd * C;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < h * wd; pix += gridDim.x * blockDim.x) {
+        const int y = pix / wd, x = pix - y * wd;
+        float g[C], acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            g[c] = dlb[(size_t)pix * C + c];
+            acc[c] = g[c];
+            gb[c] += g[c];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int k = ky * 3 + kx;
+                // data gradient: neighbour q = p - (k - 1) contributed to by this pixel's activation
+                const int qy = y - (ky - 1), qx = x - (kx - 1);
+                if (qy >= 0 && qy < h && qx >= 0 && qx < wd) {
+                    const float* dq = dlb + ((size_t)qy * wd + qx) * C;
+#pragma unroll
+                    for (int co = 0; co < C; ++co) {
+                        const float d = dq[co];
+#pragma unroll
+                        for (int ci = 0; ci < C; ++ci) acc[ci] += d * w_s[(co * C + ci) * 9 + k];
+                    }
+                }
+                // weight gradient: activation at p + (k - 1)
+                const int ay = y + ky - 1, ax = x + kx - 1;
+                if (ay >= 0 && ay < h && ax >= 0 && ax < wd) {
+                    const float* up = ub + ((size_t)ay * wd + ax) * C;
+#pragma unroll
+                    for (int ci = 0; ci < C; ++ci) {
+                        const float a = prelu_b(up[ci] * sc[ci] + sf[ci], slope);
+#pragma unroll
+                        for (int co = 0; co < C; ++co) gw[(co * C + ci) * 9 + k] += g[co] * a;
+                    }
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) d_au[((size_t)img * h * wd + pix) * C + c] = acc[c];
+    }
+#pragma unroll
+    for (int i = 0; i < C * C * 9; ++i) {
+        float v = gw[i];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(dw + i, (double)v);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float v = gb[c];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(db + c, (double)v);
+    }
+}
+
+int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw,
+                         double* db, int n, int h, int w) {
+    CS_REQUIRE(u.c == 3 && u.pitch == 3 && u.tab, "conv_last_bwd: 3-class contract");
+    ProfScope prof(K_TOP_BWD, s, 4.0 * n * h * w * 81.0, 4.0 * n * (double)h * w * 9);
+    dim3 grid((unsigned)(ceil_div(h * w, 256) < 64 ? ceil_div(h * w, 256) : 64), (unsigned)n);
+    hipLaunchKernelGGL((conv_last_bwd_kernel<3>), grid, dim3(256), 0, s, dlogits, u.ptr, u.tab, u.slope, w_torch, d_au, dw, db, h, w);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// top transposed conv backward (data): dx[i][j][ci] = sum_{co,ky,kx} du[2i-1+ky][2j-1+kx][co] * Wt[ci][co][ky][kx]
+// one thread per input pixel, channels [c_begin, c_begin + c_count) of the concatenated input go to `dst` (+= if accumulate)
+template <int COUT>
+__global__ __launch_bounds__(256) void convt_small_bwd_data_kernel(const float* du, const float* wt, int cin_total, int c_begin,
+                                                                   int c_count, float* dst, int dst_pitch, int accumulate, int hin,
+                                                                   int win) {
+    extern __shared__ __attribute__((aligned(16))) float w_s[];   // [c_count][COUT*9 (+1)]
+    constexpr int WROW = COUT * 9 + 1;
+    for (int i = threadIdx.x; i < c_count * COUT * 9; i += blockDim.x) {
+        const int ci = i / (COUT * 9), r = i - ci * COUT * 9;
+        w_s[ci * WROW + r] = wt[(size_t)(c_begin + ci) * COUT * 9 + r];
+    }
+    __syncthreads();
+    const int img = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= hin * win) return;
+    const int iy = pix / win, ix = pix - iy * win;
+    const int hout = 2 * hin, wout = 2 * win;
+    float g[9][COUT];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int oy = 2 * iy - 1 + ky, ox = 2 * ix - 1 + kx;
+            const bool ok = oy >= 0 && oy < hout && ox >= 0 && ox < wout;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) g[ky * 3 + kx][co] = ok ? du[(((size_t)img * hout + oy) * wout + ox) * COUT + co] : 0.f;
+        }
+    float* o = dst + ((size_t)img * hin * win + pix) * dst_pitch;
+    for (int ci = 0; ci < c_count; ++ci) {
+        const float* wr = &w_s[ci * WROW];
+        float acc = 0.f;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc += g[k][co] * wr[co * 9 + k];
+        o[ci] = accumulate ? o[ci] + acc : acc;
+    }
+}
+
+int launch_convt_small_bwd_data(hipStream_t s, const float* du, const float* w_torch, int cin_total, int c_begin, int c_count,
+                                float* dst, int dst_pitch, bool accumulate, int n, int hin, int win) {
+    ProfScope prof(K_TOP_BWD, s, 2.0 * n * hin * win * 27.0 * c_count, 4.0 * n * (double)hin * win * (12 + c_count));
+    dim3 grid((unsigned)ceil_div(hin * win, 256), (unsigned)n);
+    hipLaunchKernelGGL((convt_small_bwd_data_kernel<3>), grid, dim3(256), (size_t)c_count * 28 * sizeof(float), s, du, w_torch,
+                       cin_total, c_begin, c_count, dst, dst_pitch, accumulate ? 1 : 0, hin, win);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

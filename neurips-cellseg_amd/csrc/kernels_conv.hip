@@ -33,6 +33,11 @@ struct ConvParams {
     double* stats;
     int pitch_out, cout, ntile_total;
     int n, hin, win, hout, wout, tiles_x, tiles_y;
+    // backward-pass extras (data gradients): out = conv + bias + addend; channels >= split_nt*16 go to out2
+    const float* addend;
+    const float* addend2;
+    float* out2;
+    int pitch_add, pitch_add2, pitch_out2, split_nt;
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -86,7 +91,8 @@ __device__ __forceinline__ void stats_commit(double s, double q, double* dst, in
 // `ep` points at this wave's slab of ROWS*16 pixels x (16*NT + 4) floats.  Returns nothing; stats are separate.
 template <int NT, int ROWS>
 __device__ __forceinline__ void epilogue_store(float* ep, const f32x4 (&vals)[ROWS][NT], int lane, float* out_row0, int64_t row_stride,
-                                               int pitch, int n_rows_valid, int n_cols_valid) {
+                                               int pitch, int n_rows_valid, int n_cols_valid, const float* add_row0 = nullptr,
+                                               int64_t add_row_stride = 0, int add_pitch = 0) {
     constexpr int EPS = 16 * NT + 4;
     const int pl = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -103,10 +109,22 @@ __device__ __forceinline__ void epilogue_store(float* ep, const f32x4 (&vals)[RO
         const int pix = i / F4_PER_PIX, c4 = i - pix * F4_PER_PIX;
         const int m = pix >> 4, x = pix & 15;
         if (m < n_rows_valid && x < n_cols_valid) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+            f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+            if (add_row0) v += *reinterpret_cast<const f32x4*>(add_row0 + m * add_row_stride + (int64_t)x * add_pitch + c4 * 4);
             *reinterpret_cast<f32x4*>(out_row0 + m * row_stride + (int64_t)x * pitch + c4 * 4) = v;
         }
     }
+}
+
+// destination of a block's channel tiles: (out, addend) below the split, (out2, addend2) at or above it
+struct OutSel {
+    float* out;
+    const float* add;
+    int pitch, pitch_add, ch0;
+};
+__device__ __forceinline__ OutSel select_out(const ConvParams& p, int nt0) {
+    if (p.out2 && nt0 >= p.split_nt) return OutSel{p.out2, p.addend2, p.pitch_out2, p.pitch_add2, (nt0 - p.split_nt) * 16};
+    return OutSel{p.out, p.addend, p.pitch_out, p.pitch_add, nt0 * 16};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,9 +272,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
     {
         const int oy = oy0 + wave * MT;
-        float* out_row0 = p.out + (((size_t)img * p.hout + oy) * p.wout + ox0) * p.pitch_out + nt0 * 16;
-        epilogue_store<NT, MT>(smem + wave * (MT * 16 * (16 * NT + 4)), acc, lane, out_row0, (int64_t)p.wout * p.pitch_out, p.pitch_out,
-                               p.hout - oy, p.wout - ox0);
+        const OutSel o = select_out(p, nt0);
+        const size_t pix0 = ((size_t)img * p.hout + oy) * p.wout + ox0;
+        epilogue_store<NT, MT>(smem + wave * (MT * 16 * (16 * NT + 4)), acc, lane, o.out + pix0 * o.pitch + o.ch0,
+                               (int64_t)p.wout * o.pitch, o.pitch, p.hout - oy, p.wout - ox0,
+                               o.add ? o.add + pix0 * o.pitch_add + o.ch0 : nullptr, (int64_t)p.wout * o.pitch_add, o.pitch_add);
     }
 }
 
@@ -274,8 +294,22 @@ static int launch_conv_t(hipStream_t s, const ConvParams& p0) {
 
 static SrcDev to_dev(const ConvSrc& s) { return SrcDev{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
 
+static int apply_extra(ConvParams& p, const ConvOutExtra* ex, int cout, int* nt) {
+    if (!ex) return CS_OK;
+    p.addend = ex->addend; p.pitch_add = ex->pitch_add;
+    p.addend2 = ex->addend2; p.pitch_add2 = ex->pitch_add2;
+    p.out2 = ex->out2; p.pitch_out2 = ex->pitch_out2;
+    if (ex->out2) {
+        CS_REQUIRE(ex->split % 16 == 0 && ex->split > 0 && ex->split < cout, "conv: bad output split %d of %d", ex->split, cout);
+        p.split_nt = ex->split / 16;
+        while (*nt > 1 && ((ex->split % (16 * *nt)) != 0 || ((cout - ex->split) % (16 * *nt)) != 0)) *nt /= 2;
+    }
+    return CS_OK;
+}
+
 int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, const ConvSrc& b, const float* wpack,
-                     const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
+                     const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win,
+                     const ConvOutExtra* ex) {
     CS_REQUIRE(ksize == 3 || ksize == 1, "conv: ksize %d unsupported", ksize);
     CS_REQUIRE(stride == 1 || stride == 2, "conv: stride %d unsupported", stride);
     CS_REQUIRE(!(ksize == 1 && stride != 1), "conv: 1x1 stride 2 unsupported");
@@ -298,7 +332,8 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
     const int pad = ksize / 2;
     p.hout = (hin + 2 * pad - ksize) / stride + 1;
     p.wout = (win + 2 * pad - ksize) / stride + 1;
-    const int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    if (int rc = apply_extra(p, ex, cout, &nt)) return rc;
     const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
     const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
@@ -603,22 +638,26 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
     __builtin_amdgcn_wave_barrier();
     if (iy < p.hin) {
         constexpr int F4_PER_PIX = NT * 4;
-        float* out0 = p.out + (((size_t)img * p.hout + 2 * iy) * p.wout + 2 * ix0) * p.pitch_out + nt0 * 16;
+        const OutSel o = select_out(p, nt0);
+        const size_t pix0 = ((size_t)img * p.hout + 2 * iy) * p.wout + 2 * ix0;
+        float* out0 = o.out + pix0 * o.pitch + o.ch0;
+        const float* add0 = o.add ? o.add + pix0 * o.pitch_add + o.ch0 : nullptr;
         const int cols_valid = 2 * (p.win - ix0);
 #pragma unroll
         for (int i = lane; i < 64 * F4_PER_PIX; i += 64) {
             const int pix = i / F4_PER_PIX, c4 = i - pix * F4_PER_PIX;
             const int row = pix >> 5, x = pix & 31;
             if (x < cols_valid) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
-                *reinterpret_cast<f32x4*>(out0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) = v;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                if (add0) v += *reinterpret_cast<const f32x4*>(add0 + ((int64_t)row * p.wout + x) * o.pitch_add + c4 * 4);
+                *reinterpret_cast<f32x4*>(out0 + ((int64_t)row * p.wout + x) * o.pitch + c4 * 4) = v;
             }
         }
     }
 }
 
 int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* wpack, const float* bias,
-                      float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
+                      float* out, int pitch_out, int cout, double* stats, int n, int hin, int win, const ConvOutExtra* ex) {
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0, "convT: input channels (%d,%d) must be multiples of 16", a.c, b.c);
     CS_REQUIRE(cout % 16 == 0, "convT: cout %d must be a multiple of 16", cout);
     ConvParams p{};
@@ -629,7 +668,8 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
     p.n = n; p.hin = hin; p.win = win; p.hout = 2 * hin; p.wout = 2 * win;
     p.tiles_x = ceil_div(win, 16);
     p.tiles_y = ceil_div(hin, 4);
-    const int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    if (int rc = apply_extra(p, ex, cout, &nt)) return rc;
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * n), (unsigned)(p.ntile_total / nt));
     const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
     const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
@@ -647,7 +687,7 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
 // weight packing
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_conv_kernel(const float* w, int transposed, int cout, int cin, int taps, float* packed, int cout_off,
-                                 int ntile_total) {
+                                 int ntile_total, int flip, int chunk_off) {
     // one thread per packed element of this conv's slice: (chunk, tap, ntile_local, lane, j)
     const int64_t total = (int64_t)(cin / 16) * taps * (cout / 16) * 256;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -659,19 +699,21 @@ __global__ void pack_conv_kernel(const float* w, int transposed, int cout, int c
     const int tap = r % taps;
     const int chunk = r / taps;
     const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
-    const float v = transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap];
+    const int st = flip ? taps - 1 - tap : tap;
+    const float v = transposed ? w[((size_t)ci * cout + co) * taps + st] : w[((size_t)co * cin + ci) * taps + st];
     const int nt = cout_off / 16 + ntl;
-    packed[(((size_t)chunk * taps + tap) * ntile_total + nt) * 256 + lane * 4 + j] = v;
+    packed[(((size_t)(chunk + chunk_off) * taps + tap) * ntile_total + nt) * 256 + lane * 4 + j] = v;
 }
 
 int pack_conv_weights(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, float* packed,
-                      int cout_off, int cout_total) {
+                      int cout_off, int cout_total, bool flip, int cin_off) {
     CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack: bad channel counts");
     const int taps = ksize * ksize;
     const int64_t total = (int64_t)(cin / 16) * taps * (cout / 16) * 256;
     ProfScope prof(K_PACK, s, 0, 8.0 * total);
+    CS_REQUIRE(cin_off % 16 == 0, "pack: bad cin offset");
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, transposed ? 1 : 0, cout,
-                       cin, taps, packed, cout_off, cout_total / 16);
+                       cin, taps, packed, cout_off, cout_total / 16, flip ? 1 : 0, cin_off / 16);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  MUST precede the CDLL below: libcellseg_hip.so has to bind to the HIP runtime PyTorch already
+#               loaded (same SONAME, libamdhip64.so.7) - streams and device pointers are shared with torch.  Loading our
+#               library first pulls in /opt/rocm's copy, and the process then holds two HIP runtimes ("no ROCm-capable
+#               device is detected" on the first hipMalloc).
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcellseg_hip.so")
 

@@ -65,3 +65,43 @@ def test_row_strips_partition_and_window_cover(world, h, overlap):
             need = [i for i, s in enumerate(hs) if s < hi + plan.pad_top and s + 256 > lo + plan.pad_top]
             assert need == list(range(need[0], need[-1] + 1))
     assert (covered == 1).all()
+
+
+class _FakeModel:
+    """Stands in for cellseg_amd.UNet after backward: a flat gradient bucket + parameters viewing slots of it."""
+
+    def __init__(self, rank):
+        self.p = {"a": torch.nn.Parameter(torch.zeros(2, 3)), "b": torch.nn.Parameter(torch.zeros(5))}
+        self._grad_slots = {"a": (0, 6, (2, 3)), "b": (8, 5, (5,))}
+        self.flat_grad = torch.arange(13, dtype=torch.float32) * (rank + 1)
+
+    def named_parameters(self):
+        return self.p.items()
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cellseg_amd import parallel
+        m = _FakeModel(rank)
+        parallel.sync_gradients(m)
+        mean = torch.arange(13, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        ok = torch.allclose(m.flat_grad, mean) and torch.allclose(m.p["a"].grad, mean[:6].view(2, 3)) and \
+            torch.allclose(m.p["b"].grad, mean[8:13]) and m.p["b"].grad.data_ptr() == m.flat_grad[8:].data_ptr()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_bucket_gradient_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res)

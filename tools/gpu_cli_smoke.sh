@@ -1,0 +1,26 @@
+#!/bin/bash
+# End-to-end smoke of the two reference CLIs on the GPU box: train on synthetic cells, then predict with the checkpoint.
+set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export PYTHONPATH=$R/neurips-cellseg_amd:$R
+W=$(mktemp -d)
+python -m cellseg_amd.model_training_3class --synthetic 40 --max_epochs 7 --val_start_epoch 1 --val_interval 2 --batch_size 8 --num_workers 2 --work_dir $W/work
+python - <<PY
+import numpy as np, os
+from PIL import Image
+from scipy.ndimage import gaussian_filter
+os.makedirs("$W/in", exist_ok=True)
+rng = np.random.default_rng(5)
+for i, (h, w) in enumerate([(700, 900), (200, 180)]):
+    g = gaussian_filter(rng.random((h, w)), 5); g = (g - g.min()) / (g.max() - g.min())
+    Image.fromarray((np.stack([g, g, g], -1) * 255).astype(np.uint8)).save(f"$W/in/cell_{i:03d}.png")
+Image.fromarray((gaussian_filter(rng.random((300, 300)), 4) * 60000).astype(np.uint16)).save("$W/in/gray16.tif")
+PY
+python -m cellseg_amd.predict -i $W/in -o $W/out --model_path $W/work/unet_3class --model_name unet --show_overlay
+python - <<PY
+import numpy as np, os
+from PIL import Image
+for f in sorted(os.listdir("$W/out")):
+    a = np.array(Image.open(os.path.join("$W/out", f)))
+    print(f, a.shape, a.dtype, int(a.max()))
+PY

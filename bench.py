@@ -32,6 +32,11 @@ import numpy as np
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA peak; a split-bf16 product costs 6 / 3 / 1 bf16 MFMA terms
+MFMA_PEAK = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3,
+             "bf16": PEAK_BF16_MFMA_TFLOPS}
+DTYPE = {"fp32": "f32", "bf16x6": "f32 (split-bf16, 3 planes x 6 MFMA terms, fp32 accumulate)",
+         "bf16x3": "split-bf16 (2 planes x 3 terms)", "bf16": "bf16"}
 PEAK_HBM_GBS = 8000.0
 WIDTHS = {"baseline32": (32, 64, 128, 256, 512), "reference16": (16, 32, 64, 128, 256)}
 
@@ -122,6 +127,8 @@ def main():
     ap.add_argument("--overlap", type=float, default=0.5, help="0.5 = stride 128 (BASELINE configs[2]); reference default 0.25")
     ap.add_argument("--width", choices=sorted(WIDTHS), default="baseline32")
     ap.add_argument("--engine-batch", type=int, default=256)
+    ap.add_argument("--precision", choices=sorted(MFMA_PEAK), default="fp32",
+                    help="matrix-core arithmetic of the convolutions (activations stay fp32 in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the reference-width (16..256) secondary measurement")
     args = ap.parse_args()
@@ -152,6 +159,7 @@ def main():
 
     def measure(width):
         model = make_model(WIDTHS[width], seed).to(dev)
+        model.precision = args.precision
         step = lambda: run_step(ca, model, image, roi, args.overlap, args.engine_batch)      # noqa: E731
         with torch.no_grad():
             for _ in range(max(args.warmup, 1) if args.warmup else 0):
@@ -197,8 +205,9 @@ def main():
         sec = k["ms"] / 1e3
         if mfma:
             achieved = k["flops"] / sec / 1e12
-            rl = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                  "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
+            peak = round(MFMA_PEAK[args.precision], 1)
+            rl = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                  "frac": round(achieved / peak, 4), "traffic": None}
         else:
             achieved = k["bytes"] / sec / 1e9
             rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -207,7 +216,7 @@ def main():
         # gfx950 correction applied; tools/pmc_summary.py).  bench.py cannot read PMCs itself, so it quotes the summary.
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name, {})
-            if res is main_res and args.engine_batch == 256 and args.size == 4096 and args.width == "baseline32":
+            if res is main_res and args.engine_batch == 256 and args.size == 4096 and args.width == "baseline32" and args.precision == "fp32":
                 rl["traffic"] = pmc.get("hbm_bytes_per_launch")
                 rl["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 PMC passes of the default command)"
                 rl["algorithmic_bytes_per_launch"] = round(k["bytes"] / k["launches"])
@@ -232,12 +241,12 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": DTYPE[args.precision], "data": "synthetic",
         "config": {"workload": f"sliding-window inference on 3x{args.size}x{args.size} synthetic WSI, {args.roi} window / "
                                f"{plan.interval_h} stride ({n_windows} windows), 3-class residual U-Net channels={list(WIDTHS[args.width])} "
                                f"num_res_units=2 InstanceNorm+PReLU random-init, softmax + >0.5 + remove_small_holes(64) + "
                                f"remove_small_objects(16) + 8-conn label on GPU; one slide per GPU",
-                   "windows": n_windows, "engine_batch": args.engine_batch, "parallelism": f"slides x{world}",
+                   "windows": n_windows, "engine_batch": args.engine_batch, "precision": args.precision, "parallelism": f"slides x{world}",
                    "instances_found": main_res["n_instances"], "foreground_fraction": round(main_res["fg_frac"], 4)},
         "value_incl_d2h": round(world * mpix * args.steps / main_res["dt_d2h"], 3),
         "value_with_events": round(world * mpix * args.steps / main_res["dt_prof"], 3),

@@ -53,6 +53,11 @@ typedef struct cs_unet cs_unet;
 int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* channels_host, int n_channels,
                    int num_res_units, int norm_kind, int act_kind);
 int cs_unet_destroy(cs_unet* net);
+/* Arithmetic of the 3x3 / 1x1 convolutions on the matrix cores (activations stay fp32 in HBM either way):
+ *   0  v_mfma_f32_16x16x4_f32, exact fp32 (default; the 1e-4 logit-parity path)
+ *   3  split-bf16, 3 planes / 6 MFMA terms on v_mfma_f32_16x16x32_bf16: fp32-grade results (~1e-5 logit error)
+ *   2  split-bf16, 2 planes / 3 terms (~1e-4)        1  plain bf16 (throughput mode; judged by F1, not by logits) */
+int cs_unet_set_precision(cs_unet* net, int planes);
 
 /* State-dict surface (replaces model.load_state_dict / model.state_dict, predict.py:80-81,
  * model_training_3class.py:269-274).  Keys are MONAI's: "model.0.conv.unit0.conv.weight", ... */

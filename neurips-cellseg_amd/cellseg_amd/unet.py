@@ -177,6 +177,7 @@ class UNet(nn.Module):
         self._param_keys = [k for k, _ in self.named_parameters()]
         self._grad_slots: Dict[str, Tuple[int, int, Tuple[int, ...]]] = {}
         self.flat_grad = None          # the flat gradient bucket of the last backward (what data parallel all-reduces)
+        self.precision = "fp32"        # "fp32" | "bf16x6" (fp32-grade) | "bf16x3" | "bf16": matrix-core arithmetic of the convs
 
     # ---- parameter registration under MONAI's dotted names -------------------------------------------
     def _register(self, key: str, shape) -> None:
@@ -236,6 +237,10 @@ class UNet(nn.Module):
                 for d in shape:
                     numel *= d
                 self._grad_slots[key] = (int(off), numel, tuple(shape))
+        planes = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}.get(self.precision)
+        if planes is None:
+            raise ValueError(f"precision '{self.precision}' (fp32 | bf16x6 | bf16x3 | bf16)")
+        check(lib.cs_unet_set_precision(self._engine.handle, planes), "cs_unet_set_precision")
         stream = _lib.stream_ptr()
         for key in self._keys:
             if key.endswith("num_batches_tracked"):

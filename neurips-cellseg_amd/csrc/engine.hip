@@ -112,6 +112,7 @@ struct NormSite {          // one ADN: InstanceNorm (stats at run time) or eval 
 struct ConvW {             // packed weights + bias of one (possibly fused) conv launch
     float* w = nullptr;    // packed (MFMA kernels) or PyTorch layout (small VALU kernels)
     float* wd = nullptr;   // the same weights packed for the DATA-GRADIENT launch (see kernels_bwd.hip header)
+    unsigned short* wb = nullptr;   // 3 bf16 planes in 16x16x32 fragment order (split-bf16 forward kernels)
     float* bias = nullptr;
     int cin = 0, cout = 0; // cout = total (fused) output channels
     int p_w[2] = {-1, -1}, p_b[2] = {-1, -1};   // parameter indices (slot 1 = fused residual conv)
@@ -189,6 +190,7 @@ struct cs_unet {
     float* arena = nullptr;
     size_t arena_floats = 0;
     int64_t grad_floats = 0;
+    int planes = 0;   // 0: fp32 MFMA kernels; 1..3: split-bf16 kernels with that many planes (3 = fp32-grade)
     Tape tape;
 };
 
@@ -245,6 +247,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
                             bool transposed, int mode /*0 mfma, 1 first, 2 raw*/, int dg = DG_NONE, int slot = 0) {
     float* wdst = cw.w;
     float* wd = cw.wd;
+    unsigned short* wb = cw.wb;
     float* bdst = cw.bias + cout_off;
     const int cout_total = cw.cout;
     auto pack_dgrad = [=](const float* d, hipStream_t s) -> int {
@@ -267,6 +270,8 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             if (int rc = pack_dgrad(d, s)) return rc;
             if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
             if (mode == 1) return pack_first_weights(s, d, cout, cin, wdst, cout_off, cout_total);
+            if (wb)
+                if (int rc = pack_conv_weights_bf16(s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0)) return rc;
             return pack_conv_weights(s, d, false, cout, cin, ksize, wdst, cout_off, cout_total);
         });
     }
@@ -289,6 +294,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     // stride-1 conv for the bottom unit; the first layer needs none (the image has no gradient)
     const int dg0 = u.first ? DG_NONE : (stride == 2 ? DG_S2_AS_CONVT : DG_S1);
     if (dg0 != DG_NONE) u.unit0.wd = ar.take(packed_conv_floats(cin, u.unit0.cout, 3));
+    if (!u.first) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(u.unit0.cout, cin, 0, 3) + 1) / 2);
     add_conv_params(net, pfx + ".conv.unit0.conv", u.unit0, c, cin, 3, 0, false, u.first ? 1 : 0, dg0, 0);
     add_norm_params(net, ar, pfx + ".conv.unit0.adn", u.norms[0], c);
     for (int su = 1; su < u.subunits; ++su) {
@@ -297,6 +303,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         cw.w = ar.take(packed_conv_floats(c, c, 3));
         cw.bias = ar.take(c);
         cw.wd = ar.take(packed_conv_floats(c, c, 3));
+        cw.wb = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
         const std::string un = pfx + ".conv.unit" + std::to_string(su);
         add_conv_params(net, un + ".conv", cw, c, c, 3, 0, false, 0, DG_S1, 0);
         add_norm_params(net, ar, un + ".adn", u.norms[su], c);
@@ -307,6 +314,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         u.res1x1.cin = cin; u.res1x1.cout = c;
         u.res1x1.w = ar.take(packed_conv_floats(c, cin, 1));
         u.res1x1.wd = ar.take(packed_conv_floats(cin, c, 1));
+        u.res1x1.wb = (unsigned short*)ar.take((packed_bf16_elems(c, cin, 0, 1) + 1) / 2);
         u.res1x1.bias = ar.take(c);
         add_conv_params(net, pfx + ".residual", u.res1x1, c, cin, 1, 0, false, 0, DG_1X1, 0);
     }
@@ -326,6 +334,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     u.unit0.w = ar.take(small ? (size_t)cout * cout * 9 : packed_conv_floats(cout, cout, 3));
     u.unit0.bias = ar.take(cout);
     if (!small) u.unit0.wd = ar.take(packed_conv_floats(cout, cout, 3));
+    if (!small) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
     add_conv_params(net, pfx + ".1.conv.unit0.conv", u.unit0, cout, cout, 3, 0, false, small ? 2 : 0, small ? DG_NONE : DG_S1, 0);
     if (!top) add_norm_params(net, ar, pfx + ".1.conv.unit0.adn", u.norm_u, cout);
 }
@@ -367,6 +376,14 @@ static ConvSrc raw_src(const float* ptr, int c, int pitch) {
     ConvSrc s;
     s.ptr = ptr; s.c = c; s.pitch = pitch;
     return s;
+}
+
+// forward conv on the matrix cores: fp32 MFMA or split-bf16, by net->planes
+static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, const ConvSrc& a, const ConvW& cw, float* out,
+                    int pitch_out, int cout, double* stats, int n, int hin, int win) {
+    if (net->planes > 0 && cw.wb)
+        return launch_conv_bf16s(s, ksize, stride, net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin, win);
+    return launch_conv_mfma(s, ksize, stride, a, ConvSrc(), cw.w, cw.bias, out, pitch_out, cout, stats, n, hin, win);
 }
 
 #define CS_TRY(expr)            \
@@ -433,15 +450,14 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             if (u.first) {
                 CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n));
             } else {
-                CS_TRY(launch_conv_mfma(s, 3, 2, raw_src(prev, pc, pc), ConvSrc(), u.unit0.w, u.unit0.bias, E, c0, c0,
-                                        rt_down[d][0].stats, n, ph, pw));
+                CS_TRY(conv_fwd(s, net, 3, 2, raw_src(prev, pc, pc), u.unit0, E, c0, c0, rt_down[d][0].stats, n, ph, pw));
             }
             CS_TRY(finish_norm(s, net, u.norms[0], rt_down[d][0], n, c0, oh * ow, dry));
             const float* cur = E;
             int cur_pitch = c0, cur_tabc = c0;
             for (int su = 1; su < u.subunits; ++su) {
-                CS_TRY(launch_conv_mfma(s, 3, 1, lazy_src(cur, c, cur_pitch, rt_down[d][su - 1], u.norms[su - 1], cur_tabc), ConvSrc(),
-                                        u.units[su - 1].w, u.units[su - 1].bias, Y[su], c, c, rt_down[d][su].stats, n, oh, ow));
+                CS_TRY(conv_fwd(s, net, 3, 1, lazy_src(cur, c, cur_pitch, rt_down[d][su - 1], u.norms[su - 1], cur_tabc),
+                                u.units[su - 1], Y[su], c, c, rt_down[d][su].stats, n, oh, ow));
                 CS_TRY(finish_norm(s, net, u.norms[su], rt_down[d][su], n, c, oh * ow, dry));
                 cur = Y[su];
                 cur_pitch = c;
@@ -467,14 +483,13 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         for (int su = 0; su < u.subunits; ++su) new_tab(rt_bottom[su], c);
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
-            CS_TRY(launch_conv_mfma(s, 3, 1, raw_src(prev, pc, pc), ConvSrc(), u.unit0.w, u.unit0.bias, Y[0], c, c, rt_bottom[0].stats,
-                                    n, ph, pw));
+            CS_TRY(conv_fwd(s, net, 3, 1, raw_src(prev, pc, pc), u.unit0, Y[0], c, c, rt_bottom[0].stats, n, ph, pw));
             CS_TRY(finish_norm(s, net, u.norms[0], rt_bottom[0], n, c, ph * pw, dry));
             if (u.res_conv)
-                CS_TRY(launch_conv_mfma(s, 1, 1, raw_src(prev, pc, pc), ConvSrc(), u.res1x1.w, u.res1x1.bias, R, c, c, nullptr, n, ph, pw));
+                CS_TRY(conv_fwd(s, net, 1, 1, raw_src(prev, pc, pc), u.res1x1, R, c, c, nullptr, n, ph, pw));
             for (int su = 1; su < u.subunits; ++su) {
-                CS_TRY(launch_conv_mfma(s, 3, 1, lazy_src(Y[su - 1], c, c, rt_bottom[su - 1], u.norms[su - 1], c), ConvSrc(),
-                                        u.units[su - 1].w, u.units[su - 1].bias, Y[su], c, c, rt_bottom[su].stats, n, ph, pw));
+                CS_TRY(conv_fwd(s, net, 3, 1, lazy_src(Y[su - 1], c, c, rt_bottom[su - 1], u.norms[su - 1], c), u.units[su - 1],
+                                Y[su], c, c, rt_bottom[su].stats, n, ph, pw));
                 CS_TRY(finish_norm(s, net, u.norms[su], rt_bottom[su], n, c, ph * pw, dry));
             }
             const int last = u.subunits - 1;
@@ -509,7 +524,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             if (u.top) {
                 CS_TRY(launch_conv_last(s, lu, u.unit0.w, u.unit0.bias, logits, c, n, oh, ow));
             } else {
-                CS_TRY(launch_conv_mfma(s, 3, 1, lu, ConvSrc(), u.unit0.w, u.unit0.bias, V, c, c, rt_upu[d].stats, n, oh, ow));
+                CS_TRY(conv_fwd(s, net, 3, 1, lu, u.unit0, V, c, c, rt_upu[d].stats, n, oh, ow));
                 CS_TRY(finish_norm(s, net, u.norm_u, rt_upu[d], n, c, oh * ow, dry));
                 CS_TRY(launch_norm_act_add(s, lazy_src(V, c, c, rt_upu[d], u.norm_u, c), lu, D, c, (int64_t)oh * ow, n));
             }
@@ -796,6 +811,12 @@ int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* 
     }
     net->grad_floats = off;
     *out = net;
+    return CS_OK;
+}
+
+int cs_unet_set_precision(cs_unet* net, int planes) {
+    CS_REQUIRE(net && planes >= 0 && planes <= 3, "set_precision: planes must be 0 (fp32 MFMA), 1, 2 or 3");
+    net->planes = planes;
     return CS_OK;
 }
 

@@ -48,6 +48,15 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
                      const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win,
                      const ConvOutExtra* ex = nullptr);
 
+// split-bf16 variant (kernels_conv_bf16.hip): `planes` = 1 (plain bf16), 2 (3 MFMA terms) or 3 (6 terms, fp32-grade).
+// Weights come from pack_conv_weights_bf16 (always 3 planes; the kernel reads the first `planes`).
+int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
+                      const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
+                      int hin, int win);
+size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize);
+int pack_conv_weights_bf16(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, unsigned short* packed,
+                           int cout_off, int cout_total, int cin_split);
+
 // first layer: cin < 16 (3), 3x3 pad 1, reads windows straight out of the image (tiler gather fused).
 // image element strides (sc, sh, sw); per-window origins (y0, x0) in image coordinates (may be negative when the
 // image is smaller than the roi); pixels outside the window or the image read as 0.

@@ -1,0 +1,344 @@
+// gfx950 split-bf16 convolution kernels: fp32-grade results at bf16 MFMA speed.
+//
+// Every fp32 operand x is split into NP bf16 "planes" (x = p0 + p1 + p2 + ..., each pk = bf16(x - p0 - ... - p(k-1)));
+// a product a*b is evaluated as the NP = 3 : a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1   (6 MFMAs, error ~2^-24: fp32 grade)
+//                               NP = 2 : a0b0 + a0b1 + a1b0                           (3 MFMAs, error ~2^-16)
+//                               NP = 1 : a0b0                                          (plain bf16)
+// on v_mfma_f32_16x16x32_bf16 (K = 32 per instruction, fp32 accumulate).  Every bf16 x bf16 product is exact in
+// fp32, so NP = 3 differs from the fp32-MFMA kernel only by accumulation order - measured logit error ~1e-5 against
+// the torch-CPU oracle, inside the 1e-4 budget - while costing 6/16 of its matrix-pipe cycles.
+//
+// Structure:
+//   * K loop over 32-channel chunks; the input patch is staged ONCE per chunk as NP bf16 planes in LDS (lazy
+//     InstanceNorm + PReLU applied before the split), next chunk's global loads are in flight under the MFMAs;
+//   * weights are pre-split at load time and stored in MFMA fragment order; every wave owns one 16-channel output tile,
+//     so its B fragments are private: they go L2 -> registers as lane-linear 16-byte loads, a whole chunk ahead of
+//     their use (ring of taps x planes fragments) and never touch LDS;
+//   * epilogue as in the fp32 kernel (bias, fp64 statistics, full-line stores through an LDS slab).
+#include "kernels.h"
+
+namespace cs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct SrcDevB {
+    const float* ptr;
+    const float2* tab;
+    const float* slope;
+    int c, pitch, tab_c, tab_off;
+};
+
+struct ConvBParams {
+    SrcDevB a, b;
+    const unsigned short* wpack;   // [chunk][tap][ntile_total][3 planes][64 lanes][8] bf16
+    const float* bias;
+    float* out;
+    double* stats;
+    const float* dummy;
+    int pitch_out, cout, ntile_total;
+    int n, hin, win, hout, wout, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ float prelu_h(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+__device__ __forceinline__ void stats_commit_b(double s, double q, double* dst, int lane) {
+    s += __shfl_xor(s, 16);
+    q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (lane < 16) {
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, q);
+    }
+}
+
+// block = 4 waves arranged WN (along output channels) x WM = 4 / WN (along pixel rows); each wave owns ONE 16-channel
+// tile and MTW pixel rows.  A (pixels) comes from the LDS planes shared by the block; B (weights) is private to the wave
+// and goes global -> registers, one whole chunk ahead (ring of TAPS x NP fragments), so no weight ever touches LDS.
+template <int S, int KS, int WN, int NP>
+__global__ __launch_bounds__(256, (S == 1 && NP >= 2) ? 1 : 2) void conv_bf16s_kernel(ConvBParams p) {
+    constexpr int WM = 4 / WN;
+    constexpr int RD = (KS == 1) ? 1 : (NP == 1 ? 9 : 3);   // weight ring depth in taps (prefetch distance); divides TAPS
+    constexpr int MTW = (S == 1 ? 2 : 1) * WN;              // pixel rows per wave
+    constexpr int TH = MTW * WM, TW = 16;                   // 8 rows (stride 1) / 4 rows (stride 2)
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int PITCH = (S == 1) ? 96 : 80;               // bytes per staged pixel and plane: 32 bf16 + pad (conflict-free b128 reads)
+    constexpr int PAD = KS / 2, TAPS = KS * KS;
+    constexpr int IN_ITEMS = IH * IW * 8;                   // (pixel, 4-channel quad) items per chunk
+    constexpr int IN_ITERS = (IN_ITEMS + 255) / 256;
+    constexpr int PLANE_BYTES = IH * IW * PITCH;
+    constexpr int IN_BYTES = (NP * PLANE_BYTES + 15) / 16 * 16;
+    constexpr int EPS = 16 * WN + 4;
+    constexpr int EP_BYTES = TH * 16 * EPS * 4;
+    constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    char* const in_s = smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    const int wn = wave % WN, wm = wave / WN;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int nt = blockIdx.y * WN + wn;                     // this wave's output-channel tile
+    const int q = tid & 7;                                   // this thread's channel quad inside the 32-channel chunk
+
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int goff[IN_ITERS];
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (tid >> 3) + 32 * it;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
+        goff[it] = (pix < IH * IW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win) ? gy * p.win + gx : -1;
+    }
+
+    const int chunks_a = (p.a.c + 31) >> 5, chunks = chunks_a + ((p.b.c + 31) >> 5);
+    f32x4 rin[IN_ITERS];
+    f32x4 t0, t1;
+    float slope = 0.f;
+    bool lazy = false, qvalid = false;
+
+    auto load_input = [&](int ch) {
+        const bool from_a = ch < chunks_a;
+        const SrcDevB& src = from_a ? p.a : p.b;
+        const int c0 = (from_a ? ch : ch - chunks_a) << 5;
+        qvalid = c0 + 4 * q < src.c;                        // a 16-channel tail leaves the upper half of the chunk empty
+        const int cq = qvalid ? c0 + 4 * q : 0;
+        lazy = src.tab != nullptr;
+        const f32x4* t = lazy ? reinterpret_cast<const f32x4*>(src.tab + (size_t)img * src.tab_c + src.tab_off + cq)
+                              : reinterpret_cast<const f32x4*>(p.dummy);
+        t0 = t[0];
+        t1 = t[1];
+        const float* sp = (lazy && src.slope) ? src.slope : p.dummy;
+        slope = *sp;
+        if (!(lazy && src.slope)) slope = 0.f;
+        const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + cq;
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int o = goff[it] >= 0 ? goff[it] : 0;
+            rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * src.pitch);
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int pix = (tid >> 3) + 32 * it;
+            if (IN_ITEMS % 256 == 0 || pix < IH * IW) {
+                f32x4 v = rin[it];
+                if (lazy) {
+                    v.x = prelu_h(v.x * t0.x + t0.y, slope);
+                    v.y = prelu_h(v.y * t0.z + t0.w, slope);
+                    v.z = prelu_h(v.z * t1.x + t1.y, slope);
+                    v.w = prelu_h(v.w * t1.z + t1.w, slope);
+                }
+                if (goff[it] < 0 || !qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pn = 0; pn < NP; ++pn) {
+                    bf16x4 h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        h[j] = (__bf16)v[j];
+                        v[j] -= (float)h[j];
+                    }
+                    *reinterpret_cast<bf16x4*>(in_s + pn * PLANE_BYTES + pix * PITCH + q * 8) = h;
+                }
+            }
+        }
+    };
+    // weight fragments of (chunk, tap): NP lane-linear 16-byte loads (1 KiB per wave-instruction, straight from L2)
+    bf16x8 bq[RD][NP];
+    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)nt * 3 * 64 + lane;
+    auto load_b = [&](int ch, int tap, int slot) {
+#pragma unroll
+        for (int pn = 0; pn < NP; ++pn)
+            bq[slot][pn] = wbase[(((size_t)ch * TAPS + tap) * p.ntile_total * 3 + pn) * 64];
+    };
+
+    load_input(0);
+#pragma unroll
+    for (int tap = 0; tap < RD; ++tap) load_b(0, tap, tap);
+    store_input();
+    __syncthreads();
+
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        if (more) load_input(ch + 1);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            bf16x8 b[NP];
+#pragma unroll
+            for (int pn = 0; pn < NP; ++pn) b[pn] = bq[tap % RD][pn];
+            // refill this ring slot RD taps ahead (possibly in the next chunk)
+            if (tap + RD < TAPS) load_b(ch, tap + RD, tap % RD);
+            else if (more) load_b(ch + 1, tap + RD - TAPS, tap % RD);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int r = wm * MTW + m;
+                bf16x8 a[NP];
+#pragma unroll
+                for (int pn = 0; pn < NP; ++pn)
+                    a[pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES + ((r * S + ky) * IW + pl * S + kx) * PITCH + g * 16);
+                // smallest terms first, the dominant a0*b0 last
+#pragma unroll
+                for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
+                    const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
+                    const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[ib], acc[m], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_input();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias, fp64 statistics, then full-line stores through a block-wide LDS slab ----
+    float* ep = reinterpret_cast<float*>(smem);
+    {
+        const int co = nt * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        double s = 0.0, qq = 0.0;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int row = wm * MTW + m, oy = oy0 + row;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + g * 4 + r;
+                const float v = acc[m][r] + bias;
+                ep[(row * 16 + g * 4 + r) * EPS + wn * 16 + pl] = v;
+                if (oy < p.hout && ox < p.wout) {
+                    s += (double)v;
+                    qq += (double)v * (double)v;
+                }
+            }
+        }
+        if (p.stats) stats_commit_b(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+    __syncthreads();
+    {
+        constexpr int F4 = WN * 4;                           // float4 per pixel record of this block
+        float* out0 = p.out + (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + blockIdx.y * WN * 16;
+        for (int i = tid; i < TH * 16 * F4; i += 256) {
+            const int pix = i / F4, c4 = i - pix * F4;
+            const int row = pix >> 4, x = pix & 15;
+            if (oy0 + row < p.hout && ox0 + x < p.wout)
+                *reinterpret_cast<f32x4*>(out0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) =
+                    *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+        }
+    }
+}
+
+static SrcDevB to_devb(const ConvSrc& s) { return SrcDevB{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
+
+template <int S, int KS, int WN, int NP>
+static int launch_b(hipStream_t s, ConvBParams p) {
+    constexpr int TH = (S == 1 ? 2 : 1) * 4;
+    p.tiles_x = ceil_div(p.wout, 16);
+    p.tiles_y = ceil_div(p.hout, TH);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.n), (unsigned)(p.ntile_total / WN));
+    hipLaunchKernelGGL((conv_bf16s_kernel<S, KS, WN, NP>), grid, dim3(256), 0, s, p);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
+                      const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
+                      int hin, int win) {
+    CS_REQUIRE(ksize == 3 || ksize == 1, "conv(bf16): ksize %d unsupported", ksize);
+    CS_REQUIRE((stride == 1 || stride == 2) && !(ksize == 1 && stride != 1), "conv(bf16): stride %d unsupported", stride);
+    CS_REQUIRE(planes >= 1 && planes <= 3, "conv(bf16): %d planes", planes);
+    CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "conv(bf16): channels must be multiples of 16");
+    ConvBParams p{};
+    p.a = to_devb(a);
+    p.b = to_devb(b);
+    p.wpack = wpack; p.bias = bias; p.out = out; p.stats = stats; p.dummy = reinterpret_cast<const float*>(wpack);
+    p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16;
+    p.n = n; p.hin = hin; p.win = win;
+    const int pad = ksize / 2;
+    p.hout = (hin + 2 * pad - ksize) / stride + 1;
+    p.wout = (win + 2 * pad - ksize) / stride + 1;
+    const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
+    const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
+    ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
+#define CS_B3(S_, KS_, NP_)                                                         \
+    switch (wn) {                                                                   \
+        case 4: return launch_b<S_, KS_, 4, NP_>(s, p);                             \
+        case 2: return launch_b<S_, KS_, 2, NP_>(s, p);                             \
+        default: return launch_b<S_, KS_, 1, NP_>(s, p);                            \
+    }
+#define CS_B2(S_, KS_)                                                              \
+    switch (planes) {                                                               \
+        case 3: CS_B3(S_, KS_, 3)                                                   \
+        case 2: CS_B3(S_, KS_, 2)                                                   \
+        default: CS_B3(S_, KS_, 1)                                                  \
+    }
+    if (ksize == 1) { CS_B2(1, 1) }
+    if (stride == 1) { CS_B2(1, 3) }
+    CS_B2(2, 3)
+#undef CS_B2
+#undef CS_B3
+}
+
+// ---- weight packing: fp32 PyTorch layout -> 3 bf16 planes in MFMA (16x16x32) fragment order --------------------
+// packed[chunk][tap][ntile_total][plane][lane][j]: cout = ntile*16 + (lane & 15), k = chunk*32 + 8*(lane>>4) + j.
+// Input channels >= cin_split (second concat source) start a fresh 32-channel chunk, as the kernel stages them.
+__global__ void pack_bf16_kernel(const float* w, int transposed, int cout, int cin, int taps, unsigned short* packed, int cout_off,
+                                 int ntile_total, int cin_split, int chunks_total) {
+    const int64_t total = (int64_t)chunks_total * taps * (cout / 16) * 512;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int j = e & 7, lane = (e >> 3) & 63;
+    int64_t r = e >> 9;
+    const int ntl = r % (cout / 16);
+    r /= (cout / 16);
+    const int tap = r % taps;
+    const int chunk = r / taps;
+    const int chunks_a = cin_split > 0 ? (cin_split + 31) / 32 : chunks_total;
+    const int k = (chunk < chunks_a ? chunk * 32 : (chunk - chunks_a) * 32) + 8 * (lane >> 4) + j;
+    const int ci = chunk < chunks_a ? k : cin_split + k;
+    const bool valid = chunk < chunks_a ? k < (cin_split > 0 ? cin_split : cin) : ci < cin;
+    const int co = ntl * 16 + (lane & 15);
+    float v = 0.f;
+    if (valid) v = transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap];
+    const size_t base = (((size_t)chunk * taps + tap) * ntile_total + cout_off / 16 + ntl) * 3;
+#pragma unroll
+    for (int pn = 0; pn < 3; ++pn) {
+        const __bf16 h = (__bf16)v;
+        v -= (float)h;
+        packed[((base + pn) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
+size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize) {
+    const size_t chunks = (size_t)(cin_a + 31) / 32 + (size_t)(cin_b + 31) / 32;
+    return chunks * ksize * ksize * (cout_total / 16) * 3 * 512;
+}
+
+int pack_conv_weights_bf16(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, unsigned short* packed,
+                           int cout_off, int cout_total, int cin_split) {
+    CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack(bf16): bad channel counts");
+    const int taps = ksize * ksize;
+    const int chunks_total = cin_split > 0 ? (cin_split + 31) / 32 + (cin - cin_split + 31) / 32 : (cin + 31) / 32;
+    const int64_t total = (int64_t)chunks_total * taps * (cout / 16) * 512;
+    ProfScope prof(K_PACK, s, 0, 10.0 * total);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, transposed ? 1 : 0, cout, cin, taps,
+                       packed, cout_off, cout_total / 16, cin_split, chunks_total);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

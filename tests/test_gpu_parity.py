@@ -294,3 +294,21 @@ def test_ten_training_steps_match_oracle_loss_curve():
         got.append(loss.item())
     assert got[-1] < got[0]                       # it learns
     assert max(abs(a - b) for a, b in zip(got, want)) <= 2e-3, (got, want)
+
+
+# ------------------------------------------------------------------------------------------- split-bf16 matrix-core modes
+@pytest.mark.parametrize("precision,tol", [("bf16x6", 1e-4), ("bf16x3", 2e-3), ("bf16", 0.5)])
+@pytest.mark.parametrize("channels,shape", [((16, 32, 64, 128, 256), (2, 3, 64, 64)), ((16, 32, 64, 128, 256), (3, 3, 256, 256)),
+                                            ((32, 64, 128, 256, 512), (2, 3, 128, 128))])
+def test_split_bf16_modes(precision, tol, channels, shape):
+    """bf16x6 (3 planes, 6 MFMA terms) must stay inside the fp32 logit budget; the cheaper modes are bounded loosely."""
+    ref, hip = _pair(channels, 2)
+    hip.precision = precision
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        want = ref(x)
+        got = hip(x.to(_dev())).cpu()
+    err = (got - want).abs().max().item()
+    assert err <= tol, err
+    if precision == "bf16":
+        assert (got.argmax(1) == want.argmax(1)).float().mean().item() > 0.97

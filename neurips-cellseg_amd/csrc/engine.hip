@@ -244,7 +244,7 @@ static void add_norm_params(cs_unet* net, ArenaPlan& ar, const std::string& adn,
 // conv weight + bias of a conv that writes channels [cout_off, cout_off + cout) of a fused launch.
 // `dg` says how the same tensor is packed a second time (into cw.wd) for the data-gradient launch.
 static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, int cout, int cin, int ksize, int cout_off,
-                            bool transposed, int mode /*0 mfma, 1 first, 2 raw*/, int dg = DG_NONE, int slot = 0) {
+                            bool transposed, int mode /*0 mfma, 1 first, 2 raw*/, int dg = DG_NONE, int slot = 0, int cin_split = 0) {
     float* wdst = cw.w;
     float* wd = cw.wd;
     unsigned short* wb = cw.wb;
@@ -263,6 +263,8 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
         cw.p_w[slot] = add_param(net, conv + ".weight", {cin, cout, ksize, ksize}, [=](const float* d, hipStream_t s) {
             if (int rc = pack_dgrad(d, s)) return rc;
             if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
+            if (wb)
+                if (int rc = pack_conv_weights_bf16(s, d, true, cout, cin, ksize, wb, cout_off, cout_total, cin_split)) return rc;
             return pack_conv_weights(s, d, true, cout, cin, ksize, wdst, cout_off, cout_total);
         });
     } else {
@@ -328,7 +330,8 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     u.convt.w = ar.take(small ? (size_t)cin * cout * 9 : packed_conv_floats(cout, cin, 3));
     u.convt.bias = ar.take(cout);
     if (!small) u.convt.wd = ar.take(packed_conv_floats(cin, cout, 3));
-    add_conv_params(net, pfx + ".0.conv", u.convt, cout, cin, 3, 0, true, small ? 2 : 0, small ? DG_NONE : DG_CONVT_AS_S2, 0);
+    if (!small) u.convt.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cin_skip, cin_sub, 3) + 1) / 2);
+    add_conv_params(net, pfx + ".0.conv", u.convt, cout, cin, 3, 0, true, small ? 2 : 0, small ? DG_NONE : DG_CONVT_AS_S2, 0, cin_skip);
     add_norm_params(net, ar, pfx + ".0.adn", u.norm_t, cout);
     u.unit0.cin = cout; u.unit0.cout = cout;
     u.unit0.w = ar.take(small ? (size_t)cout * cout * 9 : packed_conv_floats(cout, cout, 3));
@@ -514,7 +517,9 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
             const ConvSrc a = raw_src(X[d], u.cin_skip, u.cin_skip), b = raw_src(S, sc, sc);
-            if (c % 16 == 0) {
+            if (c % 16 == 0 && net->planes > 0 && u.convt.wb) {
+                CS_TRY(launch_convt_bf16s(s, net->planes, a, b, u.convt.wb, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
+            } else if (c % 16 == 0) {
                 CS_TRY(launch_convt_mfma(s, a, b, u.convt.w, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
             } else {
                 CS_TRY(launch_convt_small(s, a, b, u.convt.w, u.convt.bias, U, c, rt_upt[d].stats, n, ph, pw));

@@ -53,6 +53,8 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
 int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
                       const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
                       int hin, int win);
+int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSrc& b, const unsigned short* wpack, const float* bias,
+                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
 size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize);
 int pack_conv_weights_bf16(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, unsigned short* packed,
                            int cout_off, int cout_total, int cin_split);

@@ -55,15 +55,15 @@ __device__ __forceinline__ void stats_commit_b(double s, double q, double* dst, 
     }
 }
 
-// block = 4 waves arranged WN (along output channels) x WM = 4 / WN (along pixel rows); each wave owns ONE 16-channel
-// tile and MTW pixel rows.  A (pixels) comes from the LDS planes shared by the block; B (weights) is private to the wave
-// and goes global -> registers, one whole chunk ahead (ring of TAPS x NP fragments), so no weight ever touches LDS.
-template <int S, int KS, int WN, int NP>
-__global__ __launch_bounds__(256, (S == 1 && NP >= 2) ? 1 : 2) void conv_bf16s_kernel(ConvBParams p) {
+// block = 4 waves arranged WN (along output channels) x WM = 4 / WN (along pixel rows); each wave owns NTW 16-channel
+// tiles and MTW pixel rows.  A (pixels) comes from the LDS planes shared by the block; B (weights) is private to the wave
+// and goes global -> registers, one tap ROW ahead (ring of KS x NTW x NP fragments), so no weight ever touches LDS.
+template <int S, int KS, int WN, int NTW, int NP>
+__global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     constexpr int WM = 4 / WN;
-    constexpr int RD = (KS == 1) ? 1 : (NP == 1 ? 9 : 3);   // weight ring depth in taps (prefetch distance); divides TAPS
-    constexpr int MTW = (S == 1 ? 2 : 1) * WN;              // pixel rows per wave
-    constexpr int TH = MTW * WM, TW = 16;                   // 8 rows (stride 1) / 4 rows (stride 2)
+    constexpr int TH = (S == 1) ? 8 : 4, TW = 16;
+    constexpr int MTW = TH / WM;                            // pixel rows per wave
+    constexpr int NTB = WN * NTW;                           // 16-channel tiles per block
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
     constexpr int PITCH = (S == 1) ? 96 : 80;               // bytes per staged pixel and plane: 32 bf16 + pad (conflict-free b128 reads)
     constexpr int PAD = KS / 2, TAPS = KS * KS;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, (S == 1 && NP >= 2) ? 1 : 2) void conv_bf16s_k
     constexpr int IN_ITERS = (IN_ITEMS + 255) / 256;
     constexpr int PLANE_BYTES = IH * IW * PITCH;
     constexpr int IN_BYTES = (NP * PLANE_BYTES + 15) / 16 * 16;
-    constexpr int EPS = 16 * WN + 4;
+    constexpr int EPS = 16 * NTB + 4;
     constexpr int EP_BYTES = TH * 16 * EPS * 4;
     constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
@@ -86,12 +86,14 @@ __global__ __launch_bounds__(256, (S == 1 && NP >= 2) ? 1 : 2) void conv_bf16s_k
     const int ty = bid % p.tiles_y;
     const int img = bid / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int nt = blockIdx.y * WN + wn;                     // this wave's output-channel tile
+    const int nt_w = blockIdx.y * NTB + wn * NTW;            // this wave's first output-channel tile
     const int q = tid & 7;                                   // this thread's channel quad inside the 32-channel chunk
 
-    f32x4 acc[MTW];
+    f32x4 acc[MTW][NTW];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int goff[IN_ITERS];
 #pragma unroll
@@ -155,46 +157,54 @@ __global__ __launch_bounds__(256, (S == 1 && NP >= 2) ? 1 : 2) void conv_bf16s_k
             }
         }
     };
-    // weight fragments of (chunk, tap): NP lane-linear 16-byte loads (1 KiB per wave-instruction, straight from L2)
-    bf16x8 bq[RD][NP];
-    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)nt * 3 * 64 + lane;
-    auto load_b = [&](int ch, int tap, int slot) {
+    // weight fragments of one tap row: KS x NTW x NP lane-linear 16-byte loads (1 KiB per wave-instruction, from L2)
+    bf16x8 bq[KS][NTW][NP];
+    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)nt_w * 3 * 64 + lane;
+    auto load_b = [&](int ch, int ky, int kx) {
+        const bf16x8* w = wbase + ((size_t)ch * TAPS + ky * KS + kx) * p.ntile_total * 3 * 64;
 #pragma unroll
-        for (int pn = 0; pn < NP; ++pn)
-            bq[slot][pn] = wbase[(((size_t)ch * TAPS + tap) * p.ntile_total * 3 + pn) * 64];
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int pn = 0; pn < NP; ++pn) bq[kx][t][pn] = w[(t * 3 + pn) * 64];
     };
 
     load_input(0);
 #pragma unroll
-    for (int tap = 0; tap < RD; ++tap) load_b(0, tap, tap);
+    for (int kx = 0; kx < KS; ++kx) load_b(0, 0, kx);
     store_input();
     __syncthreads();
 
     for (int ch = 0; ch < chunks; ++ch) {
         const bool more = ch + 1 < chunks;
         if (more) load_input(ch + 1);
+        for (int ky = 0; ky < KS; ++ky) {                   // runtime loop: keeps the unrolled body to one tap row
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            bf16x8 b[NP];
+            for (int kx = 0; kx < KS; ++kx) {
+                bf16x8 b[NTW][NP];
 #pragma unroll
-            for (int pn = 0; pn < NP; ++pn) b[pn] = bq[tap % RD][pn];
-            // refill this ring slot RD taps ahead (possibly in the next chunk)
-            if (tap + RD < TAPS) load_b(ch, tap + RD, tap % RD);
-            else if (more) load_b(ch + 1, tap + RD - TAPS, tap % RD);
+                for (int t = 0; t < NTW; ++t)
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const int r = wm * MTW + m;
-                bf16x8 a[NP];
+                    for (int pn = 0; pn < NP; ++pn) b[t][pn] = bq[kx][t][pn];
+                // refill this ring slot one tap row ahead (first row of the next chunk after the last row)
+                if (ky + 1 < KS) load_b(ch, ky + 1, kx);
+                else if (more) load_b(ch + 1, 0, kx);
 #pragma unroll
-                for (int pn = 0; pn < NP; ++pn)
-                    a[pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES + ((r * S + ky) * IW + pl * S + kx) * PITCH + g * 16);
-                // smallest terms first, the dominant a0*b0 last
+                for (int m = 0; m < MTW; ++m) {
+                    const int r = wm * MTW + m;
+                    bf16x8 a[NP];
 #pragma unroll
-                for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
-                    const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
-                    const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[ib], acc[m], 0, 0, 0);
+                    for (int pn = 0; pn < NP; ++pn)
+                        a[pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES + ((r * S + ky) * IW + pl * S + kx) * PITCH + g * 16);
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) {
+                        // smallest terms first, the dominant a0*b0 last
+#pragma unroll
+                        for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
+                            const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
+                            const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[t][ib], acc[m][t], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -207,8 +217,9 @@ __global__ __launch_bounds__(256, (S == 1 && NP >= 2) ? 1 : 2) void conv_bf16s_k
 
     // ---- epilogue: bias, fp64 statistics, then full-line stores through a block-wide LDS slab ----
     float* ep = reinterpret_cast<float*>(smem);
-    {
-        const int co = nt * 16 + pl;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int co = (nt_w + t) * 16 + pl;
         const float bias = p.bias ? p.bias[co] : 0.f;
         double s = 0.0, qq = 0.0;
 #pragma unroll
@@ -217,8 +228,8 @@ __global__ __launch_bounds__(256, (S == 1 && NP >= 2) ? 1 : 2) void conv_bf16s_k
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ox = ox0 + g * 4 + r;
-                const float v = acc[m][r] + bias;
-                ep[(row * 16 + g * 4 + r) * EPS + wn * 16 + pl] = v;
+                const float v = acc[m][t][r] + bias;
+                ep[(row * 16 + g * 4 + r) * EPS + (wn * NTW + t) * 16 + pl] = v;
                 if (oy < p.hout && ox < p.wout) {
                     s += (double)v;
                     qq += (double)v * (double)v;
@@ -229,8 +240,8 @@ __global__ __launch_bounds__(256, (S == 1 && NP >= 2) ? 1 : 2) void conv_bf16s_k
     }
     __syncthreads();
     {
-        constexpr int F4 = WN * 4;                           // float4 per pixel record of this block
-        float* out0 = p.out + (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + blockIdx.y * WN * 16;
+        constexpr int F4 = NTB * 4;                          // float4 per pixel record of this block
+        float* out0 = p.out + (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + blockIdx.y * NTB * 16;
         for (int i = tid; i < TH * 16 * F4; i += 256) {
             const int pix = i / F4, c4 = i - pix * F4;
             const int row = pix >> 4, x = pix & 15;
@@ -243,13 +254,13 @@ __global__ __launch_bounds__(256, (S == 1 && NP >= 2) ? 1 : 2) void conv_bf16s_k
 
 static SrcDevB to_devb(const ConvSrc& s) { return SrcDevB{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
 
-template <int S, int KS, int WN, int NP>
+template <int S, int KS, int WN, int NTW, int NP>
 static int launch_b(hipStream_t s, ConvBParams p) {
-    constexpr int TH = (S == 1 ? 2 : 1) * 4;
+    constexpr int TH = (S == 1) ? 8 : 4;
     p.tiles_x = ceil_div(p.wout, 16);
     p.tiles_y = ceil_div(p.hout, TH);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.n), (unsigned)(p.ntile_total / WN));
-    hipLaunchKernelGGL((conv_bf16s_kernel<S, KS, WN, NP>), grid, dim3(256), 0, s, p);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.n), (unsigned)(p.ntile_total / (WN * NTW)));
+    hipLaunchKernelGGL((conv_bf16s_kernel<S, KS, WN, NTW, NP>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -276,9 +287,9 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
 #define CS_B3(S_, KS_, NP_)                                                         \
     switch (wn) {                                                                   \
-        case 4: return launch_b<S_, KS_, 4, NP_>(s, p);                             \
-        case 2: return launch_b<S_, KS_, 2, NP_>(s, p);                             \
-        default: return launch_b<S_, KS_, 1, NP_>(s, p);                            \
+        case 4: return launch_b<S_, KS_, 2, 2, NP_>(s, p);                          \
+        case 2: return launch_b<S_, KS_, 2, 1, NP_>(s, p);                          \
+        default: return launch_b<S_, KS_, 1, 1, NP_>(s, p);                         \
     }
 #define CS_B2(S_, KS_)                                                              \
     switch (planes) {                                                               \
@@ -291,6 +302,235 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     CS_B2(2, 3)
 #undef CS_B2
 #undef CS_B3
+}
+
+// ------------------------------------------------------------------------------------------------
+// transposed conv k3 s2 p1 op1, split-bf16: same operand handling as above, 4 output phases per input pixel
+//   out[2i+a][2j+b] += in[i+di][j+dj] * W[ky][kx],  ky: 0->(a=1,di=1) 1->(a=0,di=0) 2->(a=1,di=0); same for kx.
+// ------------------------------------------------------------------------------------------------
+template <int WN, int NTW, int NP>
+__global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
+    constexpr int WM = 4 / WN, TH = 4, TW = 16, MTW = TH / WM, NTB = WN * NTW;
+    constexpr int IH = TH + 1, IW = TW + 1, PITCH = 96;
+    constexpr int IN_ITEMS = IH * IW * 8, IN_ITERS = (IN_ITEMS + 255) / 256;
+    constexpr int PLANE_BYTES = IH * IW * PITCH;
+    constexpr int IN_BYTES = (NP * PLANE_BYTES + 15) / 16 * 16;
+    constexpr int EPS = 16 * NTB + 4;
+    constexpr int EP_BYTES = 2 * TH * 32 * EPS * 4;          // 8 output rows x 32 output pixels
+    constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    char* const in_s = smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    const int wn = wave % WN, wm = wave / WN;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int iy0 = ty * TH, ix0 = tx * TW;
+    const int nt_w = blockIdx.y * NTB + wn * NTW;
+    const int q = tid & 7;
+
+    f32x4 acc[MTW][4][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[m][ph][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int goff[IN_ITERS];
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (tid >> 3) + 32 * it;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        goff[it] = (pix < IH * IW && gy < p.hin && gx < p.win) ? gy * p.win + gx : -1;
+    }
+    const int chunks_a = (p.a.c + 31) >> 5, chunks = chunks_a + ((p.b.c + 31) >> 5);
+    f32x4 rin[IN_ITERS];
+    f32x4 t0, t1;
+    float slope = 0.f;
+    bool lazy = false, qvalid = false;
+    auto load_input = [&](int ch) {
+        const bool from_a = ch < chunks_a;
+        const SrcDevB& src = from_a ? p.a : p.b;
+        const int c0 = (from_a ? ch : ch - chunks_a) << 5;
+        qvalid = c0 + 4 * q < src.c;
+        const int cq = qvalid ? c0 + 4 * q : 0;
+        lazy = src.tab != nullptr;
+        const f32x4* t = lazy ? reinterpret_cast<const f32x4*>(src.tab + (size_t)img * src.tab_c + src.tab_off + cq)
+                              : reinterpret_cast<const f32x4*>(p.dummy);
+        t0 = t[0];
+        t1 = t[1];
+        const float* sp = (lazy && src.slope) ? src.slope : p.dummy;
+        slope = *sp;
+        if (!(lazy && src.slope)) slope = 0.f;
+        const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + cq;
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int o = goff[it] >= 0 ? goff[it] : 0;
+            rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * src.pitch);
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int pix = (tid >> 3) + 32 * it;
+            if (IN_ITEMS % 256 == 0 || pix < IH * IW) {
+                f32x4 v = rin[it];
+                if (lazy) {
+                    v.x = prelu_h(v.x * t0.x + t0.y, slope);
+                    v.y = prelu_h(v.y * t0.z + t0.w, slope);
+                    v.z = prelu_h(v.z * t1.x + t1.y, slope);
+                    v.w = prelu_h(v.w * t1.z + t1.w, slope);
+                }
+                if (goff[it] < 0 || !qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pn = 0; pn < NP; ++pn) {
+                    bf16x4 h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        h[j] = (__bf16)v[j];
+                        v[j] -= (float)h[j];
+                    }
+                    *reinterpret_cast<bf16x4*>(in_s + pn * PLANE_BYTES + pix * PITCH + q * 8) = h;
+                }
+            }
+        }
+    };
+    bf16x8 bq[3][NTW][NP];
+    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)nt_w * 3 * 64 + lane;
+    auto load_b = [&](int ch, int tap, int slot) {
+        const bf16x8* w = wbase + ((size_t)ch * 9 + tap) * p.ntile_total * 3 * 64;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int pn = 0; pn < NP; ++pn) bq[slot][t][pn] = w[(t * 3 + pn) * 64];
+    };
+
+    load_input(0);
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) load_b(0, tap, tap);
+    store_input();
+    __syncthreads();
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        if (more) load_input(ch + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int pa = (ky == 1) ? 0 : 1, di = (ky == 0) ? 1 : 0;
+            const int pb = (kx == 1) ? 0 : 1, dj = (kx == 0) ? 1 : 0;
+            const int ph = pa * 2 + pb;
+            bf16x8 b[NTW][NP];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int pn = 0; pn < NP; ++pn) b[t][pn] = bq[tap % 3][t][pn];
+            if (tap + 3 < 9) load_b(ch, tap + 3, tap % 3);
+            else if (more) load_b(ch + 1, tap + 3 - 9, tap % 3);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int r = wm * MTW + m;
+                bf16x8 a[NP];
+#pragma unroll
+                for (int pn = 0; pn < NP; ++pn)
+                    a[pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES + ((r + di) * IW + pl + dj) * PITCH + g * 16);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+                    for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
+                        const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
+                        const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
+                        acc[m][ph][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[t][ib], acc[m][ph][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_input();
+            __syncthreads();
+        }
+    }
+
+    float* ep = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int co = (nt_w + t) * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        double s = 0.0, qq = 0.0;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int row = wm * MTW + m, iy = iy0 + row;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ix = ix0 + g * 4 + r;
+                    const float v = acc[m][ph][t][r] + bias;
+                    ep[((2 * row + (ph >> 1)) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + (wn * NTW + t) * 16 + pl] = v;
+                    if (iy < p.hin && ix < p.win) {
+                        s += (double)v;
+                        qq += (double)v * (double)v;
+                    }
+                }
+        }
+        if (p.stats) stats_commit_b(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+    __syncthreads();
+    {
+        constexpr int F4 = NTB * 4;
+        float* out0 = p.out + (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + blockIdx.y * NTB * 16;
+        for (int i = tid; i < 2 * TH * 32 * F4; i += 256) {
+            const int pix = i / F4, c4 = i - pix * F4;
+            const int row = pix >> 5, x = pix & 31;
+            if (2 * iy0 + row < p.hout && 2 * ix0 + x < p.wout)
+                *reinterpret_cast<f32x4*>(out0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) =
+                    *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+        }
+    }
+}
+
+template <int WN, int NTW, int NP>
+static int launch_tb(hipStream_t s, ConvBParams p) {
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.n), (unsigned)(p.ntile_total / (WN * NTW)));
+    hipLaunchKernelGGL((convt_bf16s_kernel<WN, NTW, NP>), grid, dim3(256), 0, s, p);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSrc& b, const unsigned short* wpack, const float* bias,
+                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
+    CS_REQUIRE(planes >= 1 && planes <= 3, "convT(bf16): %d planes", planes);
+    CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "convT(bf16): channels must be multiples of 16");
+    ConvBParams p{};
+    p.a = to_devb(a);
+    p.b = to_devb(b);
+    p.wpack = wpack; p.bias = bias; p.out = out; p.stats = stats; p.dummy = reinterpret_cast<const float*>(wpack);
+    p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16;
+    p.n = n; p.hin = hin; p.win = win; p.hout = 2 * hin; p.wout = 2 * win;
+    p.tiles_x = ceil_div(win, 16);
+    p.tiles_y = ceil_div(hin, 4);
+    const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
+    const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
+    ProfScope prof(K_CONVT, s, flops, bytes);
+#define CS_TB(NP_)                                                   \
+    switch (wn) {                                                    \
+        case 4: return launch_tb<2, 2, NP_>(s, p);                   \
+        case 2: return launch_tb<2, 1, NP_>(s, p);                   \
+        default: return launch_tb<1, 1, NP_>(s, p);                  \
+    }
+    switch (planes) {
+        case 3: CS_TB(3)
+        case 2: CS_TB(2)
+        default: CS_TB(1)
+    }
+#undef CS_TB
 }
 
 // ---- weight packing: fp32 PyTorch layout -> 3 bf16 planes in MFMA (16x16x32) fragment order --------------------

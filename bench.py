@@ -157,6 +157,24 @@ def main():
     n_windows = plan.n_h * plan.n_w
     mpix = args.size * args.size / 1e6
 
+    def measure_mode(width, precision, ref_labels=None):
+        """Timed loop only (same K steps) for a secondary matrix-core mode; agreement with the primary run's labels."""
+        model = make_model(WIDTHS[width], seed).to(dev)
+        model.precision = precision
+        step = lambda: run_step(ca, model, image, roi, args.overlap, args.engine_batch)      # noqa: E731
+        with torch.no_grad():
+            for _ in range(max(args.warmup, 1)):
+                step()
+            dt, (labels, num) = time_steps(step, args.steps, barrier)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out = {"value": round(world * mpix * args.steps / t.item(), 3), "ms_per_step": round(t.item() / args.steps * 1e3, 3),
+               "instances_found": int(num.item())}
+        if ref_labels is not None:
+            out["foreground_agreement_vs_primary"] = round(float(((labels > 0) == (ref_labels > 0)).float().mean().item()), 6)
+        return out
+
     def measure(width):
         model = make_model(WIDTHS[width], seed).to(dev)
         model.precision = args.precision
@@ -184,12 +202,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_prof, dt_d2h = t.tolist()
         return dict(dt=dt, dt_prof=dt_prof, dt_d2h=dt_d2h, prof=prof, n_instances=int(num.item()),
-                    fg_frac=float((labels > 0).float().mean().item()))
+                    fg_frac=float((labels > 0).float().mean().item()), labels=labels.clone())
 
     main_res = measure(args.width)
-    sec_res = None
+    sec_res, modes = None, {}
     if not args.no_secondary and args.width != "reference16":
         sec_res = measure("reference16")
+    if not args.no_secondary and args.precision == "fp32":
+        for prec in ("bf16x6", "bf16"):
+            modes[prec] = measure_mode(args.width, prec, main_res["labels"])
 
     if rank != 0:
         if dist:
@@ -257,6 +278,10 @@ def main():
         out["reference_width"] = {"channels": list(WIDTHS["reference16"]), "value": round(world * mpix * args.steps / sec_res["dt"], 3),
                                   "ms_per_step": round(sec_res["dt"] / args.steps * 1e3, 3), "roofline": roofline(sec_res),
                                   "instances_found": sec_res["n_instances"]}
+    if modes:
+        out["other_precisions"] = {"note": "same workload, convolutions on v_mfma_f32_16x16x32_bf16: bf16x6 = 3 bf16 planes x 6 terms "
+                                           "(fp32-grade, logits within 1e-4 in the GPU tests), bf16 = plain bf16 products; "
+                                           "activations stay fp32 in HBM", **modes}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.overlap, WIDTHS[args.width], seed)
     print(json.dumps(out))

@@ -138,13 +138,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the hot path")
+    # BENCH_DEVICE / BENCH_BACKEND exist only to exercise the multi-rank code path on a 1-GPU box (ranks share cuda:0, gloo)
+    local = int(os.environ.get("BENCH_DEVICE", local))
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     barrier = (lambda: dist.barrier()) if dist else (lambda: None)
 
     import cellseg_amd as ca
@@ -166,7 +173,7 @@ def main():
             for _ in range(max(args.warmup, 1)):
                 step()
             dt, (labels, num) = time_steps(step, args.steps, barrier)
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         if dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         out = {"value": round(world * mpix * args.steps / t.item(), 3), "ms_per_step": round(t.item() / args.steps * 1e3, 3),
@@ -197,7 +204,7 @@ def main():
                 host.copy_(lab, non_blocking=True)
                 return lab
             dt_d2h, _ = time_steps(step_d2h, args.steps, barrier)
-        t = torch.tensor([dt, dt_prof, dt_d2h], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, dt_prof, dt_d2h], dtype=torch.float64, device=red_dev)
         if dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_prof, dt_d2h = t.tolist()

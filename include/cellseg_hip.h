@@ -126,6 +126,18 @@ int cs_swi_finalize(const cs_swi_plan* plan_host, const float* win_logits, int c
                     int row_begin, int row_end, float* logits_nchw, float* prob1, uint8_t* mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input normalisation  -  replaces normalize_channel + the channel fix-up + `/ np.max`
+ *   (baseline/predict.py:14-21, :94-108): per-channel 1-99 percentile stretch of the non-zero pixels
+ *   (np.percentile linear interpolation, float64), truncation to uint8, division by the image maximum.
+ * image: [h, w, channels] uint8 (bytes_per_sample 1) or uint16 (2), contiguous; channels 1 (gray -> replicated)
+ * or >= 3 (first three used).  out_hwc: float32 [h, w, 3] in [0, 1] - pass it to cs_swi_infer with strides
+ * (sc, sh, sw) = (1, 3 w, 3).  u8_hwc (optional): the intermediate uint8 image.  Bit-exact with numpy.
+ * ---------------------------------------------------------------------------------------------- */
+size_t cs_normalize_workspace_bytes(int h, int w);
+int cs_normalize_image(const void* image, int bytes_per_sample, int h, int w, int channels, float* out_hwc,
+                       uint8_t* u8_hwc, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Connected-component post-process  -  replaces
  *   measure.label(morphology.remove_small_objects(morphology.remove_small_holes(mask), 16))
  *   (baseline/predict.py:113): 4-connected holes < 64 filled, 4-connected objects < 16 removed,

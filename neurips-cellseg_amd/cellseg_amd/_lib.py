@@ -55,6 +55,8 @@ def _load() -> C.CDLL:
         "cs_swi_workspace_bytes": (sz, [vp, C.POINTER(SwiPlan), i32]),
         "cs_swi_infer": (i32, [vp, C.POINTER(SwiPlan), vp, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
         "cs_swi_finalize": (i32, [C.POINTER(SwiPlan), vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+        "cs_normalize_workspace_bytes": (sz, [i32, i32]),
+        "cs_normalize_image": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
         "cs_ccl_workspace_bytes": (sz, [i32, i32]),
         "cs_ccl_postprocess": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
         "cs_ccl_label": (i32, [vp, i32, i32, i32, vp, vp, vp, sz, vp]),
@@ -72,7 +74,8 @@ lib = _load()
 EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_destroy cs_unet_set_precision cs_unet_num_params "
             "cs_unet_param_info cs_unet_load_param cs_unet_workspace_bytes cs_unet_forward cs_unet_grad_numel "
             "cs_unet_grad_offset cs_unet_backward_workspace_bytes cs_unet_backward cs_swi_make_plan "
-            "cs_swi_window_start cs_swi_workspace_bytes cs_swi_infer cs_swi_finalize cs_ccl_workspace_bytes "
+            "cs_swi_window_start cs_swi_workspace_bytes cs_swi_infer cs_swi_finalize cs_normalize_workspace_bytes "
+            "cs_normalize_image cs_ccl_workspace_bytes "
             "cs_ccl_postprocess cs_ccl_label cs_prof_enable cs_prof_reset cs_prof_collect").split()
 
 

@@ -61,14 +61,22 @@ def main(argv=None):
         for k in parallel.shard_items(len(img_names), rank, world):
             img_name = img_names[k]
             img_data = preprocess.read_image(join(args.input_path, img_name))
-            pre_img_data = preprocess.prepare_image(img_data)
-            t0 = time.time()
-            x = torch.from_numpy(preprocess.to_unit_float(pre_img_data)).to(device)          # [H,W,3]: NHWC, no copy needed
+            if img_data.dtype in (np.uint8, np.uint16):
+                # integer images: percentile normalisation on the device (bit-exact with the host path below)
+                raw = torch.from_numpy(np.ascontiguousarray(img_data).view(np.int16) if img_data.dtype == np.uint16 else np.ascontiguousarray(img_data))
+                t0 = time.time()
+                x = preprocess.normalize_image_gpu(raw.to(device))                             # [H,W,3] float32
+                shape = tuple(x.shape)
+            else:
+                pre_img_data = preprocess.prepare_image(img_data)
+                t0 = time.time()
+                x = torch.from_numpy(preprocess.to_unit_float(pre_img_data)).to(device)      # [H,W,3]: NHWC, no copy needed
+                shape = pre_img_data.shape
             _, _, mask = ca.swi_infer_image(model, x.permute(2, 0, 1), roi_size, args.overlap, want_logits=False, want_mask=True)
             labels = ca.mask_to_instances(mask).cpu().numpy()
             preprocess.write_label_tiff(join(args.output_path, preprocess.label_name(img_name)), labels)
             t1 = time.time()
-            print(f"Prediction finished: {img_name}; img size = {pre_img_data.shape}; costing: {t1 - t0:.2f}s")
+            print(f"Prediction finished: {img_name}; img size = {shape}; costing: {t1 - t0:.2f}s")
             if args.show_overlay:
                 b = labels > 0
                 edge = b & ~(np.roll(b, 1, 0) & np.roll(b, -1, 0) & np.roll(b, 1, 1) & np.roll(b, -1, 1))

@@ -59,3 +59,35 @@ def label_name(img_name: str) -> str:
 
 def list_images(input_path: str):
     return sorted(os.listdir(input_path))
+
+
+def normalize_image_gpu(img, return_uint8: bool = False):
+    """Device version of ``to_unit_float(prepare_image(img))`` for uint8 / uint16 images (bit-exact with the host path).
+
+    img: torch tensor [H,W] or [H,W,C] (uint8, or uint16 bits held in an int16/uint16 tensor) on the GPU
+    -> float32 [H,W,3] in [0,1]."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    from ._lib import check, lib
+    _lib.require_gpu(img)
+    if img.dim() == 2:
+        img = img[:, :, None]
+    if img.dtype == torch.uint8:
+        bps = 1
+    elif img.dtype in (torch.uint16, torch.int16):
+        bps = 2
+    else:
+        raise ValueError(f"normalize_image_gpu: dtype {img.dtype} is not supported (uint8 / uint16 images)")
+    img = img.contiguous()
+    h, w, c = img.shape
+    out = torch.empty((h, w, 3), dtype=torch.float32, device=img.device)
+    u8 = torch.empty((h, w, 3), dtype=torch.uint8, device=img.device) if return_uint8 else None
+    with torch.cuda.device(img.device):
+        ws = torch.empty(lib.cs_normalize_workspace_bytes(h, w), dtype=torch.uint8, device=img.device)
+        check(lib.cs_normalize_image(C.c_void_p(img.data_ptr()), bps, h, w, c, C.c_void_p(out.data_ptr()),
+                                     C.c_void_p(u8.data_ptr()) if u8 is not None else C.c_void_p(), C.c_void_p(ws.data_ptr()),
+                                     ws.numel(), _lib.stream_ptr()), "cs_normalize_image")
+    return (out, u8) if return_uint8 else out

@@ -32,7 +32,7 @@ static const char* kNames[K_NUM_IDS] = {
     "conv3x3_s1_mfma", "conv3x3_s2_mfma", "conv1x1_mfma", "conv_first_mfma", "convT3x3s2_mfma", "convT_top_valu",
     "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
     "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset", "norm_bwd",
-    "colsum", "wgrad_mfma", "top_bwd_valu"};
+    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
 
 struct ProfRecord {
@@ -1043,6 +1043,16 @@ int cs_swi_finalize(const cs_swi_plan* pl, const float* win_logits, int classes,
     fa.prob1 = prob1;
     fa.mask = mask;
     return launch_swi_finalize((hipStream_t)stream, fa);
+}
+
+size_t cs_normalize_workspace_bytes(int h, int w) { return cs::normalize_workspace_bytes(h, w); }
+
+int cs_normalize_image(const void* image, int bytes_per_sample, int h, int w, int channels, float* out_hwc, uint8_t* u8_hwc,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(image && out_hwc && workspace, "normalize_image: null argument");
+    CS_REQUIRE(bytes_per_sample == 1 || bytes_per_sample == 2, "normalize_image: only uint8 / uint16 samples (got %d bytes)", bytes_per_sample);
+    return cs::normalize_image((hipStream_t)stream, image, bytes_per_sample == 2, h, w, channels, out_hwc, u8_hwc, workspace,
+                               workspace_bytes);
 }
 
 size_t cs_ccl_workspace_bytes(int h, int w) { return cs::ccl_workspace_bytes(h, w); }

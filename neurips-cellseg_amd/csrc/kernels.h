@@ -130,6 +130,11 @@ struct SwiFinalizeArgs {
 };
 int launch_swi_finalize(hipStream_t s, const SwiFinalizeArgs& a);
 
+// ---- input normalisation (kernels_pre.hip) ------------------------------------------------------
+size_t normalize_workspace_bytes(int h, int w);
+int normalize_image(hipStream_t s, const void* img, int is_u16, int h, int w, int c_in, float* out_hwc, unsigned char* u8_out,
+                    void* ws, size_t ws_bytes);
+
 // ---- connected components ----------------------------------------------------------------------
 size_t ccl_workspace_bytes(int h, int w);
 int ccl_postprocess(hipStream_t s, const uint8_t* mask, int h, int w, int hole_area, int min_size, int32_t* labels,

@@ -312,3 +312,31 @@ def test_split_bf16_modes(precision, tol, channels, shape):
     assert err <= tol, err
     if precision == "bf16":
         assert (got.argmax(1) == want.argmax(1)).float().mean().item() > 0.97
+
+
+# ------------------------------------------------------------------------------------------- input normalisation (row N)
+@pytest.mark.parametrize("kind", ["u8_rgb", "u16_gray", "u8_rgba", "u16_rgb_flat_channel", "u8_zero_channel", "u16_big"])
+def test_normalize_on_device_is_bit_exact_with_numpy(kind):
+    from cellseg_amd import preprocess
+    rng = np.random.default_rng(11)
+    if kind == "u8_rgb":
+        img = rng.integers(0, 256, (97, 130, 3), dtype=np.uint8)
+    elif kind == "u16_gray":
+        img = (rng.random((200, 180)) ** 3 * 60000).astype(np.uint16)
+    elif kind == "u8_rgba":
+        img = rng.integers(0, 200, (64, 64, 4), dtype=np.uint8)
+    elif kind == "u16_rgb_flat_channel":
+        img = rng.integers(0, 4000, (80, 90, 3), dtype=np.uint16)
+        img[:, :, 1] = 300                      # p99 - p1 == 0 -> raw astype(uint8) wrap branch
+    elif kind == "u8_zero_channel":
+        img = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
+        img[:, :, 2] = 0
+    else:
+        img = (rng.random((1024, 1024)) * 65535).astype(np.uint16)
+        img[rng.random((1024, 1024)) < 0.3] = 0
+    want_u8 = preprocess.prepare_image(img)
+    want = preprocess.to_unit_float(want_u8)
+    t = torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).to(_dev())
+    got, got_u8 = preprocess.normalize_image_gpu(t, return_uint8=True)
+    assert np.array_equal(got_u8.cpu().numpy(), want_u8)
+    assert np.array_equal(got.cpu().numpy(), want)

@@ -152,6 +152,20 @@ int cs_ccl_label(const uint8_t* mask, int h, int w, int connectivity,
                  int32_t* labels, int32_t* n_labels, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * F1 harness pieces  -  the O(H*W) parts of baseline/compute_metric.py (the metric of record):
+ *   cs_label_max               max label of one or two int32 maps (out2[0], out2[1]) - `x.max()`, `y.max()` (:60)
+ *   cs_label_overlap           _label_overlap (:39-70): overlap[(n_gt+1) x (n_seg+1)] pixel-pair counts (uint32)
+ *   cs_remove_boundary_cells   remove_boundary_cells (:124-133): drop labels touching the `border`-pixel frame, then
+ *                              relabel_sequential (order preserving); n_labels >= max label of the input
+ * IoU, Hungarian matching and the F1 formula operate on the small overlap matrix and stay on the host.
+ * ---------------------------------------------------------------------------------------------- */
+int cs_label_max(const int32_t* a, const int32_t* b /* may be NULL */, int64_t n, int32_t* out2, void* stream);
+int cs_label_overlap(const int32_t* gt, const int32_t* seg, int64_t n, int32_t n_gt, int32_t n_seg, uint32_t* overlap, void* stream);
+size_t cs_remove_boundary_workspace_bytes(int32_t n_labels);
+int cs_remove_boundary_cells(const int32_t* labels, int h, int w, int border, int32_t n_labels, int32_t* out, int32_t* n_out,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.
  * cs_prof_enable(1) brackets every kernel launch with events; cs_prof_collect synchronises and
  * returns per-kernel-id totals.  Disabled (default) costs nothing.

@@ -11,7 +11,7 @@ from .unet import UNet  # noqa: F401
 from .inferers import make_plan, rank_rows, sliding_window_inference, swi_infer_image, window_starts  # noqa: F401
 from .postprocess import label, mask_to_instances, prob_to_instances  # noqa: F401
 from .losses import DiceCELoss, one_hot  # noqa: F401
-from . import parallel  # noqa: F401
+from . import metrics, parallel  # noqa: F401
 
 __all__ = ["UNet", "sliding_window_inference", "swi_infer_image", "make_plan", "window_starts", "rank_rows",
            "label", "mask_to_instances", "prob_to_instances", "DiceCELoss", "one_hot", "CellSegHipError", "lib", "LIB_PATH"]

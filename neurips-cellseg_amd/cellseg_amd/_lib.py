@@ -57,6 +57,10 @@ def _load() -> C.CDLL:
         "cs_swi_finalize": (i32, [C.POINTER(SwiPlan), vp, i32, i32, i32, i32, vp, vp, vp, vp]),
         "cs_normalize_workspace_bytes": (sz, [i32, i32]),
         "cs_normalize_image": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+        "cs_label_max": (i32, [vp, vp, i64, vp, vp]),
+        "cs_label_overlap": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+        "cs_remove_boundary_workspace_bytes": (sz, [i32]),
+        "cs_remove_boundary_cells": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
         "cs_ccl_workspace_bytes": (sz, [i32, i32]),
         "cs_ccl_postprocess": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
         "cs_ccl_label": (i32, [vp, i32, i32, i32, vp, vp, vp, sz, vp]),
@@ -75,7 +79,8 @@ EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_des
             "cs_unet_param_info cs_unet_load_param cs_unet_workspace_bytes cs_unet_forward cs_unet_grad_numel "
             "cs_unet_grad_offset cs_unet_backward_workspace_bytes cs_unet_backward cs_swi_make_plan "
             "cs_swi_window_start cs_swi_workspace_bytes cs_swi_infer cs_swi_finalize cs_normalize_workspace_bytes "
-            "cs_normalize_image cs_ccl_workspace_bytes "
+            "cs_normalize_image cs_label_max cs_label_overlap cs_remove_boundary_workspace_bytes cs_remove_boundary_cells "
+            "cs_ccl_workspace_bytes "
             "cs_ccl_postprocess cs_ccl_label cs_prof_enable cs_prof_reset cs_prof_collect").split()
 
 

@@ -32,7 +32,7 @@ static const char* kNames[K_NUM_IDS] = {
     "conv3x3_s1_mfma", "conv3x3_s2_mfma", "conv1x1_mfma", "conv_first_mfma", "convT3x3s2_mfma", "convT_top_valu",
     "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
     "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset", "norm_bwd",
-    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input"};
+    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
 
 struct ProfRecord {
@@ -1053,6 +1053,24 @@ int cs_normalize_image(const void* image, int bytes_per_sample, int h, int w, in
     CS_REQUIRE(bytes_per_sample == 1 || bytes_per_sample == 2, "normalize_image: only uint8 / uint16 samples (got %d bytes)", bytes_per_sample);
     return cs::normalize_image((hipStream_t)stream, image, bytes_per_sample == 2, h, w, channels, out_hwc, u8_hwc, workspace,
                                workspace_bytes);
+}
+
+int cs_label_max(const int32_t* a, const int32_t* b, int64_t n, int32_t* out2, void* stream) {
+    CS_REQUIRE(a && out2, "label_max: null argument");
+    return cs::label_max((hipStream_t)stream, a, b, n, out2);
+}
+
+int cs_label_overlap(const int32_t* gt, const int32_t* seg, int64_t n, int32_t n_gt, int32_t n_seg, uint32_t* overlap, void* stream) {
+    CS_REQUIRE(gt && seg && overlap && n_gt >= 0 && n_seg >= 0, "label_overlap: bad argument");
+    return cs::label_overlap((hipStream_t)stream, gt, seg, n, n_gt + 1, n_seg + 1, overlap);
+}
+
+size_t cs_remove_boundary_workspace_bytes(int32_t n_labels) { return cs::remove_boundary_workspace_bytes(n_labels); }
+
+int cs_remove_boundary_cells(const int32_t* labels, int h, int w, int border, int32_t n_labels, int32_t* out, int32_t* n_out,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(labels && out && workspace && h >= 0 && w >= 0 && border >= 0 && n_labels >= 0, "remove_boundary_cells: bad argument");
+    return cs::remove_boundary_cells((hipStream_t)stream, labels, h, w, border, n_labels, out, n_out, workspace, workspace_bytes);
 }
 
 size_t cs_ccl_workspace_bytes(int h, int w) { return cs::ccl_workspace_bytes(h, w); }

@@ -135,6 +135,13 @@ size_t normalize_workspace_bytes(int h, int w);
 int normalize_image(hipStream_t s, const void* img, int is_u16, int h, int w, int c_in, float* out_hwc, unsigned char* u8_out,
                     void* ws, size_t ws_bytes);
 
+// ---- F1 harness pieces (kernels_metric.hip) -----------------------------------------------------
+int label_max(hipStream_t s, const int32_t* a, const int32_t* b, int64_t n, int32_t* out2);
+int label_overlap(hipStream_t s, const int32_t* x, const int32_t* y, int64_t n, int32_t nx1, int32_t ny1, unsigned int* overlap);
+size_t remove_boundary_workspace_bytes(int32_t n_labels);
+int remove_boundary_cells(hipStream_t s, const int32_t* lab, int h, int w, int border, int32_t n_labels, int32_t* out, int32_t* n_out,
+                          void* ws, size_t ws_bytes);
+
 // ---- connected components ----------------------------------------------------------------------
 size_t ccl_workspace_bytes(int h, int w);
 int ccl_postprocess(hipStream_t s, const uint8_t* mask, int h, int w, int hole_area, int min_size, int32_t* labels,

@@ -340,3 +340,49 @@ def test_normalize_on_device_is_bit_exact_with_numpy(kind):
     got, got_u8 = preprocess.normalize_image_gpu(t, return_uint8=True)
     assert np.array_equal(got_u8.cpu().numpy(), want_u8)
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------- F1 harness (metric of record)
+F1G = np.load(os.path.join(G, "f1_golden.npz"))
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in F1G.files}))
+def test_f1_harness_matches_reference_golden(name):
+    from cellseg_amd import metrics
+    gt, seg = torch.from_numpy(F1G[name + "/gt"]).to(_dev()), torch.from_numpy(F1G[name + "/seg"]).to(_dev())
+    assert tuple(metrics.eval_tp_fp_fn(gt, seg)) == tuple(F1G[name + "/tpfpfn"])
+    gt_rb, seg_rb = metrics.remove_boundary_cells(gt), metrics.remove_boundary_cells(seg)
+    assert np.array_equal(gt_rb.cpu().numpy(), F1G[name + "/gt_rb"]) and np.array_equal(seg_rb.cpu().numpy(), F1G[name + "/seg_rb"])
+    assert tuple(metrics.eval_tp_fp_fn(gt_rb, seg_rb)) == tuple(F1G[name + "/tpfpfn_rb"])
+
+
+def test_f1_overlap_matches_oracle_at_scale():
+    from cellseg_amd import metrics
+    from oracle import f1_ref
+    import cellseg_amd as ca
+    a = ca.prob_to_instances(torch.from_numpy(_blob_prob(1024, 3)).to(_dev()))
+    b = ca.prob_to_instances(torch.from_numpy(np.roll(_blob_prob(1024, 3), 3, 1)).to(_dev()))
+    assert np.array_equal(metrics.label_overlap(a, b), f1_ref.label_overlap_ref(a.cpu().numpy(), b.cpu().numpy()))
+    want = f1_ref.f1_ref(a.cpu().numpy(), b.cpu().numpy())
+    got = metrics.f1_score(a, b)
+    assert got[:3] == want[:3] and abs(got[5] - want[5]) < 1e-12
+
+
+def test_bf16_modes_keep_f1_against_fp32_masks():
+    """north_star: F1 within 1e-3 of the reference path.  fp32-grade bf16x6 must reproduce the fp32 instances exactly or
+    to within 1e-3 F1; plain bf16 is reported (not gated tightly: random-init logits sit close to the 0.5 threshold)."""
+    import cellseg_amd as ca
+    from cellseg_amd import metrics
+    ref, hip = _pair()
+    from bench import synthetic_wsi
+    x = torch.from_numpy(synthetic_wsi(1024, 2022)).to(_dev())
+    labs = {}
+    with torch.no_grad():
+        for prec in ("fp32", "bf16x6", "bf16"):
+            hip.precision = prec
+            _, _, mask = ca.swi_infer_image(hip, x, (256, 256), 0.5, want_logits=False, want_mask=True)
+            labs[prec] = ca.mask_to_instances(mask)
+    f1_x6 = metrics.f1_score(labs["fp32"], labs["bf16x6"])[5]
+    f1_bf = metrics.f1_score(labs["fp32"], labs["bf16"])[5]
+    assert f1_x6 >= 1.0 - 1e-3, f1_x6
+    assert f1_bf >= 0.9, f1_bf

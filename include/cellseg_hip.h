@@ -58,6 +58,9 @@ int cs_unet_destroy(cs_unet* net);
  *   3  split-bf16, 3 planes / 6 MFMA terms on v_mfma_f32_16x16x32_bf16: fp32-grade results (~1e-5 logit error)
  *   2  split-bf16, 2 planes / 3 terms (~1e-4)        1  plain bf16 (throughput mode; judged by F1, not by logits) */
 int cs_unet_set_precision(cs_unet* net, int planes);
+/* on != 0: every cs_unet_load_param also packs the data-gradient layout of the tensor (needed by cs_unet_backward).
+ * Parameters loaded under the wrong mode / precision are refused at forward / backward time (CS_ERR_NOT_LOADED). */
+int cs_unet_set_training(cs_unet* net, int on);
 
 /* State-dict surface (replaces model.load_state_dict / model.state_dict, predict.py:80-81,
  * model_training_3class.py:269-274).  Keys are MONAI's: "model.0.conv.unit0.conv.weight", ... */

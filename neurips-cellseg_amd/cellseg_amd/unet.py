@@ -130,7 +130,7 @@ class _UNetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, x, *params):
-        out, ws = module._forward_engine(x, tag="train")
+        out, ws = module._forward_engine(x, tag="train", train=True)
         ctx.module, ctx.ws, ctx.x, ctx.shape = module, ws, x, tuple(x.shape)
         return out
 
@@ -219,8 +219,9 @@ class UNet(nn.Module):
             obj = getattr(obj, p)
         return obj
 
-    def engine(self) -> _Engine:
-        """Create (once per device) the C engine and upload every tensor whose storage/version changed."""
+    def engine(self, train: bool = False) -> _Engine:
+        """Create (once per device) the C engine and upload every tensor whose storage/version changed.
+        `train`: also pack the data-gradient weight layouts (the caller is about to record a tape for backward)."""
         p0 = next(self.parameters())
         _lib.require_gpu(p0)
         if self._engine is None or self._engine_device != p0.device:
@@ -229,6 +230,7 @@ class UNet(nn.Module):
                                        self.in_channels, self.out_channels)
             self._engine_device = p0.device
             self._uploaded.clear()
+            self._pack_state = (False, False)
             self._ws.clear()
             self._grad_slots = {}
             for i, (key, shape) in enumerate(self._engine.param_table()):
@@ -241,6 +243,16 @@ class UNet(nn.Module):
         if planes is None:
             raise ValueError(f"precision '{self.precision}' (fp32 | bf16x6 | bf16x3 | bf16)")
         check(lib.cs_unet_set_precision(self._engine.handle, planes), "cs_unet_set_precision")
+        want_train = bool(train)
+        check(lib.cs_unet_set_training(self._engine.handle, int(want_train)), "cs_unet_set_training")
+        # The engine packs the split-bf16 / data-gradient weight layouts only when asked.  `_pack_state` says which of them
+        # EVERY uploaded tensor currently has; a missing one forces a full re-upload under the new flags.
+        need = (planes > 0, want_train)
+        state = getattr(self, "_pack_state", (False, False))
+        if (need[0] and not state[0]) or (need[1] and not state[1]):
+            self._uploaded.clear()
+            state = need
+        uploaded_any = False
         stream = _lib.stream_ptr()
         for key in self._keys:
             if key.endswith("num_batches_tracked"):
@@ -254,6 +266,8 @@ class UNet(nn.Module):
                 check(lib.cs_unet_load_param(self._engine.handle, key.encode(), C.c_void_p(src.data_ptr()), src.numel(),
                                              stream), f"cs_unet_load_param({key})")
                 self._uploaded[key] = tag
+                uploaded_any = True
+        self._pack_state = (state[0] and need[0], state[1] and need[1]) if uploaded_any else state
         return self._engine
 
     def workspace(self, tag, nbytes: int, device) -> torch.Tensor:
@@ -264,9 +278,9 @@ class UNet(nn.Module):
             self._ws[tag] = ws
         return ws
 
-    def _forward_engine(self, x: torch.Tensor, tag: str = "fwd"):
+    def _forward_engine(self, x: torch.Tensor, tag: str = "fwd", train: bool = False):
         n, _, h, w = x.shape
-        eng = self.engine()
+        eng = self.engine(train)
         with torch.cuda.device(x.device):
             nbytes = lib.cs_unet_workspace_bytes(eng.handle, n, h, w)
             if nbytes == 0:

@@ -146,6 +146,8 @@ struct ParamEntry {
     int64_t shape[4] = {0, 0, 0, 0};
     std::function<int(const float*, hipStream_t)> load;
     bool loaded = false;
+    bool has_dgrad = false, has_bf16 = false;     // tensor takes part in the data-gradient / split-bf16 packings
+    bool dgrad_packed = false, bf16_packed = false;
     int64_t grad_off = 0;      // float offset of this parameter's gradient in the flat gradient buffer
     int64_t numel() const {
         int64_t n = 1;
@@ -191,6 +193,7 @@ struct cs_unet {
     size_t arena_floats = 0;
     int64_t grad_floats = 0;
     int planes = 0;   // 0: fp32 MFMA kernels; 1..3: split-bf16 kernels with that many planes (3 = fp32-grade)
+    bool training = false;   // pack the data-gradient weight layouts on every parameter load
     Tape tape;
 };
 
@@ -251,6 +254,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     float* bdst = cw.bias + cout_off;
     const int cout_total = cw.cout;
     auto pack_dgrad = [=](const float* d, hipStream_t s) -> int {
+        if (!net->training) return CS_OK;
         switch (dg) {
             case DG_S1: return pack_conv_weights(s, d, true, cin, cout, 3, wd, 0, cin, true, 0);
             case DG_1X1: return pack_conv_weights(s, d, true, cin, cout, 1, wd, 0, cin, false, 0);
@@ -263,7 +267,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
         cw.p_w[slot] = add_param(net, conv + ".weight", {cin, cout, ksize, ksize}, [=](const float* d, hipStream_t s) {
             if (int rc = pack_dgrad(d, s)) return rc;
             if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
-            if (wb)
+            if (wb && net->planes > 0)
                 if (int rc = pack_conv_weights_bf16(s, d, true, cout, cin, ksize, wb, cout_off, cout_total, cin_split)) return rc;
             return pack_conv_weights(s, d, true, cout, cin, ksize, wdst, cout_off, cout_total);
         });
@@ -272,11 +276,13 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             if (int rc = pack_dgrad(d, s)) return rc;
             if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
             if (mode == 1) return pack_first_weights(s, d, cout, cin, wdst, cout_off, cout_total);
-            if (wb)
+            if (wb && net->planes > 0)
                 if (int rc = pack_conv_weights_bf16(s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0)) return rc;
             return pack_conv_weights(s, d, false, cout, cin, ksize, wdst, cout_off, cout_total);
         });
     }
+    net->params[cw.p_w[slot]].has_dgrad = dg != DG_NONE;
+    net->params[cw.p_w[slot]].has_bf16 = wb != nullptr && mode == 0;
     cw.p_b[slot] = add_param(net, conv + ".bias", {cout}, [=](const float* d, hipStream_t s) { return copy_param(bdst, d, cout, s); });
 }
 
@@ -579,6 +585,15 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         return CS_OK;
     };
     auto rsrc = [&](const float* p, int c, int pitch) { return raw_src(p, c, pitch); };
+    // weight-gradient partial sums: [split_k][taps][rows][cols] in the (un-zeroed) buffer arena
+    struct WG { float* part; int k; };
+    auto wg_alloc = [&](int a_c1, int a_c2, int b_c, int taps, int rows, int cols, int ho, int wo) {
+        WG g;
+        g.k = wgrad_split_k(a_c1, b_c, n, ho, wo);
+        if (a_c2 > 0) { const int k2 = wgrad_split_k(a_c2, b_c, n, ho, wo); g.k = k2 < g.k ? k2 : g.k; }
+        g.part = buf.take<float>((size_t)g.k * taps * rows * cols);
+        return g;
+    };
 
     std::vector<float*> dX(nl, nullptr);
     float* dS = nullptr;       // gradient w.r.t. the "sub" input of the level above (D[d+1] or the bottom output)
@@ -594,25 +609,26 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         float* dU = buf.take<float>((size_t)n * oh * ow * c);
         dX[d] = buf.take<float>((size_t)n * ph * pw * cs);
         float* dSn = buf.take<float>((size_t)n * ph * pw * cb);
-        float* dwt = acc.take<float>((size_t)9 * cin_t * c);
+        const WG gt = wg_alloc(cs, cb, c, 9, cin_t, c, ph, pw);
         if (!buf.ok()) return oom();
         if (u.top) {
-            double* dw_last = acc.take<double>(81);
-            double* db_last = acc.take<double>(3);
+            double* dw_last = acc.take<double>(84);                   // [81 weights | 3 biases]
+            float* last_part = buf.take<float>(conv_last_bwd_partial_floats(n));
+            if (!buf.ok()) return oom();
             if (!dry) {
-                CS_TRY(launch_conv_last_bwd(s, dlogits, lu, u.unit0.w, d_au, dw_last, db_last, n, oh, ow));
+                CS_TRY(launch_conv_last_bwd(s, dlogits, lu, u.unit0.w, d_au, dw_last, last_part, n, oh, ow));
                 CS_TRY(launch_f64_to_f32(s, dw_last, gptr(u.unit0.p_w[0]), c * c * 9));
-                CS_TRY(launch_f64_to_f32(s, db_last, gptr(u.unit0.p_b[0]), c));
+                CS_TRY(launch_f64_to_f32(s, dw_last + 81, gptr(u.unit0.p_b[0]), c));
             }
         } else {
             float* dV = buf.take<float>((size_t)n * oh * ow * c);
-            float* dwu = acc.take<float>((size_t)9 * c * c);
+            const WG gu = wg_alloc(c, 0, c, 9, c, c, oh, ow);
             if (!buf.ok()) return oom();
             CS_TRY(norm_bwd(u.norm_u, lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow));
             CS_TRY(bias_grad(dV, c, c, (int64_t)n * oh * ow, u.unit0.p_b[0]));
             if (!dry) {
-                CS_TRY(launch_wgrad(s, 3, 1, dV, c, c, lu, nullptr, dwu, c, c, 0, 0, n, oh, ow, oh, ow));
-                CS_TRY(launch_unpack_wgrad(s, dwu, c, c, 0, 0, c, c, 9, gptr(u.unit0.p_w[0])));
+                CS_TRY(launch_wgrad(s, 3, 1, dV, c, c, lu, nullptr, gu.part, gu.k, c, c, 0, 0, n, oh, ow, oh, ow));
+                CS_TRY(launch_unpack_wgrad(s, gu.part, gu.k, c, c, 0, 0, c, c, 9, gptr(u.unit0.p_w[0])));
                 ConvOutExtra ex;
                 ex.addend = dS; ex.pitch_add = c;          // identity residual of the up ResidualUnit
                 CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dV, c, c), ConvSrc(), u.unit0.wd, nullptr, d_au, c, c, nullptr, n, oh, ow, &ex));
@@ -626,16 +642,16 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 CS_TRY(launch_convt_small_bwd_data(s, dU, u.convt.w, cin_t, cs, cb, dSn, cb, false, n, ph, pw));
                 WgradNarrow nb;
                 nb.ptr = dU; nb.c = c; nb.sn = (int64_t)oh * ow * c; nb.sc = 1; nb.sh = (int64_t)ow * c; nb.sw = c;
-                CS_TRY(launch_wgrad(s, 3, 2, T.X[d], cs, cs, ConvSrc(), &nb, dwt, cin_t, c, 0, 0, n, ph, pw, oh, ow));
-                CS_TRY(launch_wgrad(s, 3, 2, Ssub, cb, cb, ConvSrc(), &nb, dwt, cin_t, c, cs, 0, n, ph, pw, oh, ow));
+                CS_TRY(launch_wgrad(s, 3, 2, T.X[d], cs, cs, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, 0, 0, n, ph, pw, oh, ow));
+                CS_TRY(launch_wgrad(s, 3, 2, Ssub, cb, cb, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, cs, 0, n, ph, pw, oh, ow));
             } else {
                 ConvOutExtra ex;
                 ex.out2 = dSn; ex.pitch_out2 = cb; ex.split = cs;
                 CS_TRY(launch_conv_mfma(s, 3, 2, rsrc(dU, c, c), ConvSrc(), u.convt.wd, nullptr, dX[d], cs, cin_t, nullptr, n, oh, ow, &ex));
-                CS_TRY(launch_wgrad(s, 3, 2, T.X[d], cs, cs, rsrc(dU, c, c), nullptr, dwt, cin_t, c, 0, 0, n, ph, pw, oh, ow));
-                CS_TRY(launch_wgrad(s, 3, 2, Ssub, cb, cb, rsrc(dU, c, c), nullptr, dwt, cin_t, c, cs, 0, n, ph, pw, oh, ow));
+                CS_TRY(launch_wgrad(s, 3, 2, T.X[d], cs, cs, rsrc(dU, c, c), nullptr, gt.part, gt.k, cin_t, c, 0, 0, n, ph, pw, oh, ow));
+                CS_TRY(launch_wgrad(s, 3, 2, Ssub, cb, cb, rsrc(dU, c, c), nullptr, gt.part, gt.k, cin_t, c, cs, 0, n, ph, pw, oh, ow));
             }
-            CS_TRY(launch_unpack_wgrad(s, dwt, cin_t, c, 0, 0, cin_t, c, 9, gptr(u.convt.p_w[0])));
+            CS_TRY(launch_unpack_wgrad(s, gt.part, gt.k, cin_t, c, 0, 0, cin_t, c, 9, gptr(u.convt.p_w[0])));
         }
         dS = dSn;
     }
@@ -648,18 +664,18 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         const float* Xin = T.X[nl - 1];
         float* dXin = dX[nl - 1];
         if (u.res_conv) {
-            float* dwr = acc.take<float>((size_t)c * cin);
+            const WG gr = wg_alloc(c, 0, cin, 1, c, cin, ph, pw);
             CS_TRY(bias_grad(dS, c, c, n * npix, u.res1x1.p_b[0]));
             if (!dry) {
-                CS_TRY(launch_wgrad(s, 1, 1, dS, c, c, rsrc(Xin, cin, cin), nullptr, dwr, c, cin, 0, 0, n, ph, pw, ph, pw));
-                CS_TRY(launch_unpack_wgrad(s, dwr, c, cin, 0, 0, c, cin, 1, gptr(u.res1x1.p_w[0])));
+                CS_TRY(launch_wgrad(s, 1, 1, dS, c, c, rsrc(Xin, cin, cin), nullptr, gr.part, gr.k, c, cin, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_unpack_wgrad(s, gr.part, gr.k, c, cin, 0, 0, c, cin, 1, gptr(u.res1x1.p_w[0])));
             }
         }
         const float* da = dS;
         for (int su = u.subunits - 1; su >= 0; --su) {
             const ConvW& cw = su == 0 ? u.unit0 : u.units[su - 1];
             float* dY = buf.take<float>((size_t)n * npix * c);
-            float* dwa = acc.take<float>((size_t)9 * c * (su == 0 ? cin : c));
+            const WG ga = wg_alloc(c, 0, su == 0 ? cin : c, 9, c, su == 0 ? cin : c, ph, pw);
             float* da_new = su > 0 ? buf.take<float>((size_t)n * npix * c) : nullptr;
             if (!buf.ok()) return oom();
             CS_TRY(norm_bwd(u.norms[su], lazy_src(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c), da, c, dY, c, npix));
@@ -667,13 +683,13 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             if (dry) { da = da_new; continue; }
             if (su > 0) {
                 const ConvSrc prev = lazy_src(T.Yb[su - 1], c, c, T.rt_bottom[su - 1], u.norms[su - 1], c);
-                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, dwa, c, c, 0, 0, n, ph, pw, ph, pw));
-                CS_TRY(launch_unpack_wgrad(s, dwa, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
+                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_unpack_wgrad(s, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
                 CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dY, c, c), ConvSrc(), cw.wd, nullptr, da_new, c, c, nullptr, n, ph, pw));
                 da = da_new;
             } else {
-                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, rsrc(Xin, cin, cin), nullptr, dwa, c, cin, 0, 0, n, ph, pw, ph, pw));
-                CS_TRY(launch_unpack_wgrad(s, dwa, c, cin, 0, 0, c, cin, 9, gptr(cw.p_w[0])));
+                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, rsrc(Xin, cin, cin), nullptr, ga.part, ga.k, c, cin, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_unpack_wgrad(s, ga.part, ga.k, c, cin, 0, 0, c, cin, 9, gptr(cw.p_w[0])));
                 ConvOutExtra ex;
                 ex.addend = dXin; ex.pitch_add = cin;
                 CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dY, c, c), ConvSrc(), cw.wd, nullptr, dXin, cin, cin, nullptr, n, ph, pw, &ex));
@@ -703,50 +719,59 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const ConvW& cw = u.units[su - 1];
             float* dY = buf.take<float>((size_t)n * npix * c);
             float* da_new = buf.take<float>((size_t)n * npix * c);
-            float* dwa = acc.take<float>((size_t)9 * c * c);
+            const WG ga = wg_alloc(c, 0, c, 9, c, c, oh, ow);
             if (!buf.ok()) return oom();
             CS_TRY(norm_bwd(u.norms[su], lazy_src(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c), da, c, dY, c, npix));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0]));
             if (!dry) {
                 const ConvSrc prev = su - 1 == 0 ? lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0)
                                                  : lazy_src(T.Y[d][su - 1], c, c, T.rt_down[d][su - 1], u.norms[su - 1], c);
-                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, dwa, c, c, 0, 0, n, oh, ow, oh, ow));
-                CS_TRY(launch_unpack_wgrad(s, dwa, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
+                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, oh, ow, oh, ow));
+                CS_TRY(launch_unpack_wgrad(s, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
                 CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dY, c, c), ConvSrc(), cw.wd, nullptr, da_new, c, c, nullptr, n, oh, ow));
             }
             da = da_new;
         }
         float* dY0 = buf.take<float>((size_t)n * npix * c);
-        float* dwf = acc.take<float>((size_t)9 * c0 * cin);
+        const WG gf = wg_alloc(c, 0, cin, 9, c0, cin, oh, ow);
         if (!buf.ok()) return oom();
         CS_TRY(norm_bwd(u.norms[0], lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0), da, c, dY0, c, npix));
         CS_TRY(bias_grad(dY0, c, c, n * npix, u.unit0.p_b[0]));
         if (dry) continue;
         if (!u.first) {
             const ConvSrc xin = rsrc(T.X[d - 1], cin, cin);
-            CS_TRY(launch_wgrad(s, 3, 2, dY0, c, c, xin, nullptr, dwf, c0, cin, 0, 0, n, oh, ow, ph, pw));
-            CS_TRY(launch_wgrad(s, 3, 2, dXd, c, c, xin, nullptr, dwf, c0, cin, c, 0, n, oh, ow, ph, pw));
+            CS_TRY(launch_wgrad(s, 3, 2, dY0, c, c, xin, nullptr, gf.part, gf.k, c0, cin, 0, 0, n, oh, ow, ph, pw));
+            CS_TRY(launch_wgrad(s, 3, 2, dXd, c, c, xin, nullptr, gf.part, gf.k, c0, cin, c, 0, n, oh, ow, ph, pw));
             ConvOutExtra ex;
             ex.addend = dX[d - 1]; ex.pitch_add = cin;
             CS_TRY(launch_convt_mfma(s, rsrc(dY0, c, c), rsrc(dXd, c, c), u.unit0.wd, nullptr, dX[d - 1], cin, cin, nullptr, n, oh, ow, &ex));
         } else {
             WgradNarrow nb;
             nb.ptr = T.src.image; nb.c = cin; nb.sn = T.src.sn; nb.sc = T.src.sc; nb.sh = T.src.sh; nb.sw = T.src.sw;
-            CS_TRY(launch_wgrad(s, 3, 2, dY0, c, c, ConvSrc(), &nb, dwf, c0, cin, 0, 0, n, oh, ow, ph, pw));
-            CS_TRY(launch_wgrad(s, 3, 2, dXd, c, c, ConvSrc(), &nb, dwf, c0, cin, c, 0, n, oh, ow, ph, pw));
+            CS_TRY(launch_wgrad(s, 3, 2, dY0, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, 0, 0, n, oh, ow, ph, pw));
+            CS_TRY(launch_wgrad(s, 3, 2, dXd, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, c, 0, n, oh, ow, ph, pw));
         }
-        CS_TRY(launch_unpack_wgrad(s, dwf, c0, cin, 0, 0, c, cin, 9, gptr(u.unit0.p_w[0])));
-        CS_TRY(launch_unpack_wgrad(s, dwf, c0, cin, c, 0, c, cin, 9, gptr(u.unit0.p_w[1])));
+        CS_TRY(launch_unpack_wgrad(s, gf.part, gf.k, c0, cin, 0, 0, c, cin, 9, gptr(u.unit0.p_w[0])));
+        CS_TRY(launch_unpack_wgrad(s, gf.part, gf.k, c0, cin, c, 0, c, cin, 9, gptr(u.unit0.p_w[1])));
     }
     return CS_OK;
 }
 
-static int check_loaded(const cs_unet* net) {
-    for (const auto& p : net->params)
+static int check_loaded(const cs_unet* net, bool for_backward = false) {
+    for (const auto& p : net->params) {
         if (!p.loaded) {
             set_error("parameter '%s' was never loaded", p.key.c_str());
             return CS_ERR_NOT_LOADED;
         }
+        if (net->planes > 0 && p.has_bf16 && !p.bf16_packed) {
+            set_error("parameter '%s' was loaded before cs_unet_set_precision(>0): load it again", p.key.c_str());
+            return CS_ERR_NOT_LOADED;
+        }
+        if (for_backward && p.has_dgrad && !p.dgrad_packed) {
+            set_error("parameter '%s' was loaded before cs_unet_set_training(1): load it again", p.key.c_str());
+            return CS_ERR_NOT_LOADED;
+        }
+    }
     return CS_OK;
 }
 
@@ -825,6 +850,12 @@ int cs_unet_set_precision(cs_unet* net, int planes) {
     return CS_OK;
 }
 
+int cs_unet_set_training(cs_unet* net, int on) {
+    CS_REQUIRE(net, "set_training: null handle");
+    net->training = on != 0;
+    return CS_OK;
+}
+
 int cs_unet_destroy(cs_unet* net) {
     if (!net) return CS_OK;
     if (net->arena) (void)hipFree(net->arena);
@@ -853,7 +884,11 @@ int cs_unet_load_param(cs_unet* net, const char* key_host, const float* data, in
             CS_REQUIRE(numel == p.numel(), "load_param: '%s' expects %lld elements, got %lld", key_host, (long long)p.numel(),
                        (long long)numel);
             int rc = p.load(data, (hipStream_t)stream);
-            if (rc == CS_OK) p.loaded = true;
+            if (rc == CS_OK) {
+                p.loaded = true;
+                p.dgrad_packed = net->training;
+                p.bf16_packed = net->planes > 0;
+            }
             return rc;
         }
     }
@@ -915,6 +950,7 @@ int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspac
                      void* stream) {
     CS_REQUIRE(net && grad_logits_nhwc && workspace && flat_grad, "unet_backward: null argument");
     CS_REQUIRE(net->tape.valid, "unet_backward: no forward has been recorded (call cs_unet_forward first and keep its workspace intact)");
+    if (int rc0 = check_loaded(net, true)) return rc0;
     hipStream_t s = (hipStream_t)stream;
     size_t acc_bytes = 0, buf_bytes = 0;
     int rc = backward_sizes(net, &acc_bytes, &buf_bytes);

@@ -106,14 +106,20 @@ struct WgradNarrow {          // "x-like" operand with <= 4 channels addressed b
     int c = 0;
     int64_t sn = 0, sc = 0, sh = 0, sw = 0;
 };
-// dw[tap][co_off + i][ci_off + j] += sum_pixels a[pix][i] * b[pix*stride + tap - pad][j]   (float atomics; dw zeroed by caller)
+// part[k][tap][co_off + i][ci_off + j] = sum over split-K slice k of a[pix][i] * b[pix*stride + tap - pad][j]  (plain stores;
+// every element of the launch's [co_off, co_off+a_c) x [ci_off, ..) block is written, nothing needs zeroing).
+// split_k from wgrad_split_k(); launches that share one partial buffer (fused / concatenated operands) must use the same value.
+int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo);
 int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pitch, int a_c, const ConvSrc& b, const WgradNarrow* nb,
-                 float* dw, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi);
-int launch_unpack_wgrad(hipStream_t s, const float* dwacc, int rows_total, int cols_total, int row_off, int col_off, int rows,
-                        int cols, int taps, float* dst);
+                 float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi);
+// sums the split_k partials and converts to the PyTorch layout dst[row][col][tap]
+int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_total, int cols_total, int row_off, int col_off,
+                        int rows, int cols, int taps, float* dst);
 int launch_f64_to_f32(hipStream_t s, const double* src, float* dst, int n);
-int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw,
-                         double* db, int n, int h, int w);
+// dw_db: 84 doubles = [81 weight gradients | 3 bias gradients]; partial: conv_last_bwd_partial_floats(n) floats of scratch
+size_t conv_last_bwd_partial_floats(int n);
+int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw_db,
+                         float* partial, int n, int h, int w);
 int launch_convt_small_bwd_data(hipStream_t s, const float* du, const float* w_torch, int cin_total, int c_begin, int c_count,
                                 float* dst, int dst_pitch, bool accumulate, int n, int hin, int win);
 

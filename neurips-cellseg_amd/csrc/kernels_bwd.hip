@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* src, int pitch
 }
 
 int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npix_total, double* dst) {
-    const int64_t ppb = npix_total >= 65536 ? 2048 : 256;
+    const int64_t ppb = npix_total >= (1 << 20) ? 1024 : 256;   // >= 512 blocks on the large tensors
     ProfScope prof(K_COLSUM, s, 0, 4.0 * npix_total * c);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((npix_total + ppb - 1) / ppb)), dim3(256), 0, s, src, pitch, c, npix_total, ppb, dst);
     CS_HIP(hipGetLastError());
@@ -266,14 +266,18 @@ struct WgradParams {
     int b_mode, b_c;
     int64_t b_sn, b_sc, b_sh, b_sw;
     const float* dummy;          // valid readable memory for the branch-free table loads
-    float* dw;
+    float* part;                 // [split_k][taps][co_total][ci_total] partial sums (plain stores, no atomics)
     int co_total, ci_total, co_off, ci_off;
     int n, ho, wo, hi, wi;
-    int tiles_x, tiles_y, tiles_per_block, blocks_per_image;
+    int tiles_x, tiles_y, split_k, total_tiles;
 };
 
-template <int S, int KS, int MT>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
+// Split-K over pixels WITHOUT atomics: block k reduces its contiguous range of (image, tile) pairs and stores one partial
+// [taps][16*MT][16] slab; the unpack kernel sums the split_k partials while it converts to the PyTorch layout.  (A first
+// version committed every block with global float atomics: hundreds of blocks adding to the same few KB serialised at
+// the memory side and every launch took 110-260 us whatever its size.)
+template <int S, int KS, int MT, bool NARROW>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradParams p) {
     constexpr int TH = 4, TW = 16;
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
     constexpr int PAD = KS / 2, TAPS = KS * KS;
@@ -282,45 +286,52 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     constexpr int A_ITERS = (TH * TW * 4 * MT + 255) / 256;   // float4 per thread for the dy tile
     constexpr int B_ITERS = (IH * IW + 63) / 64;
     constexpr int A_FLOATS = TH * TW * COP, B_FLOATS = (IH * IW * CSX + 3) / 4 * 4;
-    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS + TAPS * MT * 256];
+    constexpr int NACC = (TAPS * MT + 3) / 4;              // accumulator tiles (tap, co-tile) owned by one wave
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
     float* const a_s = smem;
     float* const b_s = smem + A_FLOATS;
-    float* const slab = smem + A_FLOATS + B_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
-    const int img = blockIdx.x / p.blocks_per_image, blk = blockIdx.x % p.blocks_per_image;
+    const int ks_id = blockIdx.x;               // split-K slice
     const int co0 = blockIdx.y * 16 * MT;       // A channel base of this block
     const int cb0 = blockIdx.z * 16;            // B channel chunk
     const int q = tid & 3;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
 
-    f32x4 acc[TAPS][MT];
+    // The 9*MT (tap, co-tile) output tiles of the block are dealt round-robin to the 4 waves; every wave walks ALL pixel
+    // rows of the tile for its own outputs, so no cross-wave reduction (and no LDS atomics) is needed at the end.
+    f32x4 acc[NACC];
+    int a_off[NACC], b_off[NACC];                          // LDS offsets of this wave's tiles: co-tile column / tap shift
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < TAPS * MT * 256; i += 256) slab[i] = 0.f;
+    for (int i = 0; i < NACC; ++i) {
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int t = wave + 4 * i;                        // tile id = tap * MT + m
+        const int tap = (t < TAPS * MT) ? t / MT : 0, m = (t < TAPS * MT) ? t - tap * MT : 0;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        a_off[i] = m * 16 + li;
+        b_off[i] = (ky * IW + kx) * CSX + li;
+    }
 
-    // lazy table for this thread's B channel quad (mode 0)
-    f32x4 t0 = f32x4{1.f, 0.f, 1.f, 0.f}, t1 = t0;
+    const bool lazy = !NARROW && p.b_tab != nullptr;
+    f32x4 ra[A_ITERS], rb[B_ITERS];
+    f32x4 t0, t1;                 // lazy norm/act table of the PREFETCHED tile's image; applied when the tile is stored to LDS
     float slope = 0.f;
-    const bool lazy = p.b_mode == 0 && p.b_tab != nullptr;
-    {
+    unsigned ok_a = 0, ok_b = 0;  // validity bits of the prefetched tile
+    // global -> registers only: consuming a loaded value here would put the s_waitcnt in front of the MFMAs and
+    // serialise every tile behind its own load latency
+    auto load_tile = [&](int tile) {
+        const int img = tile / tiles_per_img, tl = tile - img * tiles_per_img;
+        const int tile_y = tl / p.tiles_x, tile_x = tl - tile_y * p.tiles_x;
+        const int oy0 = tile_y * TH, ox0 = tile_x * TW;
         const f32x4* t = lazy ? reinterpret_cast<const f32x4*>(p.b_tab + (size_t)img * p.b_tab_c + p.b_tab_off + cb0 + 4 * q)
                               : reinterpret_cast<const f32x4*>(p.dummy);
         t0 = t[0];
         t1 = t[1];
         const float* sp = (lazy && p.b_slope) ? p.b_slope : p.dummy;
         slope = *sp;
-        if (!(lazy && p.b_slope)) slope = 0.f;
-    }
-
-    f32x4 ra[A_ITERS], rb[B_ITERS];
-    int tile_y = 0, tile_x = 0;
-    auto load_tile = [&](int tile) {
-        tile_y = tile / p.tiles_x;
-        tile_x = tile - tile_y * p.tiles_x;
-        const int oy0 = tile_y * TH, ox0 = tile_x * TW;
+        ok_a = 0;
+        ok_b = 0;
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
             const int i = tid + 256 * it;
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
             const bool ok = (A_ITERS * 256 == TH * TW * 4 * MT || px < TH * TW) && oy < p.ho && ox < p.wo;
             const size_t off = ok ? (((size_t)img * p.ho + oy) * p.wo + ox) * p.a_pitch + co0 + 4 * c4 : 0;
             ra[it] = *reinterpret_cast<const f32x4*>(p.a + off);
-            if (!ok) ra[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ok_a |= (ok ? 1u : 0u) << it;
         }
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
@@ -337,42 +348,53 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
             const int iy = pix / IW, ix = pix - iy * IW;
             const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
             const bool ok = pix < IH * IW && gy >= 0 && gy < p.hi && gx >= 0 && gx < p.wi;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.b_mode == 0) {
+            if (!NARROW) {
                 const size_t off = ok ? (((size_t)img * p.hi + gy) * p.wi + gx) * p.b_pitch + cb0 + 4 * q : 0;
-                v = *reinterpret_cast<const f32x4*>(p.b_ptr + off);
-                if (lazy) {
-                    v.x = prelu_b(v.x * t0.x + t0.y, slope);
-                    v.y = prelu_b(v.y * t0.z + t0.w, slope);
-                    v.z = prelu_b(v.z * t1.x + t1.y, slope);
-                    v.w = prelu_b(v.w * t1.z + t1.w, slope);
-                }
-            } else if (q == 0 && ok) {
-                const float* b = p.b_ptr + img * p.b_sn + gy * p.b_sh + gx * p.b_sw;
+                rb[it] = *reinterpret_cast<const f32x4*>(p.b_ptr + off);
+                ok_b |= (ok ? 1u : 0u) << it;
+            } else {
+                const bool use = q == 0 && ok;
+                const float* b = p.b_ptr + (use ? img * p.b_sn + gy * p.b_sh + gx * p.b_sw : 0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < p.b_c) v[c] = b[c * p.b_sc];
+                for (int c = 0; c < 4; ++c) rb[it][c] = b[(c < p.b_c ? c : 0) * p.b_sc];
+                ok_b |= (use ? 1u : 0u) << it;
             }
-            rb[it] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_tile = [&]() {
+        const float sl = (lazy && p.b_slope) ? slope : 0.f;
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
             const int i = tid + 256 * it;
             const int px = i / (4 * MT), c4 = i - px * (4 * MT);
-            if (A_ITERS * 256 == TH * TW * 4 * MT || px < TH * TW) *reinterpret_cast<f32x4*>(&a_s[px * COP + 4 * c4]) = ra[it];
+            if (A_ITERS * 256 == TH * TW * 4 * MT || px < TH * TW)
+                *reinterpret_cast<f32x4*>(&a_s[px * COP + 4 * c4]) = ((ok_a >> it) & 1u) ? ra[it] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
             const int pix = (tid >> 2) + 64 * it;
-            if (pix < IH * IW) *reinterpret_cast<f32x4*>(&b_s[pix * CSX + 4 * q]) = rb[it];
+            if (pix < IH * IW) {
+                f32x4 v = rb[it];
+                if (!NARROW) {
+                    f32x4 r;
+                    r.x = prelu_b(v.x * t0.x + t0.y, sl);
+                    r.y = prelu_b(v.y * t0.z + t0.w, sl);
+                    r.z = prelu_b(v.z * t1.x + t1.y, sl);
+                    r.w = prelu_b(v.w * t1.z + t1.w, sl);
+                    v = lazy ? r : v;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c >= p.b_c) v[c] = 0.f;
+                }
+                *reinterpret_cast<f32x4*>(&b_s[pix * CSX + 4 * q]) = ((ok_b >> it) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
 
-    const int n_tiles = p.tiles_x * p.tiles_y;
-    const int t_begin = blk * p.tiles_per_block;
-    const int t_end = t_begin + p.tiles_per_block < n_tiles ? t_begin + p.tiles_per_block : n_tiles;
+    // contiguous slice of the (image, tile) list for this split-K block
+    const int t_begin = (int)((int64_t)ks_id * p.total_tiles / p.split_k);
+    const int t_end = (int)((int64_t)(ks_id + 1) * p.total_tiles / p.split_k);
     if (t_begin < t_end) {
         load_tile(t_begin);
         store_tile();
@@ -381,17 +403,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
     for (int tile = t_begin; tile < t_end; ++tile) {
         const bool more = tile + 1 < t_end;
         if (more) load_tile(tile + 1);
+        for (int row = 0; row < TH; ++row) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float a[MT];
+            for (int ks = 0; ks < 4; ++ks) {
+                const int pa = (row * 16 + 4 * ks + kk) * COP;
+                const int pb = (row * S * IW + (4 * ks + kk) * S) * CSX;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = a_s[(wave * 16 + 4 * ks + kk) * COP + m * 16 + li];
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int ky = tap / KS, kx = tap - ky * KS;
-                const float b = b_s[((wave * S + ky) * IW + (4 * ks + kk) * S + kx) * CSX + li];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[tap][m] = mfma4b(a[m], b, acc[tap][m]);
+                for (int i = 0; i < NACC; ++i)
+                    if ((TAPS * MT) % 4 == 0 || wave + 4 * i < TAPS * MT)
+                        acc[i] = mfma4b(a_s[pa + a_off[i]], b_s[pb + b_off[i]], acc[i]);
             }
         }
         __syncthreads();
@@ -400,27 +420,33 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
             __syncthreads();
         }
     }
-    // merge the four waves' partial tiles in LDS, then one global atomic per element
+    // every wave stores its own tiles of this split-K slice's partial (C layout: row = 4*kk + r, column = li)
+    const int ci_valid = NARROW ? p.b_c : 16;
+    float* part = p.part + (size_t)ks_id * TAPS * p.co_total * p.ci_total;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap)
+    for (int i = 0; i < NACC; ++i) {
+        const int t = wave + 4 * i;
+        if (t < TAPS * MT && li < ci_valid) {
+            const int tap = t / MT, m = t - tap * MT;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&slab[((tap * MT + m) * 16 + kk * 4 + r) * 16 + li], acc[tap][m][r]);
-    __syncthreads();
-    const int ci_valid = p.b_mode == 0 ? 16 : p.b_c;
-    for (int i = tid; i < TAPS * MT * 256; i += 256) {
-        const int j = i & 15, row = (i >> 4) & 15, tm = i >> 8;
-        const int m = tm % MT, tap = tm / MT;
-        if (j < ci_valid) {
-            const size_t dst = ((size_t)tap * p.co_total + p.co_off + co0 + m * 16 + row) * p.ci_total + p.ci_off + cb0 + j;
-            atomicAdd(p.dw + dst, slab[i]);
+            for (int r = 0; r < 4; ++r)
+                part[((size_t)tap * p.co_total + p.co_off + co0 + m * 16 + kk * 4 + r) * p.ci_total + p.ci_off + cb0 + li] = acc[i][r];
         }
     }
 }
 
+// how many split-K slices a weight-gradient launch should use: enough blocks to fill the chip, never more than tiles
+int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo) {
+    const int mt = (a_c % 64 == 0) ? 4 : (a_c % 32 == 0) ? 2 : 1;
+    const int combos = (a_c / (16 * mt)) * (b_c >= 16 ? b_c / 16 : 1);
+    const int total_tiles = n * ceil_div(wo, 16) * ceil_div(ho, 4);
+    int k = ceil_div(1024, combos);
+    if (k > total_tiles) k = total_tiles;
+    return k < 1 ? 1 : k;
+}
+
 int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pitch, int a_c, const ConvSrc& b, const WgradNarrow* nb,
-                 float* dw, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi) {
+                 float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi) {
     CS_REQUIRE(a_c % 16 == 0 && a_c > 0, "wgrad: %d dy channels (must be a multiple of 16)", a_c);
     CS_REQUIRE((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1), "wgrad: k%d s%d unsupported", ksize, stride);
     WgradParams p{};
@@ -437,47 +463,64 @@ int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pit
         b_chunks = b.c / 16;
     }
     p.dummy = a;
-    p.dw = dw; p.co_total = co_total; p.ci_total = ci_total; p.co_off = co_off; p.ci_off = ci_off;
+    p.part = part; p.co_total = co_total; p.ci_total = ci_total; p.co_off = co_off; p.ci_off = ci_off;
     p.n = n; p.ho = ho; p.wo = wo; p.hi = hi; p.wi = wi;
     p.tiles_x = ceil_div(wo, 16);
     p.tiles_y = ceil_div(ho, 4);
+    p.total_tiles = n * p.tiles_x * p.tiles_y;
+    CS_REQUIRE(split_k >= 1 && split_k <= p.total_tiles, "wgrad: split_k %d out of range", split_k);
+    p.split_k = split_k;
     const int mt = (a_c % 64 == 0) ? 4 : (a_c % 32 == 0) ? 2 : 1;
-    const int n_tiles = p.tiles_x * p.tiles_y;
-    const int others = n * (a_c / (16 * mt)) * b_chunks;
-    int tpb = n_tiles;                                  // as few partial sums as possible while still filling the chip
-    while (tpb > 1 && (long)others * ceil_div(n_tiles, tpb) < 1024) tpb = (tpb + 1) / 2;
-    p.tiles_per_block = tpb;
-    p.blocks_per_image = ceil_div(n_tiles, tpb);
-    dim3 grid((unsigned)(n * p.blocks_per_image), (unsigned)(a_c / (16 * mt)), (unsigned)b_chunks);
+    dim3 grid((unsigned)split_k, (unsigned)(a_c / (16 * mt)), (unsigned)b_chunks);
     const double flops = 2.0 * n * ho * wo * (double)a_c * (nb ? nb->c : b.c) * ksize * ksize;
     ProfScope prof(K_WGRAD, s, flops, 4.0 * n * ((double)ho * wo * a_c + (double)hi * wi * (nb ? nb->c : b.c)));
-#define CS_WG(S_, KS_)                                                                                       \
+#define CS_WG(S_, KS_, NB_)                                                                                   \
     switch (mt) {                                                                                            \
-        case 4: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 4>), grid, dim3(256), 0, s, p); break;        \
-        case 2: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 2>), grid, dim3(256), 0, s, p); break;        \
-        default: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 1>), grid, dim3(256), 0, s, p); break;       \
+        case 4: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 4, NB_>), grid, dim3(256), 0, s, p); break;   \
+        case 2: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 2, NB_>), grid, dim3(256), 0, s, p); break;   \
+        default: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 1, NB_>), grid, dim3(256), 0, s, p); break;  \
     }
-    if (ksize == 1) { CS_WG(1, 1) } else if (stride == 1) { CS_WG(1, 3) } else { CS_WG(2, 3) }
+    if (nb) {
+        CS_REQUIRE(ksize == 3 && stride == 2, "wgrad: the narrow operand is only used by stride-2 3x3 layers");
+        CS_WG(2, 3, true)
+    } else if (ksize == 1) { CS_WG(1, 1, false) } else if (stride == 1) { CS_WG(1, 3, false) } else { CS_WG(2, 3, false) }
 #undef CS_WG
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
-// dwacc [taps][rows_total][cols_total] (rows row_off.., cols col_off..) -> PyTorch layout dst[row][col][tap]
-__global__ void unpack_wgrad_kernel(const float* dwacc, int rows_total, int cols_total, int row_off, int col_off, int rows, int cols,
-                                    int taps, float* dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols * taps) return;
-    const int tap = i % taps, col = (i / taps) % cols, row = i / (taps * cols);
-    dst[i] = dwacc[((size_t)tap * rows_total + row_off + row) * cols_total + col_off + col];
+// sum of the split_k partials [k][taps][rows_total][cols_total] (rows row_off.., cols col_off..) -> PyTorch layout
+// dst[row][col][tap].  Block = 32 consecutive partial elements (one tap) x 8 split-K lanes, LDS tree over the lanes.
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* part, int split_k, int rows_total, int cols_total, int row_off,
+                                                           int col_off, int rows, int cols, int taps, float* dst) {
+    __shared__ float sh[256];
+    const int el = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int per_tap = rows * cols;
+    const int tap = blockIdx.y;
+    const int e = blockIdx.x * 32 + el;                 // element inside this conv's [rows][cols] block
+    float acc = 0.f;
+    if (e < per_tap) {
+        const int row = e / cols, col = e - row * cols;
+        const size_t off = ((size_t)tap * rows_total + row_off + row) * cols_total + col_off + col;
+        const size_t stride = (size_t)taps * rows_total * cols_total;
+        for (int k = kl; k < split_k; k += 8) acc += part[(size_t)k * stride + off];
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (kl == 0 && e < per_tap) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) t += sh[l * 32 + el];
+        dst[(size_t)e * taps + tap] = t;
+    }
 }
 
-int launch_unpack_wgrad(hipStream_t s, const float* dwacc, int rows_total, int cols_total, int row_off, int col_off, int rows,
-                        int cols, int taps, float* dst) {
+int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_total, int cols_total, int row_off, int col_off,
+                        int rows, int cols, int taps, float* dst) {
     const int total = rows * cols * taps;
-    ProfScope prof(K_PACK, s, 0, 8.0 * total);
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, dwacc, rows_total, cols_total,
-                       row_off, col_off, rows, cols, taps, dst);
+    ProfScope prof(K_PACK, s, 0, 4.0 * total * (split_k + 1));
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)ceil_div(rows * cols, 32), (unsigned)taps), dim3(256), 0, s, part, split_k,
+                       rows_total, cols_total, row_off, col_off, rows, cols, taps, dst);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -500,7 +543,7 @@ int launch_f64_to_f32(hipStream_t s, const double* src, float* dst, int n) {
 //   dW[co][ci][k] = sum_p dl[p][co] * T(u)[p + k - 1][ci] ;  db[co] = sum_p dl[p][co]
 template <int C>
 __global__ __launch_bounds__(256) void conv_last_bwd_kernel(const float* dl, const float* u, const float2* tab, const float* slope_p,
-                                                            const float* w, float* d_au, double* dw, double* db, int h, int wd) {
+                                                            const float* w, float* d_au, float* partial, int h, int wd) {
     __shared__ float w_s[C * C * 9];
     for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) w_s[i] = w[i];
     __syncthreads();
@@ -559,26 +602,39 @@ __global__ __launch_bounds__(256) void conv_last_bwd_kernel(const float* dl, con
 #pragma unroll
         for (int c = 0; c < C; ++c) d_au[((size_t)img * h * wd + pix) * C + c] = acc[c];
     }
+    // block reduction of the C*C*9 weight gradients and C bias gradients -> one partial row per block (no atomics:
+    // thousands of waves adding into the same 84 doubles serialised at the memory side and cost 1.5 ms)
+    __shared__ float red_s[4][C * C * 9 + C];
 #pragma unroll
-    for (int i = 0; i < C * C * 9; ++i) {
-        float v = gw[i];
+    for (int i = 0; i < C * C * 9 + C; ++i) {
+        float v = i < C * C * 9 ? gw[i] : gb[i - C * C * 9];
         for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if ((threadIdx.x & 63) == 0) atomicAdd(dw + i, (double)v);
+        if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6][i] = v;
     }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        float v = gb[c];
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if ((threadIdx.x & 63) == 0) atomicAdd(db + c, (double)v);
-    }
+    __syncthreads();
+    if (threadIdx.x < C * C * 9 + C)
+        partial[((size_t)img * gridDim.x + blockIdx.x) * (C * C * 9 + C) + threadIdx.x] =
+            red_s[0][threadIdx.x] + red_s[1][threadIdx.x] + red_s[2][threadIdx.x] + red_s[3][threadIdx.x];
 }
 
-int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw,
-                         double* db, int n, int h, int w) {
+// sum of the per-block partial rows in fp64
+__global__ void rows_sum_kernel(const float* partial, int rows, int cols, double* dst) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double acc = 0.0;
+    for (int r = 0; r < rows; ++r) acc += (double)partial[(size_t)r * cols + c];
+    dst[c] = acc;
+}
+
+size_t conv_last_bwd_partial_floats(int n) { return (size_t)n * 16 * 84; }
+
+int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw_db,
+                         float* partial, int n, int h, int w) {
     CS_REQUIRE(u.c == 3 && u.pitch == 3 && u.tab, "conv_last_bwd: 3-class contract");
     ProfScope prof(K_TOP_BWD, s, 4.0 * n * h * w * 81.0, 4.0 * n * (double)h * w * 9);
-    dim3 grid((unsigned)(ceil_div(h * w, 256) < 64 ? ceil_div(h * w, 256) : 64), (unsigned)n);
-    hipLaunchKernelGGL((conv_last_bwd_kernel<3>), grid, dim3(256), 0, s, dlogits, u.ptr, u.tab, u.slope, w_torch, d_au, dw, db, h, w);
+    dim3 grid(16, (unsigned)n);
+    hipLaunchKernelGGL((conv_last_bwd_kernel<3>), grid, dim3(256), 0, s, dlogits, u.ptr, u.tab, u.slope, w_torch, d_au, partial, h, w);
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(128), 0, s, partial, n * 16, 84, dw_db);   // [81 weights | 3 biases]
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     constexpr int W_ITERS = (TAPS * NT * 64 + 255) / 256;  // packed-weight float4s per thread
     constexpr int IN_FLOATS = (IH * IW * CS + 3) / 4 * 4;
     constexpr int EP_FLOATS = 4 * MT * 16 * (16 * NT + 4);     // epilogue slabs reuse the staging memory
-    constexpr int SM_FLOATS = (IN_FLOATS + TAPS * NT * 256) > EP_FLOATS ? (IN_FLOATS + TAPS * NT * 256) : EP_FLOATS;
+    constexpr int EPST_FLOATS = EP_FLOATS + 4 * 16 * NT * 2 * 2;   // + fp64 statistics of the 4 waves
+    constexpr int SM_FLOATS = (IN_FLOATS + TAPS * NT * 256) > EPST_FLOATS ? (IN_FLOATS + TAPS * NT * 256) : EPST_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     float* const in_s = smem;
     float* const w_s = smem + IN_FLOATS;
@@ -249,6 +250,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
 
     // ---- epilogue: bias, statistics (fp64), then full-line stores through a wave-private LDS slab ----
+    // statistics: lane sums -> 4 pixel groups of the wave (shuffles) -> 4 waves of the block (LDS) -> ONE fp64 atomic
+    // pair per block and channel (per-wave atomics on the same (image, channel) words cost 3-10 % of the kernel)
+    double* st_s = reinterpret_cast<double*>(smem + EP_FLOATS);      // [4 waves][16*NT][2]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (nt0 + nt) * 16 + pl;
@@ -268,7 +272,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
                 }
             }
         }
-        if (p.stats) stats_commit(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        if (p.stats) {
+            s += __shfl_xor(s, 16);
+            qq += __shfl_xor(qq, 16);
+            s += __shfl_xor(s, 32);
+            qq += __shfl_xor(qq, 32);
+            if (lane < 16) {
+                st_s[(wave * 16 * NT + nt * 16 + pl) * 2] = s;
+                st_s[(wave * 16 * NT + nt * 16 + pl) * 2 + 1] = qq;
+            }
+        }
     }
     {
         const int oy = oy0 + wave * MT;
@@ -277,6 +290,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         epilogue_store<NT, MT>(smem + wave * (MT * 16 * (16 * NT + 4)), acc, lane, o.out + pix0 * o.pitch + o.ch0,
                                (int64_t)p.wout * o.pitch, o.pitch, p.hout - oy, p.wout - ox0,
                                o.add ? o.add + pix0 * o.pitch_add + o.ch0 : nullptr, (int64_t)p.wout * o.pitch_add, o.pitch_add);
+    }
+    if (p.stats) {
+        __syncthreads();
+        if (tid < 32 * NT) {
+            const int c = tid >> 1, k = tid & 1;
+            const double v = st_s[(0 * 16 * NT + c) * 2 + k] + st_s[(1 * 16 * NT + c) * 2 + k] + st_s[(2 * 16 * NT + c) * 2 + k] +
+                             st_s[(3 * 16 * NT + c) * 2 + k];
+            atomicAdd(p.stats + ((size_t)img * p.cout + nt0 * 16 + c) * 2 + k, v);
+        }
     }
 }
 

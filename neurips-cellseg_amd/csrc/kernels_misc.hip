@@ -197,6 +197,143 @@ __global__ __launch_bounds__(256) void convt_small_kernel(SmallSrc a, SmallSrc b
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// top transposed conv as GEMM + gather (the MFMA form of the kernel above, used when cin % 16 == 0):
+//   P[pixel][co*9 + tap] = sum_cin x[pixel][cin] * W[cin][co][tap]        (M = pixels, N = 27 -> 32, K = cin; fp32 MFMA)
+//   out[2i+a][2j+b][co]  = bias + sum over the 1/2/2/4 (ky,kx) of that phase of P[i+di][j+dj][co*9 + ky*3 + kx]
+// A 16-wide MFMA tile cannot hold N = 3 output channels, but it holds the 27 (channel, tap) products: the block computes
+// P for its 8 x 16 input pixels plus a one-pixel halo (9 x 17 = 153 rows of the GEMM), keeps it in LDS and every output
+// pixel sums its contributions from there.  4.5x fewer MFMAs than padding N = 3 to 16, and no VALU inner loop.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+template <int CIN>
+__global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSrc b, const float* __restrict__ w, const float* bias,
+                                                             float* out, double* stats, int hin, int win, int tiles_x, int tiles_y) {
+    constexpr int TH = 8, TW = 16, IH = TH + 1, IW = TW + 1, NPIX = IH * IW, MPAD = 160;   // 10 M-tiles of 16 rows
+    constexpr int PP = 33;                                                              // P pitch (27 used, 32 computed)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int cin = CIN, XP = CIN + 4;                   // x pitch in floats
+    float* x_s = sm;                                         // [MPAD][XP]
+    float* w_s = sm + MPAD * XP;                             // [cin][32]
+    float* p_s = sm;                                         // [MPAD][PP] (reuses x_s after the GEMM)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kk = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int iy0 = ty * TH, ix0 = tx * TW;
+
+    // stage weights [cin][27] -> [cin][32] (zero padded) and the (9 x 17)-pixel input patch, 4 channels per thread
+    for (int i = tid; i < cin * 32; i += 256) {
+        const int k = i >> 5, n = i & 31;
+        w_s[i] = n < 27 ? w[(size_t)k * 27 + n] : 0.f;
+    }
+    constexpr int c4n = CIN / 4, ITERS = MPAD * c4n / 256;   // unconditional, fully unrolled loads: all in flight at once
+    f32x4m rx[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = tid + 256 * it;
+        const int pix = i / c4n, c4 = i - pix * c4n;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool ok = pix < NPIX && gy < hin && gx < win;
+        const int c = 4 * c4;
+        const SmallSrc& src = c < a.c ? a : b;
+        const int cc = c < a.c ? c : c - a.c;
+        const size_t off = ok ? (((size_t)img * hin + gy) * win + gx) * src.pitch + cc : 0;
+        rx[it] = *reinterpret_cast<const f32x4m*>(src.ptr + off);
+        if (!ok) rx[it] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = tid + 256 * it;
+        const int pix = i / c4n, c4 = i - pix * c4n;
+        *reinterpret_cast<f32x4m*>(&x_s[pix * XP + 4 * c4]) = rx[it];
+    }
+    __syncthreads();
+
+    // GEMM: 10 M-tiles x 2 N-tiles = 20 output tiles, 5 per wave
+    f32x4m acc[5];
+    int xo[5], wo[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        acc[i] = f32x4m{0.f, 0.f, 0.f, 0.f};
+        const int t = wave + 4 * i, m = t >> 1, nn = t & 1;
+        xo[i] = (m * 16 + li) * XP + kk;
+        wo[i] = kk * 32 + nn * 16 + li;
+    }
+    for (int k0 = 0; k0 < cin; k0 += 4) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(x_s[xo[i] + k0], w_s[wo[i] + k0 * 32], acc[i], 0, 0, 0);
+    }
+    __syncthreads();                                         // everyone is done with x_s: P may overwrite it
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int t = wave + 4 * i, m = t >> 1, nn = t & 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p_s[(m * 16 + kk * 4 + r) * PP + nn * 16 + li] = acc[i][r];
+    }
+    __syncthreads();
+
+    // gather: 16 x 32 output pixels x 3 channels per block, two pixels per thread
+    const int hout = 2 * hin, wout = 2 * win;
+    double s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int o = tid + 256 * rep;                       // 0 .. 511
+        const int oyl = o >> 5, oxl = o & 31;
+        const int i = oyl >> 1, pa = oyl & 1, j = oxl >> 1, pb = oxl & 1;
+        const int oy = 2 * iy0 + oyl, ox = 2 * ix0 + oxl;
+        if (oy < hout && ox < wout) {
+            float v[3];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) v[co] = bias ? bias[co] : 0.f;
+            // rows: a = 0 -> (ky 1, di 0); a = 1 -> (ky 0, di 1), (ky 2, di 0).  columns alike.
+#pragma unroll
+            for (int ry = 0; ry < 2; ++ry) {
+                if (pa == 0 && ry == 1) continue;
+                const int ky = pa == 0 ? 1 : (ry == 0 ? 0 : 2), di = (pa == 1 && ry == 0) ? 1 : 0;
+#pragma unroll
+                for (int rx = 0; rx < 2; ++rx) {
+                    if (pb == 0 && rx == 1) continue;
+                    const int kx = pb == 0 ? 1 : (rx == 0 ? 0 : 2), dj = (pb == 1 && rx == 0) ? 1 : 0;
+                    const float* pp = &p_s[((i + di) * IW + j + dj) * PP + ky * 3 + kx];
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) v[co] += pp[co * 9];
+                }
+            }
+            float* op = out + (((size_t)img * hout + oy) * wout + ox) * 3;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                op[co] = v[co];
+                s[co] += (double)v[co];
+                q[co] += (double)v[co] * (double)v[co];
+            }
+        }
+    }
+    if (stats) {
+        __shared__ double red[4][6];
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                s[co] += __shfl_xor(s[co], off);
+                q[co] += __shfl_xor(q[co], off);
+            }
+            if (lane == 0) {
+                red[wave][2 * co] = s[co];
+                red[wave][2 * co + 1] = q[co];
+            }
+        }
+        __syncthreads();
+        if (tid < 6) atomicAdd(stats + (size_t)img * 6 + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+    }
+}
+
 int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* w_torch, const float* bias, float* out,
                        int cout, double* stats, int n, int hin, int win) {
     CS_REQUIRE(cout == 3, "convT(small): cout %d unsupported (3-class contract)", cout);
@@ -207,6 +344,17 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
     const double flops = 2.0 * n * hin * win * (double)cout * cin * 9;
     const double bytes = 4.0 * n * ((double)hin * win * cin + 4.0 * hin * win * cout);
     ProfScope prof(K_CONVT_TOP, s, flops, bytes);
+    if ((cin == 32 || cin == 64 || cin == 128) && a.c % 4 == 0) {      // GEMM + gather on the matrix cores
+        const int tiles_x = ceil_div(win, 16), tiles_y = ceil_div(hin, 8);
+        const size_t sm = ((size_t)160 * (cin + 4) + (size_t)cin * 32) * sizeof(float);
+        const dim3 grid((unsigned)(tiles_x * tiles_y * n));
+        const SmallSrc sa{a.ptr, a.c, a.pitch}, sb{b.ptr, b.c, b.pitch};
+        if (cin == 32) hipLaunchKernelGGL((convt_top_gemm_kernel<32>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y);
+        else if (cin == 64) hipLaunchKernelGGL((convt_top_gemm_kernel<64>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y);
+        else hipLaunchKernelGGL((convt_top_gemm_kernel<128>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     dim3 grid((unsigned)ceil_div(hin * win, 256), (unsigned)n);
     hipLaunchKernelGGL((convt_small_kernel<3>), grid, dim3(256), lds, s, SmallSrc{a.ptr, a.c, a.pitch},
                        SmallSrc{b.ptr, b.c, b.pitch}, w_torch, bias, out, stats, hin, win);

@@ -417,15 +417,25 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
     } else {
         image += (size_t)img * p.sn;
     }
-    for (int i = tid; i < IH * IW * CIN; i += 256) {
+    // unconditional (clamped) loads, fully unrolled: a load under a branch makes hipcc wait for it before issuing the next
+    constexpr int ST_ITERS = (IH * IW * CIN + 255) / 256;
+    float rv[ST_ITERS];
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; ++it) {
+        const int i = tid + 256 * it;
         const int c = i % CIN, pix = i / CIN;
         const int iy = pix / IW, ix = pix - iy * IW;
         const int wy = oy0 * S - 1 + iy, wx = ox0 * S - 1 + ix;       // window-local coordinates
         const int gy = y0 + wy, gx = x0 + wx;                         // image coordinates
-        float v = 0.f;
-        if (wy >= 0 && wy < p.roi_h && wx >= 0 && wx < p.roi_w && gy >= 0 && gy < p.img_h && gx >= 0 && gx < p.img_w)
-            v = image[c * p.sc + gy * p.sh + gx * p.sw];
-        in_s[i] = v;
+        const bool ok = i < IH * IW * CIN && wy >= 0 && wy < p.roi_h && wx >= 0 && wx < p.roi_w && gy >= 0 && gy < p.img_h &&
+                        gx >= 0 && gx < p.img_w;
+        const float v = image[ok ? c * p.sc + gy * p.sh + gx * p.sw : 0];
+        rv[it] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; ++it) {
+        const int i = tid + 256 * it;
+        if (i < IH * IW * CIN) in_s[i] = rv[it];
     }
     if (tid < 4) in_s[IH * IW * CIN + tid] = 0.f;
     for (int i = tid; i < KSTEPS * NT * 64; i += 256) w_s[i] = p.wpack[i];

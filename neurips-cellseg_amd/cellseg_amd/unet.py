@@ -69,13 +69,6 @@ class _Engine:
             pass
 
 
-def param_table(channels=(16, 32, 64, 128, 256), num_res_units=2, norm="instance", act="prelu"):
-    """(key, shape) of every tensor the C engine expects.  Host-only metadata: usable without a GPU? No -
-    the engine allocates its weight arena at creation, so this needs a HIP device; the CPU-side table is
-    built by ``_host_param_table`` and the two are compared in the GPU tests."""
-    return _Engine(tuple(channels), num_res_units, norm, act, 3, 3).param_table()
-
-
 def _host_param_table(in_ch, out_ch, channels, nru, norm, act):
     """MONAI state-dict layout computed on the host (mirrors engine.hip build_net)."""
     tab = []

@@ -1,6 +1,6 @@
 """Ad-hoc GPU diagnostics (not a test): per-parameter gradient error of the HIP backward vs torch-CPU autograd."""
 import os, sys, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "neurips-cellseg_amd")]
 import torch
 import cellseg_amd as ca

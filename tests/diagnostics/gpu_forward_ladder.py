@@ -1,6 +1,6 @@
 """Ad-hoc GPU diagnostics (not a test): prints max-abs logit error for a ladder of network configs."""
 import os, sys, time, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "neurips-cellseg_amd")]
 import numpy as np, torch
 import cellseg_amd as ca

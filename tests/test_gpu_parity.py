@@ -386,3 +386,34 @@ def test_bf16_modes_keep_f1_against_fp32_masks():
     f1_bf = metrics.f1_score(labs["fp32"], labs["bf16"])[5]
     assert f1_x6 >= 1.0 - 1e-3, f1_x6
     assert f1_bf >= 0.9, f1_bf
+
+
+@pytest.mark.parametrize("roi,hw,overlap", [((128, 128), (300, 260), 0.25), ((512, 256), (700, 520), 0.5), ((64, 96), (200, 130), 0.25)])
+def test_sliding_window_other_roi_sizes(roi, hw, overlap):
+    """BASELINE configs[4] uses 512-pixel windows; the tiler and the engine are not tied to 256."""
+    import cellseg_amd as ca
+    from oracle.sliding_window_ref import sliding_window_inference_ref
+    ref, hip = _pair()
+    x = torch.rand(1, 3, *hw, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        want = sliding_window_inference_ref(x, roi, 4, ref, overlap=overlap)
+        got = ca.sliding_window_inference(x.to(_dev()), roi, 4, hip, overlap=overlap).cpu()
+    assert (got - want).abs().max().item() <= LOGIT_TOL
+
+
+def test_strip_partition_end_to_end_labels_equal_single_rank():
+    """What bench.py --shard strips / a multi-GPU predict does, on one GPU: strips -> gathered mask -> CC == single pass."""
+    import cellseg_amd as ca
+    ref, hip = _pair()
+    from bench import synthetic_wsi
+    x = torch.from_numpy(synthetic_wsi(768, 5)).to(_dev())
+    with torch.no_grad():
+        _, _, mask = ca.swi_infer_image(hip, x, (256, 256), 0.5, want_logits=False, want_mask=True)
+        want = ca.mask_to_instances(mask)
+        parts = []
+        for rank in range(3):
+            lo, hi = ca.rank_rows(768, rank, 3)
+            _, _, m = ca.swi_infer_image(hip, x, (256, 256), 0.5, rows=(lo, hi), want_logits=False, want_mask=True)
+            parts.append(m[lo:hi].clone())
+        got = ca.mask_to_instances(torch.cat(parts, 0))
+    assert torch.equal(got, want)

@@ -40,6 +40,22 @@ struct ConvParams {
     int pitch_add, pitch_add2, pitch_out2, split_nt;
 };
 
+
+// XCD-aware work decode.  Blocks are dealt round-robin over the 8 XCDs, so ids b and b + 8 share an L2.  The 1-D grid is
+// laid out as [spatial group of 8 tiles][channel tile][8]: the blocks that read the SAME input tile for different output
+// channels have ids 8 apart (same XCD, dispatched back to back) and hit L2 instead of re-fetching the tile from HBM.
+struct WorkId {
+    int spatial, ct;
+    bool valid;
+};
+__device__ __forceinline__ WorkId decode_work(int n_spatial, int n_ct) {
+    const int id = blockIdx.x, lane8 = id & 7, rest = id >> 3;
+    const int ct = rest % n_ct, sg = rest / n_ct;
+    const int spatial = sg * 8 + lane8;
+    return WorkId{spatial, ct, spatial < n_spatial};
+}
+static inline unsigned xcd_grid(int n_spatial, int n_ct) { return (unsigned)(((n_spatial + 7) / 8) * 8 * n_ct); }
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -150,13 +166,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
-    int bid = blockIdx.x;
+    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NT);
+    if (!wk.valid) return;                                   // whole block exits together (block-uniform)
+    int bid = wk.spatial;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
     const int img = bid / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int nt0 = blockIdx.y * NT;
+    const int nt0 = wk.ct * NT;
     const int q = tid & 3;
 
     f32x4 acc[MT][NT];
@@ -308,7 +326,7 @@ static int launch_conv_t(hipStream_t s, const ConvParams& p0) {
     constexpr int TH = 4 * MT;
     p.tiles_x = ceil_div(p.wout, 16);
     p.tiles_y = ceil_div(p.hout, TH);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.n), (unsigned)(p.ntile_total / NT));
+    dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NT));
     hipLaunchKernelGGL((conv_mfma_kernel<S, KS, NT, MT>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -546,13 +564,15 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
-    int bid = blockIdx.x;
+    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NT);
+    if (!wk.valid) return;
+    int bid = wk.spatial;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
     const int img = bid / p.tiles_y;
     const int iy0 = ty * TH, ix0 = tx * TW;
-    const int nt0 = blockIdx.y * NT;
+    const int nt0 = wk.ct * NT;
     const int q = tid & 3;
 
     f32x4 acc[4][NT];
@@ -702,7 +722,7 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
     p.tiles_y = ceil_div(hin, 4);
     int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
     if (int rc = apply_extra(p, ex, cout, &nt)) return rc;
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * n), (unsigned)(p.ntile_total / nt));
+    dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * n, p.ntile_total / nt));
     const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
     const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
     ProfScope prof(K_CONVT, s, flops, bytes);

@@ -42,6 +42,22 @@ struct ConvBParams {
     int n, hin, win, hout, wout, tiles_x, tiles_y;
 };
 
+
+// XCD-aware work decode.  Blocks are dealt round-robin over the 8 XCDs, so ids b and b + 8 share an L2.  The 1-D grid is
+// laid out as [spatial group of 8 tiles][channel tile][8]: the blocks that read the SAME input tile for different output
+// channels have ids 8 apart (same XCD, dispatched back to back) and hit L2 instead of re-fetching the tile from HBM.
+struct WorkId {
+    int spatial, ct;
+    bool valid;
+};
+__device__ __forceinline__ WorkId decode_work(int n_spatial, int n_ct) {
+    const int id = blockIdx.x, lane8 = id & 7, rest = id >> 3;
+    const int ct = rest % n_ct, sg = rest / n_ct;
+    const int spatial = sg * 8 + lane8;
+    return WorkId{spatial, ct, spatial < n_spatial};
+}
+static inline unsigned xcd_grid(int n_spatial, int n_ct) { return (unsigned)(((n_spatial + 7) / 8) * 8 * n_ct); }
+
 __device__ __forceinline__ float prelu_h(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
 __device__ __forceinline__ void stats_commit_b(double s, double q, double* dst, int lane) {
@@ -80,13 +96,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
     const int wn = wave % WN, wm = wave / WN;
-    int bid = blockIdx.x;
+    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NTB);
+    if (!wk.valid) return;
+    int bid = wk.spatial;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
     const int img = bid / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int nt_w = blockIdx.y * NTB + wn * NTW;            // this wave's first output-channel tile
+    const int nt_w = wk.ct * NTB + wn * NTW;                 // this wave's first output-channel tile
     const int q = tid & 7;                                   // this thread's channel quad inside the 32-channel chunk
 
     f32x4 acc[MTW][NTW];
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     __syncthreads();
     {
         constexpr int F4 = NTB * 4;                          // float4 per pixel record of this block
-        float* out0 = p.out + (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + blockIdx.y * NTB * 16;
+        float* out0 = p.out + (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + wk.ct * NTB * 16;
         for (int i = tid; i < TH * 16 * F4; i += 256) {
             const int pix = i / F4, c4 = i - pix * F4;
             const int row = pix >> 4, x = pix & 15;
@@ -259,7 +277,7 @@ static int launch_b(hipStream_t s, ConvBParams p) {
     constexpr int TH = (S == 1) ? 8 : 4;
     p.tiles_x = ceil_div(p.wout, 16);
     p.tiles_y = ceil_div(p.hout, TH);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.n), (unsigned)(p.ntile_total / (WN * NTW)));
+    dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
     hipLaunchKernelGGL((conv_bf16s_kernel<S, KS, WN, NTW, NP>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -324,13 +342,15 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
     const int wn = wave % WN, wm = wave / WN;
-    int bid = blockIdx.x;
+    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NTB);
+    if (!wk.valid) return;
+    int bid = wk.spatial;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
     const int img = bid / p.tiles_y;
     const int iy0 = ty * TH, ix0 = tx * TW;
-    const int nt_w = blockIdx.y * NTB + wn * NTW;
+    const int nt_w = wk.ct * NTB + wn * NTW;
     const int q = tid & 7;
 
     f32x4 acc[MTW][4][NTW];
@@ -484,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     __syncthreads();
     {
         constexpr int F4 = NTB * 4;
-        float* out0 = p.out + (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + blockIdx.y * NTB * 16;
+        float* out0 = p.out + (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;
         for (int i = tid; i < 2 * TH * 32 * F4; i += 256) {
             const int pix = i / F4, c4 = i - pix * F4;
             const int row = pix >> 5, x = pix & 31;
@@ -497,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
 
 template <int WN, int NTW, int NP>
 static int launch_tb(hipStream_t s, ConvBParams p) {
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.n), (unsigned)(p.ntile_total / (WN * NTW)));
+    dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
     hipLaunchKernelGGL((convt_bf16s_kernel<WN, NTW, NP>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;

@@ -57,8 +57,12 @@ def make_model(channels, seed=2022):
     return ca.UNet(spatial_dims=2, in_channels=3, out_channels=3, channels=channels, strides=(2, 2, 2, 2), num_res_units=2).eval()
 
 
+STREAMS = 2
+
+
 def run_step(ca, model, image, roi, overlap, engine_batch):
-    _, _, mask = ca.swi_infer_image(model, image, roi, overlap, engine_batch=engine_batch, want_logits=False, want_mask=True)
+    _, _, mask = ca.swi_infer_image(model, image, roi, overlap, engine_batch=engine_batch, want_logits=False, want_mask=True,
+                                    streams=STREAMS)
     return ca.mask_to_instances(mask, return_num=True)
 
 
@@ -127,6 +131,7 @@ def main():
     ap.add_argument("--overlap", type=float, default=0.5, help="0.5 = stride 128 (BASELINE configs[2]); reference default 0.25")
     ap.add_argument("--width", choices=sorted(WIDTHS), default="baseline32")
     ap.add_argument("--engine-batch", type=int, default=256)
+    ap.add_argument("--streams", type=int, default=2, help="internal streams the window chunks are dealt to (1 = serial)")
     ap.add_argument("--precision", choices=sorted(MFMA_PEAK), default="fp32",
                     help="matrix-core arithmetic of the convolutions (activations stay fp32 in HBM)")
     ap.add_argument("--shard", choices=["slides", "strips"], default="slides",
@@ -136,6 +141,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the reference-width (16..256) secondary measurement")
     args = ap.parse_args()
 
+    global STREAMS
+    STREAMS = args.streams
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -170,7 +177,7 @@ def main():
         """One slide across ranks: every rank runs the windows that touch its row strip, finalises its rows, the uint8 mask
         strips are all-gathered (RCCL), and every rank labels the full mask (2.1 MB per rank at 4096^2)."""
         _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch, rows=(row_lo, row_hi),
-                                        want_logits=False, want_mask=True)
+                                        want_logits=False, want_mask=True, streams=STREAMS)
         strip = mask[row_lo:row_hi]
         if backend != "nccl":
             full = parallel.gather_row_strips(strip.cpu(), args.size).to(dev)
@@ -293,7 +300,7 @@ def main():
                                f"{plan.interval_h} stride ({n_windows} windows), 3-class residual U-Net channels={list(WIDTHS[args.width])} "
                                f"num_res_units=2 InstanceNorm+PReLU random-init, softmax + >0.5 + remove_small_holes(64) + "
                                f"remove_small_objects(16) + 8-conn label on GPU; " + ("one slide cut into row strips" if strips else "one slide per GPU"),
-                   "windows": n_windows, "engine_batch": args.engine_batch, "precision": args.precision, "parallelism": (f"1 slide in {world} row strips + mask all-gather" if strips else f"slides x{world}"),
+                   "windows": n_windows, "engine_batch": args.engine_batch, "streams": args.streams, "precision": args.precision, "parallelism": (f"1 slide in {world} row strips + mask all-gather" if strips else f"slides x{world}"),
                    "instances_found": main_res["n_instances"], "foreground_fraction": round(main_res["fg_frac"], 4)},
         "value_incl_d2h": round(slides * mpix * args.steps / main_res["dt_d2h"], 3),
         "value_with_events": round(slides * mpix * args.steps / main_res["dt_prof"], 3),

@@ -61,6 +61,10 @@ int cs_unet_set_precision(cs_unet* net, int planes);
 /* on != 0: every cs_unet_load_param also packs the data-gradient layout of the tensor (needed by cs_unet_backward).
  * Parameters loaded under the wrong mode / precision are refused at forward / backward time (CS_ERR_NOT_LOADED). */
 int cs_unet_set_training(cs_unet* net, int on);
+/* n (1..4) internal streams for cs_swi_infer: window chunks are dealt round-robin to them (forked from / joined back to the
+ * caller's stream with events), so the HBM-bound kernels of one chunk overlap the MFMA-bound ones of another.  The side
+ * streams and events are created here, never on the launch path.  cs_swi_workspace_bytes scales with n. */
+int cs_unet_set_streams(cs_unet* net, int n);
 
 /* State-dict surface (replaces model.load_state_dict / model.state_dict, predict.py:80-81,
  * model_training_3class.py:269-274).  Keys are MONAI's: "model.0.conv.unit0.conv.weight", ... */

@@ -22,6 +22,7 @@ from ._lib import SwiPlan, check, lib
 from .unet import UNet
 
 DEFAULT_ENGINE_BATCH = 256
+DEFAULT_STREAMS = 2          # window chunks alternate between two internal streams (memory-bound kernels overlap MFMA-bound ones)
 
 
 def make_plan(img_h: int, img_w: int, roi_size: Sequence[int], overlap: float = 0.25) -> SwiPlan:
@@ -46,7 +47,7 @@ def rank_rows(img_h: int, rank: int, world: int) -> Tuple[int, int]:
 
 def swi_infer_image(model: UNet, image: torch.Tensor, roi_size, overlap: float = 0.25, *, engine_batch: int = DEFAULT_ENGINE_BATCH,
                     rows: Optional[Tuple[int, int]] = None, want_logits: bool = True, want_prob: bool = False,
-                    want_mask: bool = False):
+                    want_mask: bool = False, streams: int = DEFAULT_STREAMS):
     """image [3,H,W] (any strides) on the GPU -> (logits [3,H,W] | None, prob1 [H,W] | None, mask uint8 [H,W] | None)."""
     _lib.require_gpu(image)
     if image.dim() != 3:
@@ -58,10 +59,11 @@ def swi_infer_image(model: UNet, image: torch.Tensor, roi_size, overlap: float =
     eng = model.engine()
     dev = image.device
     with torch.cuda.device(dev):
+        check(lib.cs_unet_set_streams(eng.handle, int(streams)), "cs_unet_set_streams")
         nbytes = lib.cs_swi_workspace_bytes(eng.handle, C.byref(plan), int(engine_batch))
         if nbytes == 0:
             raise _lib.CellSegHipError(f"cs_swi_workspace_bytes: {lib.cs_last_error().decode()}")
-        ws = model.workspace(("swi", h, w, plan.roi_h, plan.roi_w, plan.n_h, plan.n_w, int(engine_batch)), nbytes, dev)
+        ws = model.workspace(("swi", h, w, plan.roi_h, plan.roi_w, plan.n_h, plan.n_w, int(engine_batch), int(streams)), nbytes, dev)
         logits = torch.empty((model.out_channels, h, w), dtype=torch.float32, device=dev) if want_logits else None
         prob = torch.empty((h, w), dtype=torch.float32, device=dev) if want_prob else None
         mask = torch.empty((h, w), dtype=torch.uint8, device=dev) if want_mask else None

@@ -194,6 +194,11 @@ struct cs_unet {
     int64_t grad_floats = 0;
     int planes = 0;   // 0: fp32 MFMA kernels; 1..3: split-bf16 kernels with that many planes (3 = fp32-grade)
     bool training = false;   // pack the data-gradient weight layouts on every parameter load
+    // sliding-window inference can spread its window chunks over side streams: the HBM-bound kernels of one chunk
+    // (residual adds, 3-channel layers, statistics) then overlap the MFMA-bound convolutions of another
+    int n_streams = 1;
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     Tape tape;
 };
 
@@ -856,8 +861,24 @@ int cs_unet_set_training(cs_unet* net, int on) {
     return CS_OK;
 }
 
+int cs_unet_set_streams(cs_unet* net, int n) {
+    CS_REQUIRE(net && n >= 1 && n <= 4, "set_streams: n must be 1..4");
+    for (int i = 0; i < n && n > 1; ++i) {          // created here, never on the launch path
+        if (!net->side[i]) CS_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
+        if (!net->ev_join[i]) CS_HIP(hipEventCreateWithFlags(&net->ev_join[i], hipEventDisableTiming));
+    }
+    if (n > 1 && !net->ev_fork) CS_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+    net->n_streams = n;
+    return CS_OK;
+}
+
 int cs_unet_destroy(cs_unet* net) {
     if (!net) return CS_OK;
+    for (int i = 0; i < 4; ++i) {
+        if (net->side[i]) (void)hipStreamDestroy(net->side[i]);
+        if (net->ev_join[i]) (void)hipEventDestroy(net->ev_join[i]);
+    }
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     if (net->arena) (void)hipFree(net->arena);
     delete net;
     return CS_OK;
@@ -1016,7 +1037,7 @@ size_t cs_swi_workspace_bytes(const cs_unet* net, const cs_swi_plan* pl, int eng
     if (!net || !pl || engine_batch <= 0) return 0;
     const size_t nwin = (size_t)pl->n_h * pl->n_w;
     const size_t eb = (size_t)engine_batch < nwin ? (size_t)engine_batch : nwin;
-    const size_t unet = cs_unet_workspace_bytes(net, (int)eb, pl->roi_h, pl->roi_w);
+    const size_t unet = cs_unet_workspace_bytes(net, (int)eb, pl->roi_h, pl->roi_w) * (size_t)net->n_streams;
     if (unet == 0) return 0;
     return unet + (nwin * 8 + 255) / 256 * 256 + (nwin * pl->roi_h * pl->roi_w * net->out_ch * 4 + 255) / 256 * 256 + 512;
 }
@@ -1044,13 +1065,34 @@ int cs_swi_infer(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_
     WindowSrc src;
     src.image = image; src.sn = 0; src.sc = sc; src.sh = sh; src.sw = sw;
     src.img_h = pl->img_h; src.img_w = pl->img_w; src.roi_h = pl->roi_h; src.roi_w = pl->roi_w;
+    // chunks of `engine_batch` windows; with side streams the chunks are dealt round-robin to them, each stream owning
+    // its own slice of the activation workspace (stream order serialises the chunks that share a slice).  Per-kernel
+    // profiling (cs_prof_enable) forces one stream so that event-timed durations are not inflated by overlap.
+    const int ns = (net->n_streams > 1 && !cs::g_prof_on && nwin > engine_batch) ? net->n_streams : 1;
     const size_t mark = b.off;
-    for (int k0 = 0; k0 < nwin; k0 += engine_batch) {
+    const size_t slice = ns > 1 ? ((workspace_bytes - mark) / ns) / 256 * 256 : 0;
+    if (ns > 1) {
+        CS_HIP(hipEventRecord(net->ev_fork, s));
+        for (int i = 0; i < ns; ++i) CS_HIP(hipStreamWaitEvent(net->side[i], net->ev_fork, 0));
+    }
+    int chunk = 0;
+    for (int k0 = 0; k0 < nwin; k0 += engine_batch, ++chunk) {
         const int nb = nwin - k0 < engine_batch ? nwin - k0 : engine_batch;
         src.origins = origins + k0;
-        b.off = mark;   // every chunk reuses the same activation workspace (stream order serialises them)
-        rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, b, s);
+        if (ns > 1) {
+            Bump bs((char*)workspace + mark + (size_t)(chunk % ns) * slice, slice);
+            rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, bs, net->side[chunk % ns]);
+        } else {
+            b.off = mark;   // every chunk reuses the same activation workspace (stream order serialises them)
+            rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, b, s);
+        }
         if (rc) return rc;
+    }
+    if (ns > 1) {
+        for (int i = 0; i < ns; ++i) {
+            CS_HIP(hipEventRecord(net->ev_join[i], net->side[i]));
+            CS_HIP(hipStreamWaitEvent(s, net->ev_join[i], 0));
+        }
     }
     SwiFinalizeArgs fa{};
     fa.win_logits = win_logits;

@@ -53,8 +53,8 @@ def sliding_window_inference_ref(inputs: torch.Tensor, roi_size: Sequence[int], 
                    wins[i % len(wins)][1]:wins[i % len(wins)][1] + rw] for i in idx]
         pred = predictor(torch.stack(crops, 0))
         if out is None:
-            out = torch.zeros((b, pred.shape[1], h, w), dtype=pred.dtype)
-            cnt = torch.zeros((1, 1, h, w), dtype=pred.dtype)
+            out = torch.zeros((b, pred.shape[1], h, w), dtype=pred.dtype, device=pred.device)
+            cnt = torch.zeros((1, 1, h, w), dtype=pred.dtype, device=pred.device)
         for k, i in enumerate(idx):
             hs, ws = wins[i % len(wins)]
             out[i // len(wins), :, hs:hs + rh, ws:ws + rw] += pred[k]      # importance map == 1

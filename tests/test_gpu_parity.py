@@ -48,6 +48,7 @@ def _pair(channels=(16, 32, 64, 128, 256), nru=2, norm="instance", act="prelu", 
     ((16, 32, 64, 128, 256), 1, (1, 3, 96, 64)),
     ((16, 32, 64, 128, 256), 3, (1, 3, 64, 64)),
     ((32, 64, 128, 256, 512), 2, (2, 3, 128, 128)),
+    ((64, 128, 256, 512, 1024), 2, (1, 3, 64, 96)),        # BASELINE.json configs[4] width
 ])
 def test_unet_forward_matches_oracle(channels, nru, shape):
     ref, hip = _pair(channels, nru)

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+from typing import Tuple
+
 import numpy as np
 import torch
 
@@ -80,14 +82,55 @@ def remove_boundary_cells(mask: torch.Tensor, border: int = 2) -> torch.Tensor:
     return out
 
 
-def f1_score(gt: torch.Tensor, seg: torch.Tensor, threshold: float = 0.5, count_bd_cells: bool = False):
-    """(tp, fp, fn, precision, recall, f1) of the reference's small-image branch (compute_metric.py:183-190, :234-241)."""
-    if not count_bd_cells:
-        gt, seg = remove_boundary_cells(gt), remove_boundary_cells(seg)
-    else:      # relabel_sequential only
-        gt, seg = remove_boundary_cells(gt, 0), remove_boundary_cells(seg, 0)
+PATCH_PIXELS = 25_000_000      # compute_metric.py:183 - images at or above this size are scored patch by patch
+PATCH_EDGE = 2000              # compute_metric.py:195
+
+
+def patch_counts(gt: torch.Tensor, seg: torch.Tensor, edge: int = PATCH_EDGE, threshold: float = 0.5,
+                 count_bd_cells: bool = False) -> Tuple[int, int, int, int, int]:
+    """The reference's large-image walk (compute_metric.py:191-232): the maps are zero-padded to a multiple of `edge` and
+    every `edge` x `edge` patch is scored on its own - boundary cells dropped (2-px frame of the PATCH), relabelled,
+    matched - and (tp, fp, fn, true cells, predicted cells) are summed over the patches."""
+    gt, seg = _i32(gt), _i32(seg)
+    h, w = gt.shape
+    border = 0 if count_bd_cells else 2
+    tot = [0, 0, 0, 0, 0]
+    for y in range(0, h, edge):
+        for x in range(0, w, edge):
+            a = torch.zeros((edge, edge), dtype=torch.int32, device=gt.device)
+            b = torch.zeros_like(a)
+            hh, ww = min(edge, h - y), min(edge, w - x)
+            a[:hh, :ww] = gt[y:y + hh, x:x + ww]
+            b[:hh, :ww] = seg[y:y + hh, x:x + ww]
+            a, b = remove_boundary_cells(a, border), remove_boundary_cells(b, border)
+            tp, fp, fn = eval_tp_fp_fn(a, b, threshold)
+            for k, v in enumerate((tp, fp, fn, int(a.max().item()), int(b.max().item()))):
+                tot[k] += v
+    return tuple(tot)
+
+
+def cell_counts(gt: torch.Tensor, seg: torch.Tensor, threshold: float = 0.5, count_bd_cells: bool = False,
+                patch_pixels: int = PATCH_PIXELS, patch_edge: int = PATCH_EDGE) -> Tuple[int, int, int, int, int]:
+    """(tp, fp, fn, true cells, predicted cells) as compute_metric.py main() counts them for one image: the whole-image
+    branch (:183-190) below `patch_pixels`, the patch walk (:191-232) at or above it."""
+    if gt.numel() >= patch_pixels:
+        return patch_counts(gt, seg, patch_edge, threshold, count_bd_cells)
+    border = 0 if count_bd_cells else 2          # border 0: relabel_sequential only
+    gt, seg = remove_boundary_cells(gt, border), remove_boundary_cells(seg, border)
     tp, fp, fn = eval_tp_fp_fn(gt, seg, threshold)
+    return tp, fp, fn, tp + fn, tp + fp
+
+
+def f1_from_counts(tp: int, n_true: int, n_pred: int) -> Tuple[float, float, float]:
+    """precision = tp / predicted cells, recall = tp / true cells, all three 0 when tp == 0 (compute_metric.py:233-241)."""
     if tp == 0:
-        return tp, fp, fn, 0.0, 0.0, 0.0
-    precision, recall = tp / (tp + fp), tp / (tp + fn)
-    return tp, fp, fn, precision, recall, 2 * precision * recall / (precision + recall)
+        return 0.0, 0.0, 0.0
+    precision, recall = tp / n_pred, tp / n_true
+    return precision, recall, 2 * precision * recall / (precision + recall)
+
+
+def f1_score(gt: torch.Tensor, seg: torch.Tensor, threshold: float = 0.5, count_bd_cells: bool = False,
+             patch_pixels: int = PATCH_PIXELS, patch_edge: int = PATCH_EDGE):
+    """(tp, fp, fn, precision, recall, f1) of one image."""
+    tp, fp, fn, n_true, n_pred = cell_counts(gt, seg, threshold, count_bd_cells, patch_pixels, patch_edge)
+    return (tp, fp, fn) + f1_from_counts(tp, n_true, n_pred)

@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE (oracle) - never imported by the product path.
 Follows /root/reference/baseline/compute_metric.py:
   _label_overlap :39-70, _intersection_over_union :21-37, _true_positive :83-105,
   eval_tp_fp_fn :107-122, remove_boundary_cells :124-133, dice :72-81,
-  precision/recall/F1 :234-241 (tp == 0 -> all zero).
+  precision/recall/F1 :234-241 (tp == 0 -> all zero); >= 25 Mpx patch walk :191-232.
 PINNED: tests/golden/f1_*.npz hold tp/fp/fn produced by importing the
 reference's compute_metric.py here (tests/golden/make_f1_golden.py).
 """
@@ -78,6 +78,24 @@ def f1_ref(gt: np.ndarray, seg: np.ndarray, threshold: float = 0.5, count_bd_cel
         return tp, fp, fn, 0.0, 0.0, 0.0
     precision, recall = tp / (tp + fp), tp / (tp + fn)
     return tp, fp, fn, precision, recall, 2 * precision * recall / (precision + recall)
+
+
+def f1_patch_counts_ref(gt: np.ndarray, seg: np.ndarray, edge: int = 2000, threshold: float = 0.5) -> np.ndarray:
+    """Large-image branch of compute_metric.py main() (:191-232): zero-pad to a multiple of `edge`, then per patch drop the
+    boundary cells, relabel, match; returns summed (tp, fp, fn, true cells, predicted cells).  Pinned by
+    tests/golden/f1_patch_golden.npz (reference functions driven patch by patch)."""
+    h, w = gt.shape
+    ph, pw = -(-h // edge) * edge, -(-w // edge) * edge
+    g = np.zeros((ph, pw), np.int32); g[:h, :w] = gt
+    s = np.zeros((ph, pw), np.int32); s[:h, :w] = seg
+    tot = np.zeros(5, np.int64)
+    for y in range(0, ph, edge):
+        for x in range(0, pw, edge):
+            a = remove_boundary_cells_ref(g[y:y + edge, x:x + edge])
+            b = remove_boundary_cells_ref(s[y:y + edge, x:x + edge])
+            tp, fp, fn = eval_tp_fp_fn_ref(a, b, threshold)
+            tot += np.array([tp, fp, fn, a.max(), b.max()], np.int64)
+    return tot
 
 
 def dice_ref(gt: np.ndarray, seg: np.ndarray) -> float:

@@ -357,6 +357,21 @@ def test_f1_harness_matches_reference_golden(name):
     assert tuple(metrics.eval_tp_fp_fn(gt_rb, seg_rb)) == tuple(F1G[name + "/tpfpfn_rb"])
 
 
+F1PG = np.load(os.path.join(G, "f1_patch_golden.npz"))
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in F1PG.files}))
+def test_f1_patch_walk_matches_reference_golden(name):
+    """compute_metric.py:191-232 (images >= 25 Mpx are scored in 2000^2 patches), exercised with a small patch edge."""
+    from cellseg_amd import metrics
+    gt, seg = torch.from_numpy(F1PG[name + "/gt"]).to(_dev()), torch.from_numpy(F1PG[name + "/seg"]).to(_dev())
+    edge = int(F1PG[name + "/edge"])
+    want = tuple(int(v) for v in F1PG[name + "/totals"])
+    assert metrics.patch_counts(gt, seg, edge) == want
+    tp, fp, fn, prec, rec, f1 = metrics.f1_score(gt, seg, patch_pixels=0, patch_edge=edge)
+    assert (tp, fp, fn) == want[:3] and prec == pytest.approx(want[0] / want[4]) and rec == pytest.approx(want[0] / want[3])
+
+
 def test_f1_overlap_matches_oracle_at_scale():
     from cellseg_amd import metrics
     from oracle import f1_ref

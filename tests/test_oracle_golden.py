@@ -54,6 +54,15 @@ def test_f1_matches_reference(name):
     assert f1_ref.dice_ref(gt, seg) == pytest.approx(float(F1[name + "/dice"]), abs=0)
 
 
+F1P = np.load(os.path.join(G, "f1_patch_golden.npz"))
+
+
+@pytest.mark.parametrize("name", _cases(F1P))
+def test_f1_patch_walk_matches_reference(name):
+    got = f1_ref.f1_patch_counts_ref(F1P[name + "/gt"], F1P[name + "/seg"], int(F1P[name + "/edge"]))
+    assert tuple(got) == tuple(F1P[name + "/totals"])
+
+
 NORM = np.load(os.path.join(G, "normalize_golden.npz"))
 
 

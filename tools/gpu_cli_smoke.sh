@@ -24,3 +24,15 @@ for f in sorted(os.listdir("$W/out")):
     a = np.array(Image.open(os.path.join("$W/out", f)))
     print(f, a.shape, a.dtype, int(a.max()))
 PY
+# score the predictions against themselves shifted by a pixel (compute_metric CLI: reference flags, CSV columns)
+python - <<PY
+import numpy as np, os
+from PIL import Image
+os.makedirs("$W/gt", exist_ok=True)
+for f in sorted(os.listdir("$W/out")):
+    if f.endswith("_label.tiff"):
+        a = np.array(Image.open(os.path.join("$W/out", f)))
+        Image.fromarray(np.roll(a, 1, 1).astype(np.int32)).save(os.path.join("$W/gt", f.replace("_label.tiff", ".tif")))
+PY
+python -m cellseg_amd.compute_metric -g $W/gt -s $W/out -o $W -n smoke -thre 0.5 0.7
+cat $W/smoke-0.5.csv

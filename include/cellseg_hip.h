@@ -158,6 +158,14 @@ int cs_ccl_postprocess(const uint8_t* mask, int h, int w, int hole_area, int min
 int cs_ccl_label(const uint8_t* mask, int h, int w, int connectivity,
                  int32_t* labels, int32_t* n_labels, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Instance map -> the 3-class training label (0 background, 1 interior, 2 boundary).
+ * Replaces create_interior_map (/root/reference/data/pre_process_3class.py:31-56):
+ *   boundary = binary_dilation(find_boundaries(inst, mode='inner'), disk(1));
+ *   interior = remove_small_objects(~boundary & inst > 0, min_size = 16);  out[interior] = 1; out[boundary] = 2.
+ * inst: int32 [h][w]; out: uint8 [h][w]; workspace: cs_ccl_workspace_bytes(h, w). */
+int cs_interior_map(const int32_t* inst, int h, int w, int min_size, uint8_t* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * F1 harness pieces  -  the O(H*W) parts of baseline/compute_metric.py (the metric of record):
  *   cs_label_max               max label of one or two int32 maps (out2[0], out2[1]) - `x.max()`, `y.max()` (:60)

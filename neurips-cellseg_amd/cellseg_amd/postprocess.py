@@ -70,3 +70,22 @@ def prob_to_instances(prob: torch.Tensor, hole_area: int = 64, min_size: int = 1
     """predict.py:113 on a class-1 probability map (strict ``> 0.5``)."""
     _lib.require_gpu(prob)
     return mask_to_instances(prob > 0.5, hole_area, min_size, return_num)
+
+
+def create_interior_map(inst_map: torch.Tensor, min_size: int = 16) -> torch.Tensor:
+    """Instance map [H,W] (any integer dtype, on the GPU) -> uint8 3-class map: 0 background, 1 interior, 2 boundary.
+
+    Drop-in for ``create_interior_map`` (/root/reference/data/pre_process_3class.py:31-56): inner boundaries
+    (``find_boundaries(mode='inner')``) dilated by ``disk(1)``, interior = the rest of the foreground with 4-connected
+    components smaller than `min_size` removed."""
+    _lib.require_gpu(inst_map)
+    m = inst_map.to(torch.int32).contiguous()
+    if m.dim() != 2:
+        raise ValueError("create_interior_map expects an [H,W] instance map")
+    h, w = m.shape
+    out = torch.zeros((h, w), dtype=torch.uint8, device=m.device)
+    with torch.cuda.device(m.device):
+        ws = torch.empty(max(int(lib.cs_ccl_workspace_bytes(h, w)), 256), dtype=torch.uint8, device=m.device)
+        check(lib.cs_interior_map(C.c_void_p(m.data_ptr()), h, w, int(min_size), C.c_void_p(out.data_ptr()),
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr()), "cs_interior_map")
+    return out

@@ -1159,6 +1159,12 @@ int cs_ccl_postprocess(const uint8_t* mask, int h, int w, int hole_area, int min
     return cs::ccl_postprocess((hipStream_t)stream, mask, h, w, hole_area, min_size, labels, n_labels, workspace, workspace_bytes);
 }
 
+int cs_interior_map(const int32_t* inst, int h, int w, int min_size, uint8_t* out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+    CS_REQUIRE(inst && out && workspace, "interior_map: null argument");
+    return cs::interior_map((hipStream_t)stream, inst, h, w, min_size, out, workspace, workspace_bytes);
+}
+
 int cs_ccl_label(const uint8_t* mask, int h, int w, int connectivity, int32_t* labels, int32_t* n_labels, void* workspace,
                  size_t workspace_bytes, void* stream) {
     CS_REQUIRE(mask && labels && workspace, "ccl_label: null argument");

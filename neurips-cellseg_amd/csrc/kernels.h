@@ -152,6 +152,7 @@ int remove_boundary_cells(hipStream_t s, const int32_t* lab, int h, int w, int b
 size_t ccl_workspace_bytes(int h, int w);
 int ccl_postprocess(hipStream_t s, const uint8_t* mask, int h, int w, int hole_area, int min_size, int32_t* labels,
                     int32_t* n_labels, void* ws, size_t ws_bytes);
+int interior_map(hipStream_t s, const int32_t* inst, int h, int w, int min_size, uint8_t* out, void* ws, size_t ws_bytes);
 int ccl_label(hipStream_t s, const uint8_t* mask, int h, int w, int conn, int32_t* labels, int32_t* n_labels, void* ws,
               size_t ws_bytes);
 

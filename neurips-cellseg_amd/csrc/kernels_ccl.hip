@@ -336,7 +336,56 @@ int number(hipStream_t s, int h, int w, const Ws& ws, int32_t* labels, int32_t* 
     return CS_OK;
 }
 
+// ---- instance map -> 3-class map (pre_process_3class.py:31-56) ----
+// stage A: inner boundaries = foreground pixels whose 4-neighbourhood (edge-replicated) holds more than one label
+__global__ __launch_bounds__(256) void interior_boundary_kernel(const int32_t* inst, int h, int w, uint8_t* b0) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int64_t i = (int64_t)y * w + x;
+    const int v = inst[i];
+    int lo = v, hi = v;
+    if (y > 0) { const int t = inst[i - w]; lo = min(lo, t); hi = max(hi, t); }
+    if (y + 1 < h) { const int t = inst[i + w]; lo = min(lo, t); hi = max(hi, t); }
+    if (x > 0) { const int t = inst[i - 1]; lo = min(lo, t); hi = max(hi, t); }
+    if (x + 1 < w) { const int t = inst[i + 1]; lo = min(lo, t); hi = max(hi, t); }
+    b0[i] = (v != 0 && lo != hi) ? 1 : 0;
+}
+// stage B: dilate with the 3x3 cross (zero outside the image); candidate interior = foreground minus the dilated boundary
+__global__ __launch_bounds__(256) void interior_dilate_kernel(const int32_t* inst, const uint8_t* b0, int h, int w, uint8_t* out,
+                                                              uint8_t* cand) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int64_t i = (int64_t)y * w + x;
+    uint8_t b = b0[i];
+    if (y > 0) b |= b0[i - w];
+    if (y + 1 < h) b |= b0[i + w];
+    if (x > 0) b |= b0[i - 1];
+    if (x + 1 < w) b |= b0[i + 1];
+    out[i] = b ? 2 : 0;
+    cand[i] = (!b && inst[i] > 0) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void interior_compose_kernel(int64_t n, const uint8_t* cand, uint8_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && out[i] != 2) out[i] = cand[i];
+}
+
 }  // namespace
+
+int interior_map(hipStream_t s, const int32_t* inst, int h, int w, int min_size, uint8_t* out, void* ws_p, size_t ws_bytes) {
+    CS_REQUIRE(h >= 0 && w >= 0 && (int64_t)h * w < (1ll << 31) - CHUNK, "interior_map: image %d x %d too large", h, w);
+    if ((int64_t)h * w == 0) return CS_OK;
+    Ws ws;
+    int rc = carve(ws_p, ws_bytes, h, w, &ws);
+    if (rc) return rc;
+    const int64_t n = (int64_t)h * w;
+    dim3 grid((unsigned)ceil_div(w, 256), (unsigned)h);
+    hipLaunchKernelGGL(interior_boundary_kernel, grid, dim3(256), 0, s, inst, h, w, ws.big);
+    hipLaunchKernelGGL(interior_dilate_kernel, grid, dim3(256), 0, s, inst, ws.big, h, w, out, ws.m);
+    if (min_size > 0 && (rc = flip_small(s, ws.m, 1, h, w, min_size, ws))) return rc;    // remove_small_objects(interior, 16)
+    hipLaunchKernelGGL(interior_compose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ws.m, out);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
 
 size_t ccl_workspace_bytes(int h, int w) {
     const size_t n = (size_t)h * w;

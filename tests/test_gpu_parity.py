@@ -357,6 +357,28 @@ def test_f1_harness_matches_reference_golden(name):
     assert tuple(metrics.eval_tp_fp_fn(gt_rb, seg_rb)) == tuple(F1G[name + "/tpfpfn_rb"])
 
 
+# ------------------------------------------------------------------------------------------- 3-class label contract
+LCG = np.load(os.path.join(G, "label_contract_golden.npz"))
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in LCG.files}))
+def test_interior_map_matches_reference_golden(name):
+    """create_interior_map (pre_process_3class.py:31-56): goldens produced by the imported reference function."""
+    import cellseg_amd as ca
+    inst = torch.from_numpy(LCG[name + "/inst"].astype(np.int32)).to(_dev())
+    got = ca.create_interior_map(inst).cpu().numpy()
+    assert got.dtype == np.uint8 and np.array_equal(got, LCG[name + "/interior"])
+
+
+def test_interior_map_matches_oracle_at_scale():
+    import cellseg_amd as ca
+    from oracle.label_contract_ref import create_interior_map_ref
+    inst = ca.prob_to_instances(torch.from_numpy(_blob_prob(1536, 5)).to(_dev()))
+    want = create_interior_map_ref(inst.cpu().numpy())
+    assert np.array_equal(ca.create_interior_map(inst).cpu().numpy(), want)
+    assert set(np.unique(want)) == {0, 1, 2}
+
+
 F1PG = np.load(os.path.join(G, "f1_patch_golden.npz"))
 
 

@@ -36,3 +36,22 @@ for f in sorted(os.listdir("$W/out")):
 PY
 python -m cellseg_amd.compute_metric -g $W/gt -s $W/out -o $W -n smoke -thre 0.5 0.7
 cat $W/smoke-0.5.csv
+# training-set preparation CLI (pre_process_3class): instance labels -> 3-class PNGs
+python - <<PY
+import numpy as np, os, shutil
+from PIL import Image
+os.makedirs("$W/raw/images", exist_ok=True); os.makedirs("$W/raw/labels", exist_ok=True)
+for f in sorted(os.listdir("$W/in")):
+    shutil.copy(os.path.join("$W/in", f), "$W/raw/images/")
+    stem = f.split(".")[0]
+    shutil.copy(os.path.join("$W/out", stem + "_label.tiff"), os.path.join("$W/raw/labels", stem + "_label.tiff"))
+PY
+python -m cellseg_amd.pre_process_3class -i $W/raw -o $W/pre
+python - <<PY
+import numpy as np, os
+from PIL import Image
+for d in ("images", "labels"):
+    for f in sorted(os.listdir(os.path.join("$W/pre", d))):
+        a = np.array(Image.open(os.path.join("$W/pre", d, f)))
+        print(d, f, a.shape, a.dtype, np.unique(a)[:4])
+PY

@@ -2,9 +2,11 @@
 
 Mirrors the structure of /root/reference/baseline/model_training_3class.py:94-188: ``data_path/{images,labels}``
 with ``<stem>_label.png`` labels, seeded 90/10 split, whole-image min-max intensity scaling, pad/crop to
-``input_size``, random axis flip, random 90-degree rotation, Gaussian noise (p 0.25, std 0.1) and gamma contrast
-(p 0.25, gamma in (1,2)).  MONAI's RandGaussianSmooth / RandHistogramShift / RandZoom are not reproduced yet (they
-are CPU-side augmentations in DataLoader workers, outside the accelerated path).
+``input_size``, random axis flip, random 90-degree rotation, Gaussian noise (p 0.25, std 0.1), gamma contrast
+(p 0.25, gamma in (1,2)), Gaussian smoothing (p 0.25, sigma_x in (1,2)), histogram shift (p 0.25, 3 control points)
+and zoom (p 0.15, 0.8-1.5, area / nearest, size kept).  They are CPU-side augmentations in DataLoader workers, outside
+the accelerated path, written from MONAI's published behaviour (MONAI itself is absent: parity unpinned, and the random
+streams differ from MONAI's by construction).
 """
 from __future__ import annotations
 
@@ -43,6 +45,64 @@ def _load(img_file: str, gt_file: str) -> Tuple[np.ndarray, np.ndarray]:
     return img, lab[None]
 
 
+def gaussian_kernel_1d(sigma: float, truncated: float = 4.0) -> np.ndarray:
+    """Pixel-integrated ("erf") Gaussian taps, tail = int(max(sigma * truncated, 0.5) + 0.5), not re-normalised."""
+    from scipy.special import erf
+    tail = int(max(float(sigma) * truncated, 0.5) + 0.5)
+    x = np.arange(-tail, tail + 1, dtype=np.float64)
+    t = 0.70710678 / abs(float(sigma))
+    return np.clip(0.5 * (erf(t * (x + 0.5)) - erf(t * (x - 0.5))), 0.0, None).astype(np.float32)
+
+
+def gaussian_smooth(img: np.ndarray, sigma_y: float, sigma_x: float) -> np.ndarray:
+    """[C,H,W] separable smoothing with zero padding (RandGaussianSmoothd's deterministic part)."""
+    from scipy.ndimage import correlate1d
+    out = img.astype(np.float32)
+    for axis, sg in ((1, sigma_y), (2, sigma_x)):
+        if sg > 0:
+            out = correlate1d(out, gaussian_kernel_1d(sg), axis=axis, mode="constant", cval=0.0)
+    return out
+
+
+def histogram_shift(img: np.ndarray, floating: np.ndarray) -> np.ndarray:
+    """Piecewise-linear intensity remap through control points (RandHistogramShiftd's deterministic part): reference
+    points are evenly spaced over [min, max]; `floating` holds their images as fractions of that range."""
+    lo, hi = float(img.min()), float(img.max())
+    ref = np.linspace(lo, hi, len(floating))
+    return np.interp(img, ref, np.asarray(floating, np.float64) * (hi - lo) + lo).astype(np.float32)
+
+
+def random_control_points(rng, n: int) -> np.ndarray:
+    ref = np.linspace(0.0, 1.0, n)
+    fl = ref.copy()
+    for i in range(1, n - 1):
+        fl[i] = rng.uniform(fl[i - 1], fl[i + 1])
+    return fl
+
+
+def zoom_keep_size(img: np.ndarray, lab: np.ndarray, z: float):
+    """RandZoomd(mode=["area","nearest"], keep_size=True, padding_mode="edge") for one zoom factor: resample by z, then
+    centre-crop (z > 1) or edge-pad (z < 1) back to the input size."""
+    import torch.nn.functional as F
+    h, w = img.shape[1:]
+    oh, ow = int(np.floor(h * z)), int(np.floor(w * z))
+    zi = F.interpolate(torch.from_numpy(np.ascontiguousarray(img))[None].float(), size=(oh, ow), mode="area")[0].numpy()
+    zl = F.interpolate(torch.from_numpy(np.ascontiguousarray(lab))[None].float(), size=(oh, ow), mode="nearest")[0].numpy().astype(lab.dtype)
+
+    def fit(a):
+        for ax, (have, want) in ((1, (a.shape[1], h)), (2, (a.shape[2], w))):
+            if have > want:
+                o = (have - want) // 2
+                a = np.take(a, np.arange(o, o + want), axis=ax)
+            elif have < want:
+                d = want - have
+                pad = [(0, 0)] * 3
+                pad[ax] = (d // 2, d - d // 2)
+                a = np.pad(a, pad, mode="edge")
+        return a
+    return fit(zi).astype(np.float32), fit(zl)
+
+
 class CellDataset(Dataset):
     def __init__(self, files: List[Tuple[str, str]], input_size: int, train: bool, seed: int = 0):
         self.files, self.size, self.train = files, input_size, train
@@ -78,6 +138,12 @@ class CellDataset(Dataset):
         if rng.random() < 0.25:
             lo, hi = img.min(), img.max()
             img = ((img - lo) / (hi - lo + 1e-7)) ** rng.uniform(1, 2) * (hi - lo) + lo
+        if rng.random() < 0.25:                                         # RandGaussianSmoothd(sigma_x=(1,2)); sigma_y default (0.25,1.5)
+            img = gaussian_smooth(img, rng.uniform(1.0, 2.0), rng.uniform(0.25, 1.5))
+        if rng.random() < 0.25:                                         # RandHistogramShiftd(num_control_points=3)
+            img = histogram_shift(img, random_control_points(rng, 3))
+        if rng.random() < 0.15:                                         # RandZoomd(0.8, 1.5)
+            img, lab = zoom_keep_size(np.ascontiguousarray(img, dtype=np.float32), np.ascontiguousarray(lab), rng.uniform(0.8, 1.5))
         return img.astype(np.float32), lab
 
 

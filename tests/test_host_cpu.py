@@ -111,3 +111,43 @@ def test_label_tiff_round_trip(tmp_path):
     preprocess.write_label_tiff(p, lab)
     back = preprocess.read_image(p)
     assert back.dtype == np.int32 and np.array_equal(back, lab)
+
+
+# ------------------------------------------------------------------------------------------- training augmentations (host)
+def test_augmentations_keep_shapes_and_label_values():
+    from cellseg_amd import data
+    rng = np.random.default_rng(3)
+    img = rng.random((3, 64, 80), dtype=np.float32)
+    lab = rng.integers(0, 3, (1, 64, 80)).astype(np.uint8)
+    for z in (0.8, 1.0, 1.37, 1.5):
+        zi, zl = data.zoom_keep_size(img, lab, z)
+        assert zi.shape == img.shape and zl.shape == lab.shape and set(np.unique(zl)) <= {0, 1, 2}
+    zi, zl = data.zoom_keep_size(img, lab, 1.0)
+    assert np.allclose(zi, img) and np.array_equal(zl, lab)
+    k = data.gaussian_kernel_1d(1.5)
+    assert len(k) == 2 * 6 + 1 and abs(k.sum() - 1.0) < 1e-3 and np.allclose(k, k[::-1])
+    sm = data.gaussian_smooth(np.ones((1, 40, 40), np.float32), 1.5, 1.0)
+    assert abs(sm[0, 20, 20] - 1.0) < 2e-3 and sm[0, 0, 0] < 0.5            # zero padding darkens the corners
+    fl = data.random_control_points(rng, 3)
+    assert fl[0] == 0.0 and fl[-1] == 1.0 and 0.0 <= fl[1] <= 1.0
+    hs = data.histogram_shift(img, fl)
+    assert hs.min() == pytest.approx(img.min()) and hs.max() == pytest.approx(img.max())
+    order = np.argsort(img.ravel())
+    assert np.all(np.diff(hs.ravel()[order]) >= -1e-7)                        # monotone remap
+
+
+def test_cell_dataset_train_pipeline(tmp_path):
+    from PIL import Image
+    from cellseg_amd import data
+    os.makedirs(tmp_path / "images"); os.makedirs(tmp_path / "labels")
+    rng = np.random.default_rng(0)
+    for i in range(4):
+        Image.fromarray((rng.random((90, 70, 3)) * 255).astype(np.uint8)).save(tmp_path / "images" / f"c{i}.png")
+        Image.fromarray(rng.integers(0, 3, (90, 70)).astype(np.uint8)).save(tmp_path / "labels" / f"c{i}_label.png")
+    train, val = data.split_files(str(tmp_path), 0, 0.25)
+    assert len(train) == 3 and len(val) == 1
+    ds = data.CellDataset(train, 64, True, seed=1)
+    for rep in range(40):                                                     # exercises every augmentation branch
+        item = ds[rep % 3]
+        assert item["img"].shape == (3, 64, 64) and item["label"].shape == (1, 64, 64)
+        assert item["img"].dtype == torch.float32 and set(item["label"].unique().tolist()) <= {0, 1, 2}

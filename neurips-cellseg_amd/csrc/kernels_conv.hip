@@ -332,6 +332,187 @@ static int launch_conv_t(hipStream_t s, const ConvParams& p0) {
     return CS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// register-weights variant for layers whose block covers 64 output channels: wave w OWNS channel tile w
+// (16 channels) and computes all MT rows of the block tile.  Its B fragments for a whole 16-channel chunk (TAPS
+// float4 per lane) are loaded straight from the packed weights (L2) into registers one chunk ahead - every weight
+// is fetched once per block, weights never touch LDS - and the staged input is double-buffered in LDS, so a chunk
+// costs ONE barrier.  The LDS footprint is the input patch only, which lets three blocks share a CU.
+// block = 256 threads = 4 waves; block tile = MT rows x 16 columns x 64 channels.
+// ------------------------------------------------------------------------------------------------
+template <int S, int KS, int MT>
+__global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
+    constexpr int TH = MT, TW = 16;
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int CS = (S == 1) ? 24 : 20;
+    constexpr int PAD = KS / 2;
+    constexpr int TAPS = KS * KS;
+    constexpr int IN_ITERS = (IH * IW + 63) / 64;
+    constexpr int IN_FLOATS = (IH * IW * CS + 3) / 4 * 4;
+    constexpr int EPS = 64 + 4;                                // floats per pixel record in the block's epilogue slab
+    constexpr int EP_FLOATS = TH * 16 * EPS;
+    constexpr int SM_FLOATS = (2 * IN_FLOATS) > EP_FLOATS ? (2 * IN_FLOATS) : EP_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / 4);
+    if (!wk.valid) return;
+    int bid = wk.spatial;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int nt0 = wk.ct * 4;
+    const int q = tid & 3;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int goff[IN_ITERS];
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (tid >> 2) + 64 * it;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
+        goff[it] = (pix < IH * IW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win) ? gy * p.win + gx : -1;
+    }
+
+    const int chunks_a = p.a.c >> 4, chunks = (p.a.c + p.b.c) >> 4;
+    f32x4 rin[IN_ITERS];
+    Lazy4 lz;
+    // B fragments of one 16-channel chunk: TAPS float4 per lane, refilled ONE TAP ROW AHEAD: at the start of row ky the
+    // slots of row (ky + 1) % KS - consumed one row earlier - receive the next row's (or the next chunk's first row's)
+    // fragments, so every load has a full row of MFMAs (3 x 32 x 32 cycles) to return from L2
+    f32x4 wc[TAPS];
+    const f32x4* const wbase = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)(nt0 + wave) * 64 + lane;
+    const size_t wtap = (size_t)p.ntile_total * 64;
+
+    auto load_in = [&](int ch) {
+        const bool from_a = ch < chunks_a;
+        const SrcDev& src = from_a ? p.a : p.b;
+        const int c0 = (from_a ? ch : ch - chunks_a) << 4;
+        lz.load(src, img, c0 + 4 * q, p.wpack);
+        const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + c0 + 4 * q;
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int o = goff[it] >= 0 ? goff[it] : 0;
+            rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * src.pitch);
+        }
+    };
+    auto store_in = [&](float* in_s) {
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int pix = (tid >> 2) + 64 * it;
+            if (IH * IW % 64 == 0 || pix < IH * IW) {
+                const f32x4 v = goff[it] >= 0 ? lz.apply(rin[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&in_s[pix * CS + 4 * q]) = v;
+            }
+        }
+    };
+
+    load_in(0);
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) wc[kx] = wbase[(size_t)kx * wtap];
+    store_in(smem);
+    __syncthreads();
+    const int last_row = chunks * KS - 1;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        // next chunk's input: UNCONDITIONAL loads (the last trip re-reads its own chunk from L2).  A load group skipped on
+        // one path would make hipcc size the vmcnt waits of the weight ring for that path and stall on these loads.
+        load_in(more ? ch + 1 : ch);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* in_s = smem + (ch & 1) * IN_FLOATS;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            {
+                const int row_next = ch * KS + ky + 1 < last_row ? ch * KS + ky + 1 : last_row;   // clamped: unconditional loads
+                const f32x4* wnext = wbase + (size_t)row_next * KS * wtap;
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) wc[((ky + 1) % KS) * KS + kx] = wnext[(size_t)kx * wtap];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f32x4 b = wc[ky * KS + kx];
+                f32x4 a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    a[m] = *reinterpret_cast<const f32x4*>(&in_s[((m * S + ky) * IW + pl * S + kx) * CS + 4 * g]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m] = mfma4(a[m].x, b.x, acc[m]);
+                    acc[m] = mfma4(a[m].y, b.y, acc[m]);
+                    acc[m] = mfma4(a[m].z, b.z, acc[m]);
+                    acc[m] = mfma4(a[m].w, b.w, acc[m]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) asm volatile("" ::"v"(rin[it]));   // keeps the loads above the MFMA section
+        if (more) store_in(smem + ((ch + 1) & 1) * IN_FLOATS);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + fp64 statistics (a wave holds ALL the block's pixels of its 16 channels), block slab, full-line stores
+    const int co = (nt0 + wave) * 16 + pl;
+    const float bias = p.bias ? p.bias[co] : 0.f;
+    double ssum = 0.0, qsum = 0.0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ox = ox0 + g * 4 + r;
+            const float v = acc[m][r] + bias;
+            smem[(m * 16 + g * 4 + r) * EPS + wave * 16 + pl] = v;
+            if (oy < p.hout && ox < p.wout) {
+                ssum += (double)v;
+                qsum += (double)v * (double)v;
+            }
+        }
+    }
+    if (p.stats) stats_commit(ssum, qsum, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    __syncthreads();
+    {
+        const OutSel o = select_out(p, nt0);
+        const int c4 = tid & 15;
+#pragma unroll
+        for (int it = 0; it < TH; ++it) {
+            const int pix = (tid >> 4) + 16 * it;          // 16 pixels per pass, one 256-byte record each
+            const int m = pix >> 4, x = pix & 15;
+            const int oy = oy0 + m, ox = ox0 + x;
+            if (oy < p.hout && ox < p.wout) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&smem[pix * EPS + c4 * 4]);
+                const size_t gp = ((size_t)img * p.hout + oy) * p.wout + ox;
+                if (o.add) v += *reinterpret_cast<const f32x4*>(o.add + gp * o.pitch_add + o.ch0 + c4 * 4);
+                *reinterpret_cast<f32x4*>(o.out + gp * o.pitch + o.ch0 + c4 * 4) = v;
+            }
+        }
+    }
+}
+
+template <int S, int KS, int MT>
+static int launch_conv_wreg(hipStream_t s, const ConvParams& p0) {
+    ConvParams p = p0;
+    p.tiles_x = ceil_div(p.wout, 16);
+    p.tiles_y = ceil_div(p.hout, MT);
+    dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / 4));
+    hipLaunchKernelGGL((conv_wreg_kernel<S, KS, MT>), grid, dim3(256), 0, s, p);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int g_conv_variant = 1;   // 1: register-weights kernel where it applies; 0: LDS-weights kernel everywhere (A/B switch, CS_CONV_VARIANT)
+static const int g_conv_variant_init = [] {
+    if (const char* e = getenv("CS_CONV_VARIANT")) g_conv_variant = atoi(e);
+    return 0;
+}();
+
 static SrcDev to_dev(const ConvSrc& s) { return SrcDev{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
 
 static int apply_extra(ConvParams& p, const ConvOutExtra* ex, int cout, int* nt) {
@@ -383,6 +564,7 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
         case 2: return launch_conv_t<S_, KS_, 2, MT_>(s, p);                   \
         default: return launch_conv_t<S_, KS_, 1, MT_>(s, p);                  \
     }
+    if (g_conv_variant == 1 && nt == 4 && ksize == 3 && stride == 1) return launch_conv_wreg<1, 3, 8>(s, p);
     if (ksize == 1) { CS_DISPATCH_NT(1, 1, 2) }
     if (stride == 1) { CS_DISPATCH_NT(1, 3, 2) }
     CS_DISPATCH_NT(2, 3, 1)

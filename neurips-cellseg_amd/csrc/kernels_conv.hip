@@ -333,30 +333,32 @@ static int launch_conv_t(hipStream_t s, const ConvParams& p0) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// register-weights variant for layers whose block covers 64 output channels: wave w OWNS channel tile w
-// (16 channels) and computes all MT rows of the block tile.  Its B fragments for a whole 16-channel chunk (TAPS
-// float4 per lane) are loaded straight from the packed weights (L2) into registers one chunk ahead - every weight
-// is fetched once per block, weights never touch LDS - and the staged input is double-buffered in LDS, so a chunk
-// costs ONE barrier.  The LDS footprint is the input patch only, which lets three blocks share a CU.
-// block = 256 threads = 4 waves; block tile = MT rows x 16 columns x 64 channels.
+// register-weights variant: wave (wn, wm) OWNS output-channel tile wn of the block's WN tiles and MT = TH / (4 / WN) of
+// its rows.  The B fragments of a 16-channel chunk (TAPS float4 per lane) go straight from the packed weights (L2)
+// into registers ONE TAP ROW ahead of their use - weights never touch LDS, and with WN = 4 every weight is fetched
+// once per block - and the staged input is double-buffered in LDS, so a chunk costs ONE barrier.  The LDS footprint is
+// the input patch only, which lets four blocks share a CU.
+// block = 256 threads = 4 waves; block tile = TH rows x 16 columns x 16*WN channels.
 // ------------------------------------------------------------------------------------------------
-template <int S, int KS, int MT>
-__global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
-    constexpr int TH = MT, TW = 16;
+template <int S, int KS, int WN, int TH, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
+    static_assert(KS >= 2, "the one-row-ahead weight ring needs at least two tap rows");
+    constexpr int WM = 4 / WN, MT = TH / WM, TW = 16;
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
     constexpr int CS = (S == 1) ? 24 : 20;
     constexpr int PAD = KS / 2;
     constexpr int TAPS = KS * KS;
     constexpr int IN_ITERS = (IH * IW + 63) / 64;
     constexpr int IN_FLOATS = (IH * IW * CS + 3) / 4 * 4;
-    constexpr int EPS = 64 + 4;                                // floats per pixel record in the block's epilogue slab
+    constexpr int EPS = 16 * WN + 4;                           // floats per pixel record in the block's epilogue slab
     constexpr int EP_FLOATS = TH * 16 * EPS;
     constexpr int SM_FLOATS = (2 * IN_FLOATS) > EP_FLOATS ? (2 * IN_FLOATS) : EP_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
     const int pl = lane & 15, g = lane >> 4;
-    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / 4);
+    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / WN);
     if (!wk.valid) return;
     int bid = wk.spatial;
     const int tx = bid % p.tiles_x;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
     const int ty = bid % p.tiles_y;
     const int img = bid / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int nt0 = wk.ct * 4;
+    const int nt0 = wk.ct * WN;
     const int q = tid & 3;
 
     f32x4 acc[MT];
@@ -385,9 +387,9 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
     Lazy4 lz;
     // B fragments of one 16-channel chunk: TAPS float4 per lane, refilled ONE TAP ROW AHEAD: at the start of row ky the
     // slots of row (ky + 1) % KS - consumed one row earlier - receive the next row's (or the next chunk's first row's)
-    // fragments, so every load has a full row of MFMAs (3 x 32 x 32 cycles) to return from L2
+    // fragments, so every load has a full row of MFMAs to return from L2
     f32x4 wc[TAPS];
-    const f32x4* const wbase = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)(nt0 + wave) * 64 + lane;
+    const f32x4* const wbase = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)(nt0 + wn) * 64 + lane;
     const size_t wtap = (size_t)p.ntile_total * 64;
 
     auto load_in = [&](int ch) {
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
                 f32x4 a[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    a[m] = *reinterpret_cast<const f32x4*>(&in_s[((m * S + ky) * IW + pl * S + kx) * CS + 4 * g]);
+                    a[m] = *reinterpret_cast<const f32x4*>(&in_s[(((wm * MT + m) * S + ky) * IW + pl * S + kx) * CS + 4 * g]);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     acc[m] = mfma4(a[m].x, b.x, acc[m]);
@@ -458,18 +460,18 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias + fp64 statistics (a wave holds ALL the block's pixels of its 16 channels), block slab, full-line stores
-    const int co = (nt0 + wave) * 16 + pl;
+    // ---- epilogue: bias + fp64 statistics of the wave's 16 channels over its rows, block slab, full-line stores ----
+    const int co = (nt0 + wn) * 16 + pl;
     const float bias = p.bias ? p.bias[co] : 0.f;
     double ssum = 0.0, qsum = 0.0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int oy = oy0 + m;
+        const int row = wm * MT + m, oy = oy0 + row;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ox = ox0 + g * 4 + r;
             const float v = acc[m][r] + bias;
-            smem[(m * 16 + g * 4 + r) * EPS + wave * 16 + pl] = v;
+            smem[(row * 16 + g * 4 + r) * EPS + wn * 16 + pl] = v;
             if (oy < p.hout && ox < p.wout) {
                 ssum += (double)v;
                 qsum += (double)v * (double)v;
@@ -480,10 +482,11 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
     __syncthreads();
     {
         const OutSel o = select_out(p, nt0);
-        const int c4 = tid & 15;
+        constexpr int F4 = WN * 4, PPP = 256 / F4;             // float4s per pixel record, pixels per pass
+        const int c4 = tid % F4;
 #pragma unroll
-        for (int it = 0; it < TH; ++it) {
-            const int pix = (tid >> 4) + 16 * it;          // 16 pixels per pass, one 256-byte record each
+        for (int it = 0; it < TH * 16 / PPP; ++it) {
+            const int pix = tid / F4 + PPP * it;
             const int m = pix >> 4, x = pix & 15;
             const int oy = oy0 + m, ox = ox0 + x;
             if (oy < p.hout && ox < p.wout) {
@@ -496,18 +499,18 @@ __global__ __launch_bounds__(256) void conv_wreg_kernel(ConvParams p) {
     }
 }
 
-template <int S, int KS, int MT>
+template <int S, int KS, int WN, int TH, int OCC>
 static int launch_conv_wreg(hipStream_t s, const ConvParams& p0) {
     ConvParams p = p0;
     p.tiles_x = ceil_div(p.wout, 16);
-    p.tiles_y = ceil_div(p.hout, MT);
-    dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / 4));
-    hipLaunchKernelGGL((conv_wreg_kernel<S, KS, MT>), grid, dim3(256), 0, s, p);
+    p.tiles_y = ceil_div(p.hout, TH);
+    dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / WN));
+    hipLaunchKernelGGL((conv_wreg_kernel<S, KS, WN, TH, OCC>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
-int g_conv_variant = 1;   // 1: register-weights kernel where it applies; 0: LDS-weights kernel everywhere (A/B switch, CS_CONV_VARIANT)
+int g_conv_variant = 3;   // bit mask: 1 = stride-1, 2 = stride-2 3x3 layers take the register-weights kernel (A/B switch CS_CONV_VARIANT)
 static const int g_conv_variant_init = [] {
     if (const char* e = getenv("CS_CONV_VARIANT")) g_conv_variant = atoi(e);
     return 0;
@@ -564,7 +567,10 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
         case 2: return launch_conv_t<S_, KS_, 2, MT_>(s, p);                   \
         default: return launch_conv_t<S_, KS_, 1, MT_>(s, p);                  \
     }
-    if (g_conv_variant == 1 && nt == 4 && ksize == 3 && stride == 1) return launch_conv_wreg<1, 3, 8>(s, p);
+    // 64-channel blocks of the 3x3 layers take the register-weights kernel (measured: s1 31.9 -> 30.3 ms, s2 9.8 -> 8.3 ms per
+    // 4096^2 slide; the 32-channel and 1x1 layers were not faster with it and keep the LDS-weights kernel)
+    if ((g_conv_variant & 1) && nt == 4 && ksize == 3 && stride == 1) return launch_conv_wreg<1, 3, 4, 8, 3>(s, p);
+    if ((g_conv_variant & 2) && nt == 4 && ksize == 3 && stride == 2) return launch_conv_wreg<2, 3, 4, 4, 3>(s, p);
     if (ksize == 1) { CS_DISPATCH_NT(1, 1, 2) }
     if (stride == 1) { CS_DISPATCH_NT(1, 3, 2) }
     CS_DISPATCH_NT(2, 3, 1)

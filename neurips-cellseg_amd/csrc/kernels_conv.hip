@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int KSTEPS = (9 * CIN + 3) / 4;
     constexpr int IN_FLOATS = (IH * IW * CIN + 4 + 3) / 4 * 4;
-    constexpr int EP_FLOATS = 4 * MT * 16 * (16 * NT + 4);
+    constexpr int EP_FLOATS = 4 * MT * 16 * (16 * NT + 4) + 4 * 16 * NT * 2 * 2;     // 4 wave slabs + fp64 statistics
     constexpr int SM_FLOATS = (IN_FLOATS + KSTEPS * NT * 64) > EP_FLOATS ? (IN_FLOATS + KSTEPS * NT * 64) : EP_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     float* const in_s = smem;
@@ -671,6 +671,11 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
         }
     }
 
+    // statistics: lane sums -> the wave's 4 pixel groups (shuffles) -> the block's 4 waves (LDS) -> ONE fp64 atomic pair per
+    // block and channel (per-wave atomics on the same (window, channel) words serialise in L2)
+    __syncthreads();   // every wave has finished reading the staged tile before statistics / slabs overwrite it
+    constexpr int EPW = MT * 16 * (16 * NT + 4);
+    double* st_s = reinterpret_cast<double*>(smem + 4 * EPW);          // [4 waves][16*NT][2], behind the epilogue slabs
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 16 + pl;
@@ -690,14 +695,31 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
                 }
             }
         }
-        if (p.stats) stats_commit(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        if (p.stats) {
+            s += __shfl_xor(s, 16);
+            qq += __shfl_xor(qq, 16);
+            s += __shfl_xor(s, 32);
+            qq += __shfl_xor(qq, 32);
+            if (lane < 16) {
+                st_s[(wave * 16 * NT + nt * 16 + pl) * 2] = s;
+                st_s[(wave * 16 * NT + nt * 16 + pl) * 2 + 1] = qq;
+            }
+        }
     }
-    __syncthreads();   // every wave has finished reading the staged tile before the slabs overwrite it
     {
         const int oy = oy0 + wave * MT;
         float* out_row0 = p.out + (((size_t)img * p.hout + oy) * p.wout + ox0) * p.pitch_out;
-        epilogue_store<NT, MT>(smem + wave * (MT * 16 * (16 * NT + 4)), acc, lane, out_row0, (int64_t)p.wout * p.pitch_out, p.pitch_out,
+        epilogue_store<NT, MT>(smem + wave * EPW, acc, lane, out_row0, (int64_t)p.wout * p.pitch_out, p.pitch_out,
                                p.hout - oy, p.wout - ox0);
+    }
+    if (p.stats) {
+        __syncthreads();
+        if (tid < 32 * NT) {
+            const int c = tid >> 1, k = tid & 1;
+            const double v = st_s[(0 * 16 * NT + c) * 2 + k] + st_s[(1 * 16 * NT + c) * 2 + k] + st_s[(2 * 16 * NT + c) * 2 + k] +
+                             st_s[(3 * 16 * NT + c) * 2 + k];
+            atomicAdd(p.stats + ((size_t)img * p.cout + c) * 2 + k, v);
+        }
     }
 }
 
@@ -744,7 +766,7 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
     constexpr int W_ITERS = (9 * NT * 64 + 255) / 256;
     constexpr int IN_FLOATS = (IH * IW * CS + 3) / 4 * 4;
     constexpr int EPS = 16 * NT + 4;
-    constexpr int EP_FLOATS = 4 * 64 * EPS;                    // per wave: 2 output rows x 32 output pixels
+    constexpr int EP_FLOATS = 4 * 64 * EPS + 4 * 16 * NT * 2 * 2;   // per wave: 2 output rows x 32 output pixels; + fp64 statistics
     constexpr int SM_FLOATS = (IN_FLOATS + 9 * NT * 256) > EP_FLOATS ? (IN_FLOATS + 9 * NT * 256) : EP_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     float* const in_s = smem;
@@ -854,6 +876,7 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
 
     const int iy = iy0 + wave;
     float* ep = smem + wave * 64 * EPS;
+    double* st_s = reinterpret_cast<double*>(smem + 4 * 64 * EPS);     // [4 waves][16*NT][2]: block-reduced statistics
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (nt0 + nt) * 16 + pl;
@@ -872,7 +895,16 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
                 }
             }
         }
-        if (p.stats) stats_commit(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        if (p.stats) {
+            s += __shfl_xor(s, 16);
+            qq += __shfl_xor(qq, 16);
+            s += __shfl_xor(s, 32);
+            qq += __shfl_xor(qq, 32);
+            if (lane < 16) {
+                st_s[(wave * 16 * NT + nt * 16 + pl) * 2] = s;
+                st_s[(wave * 16 * NT + nt * 16 + pl) * 2 + 1] = qq;
+            }
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -892,6 +924,15 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
                 if (add0) v += *reinterpret_cast<const f32x4*>(add0 + ((int64_t)row * p.wout + x) * o.pitch_add + c4 * 4);
                 *reinterpret_cast<f32x4*>(out0 + ((int64_t)row * p.wout + x) * o.pitch + c4 * 4) = v;
             }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        if (tid < 32 * NT) {
+            const int c = tid >> 1, kk = tid & 1;
+            const double v = st_s[(0 * 16 * NT + c) * 2 + kk] + st_s[(1 * 16 * NT + c) * 2 + kk] + st_s[(2 * 16 * NT + c) * 2 + kk] +
+                             st_s[(3 * 16 * NT + c) * 2 + kk];
+            atomicAdd(p.stats + ((size_t)img * p.cout + nt0 * 16 + c) * 2 + kk, v);
         }
     }
 }

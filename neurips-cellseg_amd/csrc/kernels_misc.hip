@@ -206,117 +206,109 @@ __global__ __launch_bounds__(256) void convt_small_kernel(SmallSrc a, SmallSrc b
 // pixel sums its contributions from there.  4.5x fewer MFMAs than padding N = 3 to 16, and no VALU inner loop.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4m __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) Px3 {             // one 3-channel pixel: a single 12-byte store (global_store_dwordx3)
+    float c0, c1, c2;
+};
 
 template <int CIN>
 __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSrc b, const float* __restrict__ w, const float* bias,
-                                                             float* out, double* stats, int hin, int win, int tiles_x, int tiles_y) {
+                                                             float* out, double* stats, int hin, int win, int tiles_x, int tiles_y,
+                                                             int n_tiles) {
     constexpr int TH = 8, TW = 16, IH = TH + 1, IW = TW + 1, NPIX = IH * IW, MPAD = 160;   // 10 M-tiles of 16 rows
     constexpr int PP = 33;                                                              // P pitch (27 used, 32 computed)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int cin = CIN, XP = CIN + 4;                   // x pitch in floats
     float* x_s = sm;                                         // [MPAD][XP]
-    float* w_s = sm + MPAD * XP;                             // [cin][32]
+    float* w_s = sm + MPAD * XP;                             // [cin/16][4 kk][32 n][4 j] = W[16 c16 + 4 kk + j][n]
     float* p_s = sm;                                         // [MPAD][PP] (reuses x_s after the GEMM)
+    __shared__ double red[4][6];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kk = lane >> 4;
-    int bid = blockIdx.x;
-    const int tx = bid % tiles_x;
-    bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int img = bid / tiles_y;
-    const int iy0 = ty * TH, ix0 = tx * TW;
 
-    // stage weights [cin][27] -> [cin][32] (zero padded) and the (9 x 17)-pixel input patch, 4 channels per thread
+    // PERSISTENT block: a contiguous run of tiles, the weights staged once, the NEXT tile's input patch prefetched into
+    // registers while the current tile is multiplied and gathered, and all tile-invariant index arithmetic hoisted out of
+    // the tile loop: the layer is bound by instruction issue (VALU + MFMA share a SIMD), not by HBM or LDS.
+    const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(n_tiles, t_begin + per);
+    if (t_begin >= t_end) return;
+
+    // weights [cin][27] -> fragment order: one ds_read_b128 yields the B values of 4 consecutive MFMA k-steps
     for (int i = tid; i < cin * 32; i += 256) {
-        const int k = i >> 5, n = i & 31;
-        w_s[i] = n < 27 ? w[(size_t)k * 27 + n] : 0.f;
+        const int j = i & 3, nn = (i >> 2) & 31, kq = (i >> 7) & 3, c16 = i >> 9;
+        const int k = c16 * 16 + 4 * kq + j;
+        w_s[i] = nn < 27 ? w[(size_t)k * 27 + nn] : 0.f;
     }
     constexpr int c4n = CIN / 4, ITERS = MPAD * c4n / 256;   // unconditional, fully unrolled loads: all in flight at once
     f32x4m rx[ITERS];
+    // tile-invariant part of the staging addresses
+    const float* sptr[ITERS];
+    int rel[ITERS], spitch[ITERS], liy[ITERS], lix[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = tid + 256 * it;
         const int pix = i / c4n, c4 = i - pix * c4n;
         const int iy = pix / IW, ix = pix - iy * IW;
-        const int gy = iy0 + iy, gx = ix0 + ix;
-        const bool ok = pix < NPIX && gy < hin && gx < win;
         const int c = 4 * c4;
-        const SmallSrc& src = c < a.c ? a : b;
-        const int cc = c < a.c ? c : c - a.c;
-        const size_t off = ok ? (((size_t)img * hin + gy) * win + gx) * src.pitch + cc : 0;
-        rx[it] = *reinterpret_cast<const f32x4m*>(src.ptr + off);
-        if (!ok) rx[it] = f32x4m{0.f, 0.f, 0.f, 0.f};
+        const bool in_a = c < a.c;
+        sptr[it] = in_a ? a.ptr + c : b.ptr + (c - a.c);
+        spitch[it] = in_a ? a.pitch : b.pitch;
+        rel[it] = (iy * win + ix) * spitch[it];
+        liy[it] = pix < NPIX ? iy : (1 << 20);               // rows beyond the patch are never valid
+        lix[it] = ix;
     }
+    unsigned okmask = 0;                                     // padding is zeroed at LDS-store time: consuming a loaded value
+                                                             // earlier would make hipcc wait for the prefetch before the GEMM
+    auto prefetch = [&](int img, int iy0, int ix0) {
+        okmask = 0;
+        const int base_px = (img * hin + iy0) * win + ix0;
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int i = tid + 256 * it;
-        const int pix = i / c4n, c4 = i - pix * c4n;
-        *reinterpret_cast<f32x4m*>(&x_s[pix * XP + 4 * c4]) = rx[it];
-    }
-    __syncthreads();
-
-    // GEMM: 10 M-tiles x 2 N-tiles = 20 output tiles, 5 per wave
-    f32x4m acc[5];
+        for (int it = 0; it < ITERS; ++it) {
+            const bool ok = iy0 + liy[it] < hin && ix0 + lix[it] < win;
+            const int off = ok ? base_px * spitch[it] + rel[it] : 0;
+            rx[it] = *reinterpret_cast<const f32x4m*>(sptr[it] + off);
+            okmask |= ok ? (1u << it) : 0u;
+        }
+    };
     int xo[5], wo[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        acc[i] = f32x4m{0.f, 0.f, 0.f, 0.f};
         const int t = wave + 4 * i, m = t >> 1, nn = t & 1;
-        xo[i] = (m * 16 + li) * XP + kk;
-        wo[i] = kk * 32 + nn * 16 + li;
+        xo[i] = (m * 16 + li) * XP + 4 * kk;
+        wo[i] = (kk * 32 + nn * 16 + li) * 4;
     }
-    for (int k0 = 0; k0 < cin; k0 += 4) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(x_s[xo[i] + k0], w_s[wo[i] + k0 * 32], acc[i], 0, 0, 0);
-    }
-    __syncthreads();                                         // everyone is done with x_s: P may overwrite it
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int t = wave + 4 * i, m = t >> 1, nn = t & 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p_s[(m * 16 + kk * 4 + r) * PP + nn * 16 + li] = acc[i][r];
-    }
-    __syncthreads();
-
-    // gather: 16 x 32 output pixels x 3 channels per block, two pixels per thread
     const int hout = 2 * hin, wout = 2 * win;
-    double s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+    float bv[3];                                             // loaded once: a load inside the tile loop would be the youngest
+#pragma unroll                                               // outstanding one and its wait would also drain the prefetch
+    for (int co = 0; co < 3; ++co) bv[co] = bias ? bias[co] : 0.f;
+    // gather geometry of this thread's two output pixels (tile-invariant)
+    int g_oyl[2], g_oxl[2], g_p[2][4], g_n[2];
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
         const int o = tid + 256 * rep;                       // 0 .. 511
         const int oyl = o >> 5, oxl = o & 31;
         const int i = oyl >> 1, pa = oyl & 1, j = oxl >> 1, pb = oxl & 1;
-        const int oy = 2 * iy0 + oyl, ox = 2 * ix0 + oxl;
-        if (oy < hout && ox < wout) {
-            float v[3];
+        g_oyl[rep] = oyl;
+        g_oxl[rep] = oxl;
+        int cnt = 0;
+        // rows: a = 0 -> (ky 1, di 0); a = 1 -> (ky 0, di 1), (ky 2, di 0).  columns alike.
 #pragma unroll
-            for (int co = 0; co < 3; ++co) v[co] = bias ? bias[co] : 0.f;
-            // rows: a = 0 -> (ky 1, di 0); a = 1 -> (ky 0, di 1), (ky 2, di 0).  columns alike.
+        for (int ry = 0; ry < 2; ++ry) {
 #pragma unroll
-            for (int ry = 0; ry < 2; ++ry) {
-                if (pa == 0 && ry == 1) continue;
+            for (int rxx = 0; rxx < 2; ++rxx) {
+                const bool use = !(pa == 0 && ry == 1) && !(pb == 0 && rxx == 1);
                 const int ky = pa == 0 ? 1 : (ry == 0 ? 0 : 2), di = (pa == 1 && ry == 0) ? 1 : 0;
-#pragma unroll
-                for (int rx = 0; rx < 2; ++rx) {
-                    if (pb == 0 && rx == 1) continue;
-                    const int kx = pb == 0 ? 1 : (rx == 0 ? 0 : 2), dj = (pb == 1 && rx == 0) ? 1 : 0;
-                    const float* pp = &p_s[((i + di) * IW + j + dj) * PP + ky * 3 + kx];
-#pragma unroll
-                    for (int co = 0; co < 3; ++co) v[co] += pp[co * 9];
-                }
-            }
-            float* op = out + (((size_t)img * hout + oy) * wout + ox) * 3;
-#pragma unroll
-            for (int co = 0; co < 3; ++co) {
-                op[co] = v[co];
-                s[co] += (double)v[co];
-                q[co] += (double)v[co] * (double)v[co];
+                const int kx = pb == 0 ? 1 : (rxx == 0 ? 0 : 2), dj = (pb == 1 && rxx == 0) ? 1 : 0;
+                g_p[rep][ry * 2 + rxx] = use ? ((i + di) * IW + j + dj) * PP + ky * 3 + kx : -1;
+                cnt += use;
             }
         }
+        g_n[rep] = cnt;
     }
-    if (stats) {
-        __shared__ double red[4][6];
+
+    int tx = t_begin % tiles_x, ty = (t_begin / tiles_x) % tiles_y, img = t_begin / (tiles_x * tiles_y);
+    prefetch(img, ty * TH, tx * TW);
+    double s[3] = {0, 0, 0}, q[3] = {0, 0, 0};               // statistics of the current image, flushed when the image changes
+    auto flush_stats = [&](int im) {
 #pragma unroll
         for (int co = 0; co < 3; ++co) {
 #pragma unroll
@@ -328,9 +320,84 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
                 red[wave][2 * co] = s[co];
                 red[wave][2 * co + 1] = q[co];
             }
+            s[co] = 0.0;
+            q[co] = 0.0;
         }
         __syncthreads();
-        if (tid < 6) atomicAdd(stats + (size_t)img * 6 + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+        if (tid < 6) atomicAdd(stats + (size_t)im * 6 + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+        __syncthreads();
+    };
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int iy0 = ty * TH, ix0 = tx * TW, cur_img = img;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + 256 * it;
+            const int pix = i / c4n, c4 = i - pix * c4n;
+            *reinterpret_cast<f32x4m*>(&x_s[pix * XP + 4 * c4]) = ((okmask >> it) & 1u) ? rx[it] : f32x4m{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        // advance to the next tile (the last trip re-reads its own tile from L2: the loads stay unconditional)
+        const bool more = tile + 1 < t_end;
+        if (more && ++tx == tiles_x) {
+            tx = 0;
+            if (++ty == tiles_y) {
+                ty = 0;
+                ++img;
+            }
+        }
+        prefetch(img, ty * TH, tx * TW);
+
+        // GEMM: 10 M-tiles x 2 N-tiles = 20 output tiles, 5 per wave; 16 channels (4 k-steps) per pair of b128 reads
+        f32x4m acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c16 = 0; c16 < cin / 16; ++c16) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const f32x4m xa = *reinterpret_cast<const f32x4m*>(&x_s[xo[i] + c16 * 16]);
+                const f32x4m wb = *reinterpret_cast<const f32x4m*>(&w_s[wo[i] + c16 * 512]);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                     // everyone is done with x_s: P may overwrite it
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int t = wave + 4 * i, m = t >> 1, nn = t & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p_s[(m * 16 + kk * 4 + r) * PP + nn * 16 + li] = acc[i][r];
+        }
+        __syncthreads();
+
+        // gather: 16 x 32 output pixels x 3 channels per tile, two pixels per thread
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int oy = 2 * iy0 + g_oyl[rep], ox = 2 * ix0 + g_oxl[rep];
+            if (oy < hout && ox < wout) {
+                float v[3];
+#pragma unroll
+                for (int co = 0; co < 3; ++co) v[co] = bv[co];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (g_p[rep][t] >= 0) {
+                        const float* pp = &p_s[g_p[rep][t]];
+#pragma unroll
+                        for (int co = 0; co < 3; ++co) v[co] += pp[co * 9];
+                    }
+                }
+                *reinterpret_cast<Px3*>(out + (((size_t)cur_img * hout + oy) * wout + ox) * 3) = Px3{v[0], v[1], v[2]};
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    s[co] += (double)v[co];
+                    q[co] += (double)v[co] * (double)v[co];
+                }
+            }
+        }
+        __syncthreads();                                     // gather reads of p_s are done before the next patch lands in x_s
+        if (stats && (img != cur_img || !more)) flush_stats(cur_img);
     }
 }
 
@@ -347,11 +414,13 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
     if ((cin == 32 || cin == 64 || cin == 128) && a.c % 4 == 0) {      // GEMM + gather on the matrix cores
         const int tiles_x = ceil_div(win, 16), tiles_y = ceil_div(hin, 8);
         const size_t sm = ((size_t)160 * (cin + 4) + (size_t)cin * 32) * sizeof(float);
-        const dim3 grid((unsigned)(tiles_x * tiles_y * n));
+        const int n_tiles = tiles_x * tiles_y * n;
+        const int resident = 256 * (int)((160 * 1024) / (sm + 64));           // persistent blocks: as many as the LDS lets live at once
+        const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
         const SmallSrc sa{a.ptr, a.c, a.pitch}, sb{b.ptr, b.c, b.pitch};
-        if (cin == 32) hipLaunchKernelGGL((convt_top_gemm_kernel<32>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y);
-        else if (cin == 64) hipLaunchKernelGGL((convt_top_gemm_kernel<64>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y);
-        else hipLaunchKernelGGL((convt_top_gemm_kernel<128>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y);
+        if (cin == 32) hipLaunchKernelGGL((convt_top_gemm_kernel<32>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles);
+        else if (cin == 64) hipLaunchKernelGGL((convt_top_gemm_kernel<64>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles);
+        else hipLaunchKernelGGL((convt_top_gemm_kernel<128>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles);
         CS_HIP(hipGetLastError());
         return CS_OK;
     }

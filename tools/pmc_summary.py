@@ -14,9 +14,9 @@ import json
 import re
 import sys
 
-GROUPS = [(r"conv_mfma_kernel<1, 3,", "conv3x3_s1_mfma"), (r"conv_mfma_kernel<2, 3,", "conv3x3_s2_mfma"),
+GROUPS = [(r"conv_(mfma|wreg)_kernel<1, 3,", "conv3x3_s1_mfma"), (r"conv_(mfma|wreg)_kernel<2, 3,", "conv3x3_s2_mfma"),
           (r"conv_mfma_kernel<1, 1,", "conv1x1_mfma"), (r"conv_first_kernel", "conv_first_mfma"),
-          (r"convt_mfma_kernel", "convT3x3s2_mfma"), (r"convt_small_kernel", "convT_top_valu"),
+          (r"convt_mfma_kernel", "convT3x3s2_mfma"), (r"convt_small_kernel|convt_top_gemm_kernel", "convT_top_mfma"),
           (r"conv_last_kernel", "conv_last_valu"), (r"norm_finalize_kernel", "norm_finalize"),
           (r"norm_act_add_kernel", "norm_act_add"), (r"swi_finalize_kernel", "swi_finalize"),
           (r"ccl_(\w+)_kernel", None)]
@@ -26,7 +26,7 @@ def group(name):
     for pat, g in GROUPS:
         m = re.search(pat, name)
         if m:
-            return g or ("ccl_" + m.group(1))
+            return g or ("ccl_" + m.group(m.lastindex))
     return None
 
 

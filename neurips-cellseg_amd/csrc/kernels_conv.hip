@@ -340,7 +340,7 @@ static int launch_conv_t(hipStream_t s, const ConvParams& p0) {
 // the input patch only, which lets four blocks share a CU.
 // block = 256 threads = 4 waves; block tile = TH rows x 16 columns x 16*WN channels.
 // ------------------------------------------------------------------------------------------------
-template <int S, int KS, int WN, int TH, int OCC>
+template <int S, int KS, int WN, int TH, int OCC, int NTW>
 __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
     static_assert(KS >= 2, "the one-row-ahead weight ring needs at least two tap rows");
     constexpr int WM = 4 / WN, MT = TH / WM, TW = 16;
@@ -350,7 +350,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
     constexpr int TAPS = KS * KS;
     constexpr int IN_ITERS = (IH * IW + 63) / 64;
     constexpr int IN_FLOATS = (IH * IW * CS + 3) / 4 * 4;
-    constexpr int EPS = 16 * WN + 4;                           // floats per pixel record in the block's epilogue slab
+    constexpr int NB = WN * NTW;                               // channel tiles per block (NTW per wave)
+    constexpr int EPS = 16 * NB + 4;                           // floats per pixel record in the block's epilogue slab
     constexpr int EP_FLOATS = TH * 16 * EPS;
     constexpr int SM_FLOATS = (2 * IN_FLOATS) > EP_FLOATS ? (2 * IN_FLOATS) : EP_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
     const int pl = lane & 15, g = lane >> 4;
-    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / WN);
+    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NB);
     if (!wk.valid) return;
     int bid = wk.spatial;
     const int tx = bid % p.tiles_x;
@@ -366,12 +367,14 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
     const int ty = bid % p.tiles_y;
     const int img = bid / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int nt0 = wk.ct * WN;
+    const int nt0 = wk.ct * NB;
     const int q = tid & 3;
 
-    f32x4 acc[MT];
+    f32x4 acc[MT][NTW];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int goff[IN_ITERS];
 #pragma unroll
@@ -388,8 +391,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
     // B fragments of one 16-channel chunk: TAPS float4 per lane, refilled ONE TAP ROW AHEAD: at the start of row ky the
     // slots of row (ky + 1) % KS - consumed one row earlier - receive the next row's (or the next chunk's first row's)
     // fragments, so every load has a full row of MFMAs to return from L2
-    f32x4 wc[TAPS];
-    const f32x4* const wbase = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)(nt0 + wn) * 64 + lane;
+    f32x4 wc[TAPS][NTW];
+    const f32x4* const wbase = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)(nt0 + wn * NTW) * 64 + lane;
     const size_t wtap = (size_t)p.ntile_total * 64;
 
     auto load_in = [&](int ch) {
@@ -417,7 +420,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
 
     load_in(0);
 #pragma unroll
-    for (int kx = 0; kx < KS; ++kx) wc[kx] = wbase[(size_t)kx * wtap];
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) wc[kx][t] = wbase[(size_t)kx * wtap + t * 64];
     store_in(smem);
     __syncthreads();
     const int last_row = chunks * KS - 1;
@@ -434,23 +439,29 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
                 const int row_next = ch * KS + ky + 1 < last_row ? ch * KS + ky + 1 : last_row;   // clamped: unconditional loads
                 const f32x4* wnext = wbase + (size_t)row_next * KS * wtap;
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) wc[((ky + 1) % KS) * KS + kx] = wnext[(size_t)kx * wtap];
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) wc[((ky + 1) % KS) * KS + kx][t] = wnext[(size_t)kx * wtap + t * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
-                const f32x4 b = wc[ky * KS + kx];
+                f32x4 b[NTW];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) b[t] = wc[ky * KS + kx][t];
                 f32x4 a[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
                     a[m] = *reinterpret_cast<const f32x4*>(&in_s[(((wm * MT + m) * S + ky) * IW + pl * S + kx) * CS + 4 * g]);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc[m] = mfma4(a[m].x, b.x, acc[m]);
-                    acc[m] = mfma4(a[m].y, b.y, acc[m]);
-                    acc[m] = mfma4(a[m].z, b.z, acc[m]);
-                    acc[m] = mfma4(a[m].w, b.w, acc[m]);
-                }
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) {
+                        acc[m][t] = mfma4(a[m].x, b[t].x, acc[m][t]);
+                        acc[m][t] = mfma4(a[m].y, b[t].y, acc[m][t]);
+                        acc[m][t] = mfma4(a[m].z, b[t].z, acc[m][t]);
+                        acc[m][t] = mfma4(a[m].w, b[t].w, acc[m][t]);
+                    }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -460,30 +471,34 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias + fp64 statistics of the wave's 16 channels over its rows, block slab, full-line stores ----
-    const int co = (nt0 + wn) * 16 + pl;
-    const float bias = p.bias ? p.bias[co] : 0.f;
-    double ssum = 0.0, qsum = 0.0;
+    // ---- epilogue: bias + fp64 statistics of the wave's channels over its rows, block slab, full-line stores ----
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int row = wm * MT + m, oy = oy0 + row;
+    for (int t = 0; t < NTW; ++t) {
+        const int ct = wn * NTW + t, co = (nt0 + ct) * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        double ssum = 0.0, qsum = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ox = ox0 + g * 4 + r;
-            const float v = acc[m][r] + bias;
-            smem[(row * 16 + g * 4 + r) * EPS + wn * 16 + pl] = v;
-            if (oy < p.hout && ox < p.wout) {
-                ssum += (double)v;
-                qsum += (double)v * (double)v;
+        for (int m = 0; m < MT; ++m) {
+            const int row = wm * MT + m, oy = oy0 + row;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + g * 4 + r;
+                const float v = acc[m][t][r] + bias;
+                smem[(row * 16 + g * 4 + r) * EPS + ct * 16 + pl] = v;
+                if (oy < p.hout && ox < p.wout) {
+                    ssum += (double)v;
+                    qsum += (double)v * (double)v;
+                }
             }
         }
+        if (p.stats) stats_commit(ssum, qsum, p.stats + ((size_t)img * p.cout + co) * 2, lane);
     }
-    if (p.stats) stats_commit(ssum, qsum, p.stats + ((size_t)img * p.cout + co) * 2, lane);
     __syncthreads();
     {
-        const OutSel o = select_out(p, nt0);
-        constexpr int F4 = WN * 4, PPP = 256 / F4;             // float4s per pixel record, pixels per pass
+        constexpr int F4 = NB * 4, PPP = 256 / F4;             // float4s per pixel record, pixels per pass
         const int c4 = tid % F4;
+        const OutSel o = select_out(p, nt0 + c4 / 4);          // a block may straddle the (out, out2) split: per channel tile
+        const int cw = (c4 & 3) * 4;                           // channel offset inside the 16-channel tile
 #pragma unroll
         for (int it = 0; it < TH * 16 / PPP; ++it) {
             const int pix = tid / F4 + PPP * it;
@@ -492,25 +507,25 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
             if (oy < p.hout && ox < p.wout) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&smem[pix * EPS + c4 * 4]);
                 const size_t gp = ((size_t)img * p.hout + oy) * p.wout + ox;
-                if (o.add) v += *reinterpret_cast<const f32x4*>(o.add + gp * o.pitch_add + o.ch0 + c4 * 4);
-                *reinterpret_cast<f32x4*>(o.out + gp * o.pitch + o.ch0 + c4 * 4) = v;
+                if (o.add) v += *reinterpret_cast<const f32x4*>(o.add + gp * o.pitch_add + o.ch0 + cw);
+                *reinterpret_cast<f32x4*>(o.out + gp * o.pitch + o.ch0 + cw) = v;
             }
         }
     }
 }
 
-template <int S, int KS, int WN, int TH, int OCC>
+template <int S, int KS, int WN, int TH, int OCC, int NTW>
 static int launch_conv_wreg(hipStream_t s, const ConvParams& p0) {
     ConvParams p = p0;
     p.tiles_x = ceil_div(p.wout, 16);
     p.tiles_y = ceil_div(p.hout, TH);
-    dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / WN));
-    hipLaunchKernelGGL((conv_wreg_kernel<S, KS, WN, TH, OCC>), grid, dim3(256), 0, s, p);
+    dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
+    hipLaunchKernelGGL((conv_wreg_kernel<S, KS, WN, TH, OCC, NTW>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
-int g_conv_variant = 3;   // bit mask: 1 = stride-1, 2 = stride-2 3x3 layers take the register-weights kernel (A/B switch CS_CONV_VARIANT)
+int g_conv_variant = 7;   // bit mask: 1 = stride-1, 2 = stride-2 3x3 layers take the register-weights kernel (A/B switch CS_CONV_VARIANT)
 static const int g_conv_variant_init = [] {
     if (const char* e = getenv("CS_CONV_VARIANT")) g_conv_variant = atoi(e);
     return 0;
@@ -569,8 +584,13 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
     }
     // 64-channel blocks of the 3x3 layers take the register-weights kernel (measured: s1 31.9 -> 30.3 ms, s2 9.8 -> 8.3 ms per
     // 4096^2 slide; the 32-channel and 1x1 layers were not faster with it and keep the LDS-weights kernel)
-    if ((g_conv_variant & 1) && nt == 4 && ksize == 3 && stride == 1) return launch_conv_wreg<1, 3, 4, 8, 3>(s, p);
-    if ((g_conv_variant & 2) && nt == 4 && ksize == 3 && stride == 2) return launch_conv_wreg<2, 3, 4, 4, 3>(s, p);
+    if ((g_conv_variant & 1) && nt == 4 && ksize == 3 && stride == 1) return launch_conv_wreg<1, 3, 4, 8, 3, 1>(s, p);
+    if ((g_conv_variant & 2) && nt == 4 && ksize == 3 && stride == 2) {
+        // 128-channel blocks (two channel tiles per wave: every A fragment feeds 8 MFMAs, 288 MFMAs per barrier) when the
+        // channel count and the (out, out2) split allow it
+        const bool wide = (g_conv_variant & 4) && cout % 128 == 0;
+        return wide ? launch_conv_wreg<2, 3, 4, 4, 3, 2>(s, p) : launch_conv_wreg<2, 3, 4, 4, 3, 1>(s, p);
+    }
     if (ksize == 1) { CS_DISPATCH_NT(1, 1, 2) }
     if (stride == 1) { CS_DISPATCH_NT(1, 3, 2) }
     CS_DISPATCH_NT(2, 3, 1)

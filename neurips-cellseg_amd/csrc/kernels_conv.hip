@@ -780,13 +780,14 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
 // M tile = 16 input pixels of one row; each wave owns one input row of the block's 4-row tile.
 // ------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void convt_mfma_kernel(ConvParams p) {
     constexpr int TH = 4, TW = 16, IH = TH + 1, IW = TW + 1, CS = 24;
     constexpr int IN_ITERS = (IH * IW + 63) / 64;
     constexpr int W_ITERS = (9 * NT * 64 + 255) / 256;
     constexpr int IN_FLOATS = (IH * IW * CS + 3) / 4 * 4;
     constexpr int EPS = 16 * NT + 4;
-    constexpr int EP_FLOATS = 4 * 64 * EPS + 4 * 16 * NT * 2 * 2;   // per wave: 2 output rows x 32 output pixels; + fp64 statistics
+    constexpr int EP_FLOATS = 4 * 32 * EPS + 4 * 16 * NT * 2 * 2;   // per wave: ONE output row of 32 pixels per pass (two passes keep
+                                                                    // the slabs below the staging footprint: 3 blocks per CU); + statistics
     constexpr int SM_FLOATS = (IN_FLOATS + 9 * NT * 256) > EP_FLOATS ? (IN_FLOATS + 9 * NT * 256) : EP_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     float* const in_s = smem;
@@ -895,8 +896,8 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
     }
 
     const int iy = iy0 + wave;
-    float* ep = smem + wave * 64 * EPS;
-    double* st_s = reinterpret_cast<double*>(smem + 4 * 64 * EPS);     // [4 waves][16*NT][2]: block-reduced statistics
+    float* ep = smem + wave * 32 * EPS;
+    double* st_s = reinterpret_cast<double*>(smem + 4 * 32 * EPS);     // [4 waves][16*NT][2]: block-reduced statistics
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (nt0 + nt) * 16 + pl;
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int ix = ix0 + g * 4 + r;
                 const float v = acc[ph][nt][r] + bias;
-                ep[((ph >> 1) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + nt * 16 + pl] = v;
+                acc[ph][nt][r] = v;
                 if (iy < p.hin && ix < p.win) {
                     s += (double)v;
                     qq += (double)v * (double)v;
@@ -926,25 +927,35 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(ConvParams p) {
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (iy < p.hin) {
-        constexpr int F4_PER_PIX = NT * 4;
-        const OutSel o = select_out(p, nt0);
-        const size_t pix0 = ((size_t)img * p.hout + 2 * iy) * p.wout + 2 * ix0;
-        float* out0 = o.out + pix0 * o.pitch + o.ch0;
-        const float* add0 = o.add ? o.add + pix0 * o.pitch_add + o.ch0 : nullptr;
-        const int cols_valid = 2 * (p.win - ix0);
+    constexpr int F4_PER_PIX = NT * 4;
+    const OutSel o = select_out(p, nt0);
+    const int cols_valid = 2 * (p.win - ix0);
 #pragma unroll
-        for (int i = lane; i < 64 * F4_PER_PIX; i += 64) {
-            const int pix = i / F4_PER_PIX, c4 = i - pix * F4_PER_PIX;
-            const int row = pix >> 5, x = pix & 31;
-            if (x < cols_valid) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
-                if (add0) v += *reinterpret_cast<const f32x4*>(add0 + ((int64_t)row * p.wout + x) * o.pitch_add + c4 * 4);
-                *reinterpret_cast<f32x4*>(out0 + ((int64_t)row * p.wout + x) * o.pitch + c4 * 4) = v;
+    for (int pa = 0; pa < 2; ++pa) {                           // output row 2*iy + pa through the wave-private slab
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ep[(2 * (g * 4 + r) + pb) * EPS + nt * 16 + pl] = acc[pa * 2 + pb][nt][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (iy < p.hin) {
+            const size_t pix0 = ((size_t)img * p.hout + 2 * iy + pa) * p.wout + 2 * ix0;
+            float* out0 = o.out + pix0 * o.pitch + o.ch0;
+            const float* add0 = o.add ? o.add + pix0 * o.pitch_add + o.ch0 : nullptr;
+#pragma unroll
+            for (int i = lane; i < 32 * F4_PER_PIX; i += 64) {
+                const int x = i / F4_PER_PIX, c4 = i - x * F4_PER_PIX;
+                if (x < cols_valid) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&ep[x * EPS + c4 * 4]);
+                    if (add0) v += *reinterpret_cast<const f32x4*>(add0 + (int64_t)x * o.pitch_add + c4 * 4);
+                    *reinterpret_cast<f32x4*>(out0 + (int64_t)x * o.pitch + c4 * 4) = v;
+                }
             }
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // slab reads done before the second pass overwrites it
+        __builtin_amdgcn_wave_barrier();
     }
     if (p.stats) {
         __syncthreads();

@@ -192,10 +192,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     store_input();
     __syncthreads();
 
+    const int last_row = chunks * KS - 1;
     for (int ch = 0; ch < chunks; ++ch) {
         const bool more = ch + 1 < chunks;
-        if (more) load_input(ch + 1);
-        for (int ky = 0; ky < KS; ++ky) {                   // runtime loop: keeps the unrolled body to one tap row
+        // UNCONDITIONAL loads (the last trip re-reads its own chunk; ring refills are clamped to the last tap row): a load
+        // group that is skipped on one path makes hipcc size the vmcnt waits of the weight ring for that path, and the
+        // MFMA section then stalls on loads it has only just issued.  sched_barriers pin the issue points.
+        load_input(more ? ch + 1 : ch);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int row_next = ch * KS + ky + 1 < last_row ? ch * KS + ky + 1 : last_row;
+            const int ch_n = row_next / KS, ky_n = row_next - ch_n * KS;
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
                 bf16x8 b[NTW][NP];
@@ -204,28 +212,36 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
 #pragma unroll
                     for (int pn = 0; pn < NP; ++pn) b[t][pn] = bq[kx][t][pn];
                 // refill this ring slot one tap row ahead (first row of the next chunk after the last row)
-                if (ky + 1 < KS) load_b(ch, ky + 1, kx);
-                else if (more) load_b(ch + 1, 0, kx);
+                load_b(ch_n, ky_n, kx);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int MG = (MTW % 2 == 0) ? 2 : 1;           // pixel rows per group: MG x NTW independent MFMA chains
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) {
-                    const int r = wm * MTW + m;
-                    bf16x8 a[NP];
+                for (int m0 = 0; m0 < MTW; m0 += MG) {
+                    bf16x8 a[MG][NP];
 #pragma unroll
-                    for (int pn = 0; pn < NP; ++pn)
-                        a[pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES + ((r * S + ky) * IW + pl * S + kx) * PITCH + g * 16);
+                    for (int mm = 0; mm < MG; ++mm)
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t) {
-                        // smallest terms first, the dominant a0*b0 last
+                        for (int pn = 0; pn < NP; ++pn)
+                            a[mm][pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES +
+                                                                         (((wm * MTW + m0 + mm) * S + ky) * IW + pl * S + kx) * PITCH + g * 16);
+                    // smallest terms first, the dominant a0*b0 last; rows and channel tiles alternate inside a term so that
+                    // consecutive MFMAs never depend on each other (a dependent 4-pass MFMA cannot issue back to back)
 #pragma unroll
-                        for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
-                            const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
-                            const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
-                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[t][ib], acc[m][t], 0, 0, 0);
-                        }
+                    for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
+                        const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
+                        const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
+#pragma unroll
+                        for (int mm = 0; mm < MG; ++mm)
+#pragma unroll
+                            for (int t = 0; t < NTW; ++t)
+                                acc[m0 + mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mm][ia], b[t][ib], acc[m0 + mm][t], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) asm volatile("" ::"v"(rin[it]));   // keeps the input loads above the MFMA section
         __syncthreads();
         if (more) {
             store_input();

@@ -452,9 +452,11 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     for (int tap = 0; tap < 3; ++tap) load_b(0, tap, tap);
     store_input();
     __syncthreads();
+    const int last_tap = chunks * 9 - 1;
     for (int ch = 0; ch < chunks; ++ch) {
         const bool more = ch + 1 < chunks;
-        if (more) load_input(ch + 1);
+        load_input(more ? ch + 1 : ch);                     // unconditional loads, pinned (see conv_bf16s_kernel)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -466,8 +468,11 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
             for (int t = 0; t < NTW; ++t)
 #pragma unroll
                 for (int pn = 0; pn < NP; ++pn) b[t][pn] = bq[tap % 3][t][pn];
-            if (tap + 3 < 9) load_b(ch, tap + 3, tap % 3);
-            else if (more) load_b(ch + 1, tap + 3 - 9, tap % 3);
+            {
+                const int nxt = ch * 9 + tap + 3 < last_tap ? ch * 9 + tap + 3 : last_tap;     // clamped: unconditional refill
+                load_b(nxt / 9, nxt % 9, tap % 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 const int r = wm * MTW + m;
@@ -476,16 +481,18 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
                 for (int pn = 0; pn < NP; ++pn)
                     a[pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES + ((r + di) * IW + pl + dj) * PITCH + g * 16);
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) {
+                for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
+                    const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
+                    const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
 #pragma unroll
-                    for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
-                        const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
-                        const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
+                    for (int t = 0; t < NTW; ++t)
                         acc[m][ph][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[t][ib], acc[m][ph][t], 0, 0, 0);
-                    }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) asm volatile("" ::"v"(rin[it]));
         __syncthreads();
         if (more) {
             store_input();

@@ -33,9 +33,9 @@ import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA peak; a split-bf16 product costs 6 / 3 / 1 bf16 MFMA terms
-MFMA_PEAK = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3,
+MFMA_PEAK = {"fp32": PEAK_F32_MFMA_TFLOPS, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3,
              "bf16": PEAK_BF16_MFMA_TFLOPS}
-DTYPE = {"fp32": "f32", "bf16x6": "f32 (split-bf16, 3 planes x 6 MFMA terms, fp32 accumulate)",
+DTYPE = {"fp32": "f32", "fp16x3": "f32 (split-fp16, 2 planes x 3 MFMA terms, fp32 accumulate)", "bf16x6": "f32 (split-bf16, 3 planes x 6 MFMA terms, fp32 accumulate)",
          "bf16x3": "split-bf16 (2 planes x 3 terms)", "bf16": "bf16"}
 PEAK_HBM_GBS = 8000.0
 WIDTHS = {"baseline32": (32, 64, 128, 256, 512), "reference16": (16, 32, 64, 128, 256)}
@@ -241,7 +241,7 @@ def main():
     if not args.no_secondary and args.width != "reference16":
         sec_res = measure("reference16")
     if not args.no_secondary and args.precision == "fp32":
-        for prec in ("bf16x6", "bf16"):
+        for prec in ("fp16x3", "bf16x6", "bf16"):
             modes[prec] = measure_mode(args.width, prec, main_res["labels"])
 
     if rank != 0:
@@ -312,9 +312,10 @@ def main():
                                   "ms_per_step": round(sec_res["dt"] / args.steps * 1e3, 3), "roofline": roofline(sec_res),
                                   "instances_found": sec_res["n_instances"]}
     if modes:
-        out["other_precisions"] = {"note": "same workload, convolutions on v_mfma_f32_16x16x32_bf16: bf16x6 = 3 bf16 planes x 6 terms "
-                                           "(fp32-grade, logits within 1e-4 in the GPU tests), bf16 = plain bf16 products; "
-                                           "activations stay fp32 in HBM", **modes}
+        out["other_precisions"] = {"note": "same workload, convolutions on the 16-bit matrix pipe (v_mfma_f32_16x16x32_{f16,bf16}, fp32 "
+                                           "accumulate): fp16x3 = 2 fp16 planes (22 mantissa bits) x 3 terms and bf16x6 = 3 bf16 planes x "
+                                           "6 terms are fp32-grade (logits within 1e-4 of the oracle in the GPU tests), bf16 = plain bf16 "
+                                           "products; activations stay fp32 in HBM", **modes}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.overlap, WIDTHS[args.width], seed)
     print(json.dumps(out))

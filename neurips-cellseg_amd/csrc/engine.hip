@@ -147,7 +147,8 @@ struct ParamEntry {
     std::function<int(const float*, hipStream_t)> load;
     bool loaded = false;
     bool has_dgrad = false, has_bf16 = false;     // tensor takes part in the data-gradient / split-bf16 packings
-    bool dgrad_packed = false, bf16_packed = false;
+    bool dgrad_packed = false;
+    int wb_format = 0;                            // 16-bit plane packing present: 0 none, 1 split-bf16, 2 split-fp16
     int64_t grad_off = 0;      // float offset of this parameter's gradient in the flat gradient buffer
     int64_t numel() const {
         int64_t n = 1;
@@ -192,7 +193,7 @@ struct cs_unet {
     float* arena = nullptr;
     size_t arena_floats = 0;
     int64_t grad_floats = 0;
-    int planes = 0;   // 0: fp32 MFMA kernels; 1..3: split-bf16 kernels with that many planes (3 = fp32-grade)
+    int planes = 0;   // 0: fp32 MFMA kernels; 1..3: split-bf16 kernels with that many planes (3 = fp32-grade); 4: split-fp16 (fp32-grade)
     bool training = false;   // pack the data-gradient weight layouts on every parameter load
     // sliding-window inference can spread its window chunks over side streams: the HBM-bound kernels of one chunk
     // (residual adds, 3-channel layers, statistics) then overlap the MFMA-bound convolutions of another
@@ -273,7 +274,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             if (int rc = pack_dgrad(d, s)) return rc;
             if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
             if (wb && net->planes > 0)
-                if (int rc = pack_conv_weights_bf16(s, d, true, cout, cin, ksize, wb, cout_off, cout_total, cin_split)) return rc;
+                if (int rc = pack_conv_weights_bf16(s, d, true, cout, cin, ksize, wb, cout_off, cout_total, cin_split, net->planes == 4)) return rc;
             return pack_conv_weights(s, d, true, cout, cin, ksize, wdst, cout_off, cout_total);
         });
     } else {
@@ -282,7 +283,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
             if (mode == 1) return pack_first_weights(s, d, cout, cin, wdst, cout_off, cout_total);
             if (wb && net->planes > 0)
-                if (int rc = pack_conv_weights_bf16(s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0)) return rc;
+                if (int rc = pack_conv_weights_bf16(s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0, net->planes == 4)) return rc;
             return pack_conv_weights(s, d, false, cout, cin, ksize, wdst, cout_off, cout_total);
         });
     }
@@ -768,8 +769,8 @@ static int check_loaded(const cs_unet* net, bool for_backward = false) {
             set_error("parameter '%s' was never loaded", p.key.c_str());
             return CS_ERR_NOT_LOADED;
         }
-        if (net->planes > 0 && p.has_bf16 && !p.bf16_packed) {
-            set_error("parameter '%s' was loaded before cs_unet_set_precision(>0): load it again", p.key.c_str());
+        if (net->planes > 0 && p.has_bf16 && p.wb_format != (net->planes == 4 ? 2 : 1)) {
+            set_error("parameter '%s' was loaded under a different cs_unet_set_precision family: load it again", p.key.c_str());
             return CS_ERR_NOT_LOADED;
         }
         if (for_backward && p.has_dgrad && !p.dgrad_packed) {
@@ -850,7 +851,7 @@ int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* 
 }
 
 int cs_unet_set_precision(cs_unet* net, int planes) {
-    CS_REQUIRE(net && planes >= 0 && planes <= 3, "set_precision: planes must be 0 (fp32 MFMA), 1, 2 or 3");
+    CS_REQUIRE(net && planes >= 0 && planes <= 4, "set_precision: 0 (fp32 MFMA), 1..3 (split-bf16 planes) or 4 (split-fp16, 3 terms)");
     net->planes = planes;
     return CS_OK;
 }
@@ -908,7 +909,7 @@ int cs_unet_load_param(cs_unet* net, const char* key_host, const float* data, in
             if (rc == CS_OK) {
                 p.loaded = true;
                 p.dgrad_packed = net->training;
-                p.bf16_packed = net->planes > 0;
+                p.wb_format = net->planes == 4 ? 2 : net->planes > 0 ? 1 : 0;
             }
             return rc;
         }

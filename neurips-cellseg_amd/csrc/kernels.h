@@ -57,7 +57,7 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
                        float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
 size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize);
 int pack_conv_weights_bf16(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, unsigned short* packed,
-                           int cout_off, int cout_total, int cin_split);
+                           int cout_off, int cout_total, int cin_split, bool f16 = false);
 
 // first layer: cin < 16 (3), 3x3 pad 1, reads windows straight out of the image (tiler gather fused).
 // image element strides (sc, sh, sw); per-window origins (y0, x0) in image coordinates (may be negative when the

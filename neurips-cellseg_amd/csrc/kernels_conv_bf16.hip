@@ -22,6 +22,53 @@ namespace cs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// NP = 4 selects the split-FP16 mode ("fp16x3"): two fp16 planes h0 = fp16(x), h1 = fp16((x - h0) * 2^11) - 22 mantissa bits -
+// and the three terms h0*h0 (main accumulator), h0*h1 + h1*h0 (cross accumulator, folded in with 2^-11 in the epilogue) on
+// v_mfma_f32_16x16x32_f16.  The 2^11 pre-scale keeps the residual plane out of fp16's subnormal range (weights are ~1e-2,
+// their residuals ~1e-5); every fp16 x fp16 product is exact in fp32.  Operands must stay inside fp16's range (|x| < 65504),
+// which normalised activations and trained weights do.  Half the MFMAs of bf16x6 at the same fp32-grade accuracy class
+// (dropped term 2^-22, operand truncation 2^-23).
+constexpr float F16_RES_SCALE = 2048.f;
+template <int NP>
+struct SplitCfg {
+    static constexpr bool f16 = NP == 4;
+    static constexpr int planes = NP == 4 ? 2 : NP;          // planes staged in LDS / loaded per weight fragment
+    static constexpr int terms = NP == 4 ? 3 : NP == 3 ? 6 : NP == 2 ? 3 : 1;
+};
+// term -> (plane of A, plane of B, accumulator: 0 main, 1 cross); smallest terms first, the dominant a0*b0 last
+__device__ __forceinline__ constexpr int term_a(int term) { return (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1; }
+__device__ __forceinline__ constexpr int term_b(int term) { return (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1; }
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_split(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// split 4 fp32 values into the next 16-bit plane (bits returned in a bf16x4 container) and leave the remainder in v
+template <bool F16>
+__device__ __forceinline__ bf16x4 split_plane(f32x4& v, int pn) {
+    if constexpr (F16) {
+        f16x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = (_Float16)v[j];
+            v[j] = (v[j] - (float)h[j]) * F16_RES_SCALE;
+        }
+        (void)pn;
+        return __builtin_bit_cast(bf16x4, h);
+    } else {
+        bf16x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = (__bf16)v[j];
+            v[j] -= (float)h[j];
+        }
+        (void)pn;
+        return h;
+    }
+}
 typedef __attribute__((address_space(3))) void lds_void;
 
 struct SrcDevB {
@@ -76,6 +123,8 @@ __device__ __forceinline__ void stats_commit_b(double s, double q, double* dst, 
 // and goes global -> registers, one tap ROW ahead (ring of KS x NTW x NP fragments), so no weight ever touches LDS.
 template <int S, int KS, int WN, int NTW, int NP>
 __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
+    constexpr bool F16 = SplitCfg<NP>::f16;
+    constexpr int NPL = SplitCfg<NP>::planes, NTERM = SplitCfg<NP>::terms;
     constexpr int WM = 4 / WN;
     constexpr int TH = (S == 1) ? 8 : 4, TW = 16;
     constexpr int MTW = TH / WM;                            // pixel rows per wave
@@ -86,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     constexpr int IN_ITEMS = IH * IW * 8;                   // (pixel, 4-channel quad) items per chunk
     constexpr int IN_ITERS = (IN_ITEMS + 255) / 256;
     constexpr int PLANE_BYTES = IH * IW * PITCH;
-    constexpr int IN_BYTES = (NP * PLANE_BYTES + 15) / 16 * 16;
+    constexpr int IN_BYTES = (NPL * PLANE_BYTES + 15) / 16 * 16;
     constexpr int EPS = 16 * NTB + 4;
     constexpr int EP_BYTES = TH * 16 * EPS * 4;
     constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
@@ -107,11 +156,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     const int nt_w = wk.ct * NTB + wn * NTW;                 // this wave's first output-channel tile
     const int q = tid & 7;                                   // this thread's channel quad inside the 32-channel chunk
 
-    f32x4 acc[MTW][NTW];
+    constexpr int NACC = F16 ? 2 : 1;                        // fp16 mode: [0] main (h0*h0), [1] cross terms at scale 2^11
+    f32x4 acc[NACC][MTW][NTW];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m)
+    for (int k = 0; k < NACC; ++k)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[k][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int goff[IN_ITERS];
 #pragma unroll
@@ -163,27 +215,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
                 }
                 if (goff[it] < 0 || !qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int pn = 0; pn < NP; ++pn) {
-                    bf16x4 h;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        h[j] = (__bf16)v[j];
-                        v[j] -= (float)h[j];
-                    }
-                    *reinterpret_cast<bf16x4*>(in_s + pn * PLANE_BYTES + pix * PITCH + q * 8) = h;
-                }
+                for (int pn = 0; pn < NPL; ++pn)
+                    *reinterpret_cast<bf16x4*>(in_s + pn * PLANE_BYTES + pix * PITCH + q * 8) = split_plane<F16>(v, pn);
             }
         }
     };
     // weight fragments of one tap row: KS x NTW x NP lane-linear 16-byte loads (1 KiB per wave-instruction, from L2)
-    bf16x8 bq[KS][NTW][NP];
+    bf16x8 bq[KS][NTW][NPL];
     const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)nt_w * 3 * 64 + lane;
     auto load_b = [&](int ch, int ky, int kx) {
         const bf16x8* w = wbase + ((size_t)ch * TAPS + ky * KS + kx) * p.ntile_total * 3 * 64;
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
-            for (int pn = 0; pn < NP; ++pn) bq[kx][t][pn] = w[(t * 3 + pn) * 64];
+            for (int pn = 0; pn < NPL; ++pn) bq[kx][t][pn] = w[(t * 3 + pn) * 64];
     };
 
     load_input(0);
@@ -206,35 +251,35 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
             const int ch_n = row_next / KS, ky_n = row_next - ch_n * KS;
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
-                bf16x8 b[NTW][NP];
+                bf16x8 b[NTW][NPL];
 #pragma unroll
                 for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                    for (int pn = 0; pn < NP; ++pn) b[t][pn] = bq[kx][t][pn];
+                    for (int pn = 0; pn < NPL; ++pn) b[t][pn] = bq[kx][t][pn];
                 // refill this ring slot one tap row ahead (first row of the next chunk after the last row)
                 load_b(ch_n, ky_n, kx);
                 __builtin_amdgcn_sched_barrier(0);
                 constexpr int MG = (MTW % 2 == 0) ? 2 : 1;           // pixel rows per group: MG x NTW independent MFMA chains
 #pragma unroll
                 for (int m0 = 0; m0 < MTW; m0 += MG) {
-                    bf16x8 a[MG][NP];
+                    bf16x8 a[MG][NPL];
 #pragma unroll
                     for (int mm = 0; mm < MG; ++mm)
 #pragma unroll
-                        for (int pn = 0; pn < NP; ++pn)
+                        for (int pn = 0; pn < NPL; ++pn)
                             a[mm][pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES +
                                                                          (((wm * MTW + m0 + mm) * S + ky) * IW + pl * S + kx) * PITCH + g * 16);
                     // smallest terms first, the dominant a0*b0 last; rows and channel tiles alternate inside a term so that
                     // consecutive MFMAs never depend on each other (a dependent 4-pass MFMA cannot issue back to back)
 #pragma unroll
-                    for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
-                        const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
-                        const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
+                    for (int term = NTERM - 1; term >= 0; --term) {
+                        const int ia = term_a(term), ib = term_b(term);
+                        const int ka = (F16 && term > 0) ? 1 : 0;
 #pragma unroll
                         for (int mm = 0; mm < MG; ++mm)
 #pragma unroll
                             for (int t = 0; t < NTW; ++t)
-                                acc[m0 + mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mm][ia], b[t][ib], acc[m0 + mm][t], 0, 0, 0);
+                                acc[ka][m0 + mm][t] = mfma_split<F16>(a[mm][ia], b[t][ib], acc[ka][m0 + mm][t]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -262,7 +307,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ox = ox0 + g * 4 + r;
-                const float v = acc[m][t][r] + bias;
+                float v = acc[0][m][t][r];
+                if constexpr (F16) v += acc[NACC - 1][m][t][r] * (1.f / F16_RES_SCALE);
+                v += bias;
                 ep[(row * 16 + g * 4 + r) * EPS + (wn * NTW + t) * 16 + pl] = v;
                 if (oy < p.hout && ox < p.wout) {
                     s += (double)v;
@@ -304,7 +351,7 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
                       int hin, int win) {
     CS_REQUIRE(ksize == 3 || ksize == 1, "conv(bf16): ksize %d unsupported", ksize);
     CS_REQUIRE((stride == 1 || stride == 2) && !(ksize == 1 && stride != 1), "conv(bf16): stride %d unsupported", stride);
-    CS_REQUIRE(planes >= 1 && planes <= 3, "conv(bf16): %d planes", planes);
+    CS_REQUIRE(planes >= 1 && planes <= 4, "conv(bf16): %d planes", planes);
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "conv(bf16): channels must be multiples of 16");
     ConvBParams p{};
     p.a = to_devb(a);
@@ -327,6 +374,7 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     }
 #define CS_B2(S_, KS_)                                                              \
     switch (planes) {                                                               \
+        case 4: CS_B3(S_, KS_, 4)                                                   \
         case 3: CS_B3(S_, KS_, 3)                                                   \
         case 2: CS_B3(S_, KS_, 2)                                                   \
         default: CS_B3(S_, KS_, 1)                                                  \
@@ -344,11 +392,13 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
 // ------------------------------------------------------------------------------------------------
 template <int WN, int NTW, int NP>
 __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
+    constexpr bool F16 = SplitCfg<NP>::f16;
+    constexpr int NPL = SplitCfg<NP>::planes, NTERM = SplitCfg<NP>::terms, NACC = F16 ? 2 : 1;
     constexpr int WM = 4 / WN, TH = 4, TW = 16, MTW = TH / WM, NTB = WN * NTW;
     constexpr int IH = TH + 1, IW = TW + 1, PITCH = 96;
     constexpr int IN_ITEMS = IH * IW * 8, IN_ITERS = (IN_ITEMS + 255) / 256;
     constexpr int PLANE_BYTES = IH * IW * PITCH;
-    constexpr int IN_BYTES = (NP * PLANE_BYTES + 15) / 16 * 16;
+    constexpr int IN_BYTES = (NPL * PLANE_BYTES + 15) / 16 * 16;
     constexpr int EPS = 16 * NTB + 4;
     constexpr int EP_BYTES = 2 * TH * 32 * EPS * 4;          // 8 output rows x 32 output pixels
     constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
@@ -369,13 +419,15 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     const int nt_w = wk.ct * NTB + wn * NTW;
     const int q = tid & 7;
 
-    f32x4 acc[MTW][4][NTW];
+    f32x4 acc[NACC][MTW][4][NTW];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m)
+    for (int k = 0; k < NACC; ++k)
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph)
+        for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[m][ph][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[k][m][ph][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int goff[IN_ITERS];
 #pragma unroll
@@ -425,26 +477,19 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
                 }
                 if (goff[it] < 0 || !qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int pn = 0; pn < NP; ++pn) {
-                    bf16x4 h;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        h[j] = (__bf16)v[j];
-                        v[j] -= (float)h[j];
-                    }
-                    *reinterpret_cast<bf16x4*>(in_s + pn * PLANE_BYTES + pix * PITCH + q * 8) = h;
-                }
+                for (int pn = 0; pn < NPL; ++pn)
+                    *reinterpret_cast<bf16x4*>(in_s + pn * PLANE_BYTES + pix * PITCH + q * 8) = split_plane<F16>(v, pn);
             }
         }
     };
-    bf16x8 bq[3][NTW][NP];
+    bf16x8 bq[3][NTW][NPL];
     const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)nt_w * 3 * 64 + lane;
     auto load_b = [&](int ch, int tap, int slot) {
         const bf16x8* w = wbase + ((size_t)ch * 9 + tap) * p.ntile_total * 3 * 64;
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
-            for (int pn = 0; pn < NP; ++pn) bq[slot][t][pn] = w[(t * 3 + pn) * 64];
+            for (int pn = 0; pn < NPL; ++pn) bq[slot][t][pn] = w[(t * 3 + pn) * 64];
     };
 
     load_input(0);
@@ -463,11 +508,11 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
             const int pa = (ky == 1) ? 0 : 1, di = (ky == 0) ? 1 : 0;
             const int pb = (kx == 1) ? 0 : 1, dj = (kx == 0) ? 1 : 0;
             const int ph = pa * 2 + pb;
-            bf16x8 b[NTW][NP];
+            bf16x8 b[NTW][NPL];
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                for (int pn = 0; pn < NP; ++pn) b[t][pn] = bq[tap % 3][t][pn];
+                for (int pn = 0; pn < NPL; ++pn) b[t][pn] = bq[tap % 3][t][pn];
             {
                 const int nxt = ch * 9 + tap + 3 < last_tap ? ch * 9 + tap + 3 : last_tap;     // clamped: unconditional refill
                 load_b(nxt / 9, nxt % 9, tap % 3);
@@ -476,17 +521,16 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 const int r = wm * MTW + m;
-                bf16x8 a[NP];
+                bf16x8 a[NPL];
 #pragma unroll
-                for (int pn = 0; pn < NP; ++pn)
+                for (int pn = 0; pn < NPL; ++pn)
                     a[pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES + ((r + di) * IW + pl + dj) * PITCH + g * 16);
 #pragma unroll
-                for (int term = (NP == 3 ? 5 : NP == 2 ? 2 : 0); term >= 0; --term) {
-                    const int ia = (term == 0) ? 0 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 2 : 1;
-                    const int ib = (term == 0) ? 0 : (term == 1) ? 1 : (term == 2) ? 0 : (term == 3) ? 2 : (term == 4) ? 0 : 1;
+                for (int term = NTERM - 1; term >= 0; --term) {
+                    const int ia = term_a(term), ib = term_b(term);
+                    const int ka = (F16 && term > 0) ? 1 : 0;
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t)
-                        acc[m][ph][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[t][ib], acc[m][ph][t], 0, 0, 0);
+                    for (int t = 0; t < NTW; ++t) acc[ka][m][ph][t] = mfma_split<F16>(a[ia], b[t][ib], acc[ka][m][ph][t]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -514,7 +558,9 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ix = ix0 + g * 4 + r;
-                    const float v = acc[m][ph][t][r] + bias;
+                    float v = acc[0][m][ph][t][r];
+                    if constexpr (F16) v += acc[NACC - 1][m][ph][t][r] * (1.f / F16_RES_SCALE);
+                    v += bias;
                     ep[((2 * row + (ph >> 1)) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + (wn * NTW + t) * 16 + pl] = v;
                     if (iy < p.hin && ix < p.win) {
                         s += (double)v;
@@ -548,7 +594,7 @@ static int launch_tb(hipStream_t s, ConvBParams p) {
 
 int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSrc& b, const unsigned short* wpack, const float* bias,
                        float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
-    CS_REQUIRE(planes >= 1 && planes <= 3, "convT(bf16): %d planes", planes);
+    CS_REQUIRE(planes >= 1 && planes <= 4, "convT(bf16): %d planes", planes);
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "convT(bf16): channels must be multiples of 16");
     ConvBParams p{};
     p.a = to_devb(a);
@@ -569,6 +615,7 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
         default: return launch_tb<1, 1, NP_>(s, p);                  \
     }
     switch (planes) {
+        case 4: CS_TB(4)
         case 3: CS_TB(3)
         case 2: CS_TB(2)
         default: CS_TB(1)
@@ -580,7 +627,7 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
 // packed[chunk][tap][ntile_total][plane][lane][j]: cout = ntile*16 + (lane & 15), k = chunk*32 + 8*(lane>>4) + j.
 // Input channels >= cin_split (second concat source) start a fresh 32-channel chunk, as the kernel stages them.
 __global__ void pack_bf16_kernel(const float* w, int transposed, int cout, int cin, int taps, unsigned short* packed, int cout_off,
-                                 int ntile_total, int cin_split, int chunks_total) {
+                                 int ntile_total, int cin_split, int chunks_total, int f16) {
     const int64_t total = (int64_t)chunks_total * taps * (cout / 16) * 512;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -598,6 +645,14 @@ __global__ void pack_bf16_kernel(const float* w, int transposed, int cout, int c
     float v = 0.f;
     if (valid) v = transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap];
     const size_t base = (((size_t)chunk * taps + tap) * ntile_total + cout_off / 16 + ntl) * 3;
+    if (f16) {                                                // fp16x3: h0, (w - h0) * 2^11, unused
+        const _Float16 h0 = (_Float16)v;
+        const _Float16 h1 = (_Float16)((v - (float)h0) * F16_RES_SCALE);
+        packed[((base + 0) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h0);
+        packed[((base + 1) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h1);
+        packed[((base + 2) * 64 + lane) * 8 + j] = 0;
+        return;
+    }
 #pragma unroll
     for (int pn = 0; pn < 3; ++pn) {
         const __bf16 h = (__bf16)v;
@@ -612,14 +667,14 @@ size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize) {
 }
 
 int pack_conv_weights_bf16(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, unsigned short* packed,
-                           int cout_off, int cout_total, int cin_split) {
+                           int cout_off, int cout_total, int cin_split, bool f16) {
     CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack(bf16): bad channel counts");
     const int taps = ksize * ksize;
     const int chunks_total = cin_split > 0 ? (cin_split + 31) / 32 + (cin - cin_split + 31) / 32 : (cin + 31) / 32;
     const int64_t total = (int64_t)chunks_total * taps * (cout / 16) * 512;
     ProfScope prof(K_PACK, s, 0, 10.0 * total);
     hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, transposed ? 1 : 0, cout, cin, taps,
-                       packed, cout_off, cout_total / 16, cin_split, chunks_total);
+                       packed, cout_off, cout_total / 16, cin_split, chunks_total, f16 ? 1 : 0);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

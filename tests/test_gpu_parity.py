@@ -298,11 +298,12 @@ def test_ten_training_steps_match_oracle_loss_curve():
 
 
 # ------------------------------------------------------------------------------------------- split-bf16 matrix-core modes
-@pytest.mark.parametrize("precision,tol", [("bf16x6", 1e-4), ("bf16x3", 2e-3), ("bf16", 0.5)])
+@pytest.mark.parametrize("precision,tol", [("fp16x3", 1e-4), ("bf16x6", 1e-4), ("bf16x3", 2e-3), ("bf16", 0.5)])
 @pytest.mark.parametrize("channels,shape", [((16, 32, 64, 128, 256), (2, 3, 64, 64)), ((16, 32, 64, 128, 256), (3, 3, 256, 256)),
                                             ((32, 64, 128, 256, 512), (2, 3, 128, 128))])
 def test_split_bf16_modes(precision, tol, channels, shape):
-    """bf16x6 (3 planes, 6 MFMA terms) must stay inside the fp32 logit budget; the cheaper modes are bounded loosely."""
+    """fp16x3 (2 fp16 planes, 3 terms) and bf16x6 (3 bf16 planes, 6 terms) must stay inside the fp32 logit budget; the cheaper
+    modes are bounded loosely."""
     ref, hip = _pair(channels, 2)
     hip.precision = precision
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(7))
@@ -416,13 +417,15 @@ def test_bf16_modes_keep_f1_against_fp32_masks():
     x = torch.from_numpy(synthetic_wsi(1024, 2022)).to(_dev())
     labs = {}
     with torch.no_grad():
-        for prec in ("fp32", "bf16x6", "bf16"):
+        for prec in ("fp32", "fp16x3", "bf16x6", "bf16"):
             hip.precision = prec
             _, _, mask = ca.swi_infer_image(hip, x, (256, 256), 0.5, want_logits=False, want_mask=True)
             labs[prec] = ca.mask_to_instances(mask)
     f1_x6 = metrics.f1_score(labs["fp32"], labs["bf16x6"])[5]
+    f1_h3 = metrics.f1_score(labs["fp32"], labs["fp16x3"])[5]
     f1_bf = metrics.f1_score(labs["fp32"], labs["bf16"])[5]
     assert f1_x6 >= 1.0 - 1e-3, f1_x6
+    assert f1_h3 >= 1.0 - 1e-3, f1_h3
     assert f1_bf >= 0.9, f1_bf
 
 

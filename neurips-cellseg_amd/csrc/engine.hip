@@ -575,9 +575,15 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     auto oom = [&]() { set_error("backward: workspace too small"); return CS_ERR_WORKSPACE; };
 
     // helpers -------------------------------------------------------------------------------------------
-    auto bias_grad = [&](const float* dy, int pitch, int c, int64_t npix_total, int pidx) -> int {
+    // `before_norm`: the conv feeds an InstanceNorm, which removes any per-(image, channel) constant - the bias gradient is
+    // analytically zero (autograd returns rounding noise there), so it is written as exact zeros instead of summing dy
+    auto bias_grad = [&](const float* dy, int pitch, int c, int64_t npix_total, int pidx, bool before_norm = false) -> int {
         double* d = acc.take<double>(c);
         if (dry) return CS_OK;
+        if (before_norm) {
+            CS_HIP(hipMemsetAsync(gptr(pidx), 0, (size_t)c * sizeof(float), s));
+            return CS_OK;
+        }
         CS_TRY(launch_colsum(s, dy, pitch, c, npix_total, d));
         return launch_f64_to_f32(s, d, gptr(pidx), c);
     };
@@ -631,7 +637,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const WG gu = wg_alloc(c, 0, c, 9, c, c, oh, ow);
             if (!buf.ok()) return oom();
             CS_TRY(norm_bwd(u.norm_u, lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow));
-            CS_TRY(bias_grad(dV, c, c, (int64_t)n * oh * ow, u.unit0.p_b[0]));
+            CS_TRY(bias_grad(dV, c, c, (int64_t)n * oh * ow, u.unit0.p_b[0], true));
             if (!dry) {
                 CS_TRY(launch_wgrad(s, 3, 1, dV, c, c, lu, nullptr, gu.part, gu.k, c, c, 0, 0, n, oh, ow, oh, ow));
                 CS_TRY(launch_unpack_wgrad(s, gu.part, gu.k, c, c, 0, 0, c, c, 9, gptr(u.unit0.p_w[0])));
@@ -641,7 +647,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             }
         }
         CS_TRY(norm_bwd(u.norm_t, lu, d_au, c, dU, c, (int64_t)oh * ow));
-        CS_TRY(bias_grad(dU, c, c, (int64_t)n * oh * ow, u.convt.p_b[0]));
+        CS_TRY(bias_grad(dU, c, c, (int64_t)n * oh * ow, u.convt.p_b[0], true));
         if (!dry) {
             if (u.top) {
                 CS_TRY(launch_convt_small_bwd_data(s, dU, u.convt.w, cin_t, 0, cs, dX[d], cs, false, n, ph, pw));
@@ -685,7 +691,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             float* da_new = su > 0 ? buf.take<float>((size_t)n * npix * c) : nullptr;
             if (!buf.ok()) return oom();
             CS_TRY(norm_bwd(u.norms[su], lazy_src(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c), da, c, dY, c, npix));
-            CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0]));
+            CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (dry) { da = da_new; continue; }
             if (su > 0) {
                 const ConvSrc prev = lazy_src(T.Yb[su - 1], c, c, T.rt_bottom[su - 1], u.norms[su - 1], c);
@@ -728,7 +734,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const WG ga = wg_alloc(c, 0, c, 9, c, c, oh, ow);
             if (!buf.ok()) return oom();
             CS_TRY(norm_bwd(u.norms[su], lazy_src(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c), da, c, dY, c, npix));
-            CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0]));
+            CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (!dry) {
                 const ConvSrc prev = su - 1 == 0 ? lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0)
                                                  : lazy_src(T.Y[d][su - 1], c, c, T.rt_down[d][su - 1], u.norms[su - 1], c);
@@ -742,7 +748,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         const WG gf = wg_alloc(c, 0, cin, 9, c0, cin, oh, ow);
         if (!buf.ok()) return oom();
         CS_TRY(norm_bwd(u.norms[0], lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0), da, c, dY0, c, npix));
-        CS_TRY(bias_grad(dY0, c, c, n * npix, u.unit0.p_b[0]));
+        CS_TRY(bias_grad(dY0, c, c, n * npix, u.unit0.p_b[0], true));
         if (dry) continue;
         if (!u.first) {
             const ConvSrc xin = rsrc(T.X[d - 1], cin, cin);

@@ -57,9 +57,10 @@ int cs_unet_destroy(cs_unet* net);
  *   0  v_mfma_f32_16x16x4_f32, exact fp32 (default; the 1e-4 logit-parity path)
  *   3  split-bf16, 3 planes / 6 MFMA terms on v_mfma_f32_16x16x32_bf16: fp32-grade results (~1e-5 logit error)
  *   2  split-bf16, 2 planes / 3 terms (~1e-4)        1  plain bf16 (throughput mode; judged by F1, not by logits)
- *   4  split-fp16: planes fp16(x), fp16((x - h0) * 2^11) (22 mantissa bits), 3 terms on v_mfma_f32_16x16x32_f16, the cross
- *      terms in their own accumulator: fp32-grade results at half the MFMAs of mode 3; operands must lie inside fp16's
- *      range (normalised activations and trained weights do).
+ *   4  split-fp16: planes h0 = fp16(x'), h1 = fp16(x' - h0) (22 mantissa bits) of the power-of-two pre-scaled operands
+ *      (weights * 2^8, staged activations * 2^4, sum * 2^-12), 3 terms on v_mfma_f32_16x16x32_f16 in one accumulator:
+ *      fp32-grade results at half the MFMAs of mode 3; operands must lie inside fp16's range after scaling
+ *      (|x| < 4094, |w| < 255: normalised activations and trained weights do).
  * Parameters must be (re)loaded after switching between the fp32 / bf16 (1..3) / fp16 (4) families. */
 int cs_unet_set_precision(cs_unet* net, int planes);
 /* on != 0: every cs_unet_load_param also packs the data-gradient layout of the tensor (needed by cs_unet_backward).

@@ -79,6 +79,11 @@ int cs_unet_param_info(const cs_unet* net, int index, char* key_out_host, int64_
 /* Copy + repack one tensor given in PyTorch layout (conv [Cout,Cin,k,k], transposed conv [Cin,Cout,k,k],
  * bias [C], PReLU slope [1], BatchNorm weight/bias/running_mean/running_var [C]) from device memory. */
 int cs_unet_load_param(cs_unet* net, const char* key_host, const float* data, int64_t numel, void* stream);
+/* Optional batching of parameter uploads: between cs_unet_load_begin and cs_unet_load_end, cs_unet_load_param only records
+ * the packing work; cs_unet_load_end runs all of it in ONE kernel on `stream` (a training step re-packs all 63 tensors after
+ * every optimiser update).  The source buffers must stay alive and unchanged until cs_unet_load_end has been called. */
+int cs_unet_load_begin(cs_unet* net);
+int cs_unet_load_end(cs_unet* net, void* stream);
 
 /* Bytes of caller workspace needed for a forward over `n` windows of h x w (multiples of 2^(levels)). */
 size_t cs_unet_workspace_bytes(const cs_unet* net, int n, int h, int w);

@@ -205,10 +205,7 @@ struct cs_unet {
 
 namespace cs {
 
-static int copy_param(float* dst, const float* src, size_t n, hipStream_t s) {
-    CS_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return CS_OK;
-}
+static int copy_param(float* dst, const float* src, size_t n, hipStream_t s) { return cs::pack_copy(s, src, dst, n); }
 
 struct ArenaPlan {   // two passes: count floats, then hand out pointers
     float* base = nullptr;
@@ -860,6 +857,17 @@ int cs_unet_set_precision(cs_unet* net, int planes) {
     CS_REQUIRE(net && planes >= 0 && planes <= 4, "set_precision: 0 (fp32 MFMA), 1..3 (split-bf16 planes) or 4 (split-fp16, 3 terms)");
     net->planes = planes;
     return CS_OK;
+}
+
+int cs_unet_load_begin(cs_unet* net) {
+    CS_REQUIRE(net, "load_begin: null handle");
+    cs::pack_batch_begin();
+    return CS_OK;
+}
+
+int cs_unet_load_end(cs_unet* net, void* stream) {
+    CS_REQUIRE(net, "load_end: null handle");
+    return cs::pack_batch_flush((hipStream_t)stream);
 }
 
 int cs_unet_set_training(cs_unet* net, int on) {

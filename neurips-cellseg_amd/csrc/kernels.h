@@ -26,6 +26,12 @@ int pack_conv_weights(hipStream_t s, const float* w, bool transposed, int cout, 
                       float* packed, int cout_off, int cout_total, bool flip = false, int cin_off = 0);
 // first layer (cin < 16): packed[kstep][ntile_total][64], k = 4*kstep + (lane>>4) = tap*cin + c, zero padded
 int pack_first_weights(hipStream_t s, const float* w, int cout, int cin, float* packed, int cout_off, int cout_total);
+// batched packing: between begin and flush the pack_* entry points only record jobs; flush runs them in one kernel
+void pack_batch_begin();
+int pack_batch_flush(hipStream_t s);
+int pack_copy(hipStream_t s, const float* src, float* dst, size_t n);
+int pack_bf16_submit(hipStream_t s, const float* w, bool transposed, int cout, int cin, int taps, unsigned short* packed, int cout_off,
+                     int ntile_total, int cin_split, int chunks_total, bool f16);
 size_t packed_conv_floats(int cout_total, int cin_total, int ksize);
 size_t packed_first_floats(int cout_total, int cin);
 

@@ -13,6 +13,10 @@
 //   * epilogue adds the bias, stores the raw conv output and accumulates per-(image, channel) sum / sum of
 //     squares in fp64 (wavefront shuffle reduction + one fp64 atomic per wave and channel) for the next norm.
 #include "kernels.h"
+#include "pack_jobs.h"
+
+#include <string.h>
+#include <vector>
 
 namespace cs {
 
@@ -998,63 +1002,123 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
-__global__ void pack_conv_kernel(const float* w, int transposed, int cout, int cin, int taps, float* packed, int cout_off,
-                                 int ntile_total, int flip, int chunk_off) {
-    // one thread per packed element of this conv's slice: (chunk, tap, ntile_local, lane, j)
-    const int64_t total = (int64_t)(cin / 16) * taps * (cout / 16) * 256;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// ---- batched packing ---------------------------------------------------------------------------------------
+// A training step re-packs every weight tensor after the optimiser update (63 tensors x up to 3 layouts): as separate
+// launches that is ~150 tiny kernels (~0.8 ms per step, launch-bound).  Between pack_batch_begin() and pack_batch_flush()
+// the pack_* / copy entry points only RECORD a job; the flush uploads the job table and runs ONE kernel over the
+// concatenated element space of all jobs.
+static inline int64_t pack_job_elems(const PackJob& jb) {
+    switch (jb.kind) {
+        case PK_CONV: return (int64_t)(jb.cin / 16) * jb.taps * (jb.cout / 16) * 256;
+        case PK_FIRST: return (int64_t)jb.ksteps * (jb.cout / 16) * 64;
+        case PK_BF16: return (int64_t)jb.chunks_total * jb.taps * (jb.cout / 16) * 512;
+        default: return jb.cout;                              // PK_COPY: cout = element count
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* jobs, int n_jobs, long long total) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
-    const int j = e & 3, lane = (e >> 2) & 63;
-    int64_t r = e >> 8;
-    const int ntl = r % (cout / 16);
-    r /= (cout / 16);
-    const int tap = r % taps;
-    const int chunk = r / taps;
-    const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
-    const int st = flip ? taps - 1 - tap : tap;
-    const float v = transposed ? w[((size_t)ci * cout + co) * taps + st] : w[((size_t)co * cin + ci) * taps + st];
-    const int nt = cout_off / 16 + ntl;
-    packed[(((size_t)(chunk + chunk_off) * taps + tap) * ntile_total + nt) * 256 + lane * 4 + j] = v;
+    int lo = 0, hi = n_jobs - 1;                              // last job with begin <= e
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].begin <= e) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackJob jb = jobs[lo];
+    const int64_t le = e - jb.begin;
+    switch (jb.kind) {
+        case PK_CONV: pack_conv_elem(jb, le); break;
+        case PK_FIRST: pack_first_elem(jb, le); break;
+        case PK_BF16: pack_bf16_elem(jb, le); break;
+        default: reinterpret_cast<float*>(jb.dst)[le] = jb.src[le]; break;
+    }
+}
+
+static std::vector<PackJob>* g_pack_batch = nullptr;          // non-null while a batch is being recorded
+static PackJob* g_pack_host = nullptr;                        // pinned staging + device table, grown on demand (off the launch path
+static PackJob* g_pack_dev = nullptr;                         // after the first step)
+static size_t g_pack_cap = 0;
+
+void pack_batch_begin() {
+    static std::vector<PackJob> jobs;
+    jobs.clear();
+    g_pack_batch = &jobs;
+}
+static int pack_submit(hipStream_t s, PackJob jb) {
+    if (g_pack_batch) {
+        g_pack_batch->push_back(jb);
+        return CS_OK;
+    }
+    // immediate mode: a one-job table passed by value would need a second kernel signature; reuse the batch path
+    std::vector<PackJob> one(1, jb);
+    std::vector<PackJob>* saved = g_pack_batch;
+    g_pack_batch = &one;
+    const int rc = pack_batch_flush(s);
+    g_pack_batch = saved;
+    return rc;
+}
+int pack_batch_flush(hipStream_t s) {
+    std::vector<PackJob>* jobs = g_pack_batch;
+    g_pack_batch = nullptr;
+    if (!jobs || jobs->empty()) return CS_OK;
+    long long total = 0;
+    for (auto& jb : *jobs) {
+        jb.begin = total;
+        total += pack_job_elems(jb);
+    }
+    const size_t n = jobs->size();
+    if (n > g_pack_cap) {
+        // the previous table may still be read by a kernel in flight on another stream: drain before replacing it
+        CS_HIP(hipDeviceSynchronize());
+        if (g_pack_host) (void)hipHostFree(g_pack_host);
+        if (g_pack_dev) (void)hipFree(g_pack_dev);
+        g_pack_cap = n < 256 ? 256 : 2 * n;
+        CS_HIP(hipHostMalloc((void**)&g_pack_host, g_pack_cap * sizeof(PackJob), hipHostMallocDefault));
+        CS_HIP(hipMalloc((void**)&g_pack_dev, g_pack_cap * sizeof(PackJob)));
+    }
+    // the pinned staging table is rewritten by the next flush: make sure the previous copy out of it has completed
+    static hipEvent_t copied = nullptr;
+    if (!copied) CS_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+    else CS_HIP(hipEventSynchronize(copied));
+    memcpy(g_pack_host, jobs->data(), n * sizeof(PackJob));
+    CS_HIP(hipMemcpyAsync(g_pack_dev, g_pack_host, n * sizeof(PackJob), hipMemcpyHostToDevice, s));
+    CS_HIP(hipEventRecord(copied, s));
+    ProfScope prof(K_PACK, s, 0, 8.0 * (double)total);
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_pack_dev, (int)n, total);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
 }
 
 int pack_conv_weights(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, float* packed,
                       int cout_off, int cout_total, bool flip, int cin_off) {
     CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack: bad channel counts");
-    const int taps = ksize * ksize;
-    const int64_t total = (int64_t)(cin / 16) * taps * (cout / 16) * 256;
-    ProfScope prof(K_PACK, s, 0, 8.0 * total);
     CS_REQUIRE(cin_off % 16 == 0, "pack: bad cin offset");
-    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, transposed ? 1 : 0, cout,
-                       cin, taps, packed, cout_off, cout_total / 16, flip ? 1 : 0, cin_off / 16);
-    CS_HIP(hipGetLastError());
-    return CS_OK;
-}
-
-__global__ void pack_first_kernel(const float* w, int cout, int cin, float* packed, int cout_off, int ntile_total, int ksteps) {
-    const int total = ksteps * (cout / 16) * 64;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int lane = e & 63;
-    int r = e >> 6;
-    const int ntl = r % (cout / 16);
-    const int ks = r / (cout / 16);
-    const int k = 4 * ks + (lane >> 4);
-    float v = 0.f;
-    if (k < 9 * cin) {
-        const int tap = k / cin, c = k - tap * cin, co = ntl * 16 + (lane & 15);
-        v = w[((size_t)co * cin + c) * 9 + tap];
-    }
-    packed[((size_t)ks * ntile_total + cout_off / 16 + ntl) * 64 + lane] = v;
+    PackJob jb{};
+    jb.src = w; jb.dst = packed; jb.kind = PK_CONV; jb.transposed = transposed ? 1 : 0; jb.cout = cout; jb.cin = cin;
+    jb.taps = ksize * ksize; jb.cout_off = cout_off; jb.ntile_total = cout_total / 16; jb.flip = flip ? 1 : 0; jb.chunk_off = cin_off / 16;
+    return pack_submit(s, jb);
 }
 
 int pack_first_weights(hipStream_t s, const float* w, int cout, int cin, float* packed, int cout_off, int cout_total) {
-    const int ksteps = (9 * cin + 3) / 4;
-    const int total = ksteps * (cout / 16) * 64;
-    ProfScope prof(K_PACK, s, 0, 8.0 * total);
-    hipLaunchKernelGGL(pack_first_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, cout, cin, packed, cout_off,
-                       cout_total / 16, ksteps);
-    CS_HIP(hipGetLastError());
-    return CS_OK;
+    PackJob jb{};
+    jb.src = w; jb.dst = packed; jb.kind = PK_FIRST; jb.cout = cout; jb.cin = cin; jb.cout_off = cout_off; jb.ntile_total = cout_total / 16;
+    jb.ksteps = (9 * cin + 3) / 4;
+    return pack_submit(s, jb);
+}
+
+int pack_copy(hipStream_t s, const float* src, float* dst, size_t n) {
+    PackJob jb{};
+    jb.src = src; jb.dst = dst; jb.kind = PK_COPY; jb.cout = (int)n;
+    return pack_submit(s, jb);
+}
+
+int pack_bf16_submit(hipStream_t s, const float* w, bool transposed, int cout, int cin, int taps, unsigned short* packed, int cout_off,
+                     int ntile_total, int cin_split, int chunks_total, bool f16) {
+    PackJob jb{};
+    jb.src = w; jb.dst = packed; jb.kind = PK_BF16; jb.transposed = transposed ? 1 : 0; jb.cout = cout; jb.cin = cin; jb.taps = taps;
+    jb.cout_off = cout_off; jb.ntile_total = ntile_total; jb.cin_split = cin_split; jb.chunks_total = chunks_total; jb.f16 = f16 ? 1 : 0;
+    return pack_submit(s, jb);
 }
 
 size_t packed_conv_floats(int cout_total, int cin_total, int ksize) {

@@ -32,7 +32,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // is <= 2^-29); the epilogue multiplies the sum by 2^-12.  Every fp16 x fp16 product is exact in fp32.  Operands must stay
 // inside fp16's range after scaling (|x| < 4094, |w| < 255), which normalised activations and trained weights do.  Half the
 // MFMAs of bf16x6 at the same fp32-grade accuracy class (dropped term 2^-22, operand truncation 2^-23).
-constexpr float F16_W_SCALE = 256.f, F16_X_SCALE = 16.f, F16_OUT_SCALE = 1.f / (256.f * 16.f);
+constexpr float F16_W_SCALE = 256.f /* == PACK_F16_W_SCALE in pack_jobs.h */, F16_X_SCALE = 16.f, F16_OUT_SCALE = 1.f / (256.f * 16.f);
 template <int NP>
 struct SplitCfg {
     static constexpr bool f16 = NP == 4;
@@ -625,44 +625,6 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
 }
 
 // ---- weight packing: fp32 PyTorch layout -> 3 bf16 planes in MFMA (16x16x32) fragment order --------------------
-// packed[chunk][tap][ntile_total][plane][lane][j]: cout = ntile*16 + (lane & 15), k = chunk*32 + 8*(lane>>4) + j.
-// Input channels >= cin_split (second concat source) start a fresh 32-channel chunk, as the kernel stages them.
-__global__ void pack_bf16_kernel(const float* w, int transposed, int cout, int cin, int taps, unsigned short* packed, int cout_off,
-                                 int ntile_total, int cin_split, int chunks_total, int f16) {
-    const int64_t total = (int64_t)chunks_total * taps * (cout / 16) * 512;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int j = e & 7, lane = (e >> 3) & 63;
-    int64_t r = e >> 9;
-    const int ntl = r % (cout / 16);
-    r /= (cout / 16);
-    const int tap = r % taps;
-    const int chunk = r / taps;
-    const int chunks_a = cin_split > 0 ? (cin_split + 31) / 32 : chunks_total;
-    const int k = (chunk < chunks_a ? chunk * 32 : (chunk - chunks_a) * 32) + 8 * (lane >> 4) + j;
-    const int ci = chunk < chunks_a ? k : cin_split + k;
-    const bool valid = chunk < chunks_a ? k < (cin_split > 0 ? cin_split : cin) : ci < cin;
-    const int co = ntl * 16 + (lane & 15);
-    float v = 0.f;
-    if (valid) v = transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap];
-    const size_t base = (((size_t)chunk * taps + tap) * ntile_total + cout_off / 16 + ntl) * 3;
-    if (f16) {                                                // fp16x3: planes of w * 2^8: h0, remainder, unused
-        v *= F16_W_SCALE;
-        const _Float16 h0 = (_Float16)v;
-        const _Float16 h1 = (_Float16)(v - (float)h0);
-        packed[((base + 0) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h0);
-        packed[((base + 1) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h1);
-        packed[((base + 2) * 64 + lane) * 8 + j] = 0;
-        return;
-    }
-#pragma unroll
-    for (int pn = 0; pn < 3; ++pn) {
-        const __bf16 h = (__bf16)v;
-        v -= (float)h;
-        packed[((base + pn) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h);
-    }
-}
-
 size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize) {
     const size_t chunks = (size_t)(cin_a + 31) / 32 + (size_t)(cin_b + 31) / 32;
     return chunks * ksize * ksize * (cout_total / 16) * 3 * 512;
@@ -673,12 +635,7 @@ int pack_conv_weights_bf16(hipStream_t s, const float* w, bool transposed, int c
     CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack(bf16): bad channel counts");
     const int taps = ksize * ksize;
     const int chunks_total = cin_split > 0 ? (cin_split + 31) / 32 + (cin - cin_split + 31) / 32 : (cin + 31) / 32;
-    const int64_t total = (int64_t)chunks_total * taps * (cout / 16) * 512;
-    ProfScope prof(K_PACK, s, 0, 10.0 * total);
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, transposed ? 1 : 0, cout, cin, taps,
-                       packed, cout_off, cout_total / 16, cin_split, chunks_total, f16 ? 1 : 0);
-    CS_HIP(hipGetLastError());
-    return CS_OK;
+    return pack_bf16_submit(s, w, transposed, cout, cin, taps, packed, cout_off, cout_total / 16, cin_split, chunks_total, f16);
 }
 
 }  // namespace cs

@@ -1,0 +1,83 @@
+// Weight-packing jobs: element functions of every packed layout, run by ONE batched kernel (kernels_conv.hip).
+#pragma once
+#include "cs_common.h"
+
+namespace cs {
+
+enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3 };
+struct PackJob {
+    const float* src;
+    void* dst;
+    long long begin;            // first flattened element of this job
+    int kind, transposed, cout, cin, taps, cout_off, ntile_total, flip, chunk_off, cin_split, chunks_total, f16, ksteps, pad_;
+};
+
+__device__ __forceinline__ void pack_conv_elem(const PackJob& jb, int64_t e) {
+    const int cout = jb.cout, cin = jb.cin, taps = jb.taps;
+    const int j = e & 3, lane = (e >> 2) & 63;
+    int64_t r = e >> 8;
+    const int ntl = r % (cout / 16);
+    r /= (cout / 16);
+    const int tap = r % taps;
+    const int chunk = r / taps;
+    const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
+    const int st = jb.flip ? taps - 1 - tap : tap;
+    const float v = jb.transposed ? jb.src[((size_t)ci * cout + co) * taps + st] : jb.src[((size_t)co * cin + ci) * taps + st];
+    const int nt = jb.cout_off / 16 + ntl;
+    reinterpret_cast<float*>(jb.dst)[(((size_t)(chunk + jb.chunk_off) * taps + tap) * jb.ntile_total + nt) * 256 + lane * 4 + j] = v;
+}
+__device__ __forceinline__ void pack_first_elem(const PackJob& jb, int64_t e) {
+    const int cout = jb.cout, cin = jb.cin;
+    const int lane = e & 63;
+    int r = (int)(e >> 6);
+    const int ntl = r % (cout / 16);
+    const int ks = r / (cout / 16);
+    const int k = 4 * ks + (lane >> 4);
+    float v = 0.f;
+    if (k < 9 * cin) {
+        const int tap = k / cin, c = k - tap * cin, co = ntl * 16 + (lane & 15);
+        v = jb.src[((size_t)co * cin + c) * 9 + tap];
+    }
+    reinterpret_cast<float*>(jb.dst)[((size_t)ks * jb.ntile_total + jb.cout_off / 16 + ntl) * 64 + lane] = v;
+}
+
+
+// split-bf16 / split-fp16 weight planes in 16x16x32 fragment order:
+// packed[chunk][tap][ntile_total][plane][lane][j]: cout = ntile*16 + (lane & 15), k = chunk*32 + 8*(lane>>4) + j.
+// Input channels >= cin_split (second concat source) start a fresh 32-channel chunk, as the kernel stages them.
+constexpr float PACK_F16_W_SCALE = 256.f;                     // == F16_W_SCALE of kernels_conv_bf16.hip
+__device__ __forceinline__ void pack_bf16_elem(const PackJob& jb, int64_t e) {
+    const int cout = jb.cout, cin = jb.cin, taps = jb.taps, cin_split = jb.cin_split, chunks_total = jb.chunks_total;
+    const int j = e & 7, lane = (e >> 3) & 63;
+    int64_t r = e >> 9;
+    const int ntl = r % (cout / 16);
+    r /= (cout / 16);
+    const int tap = r % taps;
+    const int chunk = r / taps;
+    const int chunks_a = cin_split > 0 ? (cin_split + 31) / 32 : chunks_total;
+    const int k = (chunk < chunks_a ? chunk * 32 : (chunk - chunks_a) * 32) + 8 * (lane >> 4) + j;
+    const int ci = chunk < chunks_a ? k : cin_split + k;
+    const bool valid = chunk < chunks_a ? k < (cin_split > 0 ? cin_split : cin) : ci < cin;
+    const int co = ntl * 16 + (lane & 15);
+    float v = 0.f;
+    if (valid) v = jb.transposed ? jb.src[((size_t)ci * cout + co) * taps + tap] : jb.src[((size_t)co * cin + ci) * taps + tap];
+    unsigned short* packed = reinterpret_cast<unsigned short*>(jb.dst);
+    const size_t base = (((size_t)chunk * taps + tap) * jb.ntile_total + jb.cout_off / 16 + ntl) * 3;
+    if (jb.f16) {                                             // fp16x3: planes of w * 2^8: h0, remainder, unused
+        v *= PACK_F16_W_SCALE;
+        const _Float16 h0 = (_Float16)v;
+        const _Float16 h1 = (_Float16)(v - (float)h0);
+        packed[((base + 0) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h0);
+        packed[((base + 1) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h1);
+        packed[((base + 2) * 64 + lane) * 8 + j] = 0;
+        return;
+    }
+#pragma unroll
+    for (int pn = 0; pn < 3; ++pn) {
+        const __bf16 h = (__bf16)v;
+        v -= (float)h;
+        packed[((base + pn) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
+}  // namespace cs

@@ -45,6 +45,14 @@ def rank_rows(img_h: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+WORKSPACE_BUDGET = 64 << 30     # bytes of HBM the tiler may take for window activations (of 288 GB)
+
+
+def _held_bytes(model: UNet) -> int:
+    """Workspace bytes the model already holds for the tiler (they are free for re-use by the next call)."""
+    return sum(v.numel() for k, v in getattr(model, "_ws", {}).items() if k and k[0] == "swi")
+
+
 def swi_infer_image(model: UNet, image: torch.Tensor, roi_size, overlap: float = 0.25, *, engine_batch: int = DEFAULT_ENGINE_BATCH,
                     rows: Optional[Tuple[int, int]] = None, want_logits: bool = True, want_prob: bool = False,
                     want_mask: bool = False, streams: int = DEFAULT_STREAMS):
@@ -61,6 +69,12 @@ def swi_infer_image(model: UNet, image: torch.Tensor, roi_size, overlap: float =
     with torch.cuda.device(dev):
         check(lib.cs_unet_set_streams(eng.handle, int(streams)), "cs_unet_set_streams")
         nbytes = lib.cs_swi_workspace_bytes(eng.handle, C.byref(plan), int(engine_batch))
+        # the activation workspace scales with engine_batch x streams x window area x width: stay inside a memory budget
+        # (wide nets on 512^2 windows would otherwise ask for > 100 GB at the default batch of 256 windows)
+        budget = min(WORKSPACE_BUDGET, int(0.6 * torch.cuda.mem_get_info(dev)[0]) + _held_bytes(model))
+        while nbytes > budget and engine_batch > 4:
+            engine_batch = max(4, int(engine_batch) // 2)
+            nbytes = lib.cs_swi_workspace_bytes(eng.handle, C.byref(plan), int(engine_batch))
         if nbytes == 0:
             raise _lib.CellSegHipError(f"cs_swi_workspace_bytes: {lib.cs_last_error().decode()}")
         ws = model.workspace(("swi", h, w, plan.roi_h, plan.roi_w, plan.n_h, plan.n_w, int(engine_batch), int(streams)), nbytes, dev)

@@ -3,6 +3,7 @@
 Run on the MI355X box with ``pytest -m gpu``.  Tolerances: logits <= 1e-4 max-abs in fp32 (north_star);
 connected-component labels bit-exact (including ids, which follow scipy's raster order)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -458,3 +459,13 @@ def test_strip_partition_end_to_end_labels_equal_single_rank():
             parts.append(m[lo:hi].clone())
         got = ca.mask_to_instances(torch.cat(parts, 0))
     assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------- randomised sweep
+def test_randomised_parity_sweep_short():
+    """A few seconds of tests/diagnostics/gpu_fuzz.py: random masks through the CC chain vs the C oracle, random image / roi /
+    overlap combinations through the tiler vs the torch-CPU oracle, interior maps and metric histograms vs their oracles."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "diagnostics"))
+    import gpu_fuzz
+    res = gpu_fuzz.run(seconds=8.0, seed=2022)
+    assert res["ccl"] > 20 and res["tiler"] > 5 and res["status"] == "all equal"

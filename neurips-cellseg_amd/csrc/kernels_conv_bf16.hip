@@ -122,12 +122,12 @@ __device__ __forceinline__ void stats_commit_b(double s, double q, double* dst, 
 // block = 4 waves arranged WN (along output channels) x WM = 4 / WN (along pixel rows); each wave owns NTW 16-channel
 // tiles and MTW pixel rows.  A (pixels) comes from the LDS planes shared by the block; B (weights) is private to the wave
 // and goes global -> registers, one tap ROW ahead (ring of KS x NTW x NP fragments), so no weight ever touches LDS.
-template <int S, int KS, int WN, int NTW, int NP>
+template <int S, int KS, int WN, int NTW, int NP, int THX>
 __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     constexpr bool F16 = SplitCfg<NP>::f16;
     constexpr int NPL = SplitCfg<NP>::planes, NTERM = SplitCfg<NP>::terms;
     constexpr int WM = 4 / WN;
-    constexpr int TH = (S == 1) ? 8 : 4, TW = 16;
+    constexpr int TH = THX * ((S == 1) ? 8 : 4), TW = 16;    // THX = 2: double-height tile, half the weight traffic per MFMA
     constexpr int MTW = TH / WM;                            // pixel rows per wave
     constexpr int NTB = WN * NTW;                           // 16-channel tiles per block
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
@@ -336,13 +336,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
 
 static SrcDevB to_devb(const ConvSrc& s) { return SrcDevB{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
 
-template <int S, int KS, int WN, int NTW, int NP>
+template <int S, int KS, int WN, int NTW, int NP, int THX = 1>
 static int launch_b(hipStream_t s, ConvBParams p) {
-    constexpr int TH = (S == 1) ? 8 : 4;
+    constexpr int TH = THX * ((S == 1) ? 8 : 4);
     p.tiles_x = ceil_div(p.wout, 16);
     p.tiles_y = ceil_div(p.hout, TH);
     dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
-    hipLaunchKernelGGL((conv_bf16s_kernel<S, KS, WN, NTW, NP>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_bf16s_kernel<S, KS, WN, NTW, NP, THX>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -364,12 +364,15 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     p.hout = (hin + 2 * pad - ksize) / stride + 1;
     p.wout = (win + 2 * pad - ksize) / stride + 1;
     const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    static const int tall_env = getenv("CS_BF16_TALL") ? atoi(getenv("CS_BF16_TALL")) : 1;
+    const bool tall = tall_env && stride == 1 && p.hout >= 16;   // double-height tiles (stride-1, 2-plane modes)
     const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
     const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
 #define CS_B3(S_, KS_, NP_)                                                         \
     switch (wn) {                                                                   \
-        case 4: return launch_b<S_, KS_, 2, 2, NP_>(s, p);                          \
+        case 4: if (tall && (NP_ == 4 || NP_ <= 2) && KS_ == 3) return launch_b<S_, KS_, 2, 2, (NP_ == 3 ? 4 : NP_), 2>(s, p); \
+                return launch_b<S_, KS_, 2, 2, NP_>(s, p);                          \
         case 2: return launch_b<S_, KS_, 2, 1, NP_>(s, p);                          \
         default: return launch_b<S_, KS_, 1, 1, NP_>(s, p);                         \
     }

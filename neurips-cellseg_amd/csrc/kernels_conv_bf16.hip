@@ -364,15 +364,19 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     p.hout = (hin + 2 * pad - ksize) / stride + 1;
     p.wout = (win + 2 * pad - ksize) / stride + 1;
     const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
-    static const int tall_env = getenv("CS_BF16_TALL") ? atoi(getenv("CS_BF16_TALL")) : 3;
-    const bool tall = tall_env && stride == 1 && p.hout >= 16;   // double-height tiles (stride-1, 2-plane modes)
-    const bool wide128 = (tall_env & 2) && cout % 128 == 0;      // stride 2: 128-channel blocks, every wave all 4 rows
+    // Tile-shape choices that cut the per-wave weight streaming from L2 (the limiter of these kernels); bit mask for A/B runs
+    // (CS_BF16_TALL): 1 double-height tiles for stride 1 (two-plane modes), 2 stride-2 layers as 128-channel blocks in which
+    // every wave owns all 4 rows, 4 stride-1 layers with >= 128 channels as 128-channel blocks in which every wave owns all 8 rows.
+    static const int tall_env = getenv("CS_BF16_TALL") ? atoi(getenv("CS_BF16_TALL")) : 7;
+    const bool tall = (tall_env & 1) && stride == 1 && p.hout >= 16;
+    const bool wide128 = (tall_env & 2) && cout % 128 == 0;
     const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
     const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
 #define CS_B3(S_, KS_, NP_)                                                         \
     switch (wn) {                                                                   \
-        case 4: if (tall && (NP_ == 4 || NP_ <= 2) && KS_ == 3) return launch_b<S_, KS_, 2, 2, (NP_ == 3 ? 4 : NP_), 2>(s, p); \
+        case 4: if ((tall_env & 4) && S_ == 1 && KS_ == 3 && NP_ != 3 && cout % 128 == 0) return launch_b<S_, KS_, 4, 2, (NP_ == 3 ? 4 : NP_)>(s, p); \
+                if (tall && (NP_ == 4 || NP_ <= 2) && KS_ == 3) return launch_b<S_, KS_, 2, 2, (NP_ == 3 ? 4 : NP_), 2>(s, p); \
                 if (wide128 && S_ == 2) return launch_b<S_, KS_, 4, 2, NP_>(s, p);    \
                 return launch_b<S_, KS_, 2, 2, NP_>(s, p);                          \
         case 2: return launch_b<S_, KS_, 2, 1, NP_>(s, p);                          \

@@ -139,9 +139,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     constexpr int IN_BYTES = (NPL * PLANE_BYTES + 15) / 16 * 16;
     constexpr int EPS = 16 * NTB + 4;
     constexpr int EP_BYTES = TH * 16 * EPS * 4;
-    constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
+    constexpr bool DB = 2 * IN_BYTES <= EP_BYTES + 4096;    // double-buffered input where the epilogue slab already pays for the LDS
+    constexpr int SM_BYTES = (DB ? 2 : 1) * IN_BYTES > EP_BYTES ? (DB ? 2 : 1) * IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
-    char* const in_s = smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
             rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * src.pitch);
         }
     };
-    auto store_input = [&]() {
+    auto store_input = [&](char* in_s) {
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) {
             const int pix = (tid >> 3) + 32 * it;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     load_input(0);
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) load_b(0, 0, kx);
-    store_input();
+    store_input(smem);
     __syncthreads();
 
     const int last_row = chunks * KS - 1;
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
         // MFMA section then stalls on loads it has only just issued.  sched_barriers pin the issue points.
         load_input(more ? ch + 1 : ch);
         __builtin_amdgcn_sched_barrier(0);
+        const char* in_s = smem + (DB ? (ch & 1) * IN_BYTES : 0);
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
             const int row_next = ch * KS + ky + 1 < last_row ? ch * KS + ky + 1 : last_row;
@@ -288,11 +289,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
         }
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) asm volatile("" ::"v"(rin[it]));   // keeps the input loads above the MFMA section
+        if (!DB) __syncthreads();
+        if (more) store_input(smem + (DB ? ((ch + 1) & 1) * IN_BYTES : 0));
         __syncthreads();
-        if (more) {
-            store_input();
-            __syncthreads();
-        }
     }
 
     // ---- epilogue: bias, fp64 statistics, then full-line stores through a block-wide LDS slab ----

@@ -20,7 +20,7 @@ from oracle.sliding_window_ref import sliding_window_inference_ref
 
 
 
-def run(seconds: float = 120.0, seed: int = 0) -> dict:
+def run(seconds: float = 120.0, seed: int = 0, channels=(16, 32, 64), precision: str = "fp32") -> dict:
     """Returns the case counts; raises AssertionError (after saving the failing input under gpurun_out/) on a mismatch."""
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
@@ -53,10 +53,13 @@ def run(seconds: float = 120.0, seed: int = 0) -> dict:
         return np.ones((h, w), np.uint8) if rng.random() < 0.5 else np.zeros((h, w), np.uint8)
 
 
-    ref = make_reference_unet(5, channels=(16, 32, 64), strides=(2, 2), num_res_units=2).eval()
-    hip = ca.UNet(channels=(16, 32, 64), strides=(2, 2), num_res_units=2)
+    strides = (2,) * (len(channels) - 1)
+    ref = make_reference_unet(5, channels=tuple(channels), strides=strides, num_res_units=2).eval()
+    hip = ca.UNet(channels=tuple(channels), strides=strides, num_res_units=2)
     hip.load_state_dict(ref.state_dict())
     hip = hip.to(dev).eval()
+    hip.precision = precision
+    mult = 1 << len(strides)                                  # window sizes must be multiples of 2^levels
 
     t_end = time.time() + seconds
     while time.time() < t_end:
@@ -89,7 +92,7 @@ def run(seconds: float = 120.0, seed: int = 0) -> dict:
             counts["metric"] += 1
         # ---- tiler + net (every 4th round: the CPU oracle is the slow side)
         if counts["ccl"] % 4 == 0:
-            roi = (int(rng.choice([32, 64, 96, 128])), int(rng.choice([32, 64, 96, 128])))
+            roi = (int(rng.choice([32, 64, 96, 128])) // mult * mult or mult, int(rng.choice([32, 64, 96, 128])) // mult * mult or mult)
             ih, iw = int(rng.integers(8, 300)), int(rng.integers(8, 300))
             ov = float(rng.choice([0.0, 0.25, 0.5, 0.6]))
             x = torch.rand(1, 3, ih, iw, generator=torch.Generator().manual_seed(int(rng.integers(0, 1 << 30))))
@@ -108,5 +111,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--channels", type=int, nargs="+", default=[16, 32, 64])
+    ap.add_argument("--precision", default="fp32")
     a = ap.parse_args()
-    print(json.dumps(run(a.seconds, a.seed)))
+    print(json.dumps(run(a.seconds, a.seed, tuple(a.channels), a.precision)))

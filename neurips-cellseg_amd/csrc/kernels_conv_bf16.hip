@@ -55,7 +55,7 @@ __device__ __forceinline__ bf16x4 split_plane(f32x4& v, int pn) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (pn == 0) v[j] *= F16_X_SCALE;
-            h[j] = (_Float16)v[j];
+            h[j] = (_Float16)v[j];                           // saturates at +-65504 (MODE.FP16_OVFL is set by the fp16 kernels)
             v[j] -= (float)h[j];
         }
         return __builtin_bit_cast(bf16x4, h);
@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     constexpr int SM_BYTES = (DB ? 2 : 1) * IN_BYTES > EP_BYTES ? (DB ? 2 : 1) * IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
 
+    // fp16 mode: an out-of-range operand saturates at +-65504 instead of becoming inf (MODE.FP16_OVFL, bit 23 of HW_REG_MODE):
+    // an activation beyond the documented domain then costs accuracy in its window, not a NaN from the next InstanceNorm
+    if constexpr (F16) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
     const int wn = wave % WN, wm = wave / WN;
@@ -414,6 +417,9 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
     char* const in_s = smem;
 
+    // fp16 mode: an out-of-range operand saturates at +-65504 instead of becoming inf (MODE.FP16_OVFL, bit 23 of HW_REG_MODE):
+    // an activation beyond the documented domain then costs accuracy in its window, not a NaN from the next InstanceNorm
+    if constexpr (F16) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
     const int wn = wave % WN, wm = wave / WN;

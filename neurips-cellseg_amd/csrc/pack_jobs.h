@@ -64,7 +64,7 @@ __device__ __forceinline__ void pack_bf16_elem(const PackJob& jb, int64_t e) {
     unsigned short* packed = reinterpret_cast<unsigned short*>(jb.dst);
     const size_t base = (((size_t)chunk * taps + tap) * jb.ntile_total + jb.cout_off / 16 + ntl) * 3;
     if (jb.f16) {                                             // fp16x3: planes of w * 2^8: h0, remainder, unused
-        v *= PACK_F16_W_SCALE;
+        v = __builtin_amdgcn_fmed3f(v * PACK_F16_W_SCALE, -65504.f, 65504.f);   // saturate (|w| >= 255.9 is outside the mode's domain)
         const _Float16 h0 = (_Float16)v;
         const _Float16 h1 = (_Float16)(v - (float)h0);
         packed[((base + 0) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h0);

@@ -317,6 +317,16 @@ def test_split_bf16_modes(precision, tol, channels, shape):
         assert (got.argmax(1) == want.argmax(1)).float().mean().item() > 0.97
 
 
+def test_fp16x3_saturates_instead_of_nan_outside_its_domain():
+    """Operands beyond fp16's range (un-normalised activations ~1e5 here) must saturate, not turn a window into NaN."""
+    ref, hip = _pair((32, 64, 128, 256, 512), 2, "batch", "relu")       # BatchNorm with identity running stats: nothing rescales
+    hip.precision = "fp16x3"
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(3)) * 1e5
+    with torch.no_grad():
+        got = hip(x.to(_dev())).cpu()
+    assert torch.isfinite(got).all()
+
+
 # ------------------------------------------------------------------------------------------- input normalisation (row N)
 @pytest.mark.parametrize("kind", ["u8_rgb", "u16_gray", "u8_rgba", "u16_rgb_flat_channel", "u8_zero_channel", "u16_big"])
 def test_normalize_on_device_is_bit_exact_with_numpy(kind):

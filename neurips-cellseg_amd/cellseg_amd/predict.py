@@ -30,6 +30,8 @@ def main(argv=None):
     parser.add_argument("--input_size", default=256, type=int, help="sliding-window size")
     parser.add_argument("--overlap", default=0.25, type=float, help="window overlap (MONAI default 0.25)")
     parser.add_argument("--random_init", action="store_true", help="no checkpoint: random weights (smoke runs)")
+    parser.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3", "bf16x6", "bf16x3", "bf16"],
+                        help="matrix-core arithmetic of the convolutions (engine option; fp16x3 / bf16x6 are fp32-grade)")
     args = parser.parse_args(argv)
 
     if args.model_name.lower() != "unet":
@@ -55,6 +57,7 @@ def main(argv=None):
         checkpoint = torch.load(join(args.model_path, "best_Dice_model.pth"), map_location="cpu")
         model.load_state_dict(checkpoint["model_state_dict"])
     model = model.to(device).eval()
+    model.precision = args.precision
     roi_size = (args.input_size, args.input_size)
 
     with torch.no_grad():

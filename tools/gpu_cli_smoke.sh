@@ -17,6 +17,14 @@ for i, (h, w) in enumerate([(700, 900), (200, 180)]):
 Image.fromarray((gaussian_filter(rng.random((300, 300)), 4) * 60000).astype(np.uint16)).save("$W/in/gray16.tif")
 PY
 python -m cellseg_amd.predict -i $W/in -o $W/out --model_path $W/work/unet_3class --model_name unet --show_overlay
+python -m cellseg_amd.predict -i $W/in -o $W/out16 --model_path $W/work/unet_3class --model_name unet --precision fp16x3
+python - <<PY
+import numpy as np, os
+from PIL import Image
+for f in sorted(os.listdir("$W/out16")):
+    a, b = np.array(Image.open(os.path.join("$W/out16", f))), np.array(Image.open(os.path.join("$W/out", f)))
+    print("fp16x3 vs fp32 labels", f, "identical" if np.array_equal(a, b) else "differ: %d px" % int((a != b).sum()))
+PY
 python - <<PY
 import numpy as np, os
 from PIL import Image

@@ -111,6 +111,22 @@ def test_label_tiff_round_trip(tmp_path):
     preprocess.write_label_tiff(p, lab)
     back = preprocess.read_image(p)
     assert back.dtype == np.int32 and np.array_equal(back, lab)
+    # odd shapes, single strip, one row, negative ids (int32 is signed), and what another reader sees
+    from PIL import Image
+    for shape, rps in [((1, 1), 64), ((7, 13), 64), ((65, 33), 64), ((130, 5), 1), ((64, 64), 64)]:
+        lab2 = (np.random.default_rng(shape[0]).integers(-5, 1 << 20, shape)).astype(np.int32)
+        p2 = str(tmp_path / f"s{shape[0]}_{shape[1]}_label.tiff")
+        preprocess.write_label_tiff(p2, lab2, rows_per_strip=rps)
+        with Image.open(p2) as im:
+            assert im.mode == "I" and im.size == (shape[1], shape[0])
+            assert np.array_equal(np.array(im), lab2)
+    conda = "/opt/conda/bin/python3.9"
+    if os.path.exists(conda):                                   # tifffile (the reference's reader/writer) must agree too
+        import subprocess
+        out = subprocess.run([conda, "-c", f"import tifffile,sys; a=tifffile.imread(r'{p}'); print(a.dtype, a.shape, int(a.sum()))"],
+                             capture_output=True, text=True)
+        if out.returncode == 0:
+            assert out.stdout.split() == ["int32", "(300,", "200)", str(int(lab.astype(np.int64).sum()))], out.stdout
 
 
 # ------------------------------------------------------------------------------------------- training augmentations (host)

@@ -19,6 +19,21 @@ import torch
 join = os.path.join
 
 
+_PINNED = {}
+
+
+def _to_host(t: torch.Tensor) -> np.ndarray:
+    """Device label map -> numpy through a cached pinned staging buffer (a pageable 67 MB copy costs ~12 ms, a pinned one ~2)."""
+    key = (tuple(t.shape), t.dtype)
+    buf = _PINNED.get(key)
+    if buf is None:
+        _PINNED.clear()                                      # one staging buffer at a time
+        buf = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    buf.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return buf.numpy()
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser("Baseline for Microscopy image segmentation (MI355X engine)", add_help=True)
     parser.add_argument("-i", "--input_path", default="./inputs", type=str, help="input images")
@@ -76,7 +91,7 @@ def main(argv=None):
                 x = torch.from_numpy(preprocess.to_unit_float(pre_img_data)).to(device)      # [H,W,3]: NHWC, no copy needed
                 shape = pre_img_data.shape
             _, _, mask = ca.swi_infer_image(model, x.permute(2, 0, 1), roi_size, args.overlap, want_logits=False, want_mask=True)
-            labels = ca.mask_to_instances(mask).cpu().numpy()
+            labels = _to_host(ca.mask_to_instances(mask))
             preprocess.write_label_tiff(join(args.output_path, preprocess.label_name(img_name)), labels)
             t1 = time.time()
             print(f"Prediction finished: {img_name}; img size = {shape}; costing: {t1 - t0:.2f}s")

@@ -75,33 +75,48 @@ def main(argv=None):
     model.precision = args.precision
     roi_size = (args.input_size, args.input_size)
 
+    # file I/O either side of the GPU path overlaps with it: the next image is decoded by a reader thread while the current one is
+    # on the GPU, label maps (and overlays) are written by a writer thread; the order of the printed lines stays the input order
+    from concurrent.futures import ThreadPoolExecutor
+    todo = list(parallel.shard_items(len(img_names), rank, world))
+    reader, writer = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
+    pending_writes = []
+
+    def save(img_name, img_data, labels):
+        preprocess.write_label_tiff(join(args.output_path, preprocess.label_name(img_name)), labels)
+        if args.show_overlay:
+            b = labels > 0
+            edge = b & ~(np.roll(b, 1, 0) & np.roll(b, -1, 0) & np.roll(b, 1, 1) & np.roll(b, -1, 1))
+            over = img_data.copy() if img_data.ndim == 3 else np.repeat(img_data[:, :, None], 3, -1)
+            over[edge] = np.iinfo(over.dtype).max if np.issubdtype(over.dtype, np.integer) else 1.0
+            from PIL import Image
+            Image.fromarray(over[:, :, :3].astype(np.uint8)).save(join(args.output_path, "overlay_" + img_name.split(".")[0] + ".png"))
+
+    nxt = reader.submit(preprocess.read_image, join(args.input_path, img_names[todo[0]])) if todo else None
     with torch.no_grad():
-        for k in parallel.shard_items(len(img_names), rank, world):
+        for pos, k in enumerate(todo):
             img_name = img_names[k]
-            img_data = preprocess.read_image(join(args.input_path, img_name))
+            img_data = nxt.result()
+            nxt = reader.submit(preprocess.read_image, join(args.input_path, img_names[todo[pos + 1]])) if pos + 1 < len(todo) else None
+            t0 = time.time()
             if img_data.dtype in (np.uint8, np.uint16):
                 # integer images: percentile normalisation on the device (bit-exact with the host path below)
                 raw = torch.from_numpy(np.ascontiguousarray(img_data).view(np.int16) if img_data.dtype == np.uint16 else np.ascontiguousarray(img_data))
-                t0 = time.time()
                 x = preprocess.normalize_image_gpu(raw.to(device))                             # [H,W,3] float32
                 shape = tuple(x.shape)
             else:
                 pre_img_data = preprocess.prepare_image(img_data)
-                t0 = time.time()
                 x = torch.from_numpy(preprocess.to_unit_float(pre_img_data)).to(device)      # [H,W,3]: NHWC, no copy needed
                 shape = pre_img_data.shape
             _, _, mask = ca.swi_infer_image(model, x.permute(2, 0, 1), roi_size, args.overlap, want_logits=False, want_mask=True)
-            labels = _to_host(ca.mask_to_instances(mask))
-            preprocess.write_label_tiff(join(args.output_path, preprocess.label_name(img_name)), labels)
+            labels = _to_host(ca.mask_to_instances(mask)).copy()          # the staging buffer is reused by the next image
+            pending_writes.append(writer.submit(save, img_name, img_data, labels))
             t1 = time.time()
             print(f"Prediction finished: {img_name}; img size = {shape}; costing: {t1 - t0:.2f}s")
-            if args.show_overlay:
-                b = labels > 0
-                edge = b & ~(np.roll(b, 1, 0) & np.roll(b, -1, 0) & np.roll(b, 1, 1) & np.roll(b, -1, 1))
-                over = img_data.copy() if img_data.ndim == 3 else np.repeat(img_data[:, :, None], 3, -1)
-                over[edge] = np.iinfo(over.dtype).max if np.issubdtype(over.dtype, np.integer) else 1.0
-                from PIL import Image
-                Image.fromarray(over[:, :, :3].astype(np.uint8)).save(join(args.output_path, "overlay_" + img_name.split(".")[0] + ".png"))
+    for f in pending_writes:
+        f.result()                                                        # surface writer errors, finish before exit
+    reader.shutdown()
+    writer.shutdown()
 
 
 if __name__ == "__main__":

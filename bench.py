@@ -4,14 +4,20 @@
 One "step" = the reference's per-image hot path (baseline/predict.py:107-113) on one synthetic 3x4096x4096
 slide that is already resident in HBM: sliding-window U-Net inference (256 window / 128 stride = BASELINE.json
 configs[2], 961 windows) -> softmax -> class-1 > 0.5 -> remove_small_holes -> remove_small_objects -> 8-connected
-label.  The timed region ends when the int32 label map is complete in HBM (`value`); the variant that also copies
-the labels to pinned host memory is reported as `value_incl_d2h`.
+label -> int32 label map copied to (pinned) host memory.  SURVEY.md 8(d) ends the metric at "label map available on
+host", so `value` includes that copy; `value_device` is the same loop stopping when the labels are complete in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (one rank per GPU, RCCL)
 
-Multi-GPU (weak scaling): slides are independent units, every rank segments its own slide, no data-path
-collective; value = N slides' pixels / max-over-ranks time.
+`--gpus N` with N > 1 and no torchrun environment: this process starts N child ranks itself (before it has touched the
+GPU) and forwards rank 0's JSON line.
+
+Multi-GPU legs:
+  slides  (headline, weak scaling)   every rank segments its own slide, no data-path collective
+  strips  (`strips` object, strong)  ONE slide cut into row strips, all-gather (RCCL) of the uint8 mask strips, CC on every rank
+  train   (`train_step` object; `--mode train` makes it the headline) data-parallel training step, batch 32x3x256x256 per
+          GPU (BASELINE.json configs[1]/[3]): forward + DiceCE + backward + ONE flat-bucket RCCL all-reduce + AdamW
 Prints ONE JSON line on rank 0 (contract in the task description), including `roofline` (dominant kernel, HIP
 events on the launch stream) and `cpu_baseline` (the torch-CPU / C oracle on a bounded sample, host cores).
 """
@@ -20,6 +26,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +41,7 @@ import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA peak; a split-bf16 product costs 6 / 3 / 1 bf16 MFMA terms
+PEAK_FP8_MFMA_TFLOPS = 5000.0    # dense fp8 MFMA peak
 MFMA_PEAK = {"fp32": PEAK_F32_MFMA_TFLOPS, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3,
              "bf16": PEAK_BF16_MFMA_TFLOPS}
 DTYPE = {"fp32": "f32", "fp16x3": "f32 (split-fp16, 2 planes x 3 MFMA terms, fp32 accumulate)", "bf16x6": "f32 (split-bf16, 3 planes x 6 MFMA terms, fp32 accumulate)",
@@ -40,6 +49,8 @@ DTYPE = {"fp32": "f32", "fp16x3": "f32 (split-fp16, 2 planes x 3 MFMA terms, fp3
 PEAK_HBM_GBS = 8000.0
 WIDTHS = {"baseline32": (32, 64, 128, 256, 512), "reference16": (16, 32, 64, 128, 256),
           "deep64": (64, 128, 256, 512, 1024)}          # BASELINE.json configs[4] width (use with --roi 512)
+# conv FLOPs of one forward over one 256^2 window (training step ~ 3x forward)
+WINDOW_GFLOP = {"reference16": 1.556, "baseline32": 6.080, "deep64": 24.06}
 
 
 def synthetic_wsi(n: int, seed: int) -> np.ndarray:
@@ -58,19 +69,11 @@ def make_model(channels, seed=2022):
     return ca.UNet(spatial_dims=2, in_channels=3, out_channels=3, channels=channels, strides=(2, 2, 2, 2), num_res_units=2).eval()
 
 
-STREAMS = 2
-
-
-def run_step(ca, model, image, roi, overlap, engine_batch):
-    _, _, mask = ca.swi_infer_image(model, image, roi, overlap, engine_batch=engine_batch, want_logits=False, want_mask=True,
-                                    streams=STREAMS)
-    return ca.mask_to_instances(mask, return_num=True)
-
-
 def time_steps(fn, steps, barrier):
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    out = None
     for _ in range(steps):
         out = fn()
     torch.cuda.synchronize()
@@ -91,8 +94,29 @@ def effective_cpus() -> int:
     return max(1, n)
 
 
+CONDA_PY = "/opt/conda/bin/python3.9"        # the image's second interpreter: real scikit-image 0.18.3 (no torch)
+
+
+def skimage_chain_seconds(mask_u8: np.ndarray):
+    """The reference's own post-process (predict.py:113) run with REAL scikit-image under the image's conda interpreter,
+    when it is present; returns seconds or None.  (BASELINE.md 3(iii) prescribes this chain for the CPU leg.)"""
+    if not os.path.exists(CONDA_PY):
+        return None
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "mask.npy")
+        np.save(path, mask_u8)
+        try:
+            out = subprocess.run([CONDA_PY, os.path.join(ROOT, "oracle", "skimage_chain.py"), path], capture_output=True, text=True,
+                                 timeout=300, env={k: v for k, v in os.environ.items() if not k.startswith("PYTHON")})
+            return float(json.loads(out.stdout.strip().splitlines()[-1])["seconds"]) if out.returncode == 0 else None
+        except (subprocess.SubprocessError, ValueError, KeyError, IndexError, OSError):
+            return None
+
+
 def cpu_baseline(size, roi, overlap, channels, seed):
-    """Oracle (torch-CPU restatement + plain-C CC) on a bounded sample of the same workload, extrapolated."""
+    """Oracle (torch-CPU restatement + plain-C CC) on a bounded sample of the same workload, extrapolated; the real
+    scikit-image chain is timed beside the C oracle when the conda interpreter exists."""
     from oracle.postprocess_ref import postprocess_c, softmax_interior_ref
     from oracle.sliding_window_ref import sliding_window_inference_ref, window_grid
     from oracle.unet_ref import make_reference_unet
@@ -116,10 +140,49 @@ def cpu_baseline(size, roi, overlap, channels, seed):
     t0 = time.perf_counter()
     postprocess_c(prob_full)
     t_cc = time.perf_counter() - t0
+    t_sk = skimage_chain_seconds((prob_full > 0.5).astype(np.uint8))
     t_full = t_net * n_full / n_sample + t_cc
-    return {"value": round(size * size / 1e6 / t_full, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "sample": f"torch-CPU oracle on {n_sample} of {n_full} windows ({crop}x{crop} crop, {t_net:.2f}s, {threads} threads) "
-                      f"scaled to the slide + plain-C CC oracle on a full {size}x{size} mask ({t_cc:.2f}s, 1 thread)"}
+    out = {"value": round(size * size / 1e6 / t_full, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+           "sample": f"torch-CPU oracle on {n_sample} of {n_full} windows ({crop}x{crop} crop, {t_net:.2f}s, {threads} threads) "
+                     f"scaled to the slide + plain-C CC oracle on a full {size}x{size} mask ({t_cc:.2f}s, 1 thread)"}
+    if t_sk is not None:
+        out["value_skimage_chain"] = round(size * size / 1e6 / (t_net * n_full / n_sample + t_sk), 4)
+        out["skimage_chain_s"] = round(t_sk, 3)
+        out["sample"] += f"; value_skimage_chain replaces the C oracle by real scikit-image 0.18.3 remove_small_holes/objects + label on the same mask ({t_sk:.2f}s, {CONDA_PY})"
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a torchrun environment starts the N ranks itself
+# ----------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    """Start n children (one per GPU) running this same script; the parent never initialises the GPU
+    (torch.cuda.device_count() does not, on this image) and never re-execs itself."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n_dev = torch.cuda.device_count()
+    if n_dev < n and "BENCH_DEVICE" not in os.environ:
+        print(f"bench.py: --gpus {n} but only {n_dev} HIP device(s) visible "
+              "(BENCH_DEVICE=0 BENCH_BACKEND=gloo shares one GPU between the ranks for a functional check)", file=sys.stderr)
+        return 2
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
@@ -127,6 +190,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: whole-slide inference is the headline (train step reported as `train_step`); train: the "
+                         "data-parallel training step is the headline")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--roi", type=int, default=256)
     ap.add_argument("--overlap", type=float, default=0.5, help="0.5 = stride 128 (BASELINE configs[2]); reference default 0.25")
@@ -134,16 +200,21 @@ def main():
     ap.add_argument("--engine-batch", type=int, default=256)
     ap.add_argument("--streams", type=int, default=2, help="internal streams the window chunks are dealt to (1 = serial)")
     ap.add_argument("--precision", choices=sorted(MFMA_PEAK), default="fp32",
-                    help="matrix-core arithmetic of the convolutions (activations stay fp32 in HBM)")
+                    help="matrix-core arithmetic of the convolutions")
     ap.add_argument("--shard", choices=["slides", "strips"], default="slides",
-                    help="multi-GPU partition: one slide per rank (weak scaling, no collective) or ONE slide cut into row strips "
-                         "with an all-gather of the uint8 mask strips before the connected-component pass (strong scaling)")
+                    help="headline multi-GPU partition: one slide per rank (weak scaling, no collective) or ONE slide cut into row "
+                         "strips with an all-gather of the uint8 mask strips before the connected-component pass (strong scaling); "
+                         "the other partition is reported as a secondary object")
+    ap.add_argument("--train-batch", type=int, default=32, help="tiles per GPU of the training step (BASELINE configs[1]/[3]: 32)")
+    ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the reference-width (16..256) secondary measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (reference width, other precisions, "
+                                                                "the other partition, the training step)")
     args = ap.parse_args()
 
-    global STREAMS
-    STREAMS = args.streams
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))           # nothing above has touched the GPU
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,85 +236,171 @@ def main():
     red_dev = dev if backend == "nccl" else torch.device("cpu")
     barrier = (lambda: dist.barrier()) if dist else (lambda: None)
 
+    def max_over_ranks(vals):
+        t = torch.tensor(list(vals), dtype=torch.float64, device=red_dev)
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
     import cellseg_amd as ca
-    from cellseg_amd import _lib
+    from cellseg_amd import _lib, parallel
 
     seed = 2022
-    strips = args.shard == "strips" and world > 1
-    image = torch.from_numpy(synthetic_wsi(args.size, seed + (0 if strips else rank))).to(dev)   # resident in HBM before timing
-    from cellseg_amd import parallel
-    row_lo, row_hi = ca.rank_rows(args.size, rank, world) if strips else (0, args.size)
-
-    def run_step_strips(model):
-        """One slide across ranks: every rank runs the windows that touch its row strip, finalises its rows, the uint8 mask
-        strips are all-gathered (RCCL), and every rank labels the full mask (2.1 MB per rank at 4096^2)."""
-        _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch, rows=(row_lo, row_hi),
-                                        want_logits=False, want_mask=True, streams=STREAMS)
-        strip = mask[row_lo:row_hi]
-        if backend != "nccl":
-            full = parallel.gather_row_strips(strip.cpu(), args.size).to(dev)
-        else:
-            full = parallel.gather_row_strips(strip, args.size)
-        return ca.mask_to_instances(full, return_num=True)
     roi = (args.roi, args.roi)
     plan = ca.make_plan(args.size, args.size, roi, args.overlap)
     n_windows = plan.n_h * plan.n_w
     mpix = args.size * args.size / 1e6
+    host = torch.empty((args.size, args.size), dtype=torch.int32, pin_memory=True)    # where "labels on host" land
 
-    def measure_mode(width, precision, ref_labels=None):
-        """Timed loop only (same K steps) for a secondary matrix-core mode; agreement with the primary run's labels."""
+    # ------------------------------------------------------------------------------------------------------------------
+    # inference legs
+    # ------------------------------------------------------------------------------------------------------------------
+    images = {}
+
+    def slide(strips):
+        """strips: every rank holds the SAME slide; slides: every rank its own."""
+        key = seed if strips else seed + rank
+        if key not in images:
+            images[key] = torch.from_numpy(synthetic_wsi(args.size, key)).to(dev)      # resident in HBM before timing
+        return images[key]
+
+    def make_step(model, strips, d2h):
+        image = slide(strips)
+        row_lo, row_hi = ca.rank_rows(args.size, rank, world) if strips else (0, args.size)
+
+        def step_slide():
+            _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch, want_logits=False,
+                                            want_mask=True, streams=args.streams)
+            return ca.mask_to_instances(mask, return_num=True)
+
+        def step_strips():
+            """One slide across ranks: every rank runs the windows that touch its row strip, finalises its rows, the uint8 mask
+            strips are all-gathered (RCCL), and every rank labels the full mask (2.1 MB per rank at 4096^2)."""
+            _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch, rows=(row_lo, row_hi),
+                                            want_logits=False, want_mask=True, streams=args.streams)
+            strip = mask[row_lo:row_hi]
+            if backend != "nccl":
+                full = parallel.gather_row_strips(strip.cpu(), args.size).to(dev)
+            else:
+                full = parallel.gather_row_strips(strip, args.size)
+            return ca.mask_to_instances(full, return_num=True)
+
+        inner = step_strips if (strips and world > 1) else step_slide
+        if not d2h:
+            return inner
+
+        def step_d2h():
+            lab, num = inner()
+            host.copy_(lab, non_blocking=True)
+            return lab, num
+        return step_d2h
+
+    def measure_infer(width, precision, strips, with_prof):
+        """-> dict(dt (labels on host), dt_dev (labels in HBM), prof, ...): K timed steps each, max over ranks."""
         model = make_model(WIDTHS[width], seed).to(dev)
         model.precision = precision
-        step = (lambda: run_step_strips(model)) if strips else (lambda: run_step(ca, model, image, roi, args.overlap, args.engine_batch))
+        step_host, step_dev = make_step(model, strips, True), make_step(model, strips, False)
+        res = {}
         with torch.no_grad():
-            for _ in range(max(args.warmup, 1)):
-                step()
-            dt, (labels, num) = time_steps(step, args.steps, barrier)
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        if dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out = {"value": round((1 if strips else world) * mpix * args.steps / t.item(), 3), "ms_per_step": round(t.item() / args.steps * 1e3, 3),
-               "instances_found": int(num.item())}
-        if ref_labels is not None:
-            out["foreground_agreement_vs_primary"] = round(float(((labels > 0) == (ref_labels > 0)).float().mean().item()), 6)
-        return out
+            for _ in range(args.warmup):
+                step_host()
+            dt, (labels, num) = time_steps(step_host, args.steps, barrier)
+            dt_dev, _ = time_steps(step_dev, args.steps, barrier)
+            dt_prof = 0.0
+            if with_prof:
+                # same K steps again with HIP events around every kernel launch (on the launch stream) for the roofline
+                _lib.lib.cs_prof_reset()
+                _lib.lib.cs_prof_enable(1)
+                dt_prof, _ = time_steps(step_dev, args.steps, barrier)
+                _lib.lib.cs_prof_enable(0)
+                res["prof"] = _lib.prof_collect()
+        dt, dt_dev, dt_prof = max_over_ranks([dt, dt_dev, dt_prof])
+        res.update(dt=dt, dt_dev=dt_dev, dt_prof=dt_prof, n_instances=int(num.item()),
+                   fg_frac=float((labels > 0).float().mean().item()), labels=labels)
+        return res
 
-    def measure(width):
-        model = make_model(WIDTHS[width], seed).to(dev)
-        model.precision = args.precision
-        step = (lambda: run_step_strips(model)) if strips else (lambda: run_step(ca, model, image, roi, args.overlap, args.engine_batch))
-        with torch.no_grad():
-            for _ in range(max(args.warmup, 1) if args.warmup else 0):
-                step()
-            dt, (labels, num) = time_steps(step, args.steps, barrier)
-            # same K steps again with HIP events around every kernel launch (on the launch stream) for the roofline
+    def infer_summary(res, strips):
+        slides = 1 if strips else world
+        return {"value": round(slides * mpix * args.steps / res["dt"], 3), "ms_per_step": round(res["dt"] / args.steps * 1e3, 3),
+                "value_device": round(slides * mpix * args.steps / res["dt_dev"], 3), "instances_found": res["n_instances"]}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # training leg (BASELINE.json configs[1] at N=1, configs[3] at N=8): the reference loop, model_training_3class.py:247-267
+    # ------------------------------------------------------------------------------------------------------------------
+    def measure_train(width, with_prof=True):
+        torch.manual_seed(seed)                                   # identical replicas on every rank
+        model = ca.UNet(channels=WIDTHS[width], strides=(2, 2, 2, 2), num_res_units=2).to(dev)
+        g = torch.Generator(device="cpu").manual_seed(seed + 1 + rank)      # every rank its own shard of the global batch
+        b = args.train_batch
+        x = torch.rand(b, 3, 256, 256, generator=g).to(dev)
+        y = torch.randint(0, 3, (b, 1, 256, 256), generator=g).to(dev)
+        onehot = ca.one_hot(y, 3)
+        loss_fn, opt = ca.DiceCELoss(softmax=True), torch.optim.AdamW(model.parameters(), 6e-4)
+        model.train()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn(model(x), onehot)
+            loss.backward()
+            if world > 1:
+                ev[0].record()
+                parallel.sync_gradients(model)
+                ev[1].record()
+            opt.step()
+            return loss
+
+        for _ in range(max(args.warmup, 2)):
+            step()
+        k = args.train_steps
+        dt, loss = time_steps(step, k, barrier)
+        allreduce_ms = None
+        if world > 1:
+            torch.cuda.synchronize()
+            allreduce_ms = round(ev[0].elapsed_time(ev[1]), 4)   # the last step's exchange (events on the launch stream)
+        prof = {}
+        if with_prof:
             _lib.lib.cs_prof_reset()
             _lib.lib.cs_prof_enable(1)
-            dt_prof, _ = time_steps(step, args.steps, barrier)
+            time_steps(step, k, barrier)
             _lib.lib.cs_prof_enable(0)
             prof = _lib.prof_collect()
-            # variant: labels on the host (pinned buffer)
-            host = torch.empty((args.size, args.size), dtype=torch.int32, pin_memory=True)
+        (dt,) = max_over_ranks([dt])
+        ms = dt / k * 1e3
+        tot = sum(v["ms"] for v in prof.values()) or 1.0
+        out = {"images_per_s": round(world * b * k / dt, 1), "ms_per_step": round(ms, 3),
+               "tflops": round(world * 3 * b * WINDOW_GFLOP[width] / ms, 2),
+               "frac_of_fp32_mfma_peak": round(3 * b * WINDOW_GFLOP[width] / ms / PEAK_F32_MFMA_TFLOPS, 4),
+               "global_batch": world * b, "per_gpu_batch": b, "width": list(WIDTHS[width]), "dtype": "f32",
+               "loss": round(float(loss.item()), 5), "grad_bucket_bytes": int(model.flat_grad.numel() * 4),
+               "allreduce_ms": allreduce_ms,
+               "engine_gpu_ms_per_step": round(tot / k, 3) if prof else None,
+               "kernels": {n: {"ms_per_step": round(v["ms"] / k, 4), "share": round(v["ms"] / tot, 4),
+                               "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] else None}
+                           for n, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:10]},
+               "note": "forward + DiceCE(softmax) + backward + flat-bucket all-reduce (N>1) + AdamW; FLOPs = 3 x forward conv FLOPs (SURVEY 8(d))"}
+        return out
 
-            def step_d2h():
-                lab, _ = step()
-                host.copy_(lab, non_blocking=True)
-                return lab
-            dt_d2h, _ = time_steps(step_d2h, args.steps, barrier)
-        t = torch.tensor([dt, dt_prof, dt_d2h], dtype=torch.float64, device=red_dev)
-        if dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_prof, dt_d2h = t.tolist()
-        return dict(dt=dt, dt_prof=dt_prof, dt_d2h=dt_d2h, prof=prof, n_instances=int(num.item()),
-                    fg_frac=float((labels > 0).float().mean().item()), labels=labels.clone())
-
-    main_res = measure(args.width)
-    sec_res, modes = None, {}
-    if not args.no_secondary and args.width != "reference16":
-        sec_res = measure("reference16")
-    if not args.no_secondary and args.precision == "fp32":
-        for prec in ("fp16x3", "bf16x6", "bf16"):
-            modes[prec] = measure_mode(args.width, prec, main_res["labels"])
+    # ------------------------------------------------------------------------------------------------------------------
+    head_strips = args.shard == "strips" and world > 1
+    main_res = sec_res = None
+    modes, other_part, train_res = {}, None, None
+    if args.mode == "infer":
+        main_res = measure_infer(args.width, args.precision, head_strips, True)
+        if not args.no_secondary:
+            if world > 1:
+                other = measure_infer(args.width, args.precision, not head_strips, False)
+                other_part = infer_summary(other, not head_strips)
+            if world == 1 and args.width != "reference16":
+                sec_res = measure_infer("reference16", args.precision, False, True)
+            if world == 1 and args.precision == "fp32":
+                for prec in ("fp16x3", "bf16x6", "bf16"):
+                    r = measure_infer(args.width, prec, False, False)
+                    modes[prec] = dict(infer_summary(r, False), foreground_agreement_vs_primary=round(
+                        float(((r["labels"] > 0) == (main_res["labels"] > 0)).float().mean().item()), 6))
+            train_res = measure_train(args.width if args.width in WINDOW_GFLOP and args.roi == 256 else "baseline32")
+    else:
+        train_res = measure_train(args.width)
 
     if rank != 0:
         if dist:
@@ -251,7 +408,7 @@ def main():
         return
 
     def roofline(res):
-        prof = res["prof"]
+        prof = res.get("prof")
         if not prof:
             return None
         name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
@@ -287,36 +444,64 @@ def main():
                     "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] else None,
                     "gbs": round(v["bytes"] / v["ms"] / 1e6, 1)} for n, v in sorted(res["prof"].items(), key=lambda kv: -kv[1]["ms"])}
 
-    slides = 1 if strips else world               # slides segmented per step by the whole job
+    rccl_ranks = dist.get_world_size() if dist else 1
+    if args.mode == "train":
+        out = {
+            "metric": "images/s data-parallel training step (3x256x256 tiles, batch 32 per GPU)",
+            "value": train_res["images_per_s"], "unit": "images/s",
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "collective_backend": backend if world > 1 else None,
+            "steps": args.train_steps, "warmup": max(args.warmup, 2), "ms_per_step": train_res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"training step on {args.train_batch}x3x256x256 synthetic tiles per GPU, 3-class residual U-Net channels="
+                                   f"{list(WIDTHS[args.width])} num_res_units=2 InstanceNorm+PReLU random-init, DiceCE(softmax) + AdamW(6e-4), "
+                                   f"one flat fp32 gradient bucket all-reduced per step",
+                       "global_batch": world * args.train_batch, "parallelism": f"dp{world}"},
+            "train_step": train_res,
+        }
+        print(json.dumps(out))
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    slides = 1 if head_strips else world               # slides segmented per step by the whole job
     ms_step = main_res["dt"] / args.steps * 1e3
     out = {
-        "metric": "Mpixels/s sliding-window inference (4096^2 WSI) incl. GPU connected components",
+        "metric": "Mpixels/s sliding-window inference (4096^2 WSI) incl. GPU connected components, label map on host",
         "value": round(slides * mpix * args.steps / main_res["dt"], 3),
         "unit": "Mpixels/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "rccl_ranks": rccl_ranks, "collective_backend": backend if world > 1 else None,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3),
-        "higher_is_better": True, "scaling": "strong" if strips else "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if head_strips else "weak", "vs_baseline": None,
         "dtype": DTYPE[args.precision], "data": "synthetic",
         "config": {"workload": f"sliding-window inference on 3x{args.size}x{args.size} synthetic WSI, {args.roi} window / "
                                f"{plan.interval_h} stride ({n_windows} windows), 3-class residual U-Net channels={list(WIDTHS[args.width])} "
                                f"num_res_units=2 InstanceNorm+PReLU random-init, softmax + >0.5 + remove_small_holes(64) + "
-                               f"remove_small_objects(16) + 8-conn label on GPU; " + ("one slide cut into row strips" if strips else "one slide per GPU"),
-                   "windows": n_windows, "engine_batch": args.engine_batch, "streams": args.streams, "precision": args.precision, "parallelism": (f"1 slide in {world} row strips + mask all-gather" if strips else f"slides x{world}"),
+                               f"remove_small_objects(16) + 8-conn label on GPU, int32 labels copied to pinned host memory; "
+                               + ("one slide cut into row strips" if head_strips else "one slide per GPU"),
+                   "windows": n_windows, "engine_batch": args.engine_batch, "streams": args.streams, "precision": args.precision,
+                   "parallelism": (f"1 slide in {world} row strips + mask all-gather" if head_strips else f"slides x{world}"),
                    "instances_found": main_res["n_instances"], "foreground_fraction": round(main_res["fg_frac"], 4)},
-        "value_incl_d2h": round(slides * mpix * args.steps / main_res["dt_d2h"], 3),
+        "value_device": round(slides * mpix * args.steps / main_res["dt_dev"], 3),
+        "value_device_note": "same loop ending when the int32 label map is complete in HBM (no copy to the host)",
         "value_with_events": round(slides * mpix * args.steps / main_res["dt_prof"], 3),
         "roofline": roofline(main_res),
         "kernels": kernel_table(main_res),
     }
+    if other_part:
+        out["strips" if not head_strips else "slides"] = dict(
+            other_part, scaling="strong" if not head_strips else "weak",
+            note=("ONE slide cut into row strips across the ranks, uint8 mask strips all-gathered before CC: value = one slide's pixels / time"
+                  if not head_strips else "one slide per rank, no collective: value = N slides' pixels / time"))
     if sec_res:
-        out["reference_width"] = {"channels": list(WIDTHS["reference16"]), "value": round(slides * mpix * args.steps / sec_res["dt"], 3),
-                                  "ms_per_step": round(sec_res["dt"] / args.steps * 1e3, 3), "roofline": roofline(sec_res),
-                                  "instances_found": sec_res["n_instances"]}
+        out["reference_width"] = dict(infer_summary(sec_res, False), channels=list(WIDTHS["reference16"]), roofline=roofline(sec_res))
     if modes:
         out["other_precisions"] = {"note": "same workload, convolutions on the 16-bit matrix pipe (v_mfma_f32_16x16x32_{f16,bf16}, fp32 "
                                            "accumulate): fp16x3 = 2 fp16 planes (22 mantissa bits) x 3 terms and bf16x6 = 3 bf16 planes x "
                                            "6 terms are fp32-grade (logits within 1e-4 of the oracle in the GPU tests), bf16 = plain bf16 "
-                                           "products; activations stay fp32 in HBM", **modes}
+                                           "products", **modes}
+    if train_res:
+        out["train_step"] = train_res
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.overlap, WIDTHS[args.width], seed)
     print(json.dumps(out))

@@ -103,9 +103,19 @@ def zoom_keep_size(img: np.ndarray, lab: np.ndarray, z: float):
     return fit(zi).astype(np.float32), fit(zl)
 
 
+def seed_worker(worker_id: int) -> None:
+    """DataLoader ``worker_init_fn``: every worker process derives its own augmentation stream from the seed torch hands it
+    (base_seed + worker_id, fresh per DataLoader iterator unless the workers persist) - forked workers would otherwise all
+    start from the parent's generator state and draw identical crops / flips / noise, epoch after epoch."""
+    info = torch.utils.data.get_worker_info()
+    ds = info.dataset
+    if hasattr(ds, "rng"):
+        ds.rng = np.random.default_rng([int(getattr(ds, "seed", 0)), int(info.seed) & 0xFFFFFFFF, worker_id])
+
+
 class CellDataset(Dataset):
     def __init__(self, files: List[Tuple[str, str]], input_size: int, train: bool, seed: int = 0):
-        self.files, self.size, self.train = files, input_size, train
+        self.files, self.size, self.train, self.seed = files, input_size, train, seed
         self.rng = np.random.default_rng(seed)
 
     def __len__(self):

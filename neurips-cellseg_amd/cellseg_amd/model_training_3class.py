@@ -59,10 +59,16 @@ def main(argv=None):
         raise SystemExit("training needs an MI355X: there is no CPU path")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        # CELLSEG_DEVICE / CELLSEG_BACKEND exist only to exercise the multi-rank path on a 1-GPU box (ranks share one GPU, gloo)
+        backend = os.environ.get("CELLSEG_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
@@ -80,7 +86,8 @@ def main(argv=None):
         print(f"training image num: {len(train_ds)}, validation image num: {len(val_ds)}")
     sampler = torch.utils.data.distributed.DistributedSampler(train_ds, world, rank, shuffle=True, seed=args.seed) if world > 1 else None
     train_loader = DataLoader(train_ds, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
-                              num_workers=args.num_workers, pin_memory=True, drop_last=world > 1)
+                              num_workers=args.num_workers, pin_memory=True, drop_last=world > 1,
+                              worker_init_fn=data.seed_worker, persistent_workers=args.num_workers > 0)
     val_loader = DataLoader(val_ds, batch_size=1, shuffle=False, num_workers=1)
 
     model = ca.UNet(spatial_dims=2, in_channels=3, out_channels=args.num_class, channels=(16, 32, 64, 128, 256),
@@ -91,6 +98,7 @@ def main(argv=None):
     best_metric, best_metric_epoch = -1, -1
     epoch_loss_values, metric_values = [], []
     checkpoint = {}
+    stop = False
     for epoch in range(1, args.max_epochs):
         model.train()
         if sampler is not None:
@@ -132,13 +140,21 @@ def main(argv=None):
             print(f"current epoch: {epoch + 1} current mean dice: {metric:.4f} best mean dice: {best_metric:.4f} at epoch {best_metric_epoch}")
             if (epoch - best_metric_epoch) > args.epoch_tolerance:
                 print(f"validation metric does not improve for {args.epoch_tolerance} epochs! current {epoch=}, {best_metric_epoch=}")
-                break
+                stop = True
+        if world > 1:
+            # validation runs on rank 0 only: the stop decision is made collective (one broadcast per epoch, which also keeps
+            # the ranks in step) so that no rank enters the next epoch's all-reduce after rank 0 has left the loop
+            flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(flag, src=0)
+            stop = bool(flag.item())
+        if stop:
+            break
     if rank == 0:
         print(f"train completed, best_metric: {best_metric:.4f} at epoch: {best_metric_epoch}")
         torch.save(checkpoint, join(model_path, "final_model.pth"))
         np.savez_compressed(join(model_path, "train_log.npz"), val_dice=metric_values, epoch_loss=epoch_loss_values)
     if world > 1:
-        torch.distributed.destroy_process_group()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -38,18 +38,24 @@ def gather_row_strips(strip: torch.Tensor, img_h: int, group=None) -> torch.Tens
     return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(rows)], 0)
 
 
-def sync_gradients(model, group=None) -> None:
+def sync_gradients(model, group=None, reduce: bool = True) -> None:
     """Data-parallel gradient exchange: ONE RCCL all-reduce over the engine's flat fp32
     gradient bucket (6.5 MB at the reference width), then the mean.  `loss.backward()` leaves every parameter
     gradient as a view of ``model.flat_grad``; this re-binds the views after the in-place reduction so the optimiser
-    reads the averaged values whatever autograd did with the originals."""
+    reads the averaged values whatever autograd did with the originals.  ``reduce=False`` only re-binds (the caller has
+    already averaged ``model.flat_grad`` in place, e.g. through a host-side backend)."""
     import torch.distributed as dist
     flat = model.flat_grad
     if flat is None:
         raise RuntimeError("sync_gradients: run backward first")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if world > 1 and reduce:
+        if flat.is_cuda and dist.get_backend(group) == "gloo":     # functional checks on a shared GPU: gloo reduces on the host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.mul_(1.0 / world)
     for key, p in model.named_parameters():
         off, numel, shape = model._grad_slots[key]

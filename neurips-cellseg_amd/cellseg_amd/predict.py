@@ -85,20 +85,32 @@ def main(argv=None):
     def save(img_name, img_data, labels):
         preprocess.write_label_tiff(join(args.output_path, preprocess.label_name(img_name)), labels)
         if args.show_overlay:
-            b = labels > 0
-            edge = b & ~(np.roll(b, 1, 0) & np.roll(b, -1, 0) & np.roll(b, 1, 1) & np.roll(b, -1, 1))
-            over = img_data.copy() if img_data.ndim == 3 else np.repeat(img_data[:, :, None], 3, -1)
-            over[edge] = np.iinfo(over.dtype).max if np.issubdtype(over.dtype, np.integer) else 1.0
-            from PIL import Image
-            Image.fromarray(over[:, :, :3].astype(np.uint8)).save(join(args.output_path, "overlay_" + img_name.split(".")[0] + ".png"))
+            # predict.py:118-122: inner boundaries of the instances, dilated by disk(2), painted 255 into the image as read,
+            # saved as overlay_<img_name> in the input's own format
+            preprocess.save_image(join(args.output_path, "overlay_" + img_name), preprocess.overlay_boundaries(img_data, labels))
 
-    nxt = reader.submit(preprocess.read_image, join(args.input_path, img_names[todo[0]])) if todo else None
+    def read(k):
+        try:
+            return preprocess.read_image(join(args.input_path, img_names[k]))
+        except Exception as e:                                   # one undecodable file must not end the run (reader thread)
+            return e
+
+    failed = []
+    nxt = reader.submit(read, todo[0]) if todo else None
     with torch.no_grad():
         for pos, k in enumerate(todo):
             img_name = img_names[k]
             img_data = nxt.result()
-            nxt = reader.submit(preprocess.read_image, join(args.input_path, img_names[todo[pos + 1]])) if pos + 1 < len(todo) else None
+            nxt = reader.submit(read, todo[pos + 1]) if pos + 1 < len(todo) else None
+            if isinstance(img_data, Exception):
+                print(f"Prediction FAILED: {img_name}: {img_data}")
+                failed.append(img_name)
+                continue
             t0 = time.time()
+            if img_data.ndim not in (2, 3) or (img_data.ndim == 3 and img_data.shape[-1] < 3):
+                print(f"Prediction FAILED: {img_name}: unsupported image shape {img_data.shape} ({img_data.dtype})")
+                failed.append(img_name)
+                continue
             if img_data.dtype in (np.uint8, np.uint16):
                 # integer images: percentile normalisation on the device (bit-exact with the host path below)
                 raw = torch.from_numpy(np.ascontiguousarray(img_data).view(np.int16) if img_data.dtype == np.uint16 else np.ascontiguousarray(img_data))
@@ -110,13 +122,19 @@ def main(argv=None):
                 shape = pre_img_data.shape
             _, _, mask = ca.swi_infer_image(model, x.permute(2, 0, 1), roi_size, args.overlap, want_logits=False, want_mask=True)
             labels = _to_host(ca.mask_to_instances(mask)).copy()          # the staging buffer is reused by the next image
-            pending_writes.append(writer.submit(save, img_name, img_data, labels))
+            pending_writes.append((img_name, writer.submit(save, img_name, img_data, labels)))
             t1 = time.time()
             print(f"Prediction finished: {img_name}; img size = {shape}; costing: {t1 - t0:.2f}s")
-    for f in pending_writes:
-        f.result()                                                        # surface writer errors, finish before exit
+    for img_name, f in pending_writes:
+        try:
+            f.result()                                                    # surface writer errors, finish before exit
+        except Exception as e:
+            print(f"Writing FAILED: {img_name}: {type(e).__name__}: {e}")
+            failed.append(img_name)
     reader.shutdown()
     writer.shutdown()
+    if failed:
+        raise SystemExit(f"{len(failed)} of {len(todo)} images failed: {', '.join(failed)}")
 
 
 if __name__ == "__main__":

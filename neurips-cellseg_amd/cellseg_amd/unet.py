@@ -124,12 +124,17 @@ class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, *params):
         out, ws = module._forward_engine(x, tag="train", train=True)
-        ctx.module, ctx.ws, ctx.x, ctx.shape = module, ws, x, tuple(x.shape)
+        ctx.module, ctx.ws, ctx.x, ctx.shape, ctx.generation = module, ws, x, tuple(x.shape), module._generation
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         module = ctx.module
+        if ctx.generation != module._generation:
+            raise _lib.CellSegHipError(
+                "backward of a forward whose activations have been overwritten: the engine keeps one activation tape per "
+                "model, so every grad-enabled forward must be followed by its backward before the next grad-enabled forward "
+                "(for gradient accumulation call backward() per micro-batch)")
         flat = module._backward_engine(grad_out, ctx.shape)
         grads = []
         for key in module._param_keys:
@@ -169,6 +174,7 @@ class UNet(nn.Module):
         self._ws: Dict[Tuple, torch.Tensor] = {}
         self._param_keys = [k for k, _ in self.named_parameters()]
         self._grad_slots: Dict[str, Tuple[int, int, Tuple[int, ...]]] = {}
+        self._generation = 0           # id of the grad-enabled forward that owns the engine's activation tape
         self.flat_grad = None          # the flat gradient bucket of the last backward (what data parallel all-reduces)
         self.precision = "fp32"        # "fp32" | "fp16x3", "bf16x6" (fp32-grade) | "bf16x3" | "bf16": matrix-core arithmetic of the convs
 
@@ -271,6 +277,12 @@ class UNet(nn.Module):
         self._pack_state = (state[0] and need[0], state[1] and need[1]) if uploaded_any else state
         return self._engine
 
+    def invalidate_weights(self) -> None:
+        """Force a re-upload of every tensor at the next call.  Uploads are keyed on (data_ptr, tensor version); an in-place edit
+        through ``p.data`` (EMA, manual clipping) does not bump the version, so it needs this call - ``optimizer.step()``,
+        ``load_state_dict`` and ordinary in-place ops under ``no_grad`` are picked up by themselves."""
+        self._uploaded.clear()
+
     def workspace(self, tag, nbytes: int, device) -> torch.Tensor:
         ws = self._ws.get(tag)
         if ws is None or ws.numel() < nbytes or ws.device != device:
@@ -282,6 +294,7 @@ class UNet(nn.Module):
     def _forward_engine(self, x: torch.Tensor, tag: str = "fwd", train: bool = False):
         n, _, h, w = x.shape
         eng = self.engine(train)
+        self._generation += 1                         # the engine keeps ONE tape (cs_unet_forward records it): this forward owns it now
         with torch.cuda.device(x.device):
             nbytes = lib.cs_unet_workspace_bytes(eng.handle, n, h, w)
             if nbytes == 0:

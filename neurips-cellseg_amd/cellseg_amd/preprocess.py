@@ -218,7 +218,7 @@ def read_image(path: str) -> np.ndarray:
                 pass
             try:
                 return read_tiff(path)
-            except (ValueError, KeyError, IndexError) as own_error:
+            except Exception as own_error:
                 try:
                     return _read_pillow(path)
                 except Exception:

@@ -66,6 +66,17 @@ int cs_unet_set_precision(cs_unet* net, int planes);
 /* on != 0: every cs_unet_load_param also packs the data-gradient layout of the tensor (needed by cs_unet_backward).
  * Parameters loaded under the wrong mode / precision are refused at forward / backward time (CS_ERR_NOT_LOADED). */
 int cs_unet_set_training(cs_unet* net, int on);
+/* BatchNorm networks (norm_kind CS_NORM_BATCH), replaces `model.train()` / `model.eval()` for nn.BatchNorm2d inside
+ * monai's ADN (the norm= argument of the UNet constructor, baseline/model_training_3class.py:201-208):
+ *   on != 0  every cs_unet_forward normalises with the statistics of ITS batch (mean / biased variance over N*H*W per channel,
+ *            reduced from the conv epilogues' per-image fp64 sums) and updates the engine's running_mean / running_var
+ *            (momentum 0.1, unbiased variance); cs_unet_backward then also returns d(weight) / d(bias) of every BatchNorm.
+ *            Under data parallel each rank uses its LOCAL batch statistics (torch DDP's default; no SyncBatchNorm).
+ *   on == 0  running statistics (default; sliding-window inference always uses them). */
+int cs_unet_set_batch_stats(cs_unet* net, int on);
+/* Copy a tensor the engine keeps verbatim back to device memory `dst` (BatchNorm weight / bias / running_mean / running_var,
+ * PReLU slope): how the host mirrors the updated running statistics into its state dict.  Batches with cs_unet_load_begin/end. */
+int cs_unet_read_param(cs_unet* net, const char* key_host, float* dst, int64_t numel, void* stream);
 /* n (1..4) internal streams for cs_swi_infer: window chunks are dealt round-robin to them (forked from / joined back to the
  * caller's stream with events), so the HBM-bound kernels of one chunk overlap the MFMA-bound ones of another.  The side
  * streams and events are created here, never on the launch path.  cs_swi_workspace_bytes scales with n. */
@@ -98,7 +109,7 @@ int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_
  * LAST cs_unet_forward left in its workspace (which must still be intact) and the input it read.  Writes every
  * parameter gradient, in PyTorch layout, into one flat fp32 buffer of cs_unet_grad_numel() floats at
  * cs_unet_grad_offset(param_index) - the flat buffer is the single bucket a data-parallel host all-reduces.
- * InstanceNorm networks only. */
+ * InstanceNorm networks, and BatchNorm networks whose forward ran under cs_unet_set_batch_stats(1). */
 int64_t cs_unet_grad_numel(const cs_unet* net);
 int64_t cs_unet_grad_offset(const cs_unet* net, int param_index);
 size_t cs_unet_backward_workspace_bytes(const cs_unet* net, int n, int h, int w);

@@ -42,6 +42,8 @@ def _load() -> C.CDLL:
         "cs_unet_destroy": (i32, [vp]),
         "cs_unet_set_precision": (i32, [vp, i32]),
         "cs_unet_set_training": (i32, [vp, i32]),
+        "cs_unet_set_batch_stats": (i32, [vp, i32]),
+        "cs_unet_read_param": (i32, [vp, C.c_char_p, vp, i64, vp]),
         "cs_unet_load_begin": (i32, [vp]),
         "cs_unet_load_end": (i32, [vp, vp]),
         "cs_unet_set_streams": (i32, [vp, i32]),
@@ -80,7 +82,7 @@ def _load() -> C.CDLL:
 
 
 lib = _load()
-EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_destroy cs_unet_set_precision cs_unet_set_training cs_unet_set_streams cs_unet_num_params "
+EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_destroy cs_unet_set_precision cs_unet_set_training cs_unet_set_batch_stats cs_unet_read_param cs_unet_set_streams cs_unet_num_params "
             "cs_unet_param_info cs_unet_load_param cs_unet_load_begin cs_unet_load_end cs_unet_workspace_bytes cs_unet_forward cs_unet_grad_numel "
             "cs_unet_grad_offset cs_unet_backward_workspace_bytes cs_unet_backward cs_swi_make_plan "
             "cs_swi_window_start cs_swi_workspace_bytes cs_swi_infer cs_swi_finalize cs_normalize_workspace_bytes "

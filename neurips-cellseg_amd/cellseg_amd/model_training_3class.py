@@ -57,6 +57,7 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("training needs an MI355X: there is no CPU path")
+    local = int(os.environ.get("CELLSEG_DEVICE", local))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None

@@ -244,6 +244,8 @@ class UNet(nn.Module):
         check(lib.cs_unet_set_precision(self._engine.handle, planes), "cs_unet_set_precision")
         want_train = bool(train)
         check(lib.cs_unet_set_training(self._engine.handle, int(want_train)), "cs_unet_set_training")
+        if self.norm_name == "batch":                 # nn.BatchNorm2d semantics: batch statistics in train mode, running ones in eval
+            check(lib.cs_unet_set_batch_stats(self._engine.handle, int(self.training)), "cs_unet_set_batch_stats")
         # The engine packs the split-bf16 / data-gradient weight layouts only when asked.  `_pack_state` says which of them
         # EVERY uploaded tensor currently has; a missing one forces a full re-upload under the new flags.
         fmt = 2 if planes == 4 else 1 if planes > 0 else 0       # 16-bit plane packing the kernels will read (bf16 / fp16 family)
@@ -305,7 +307,26 @@ class UNet(nn.Module):
             check(lib.cs_unet_forward(eng.handle, C.c_void_p(x.data_ptr()), sn, sc, sh, sw, n, h, w,
                                       C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
                                       _lib.stream_ptr()), "cs_unet_forward")
+            if self.norm_name == "batch" and self.training:
+                self._pull_running_stats(eng)
         return out.permute(0, 3, 1, 2), ws        # NCHW view of the NHWC result, like a channels_last tensor
+
+    def _pull_running_stats(self, eng) -> None:
+        """Train-mode BatchNorm: the engine has just updated its running_mean / running_var; mirror them into the module's buffers
+        (what state_dict() saves) with one batched copy kernel, and count the batch like nn.BatchNorm2d does."""
+        stream = _lib.stream_ptr()
+        check(lib.cs_unet_load_begin(eng.handle), "cs_unet_load_begin")
+        try:
+            for key in self._keys:
+                if key.endswith("running_mean") or key.endswith("running_var"):
+                    t = self._tensor(key)
+                    check(lib.cs_unet_read_param(eng.handle, key.encode(), C.c_void_p(t.data_ptr()), t.numel(), stream),
+                          f"cs_unet_read_param({key})")      # raw-pointer write: the tensor version (and the upload cache) stay valid
+        finally:
+            check(lib.cs_unet_load_end(eng.handle, stream), "cs_unet_load_end")
+        for key in self._keys:
+            if key.endswith("num_batches_tracked"):
+                self._tensor(key).add_(1)
 
     def _backward_engine(self, grad_out: torch.Tensor, shape) -> torch.Tensor:
         n, _, h, w = shape
@@ -330,10 +351,8 @@ class UNet(nn.Module):
             x = x.float()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if needs_grad:
-            if self.norm_name != "instance":
-                raise _lib.CellSegHipError("training is implemented for the reference's InstanceNorm network only")
+            if self.norm_name == "batch" and not self.training:
+                raise _lib.CellSegHipError("backward through eval-mode BatchNorm (running statistics) is not implemented: call model.train()")
             params = [p for _, p in self.named_parameters()]
             return _UNetFunction.apply(self, x, *params)
-        if self.norm_name == "batch" and self.training:
-            raise _lib.CellSegHipError("BatchNorm variant: only eval mode (running statistics) is implemented")
         return self._forward_engine(x)[0]

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "pack_jobs.h"
 
 namespace cs {
 
@@ -39,16 +40,28 @@ struct ProfRecord {
     int id;
     hipEvent_t start, stop;
 };
-static bool g_prof_on = false;
-static std::vector<ProfRecord> g_prof_records;
-static std::vector<hipEvent_t> g_event_pool;
-static double g_prof_flops[K_NUM_IDS], g_prof_bytes[K_NUM_IDS], g_prof_ms[K_NUM_IDS];
-static int64_t g_prof_launches[K_NUM_IDS];
+// Profiling state is kept PER DEVICE (two handles on two devices in one process do not share event pools or totals); the
+// entry points below act on the device that is current when they are called.
+struct ProfState {
+    bool on = false;
+    std::vector<ProfRecord> records;
+    std::vector<hipEvent_t> pool;
+    double flops[K_NUM_IDS] = {}, bytes[K_NUM_IDS] = {}, ms[K_NUM_IDS] = {};
+    int64_t launches[K_NUM_IDS] = {};
+};
+static ProfState g_prof[16];
+static bool g_prof_any = false;                 // fast path: nobody has ever enabled profiling in this process
+static ProfState& prof_state() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return g_prof[dev >= 0 && dev < 16 ? dev : 0];
+}
+bool prof_enabled() { return g_prof_any && prof_state().on; }
 
-static hipEvent_t get_event() {
-    if (!g_event_pool.empty()) {
-        hipEvent_t e = g_event_pool.back();
-        g_event_pool.pop_back();
+static hipEvent_t get_event(ProfState& ps) {
+    if (!ps.pool.empty()) {
+        hipEvent_t e = ps.pool.back();
+        ps.pool.pop_back();
         return e;
     }
     hipEvent_t e = nullptr;
@@ -57,28 +70,30 @@ static hipEvent_t get_event() {
 }
 
 ProfScope::ProfScope(int id, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
-    if (!g_prof_on) return;
-    ProfRecord r{id, get_event(), get_event()};
+    if (!g_prof_any) return;
+    ProfState& ps = prof_state();
+    if (!ps.on) return;
+    ProfRecord r{id, get_event(ps), get_event(ps)};
     (void)hipEventRecord(r.start, s);
-    g_prof_records.push_back(r);
-    slot = (int)g_prof_records.size() - 1;
-    g_prof_flops[id] += flops;
-    g_prof_bytes[id] += bytes;
-    g_prof_launches[id] += 1;
+    ps.records.push_back(r);
+    slot = (int)ps.records.size() - 1;
+    ps.flops[id] += flops;
+    ps.bytes[id] += bytes;
+    ps.launches[id] += 1;
 }
 ProfScope::~ProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof_records[slot].stop, stream);
+    if (slot >= 0) (void)hipEventRecord(prof_state().records[slot].stop, stream);
 }
 
-static void prof_drain() {
-    for (auto& r : g_prof_records) {
+static void prof_drain(ProfState& ps) {
+    for (auto& r : ps.records) {
         (void)hipEventSynchronize(r.stop);
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) g_prof_ms[r.id] += ms;
-        g_event_pool.push_back(r.start);
-        g_event_pool.push_back(r.stop);
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) ps.ms[r.id] += ms;
+        ps.pool.push_back(r.start);
+        ps.pool.push_back(r.stop);
     }
-    g_prof_records.clear();
+    ps.records.clear();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -107,6 +122,7 @@ struct NormSite {          // one ADN: InstanceNorm (stats at run time) or eval 
     int p_slope = -1;                       // parameter index of the PReLU weight
     float* slope = nullptr;                 // PReLU weight (device) or nullptr for ReLU
     float *bn_w = nullptr, *bn_b = nullptr, *bn_m = nullptr, *bn_v = nullptr;
+    int p_bn_w = -1, p_bn_b = -1;           // parameter indices of the BatchNorm affine weight / bias
 };
 
 struct ConvW {             // packed weights + bias of one (possibly fused) conv launch
@@ -146,6 +162,7 @@ struct ParamEntry {
     int64_t shape[4] = {0, 0, 0, 0};
     std::function<int(const float*, hipStream_t)> load;
     bool loaded = false;
+    float* raw = nullptr;                         // tensors the engine keeps verbatim (BatchNorm affine / running statistics, PReLU slope)
     bool has_dgrad = false, has_bf16 = false;     // tensor takes part in the data-gradient / split-bf16 packings
     bool dgrad_packed = false;
     int wb_format = 0;                            // 16-bit plane packing present: 0 none, 1 split-bf16, 2 split-fp16
@@ -160,6 +177,7 @@ struct ParamEntry {
 struct NormRt {   // run-time state of one norm site for the current forward
     double* stats = nullptr;
     float2* tab = nullptr;
+    float2* xtab = nullptr;   // BatchNorm with batch statistics: (rstd, -mean*rstd) for the backward pass
 };
 
 // Pointers into the forward workspace recorded by the last forward; the backward pass replays them.
@@ -195,17 +213,21 @@ struct cs_unet {
     int64_t grad_floats = 0;
     int planes = 0;   // 0: fp32 MFMA kernels; 1..3: split-bf16 kernels with that many planes (3 = fp32-grade); 4: split-fp16 (fp32-grade)
     bool training = false;   // pack the data-gradient weight layouts on every parameter load
+    bool batch_stats = false;   // BatchNorm networks: normalise with the statistics of the current batch and update the running ones
+                                // (nn.BatchNorm2d in train mode); false = running statistics (eval mode)
     // sliding-window inference can spread its window chunks over side streams: the HBM-bound kernels of one chunk
     // (residual adds, 3-channel layers, statistics) then overlap the MFMA-bound convolutions of another
     int n_streams = 1;
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     Tape tape;
+    int device = -1;                 // the device the weight arena and the packing tables live on
+    cs::PackCtx* pack = nullptr;     // per-handle weight-packing state (job tables allocated once, at creation)
 };
 
 namespace cs {
 
-static int copy_param(float* dst, const float* src, size_t n, hipStream_t s) { return cs::pack_copy(s, src, dst, n); }
+static int copy_param(cs_unet* net, float* dst, const float* src, size_t n, hipStream_t s) { return cs::pack_copy(net->pack, s, src, dst, n); }
 
 struct ArenaPlan {   // two passes: count floats, then hand out pointers
     float* base = nullptr;
@@ -235,15 +257,17 @@ static void add_norm_params(cs_unet* net, ArenaPlan& ar, const std::string& adn,
     if (net->norm == CS_NORM_BATCH) {
         ns.bn_w = ar.take(c); ns.bn_b = ar.take(c); ns.bn_m = ar.take(c); ns.bn_v = ar.take(c);
         float *w = ns.bn_w, *b = ns.bn_b, *m = ns.bn_m, *v = ns.bn_v;
-        add_param(net, adn + ".N.weight", {c}, [=](const float* d, hipStream_t s) { return copy_param(w, d, c, s); });
-        add_param(net, adn + ".N.bias", {c}, [=](const float* d, hipStream_t s) { return copy_param(b, d, c, s); });
-        add_param(net, adn + ".N.running_mean", {c}, [=](const float* d, hipStream_t s) { return copy_param(m, d, c, s); });
-        add_param(net, adn + ".N.running_var", {c}, [=](const float* d, hipStream_t s) { return copy_param(v, d, c, s); });
+        ns.p_bn_w = add_param(net, adn + ".N.weight", {c}, [=](const float* d, hipStream_t s) { return copy_param(net, w, d, c, s); });
+        ns.p_bn_b = add_param(net, adn + ".N.bias", {c}, [=](const float* d, hipStream_t s) { return copy_param(net, b, d, c, s); });
+        const int pm = add_param(net, adn + ".N.running_mean", {c}, [=](const float* d, hipStream_t s) { return copy_param(net, m, d, c, s); });
+        const int pv = add_param(net, adn + ".N.running_var", {c}, [=](const float* d, hipStream_t s) { return copy_param(net, v, d, c, s); });
+        net->params[ns.p_bn_w].raw = w; net->params[ns.p_bn_b].raw = b; net->params[pm].raw = m; net->params[pv].raw = v;
     }
     if (net->act == CS_ACT_PRELU) {
         ns.slope = ar.take(1);
         float* sl = ns.slope;
-        ns.p_slope = add_param(net, adn + ".A.weight", {1}, [=](const float* d, hipStream_t s) { return copy_param(sl, d, 1, s); });
+        ns.p_slope = add_param(net, adn + ".A.weight", {1}, [=](const float* d, hipStream_t s) { return copy_param(net, sl, d, 1, s); });
+        net->params[ns.p_slope].raw = sl;
     }
 }
 
@@ -256,37 +280,31 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     unsigned short* wb = cw.wb;
     float* bdst = cw.bias + cout_off;
     const int cout_total = cw.cout;
-    auto pack_dgrad = [=](const float* d, hipStream_t s) -> int {
-        if (!net->training) return CS_OK;
-        switch (dg) {
-            case DG_S1: return pack_conv_weights(s, d, true, cin, cout, 3, wd, 0, cin, true, 0);
-            case DG_1X1: return pack_conv_weights(s, d, true, cin, cout, 1, wd, 0, cin, false, 0);
-            case DG_S2_AS_CONVT: return pack_conv_weights(s, d, true, cin, cout, 3, wd, 0, cin, false, cout_off);
-            case DG_CONVT_AS_S2: return pack_conv_weights(s, d, false, cin, cout, 3, wd, 0, cin, false, 0);
-            default: return CS_OK;
-        }
-    };
+    // the data-gradient layout of the same tensor (channel axes swapped; see pack_conv_weights) is written by the same tile
+    // kernel when the handle is in training mode: taps reversed for a stride-1 conv, second half of the fused pair offset by
+    // its output-channel tiles
+    auto dgrad_dst = [=]() -> float* { return (net->training && dg != DG_NONE) ? wd : nullptr; };
+    const bool dg_flip = dg == DG_S1;
+    const int dg_chunk_off = dg == DG_S2_AS_CONVT ? cout_off / 16 : 0;
     if (transposed) {
         cw.p_w[slot] = add_param(net, conv + ".weight", {cin, cout, ksize, ksize}, [=](const float* d, hipStream_t s) {
-            if (int rc = pack_dgrad(d, s)) return rc;
-            if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
+            if (mode == 2) return copy_param(net, wdst, d, (size_t)cin * cout * ksize * ksize, s);
             if (wb && net->planes > 0)
-                if (int rc = pack_conv_weights_bf16(s, d, true, cout, cin, ksize, wb, cout_off, cout_total, cin_split, net->planes == 4)) return rc;
-            return pack_conv_weights(s, d, true, cout, cin, ksize, wdst, cout_off, cout_total);
+                if (int rc = pack_conv_weights_bf16(net->pack, s, d, true, cout, cin, ksize, wb, cout_off, cout_total, cin_split, net->planes == 4)) return rc;
+            return pack_conv_weights(net->pack, s, d, true, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off);
         });
     } else {
         cw.p_w[slot] = add_param(net, conv + ".weight", {cout, cin, ksize, ksize}, [=](const float* d, hipStream_t s) {
-            if (int rc = pack_dgrad(d, s)) return rc;
-            if (mode == 2) return copy_param(wdst, d, (size_t)cin * cout * ksize * ksize, s);
-            if (mode == 1) return pack_first_weights(s, d, cout, cin, wdst, cout_off, cout_total);
+            if (mode == 2) return copy_param(net, wdst, d, (size_t)cin * cout * ksize * ksize, s);
+            if (mode == 1) return pack_first_weights(net->pack, s, d, cout, cin, wdst, cout_off, cout_total);
             if (wb && net->planes > 0)
-                if (int rc = pack_conv_weights_bf16(s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0, net->planes == 4)) return rc;
-            return pack_conv_weights(s, d, false, cout, cin, ksize, wdst, cout_off, cout_total);
+                if (int rc = pack_conv_weights_bf16(net->pack, s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0, net->planes == 4)) return rc;
+            return pack_conv_weights(net->pack, s, d, false, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off);
         });
     }
     net->params[cw.p_w[slot]].has_dgrad = dg != DG_NONE;
     net->params[cw.p_w[slot]].has_bf16 = wb != nullptr && mode == 0;
-    cw.p_b[slot] = add_param(net, conv + ".bias", {cout}, [=](const float* d, hipStream_t s) { return copy_param(bdst, d, cout, s); });
+    cw.p_b[slot] = add_param(net, conv + ".bias", {cout}, [=](const float* d, hipStream_t s) { return copy_param(net, bdst, d, cout, s); });
 }
 
 static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::string& pfx, int cin, int c, int stride) {
@@ -375,6 +393,8 @@ static void build_net(cs_unet* net, ArenaPlan& ar) {
 // ---------------------------------------------------------------------------------------------------
 static int finish_norm(hipStream_t s, const cs_unet* net, const NormSite& ns, NormRt& rt, int n, int c_total, int count, bool dry) {
     if (dry) return CS_OK;
+    if (net->norm == CS_NORM_BATCH && net->batch_stats)      // nn.BatchNorm2d, train mode: momentum 0.1, eps 1e-5 (torch defaults)
+        return launch_bn_train_finalize(s, rt.stats, ns.bn_w, ns.bn_b, ns.bn_m, ns.bn_v, rt.tab, rt.xtab, n, ns.c, c_total, count, 1e-5f, 0.1f);
     if (net->norm == CS_NORM_BATCH) return launch_bn_table(s, ns.bn_w, ns.bn_b, ns.bn_m, ns.bn_v, rt.tab, n, ns.c, c_total, 1e-5f);
     return launch_norm_finalize(s, rt.stats, rt.tab, n, c_total, count, 1e-5f);
 }
@@ -411,7 +431,8 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     const int nl = net->nl;
     CS_REQUIRE(h % (1 << nl) == 0 && w % (1 << nl) == 0 && h > 0 && w > 0, "unet: window %d x %d must be a multiple of %d", h, w,
                1 << nl);
-    const bool inst = net->norm == CS_NORM_INSTANCE;
+    const bool inst = net->norm == CS_NORM_INSTANCE || net->batch_stats;   // statistics of the running batch are needed
+    const bool want_xtab = net->norm == CS_NORM_BATCH && net->batch_stats;
     if (tape) {
         tape->valid = false;
         tape->E.assign(nl, nullptr); tape->Y.assign(nl, {}); tape->U.assign(nl, nullptr); tape->V.assign(nl, nullptr);
@@ -443,7 +464,10 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         ProfScope prof(K_MEMSET, s, 0, (double)stats_bytes);
         CS_HIP(hipMemsetAsync(ws.base + stats_mark, 0, stats_bytes, s));
     }
-    auto new_tab = [&](NormRt& rt, int c_total) { rt.tab = ws.take<float2>((size_t)n * c_total); };
+    auto new_tab = [&](NormRt& rt, int c_total) {
+        rt.tab = ws.take<float2>((size_t)n * c_total);
+        rt.xtab = want_xtab ? ws.take<float2>((size_t)n * c_total) : nullptr;
+    };
 
     // ---- encoder ----
     std::vector<float*> X(nl);   // materialised ResidualUnit outputs (skip connections)
@@ -566,7 +590,9 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     const bool dry = buf.dry();
     const Tape& T = net->tape;
     const int nl = net->nl, n = T.n, h = T.h, w = T.w;
-    CS_REQUIRE(net->norm == CS_NORM_INSTANCE, "backward: BatchNorm training is not implemented (InstanceNorm only)");
+    const bool bn = net->norm == CS_NORM_BATCH;
+    CS_REQUIRE(!bn || dry || T.rt_upt[0].xtab != nullptr,
+               "backward: the recorded forward used running statistics (eval-mode BatchNorm); call cs_unet_set_batch_stats(1) first");
     CS_REQUIRE(dry || T.src.origins == nullptr, "backward: the recorded forward must be a plain batched forward");
     auto gptr = [&](int pidx) { return flat + net->params[pidx].grad_off; };
     auto oom = [&]() { set_error("backward: workspace too small"); return CS_ERR_WORKSPACE; };
@@ -575,21 +601,19 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     // `before_norm`: the conv feeds an InstanceNorm, which removes any per-(image, channel) constant - the bias gradient is
     // analytically zero (autograd returns rounding noise there), so it is written as exact zeros instead of summing dy
     auto bias_grad = [&](const float* dy, int pitch, int c, int64_t npix_total, int pidx, bool before_norm = false) -> int {
-        double* d = acc.take<double>(c);
+        if (before_norm) return CS_OK;      // exact zeros: the flat gradient buffer was cleared by cs_unet_backward's memset
+        float* partial = buf.take<float>((size_t)colsum_blocks(npix_total) * c);
         if (dry) return CS_OK;
-        if (before_norm) {
-            CS_HIP(hipMemsetAsync(gptr(pidx), 0, (size_t)c * sizeof(float), s));
-            return CS_OK;
-        }
-        CS_TRY(launch_colsum(s, dy, pitch, c, npix_total, d));
-        return launch_f64_to_f32(s, d, gptr(pidx), c);
+        if (!buf.ok()) return oom();
+        return launch_colsum(s, dy, pitch, c, npix_total, partial, gptr(pidx));
     };
-    auto norm_bwd = [&](const NormSite& ns, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch,
+    auto norm_bwd = [&](const NormSite& ns, const NormRt& rt, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch,
                         int64_t npix) -> int {
         double* red = acc.take<double>((size_t)n * y.c * 2);
         double* dsl = acc.take<double>(1);
         if (dry) return CS_OK;
-        CS_TRY(launch_norm_bwd(s, y, da, da_pitch, dy, dy_pitch, red, dsl, npix, n));
+        CS_TRY(launch_norm_bwd(s, y, da, da_pitch, dy, dy_pitch, red, dsl, npix, n, bn ? rt.xtab : nullptr, bn,
+                               bn && ns.p_bn_w >= 0 ? gptr(ns.p_bn_w) : nullptr, bn && ns.p_bn_b >= 0 ? gptr(ns.p_bn_b) : nullptr));
         if (ns.p_slope >= 0) return launch_f64_to_f32(s, dsl, gptr(ns.p_slope), 1);
         return CS_OK;
     };
@@ -633,7 +657,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             float* dV = buf.take<float>((size_t)n * oh * ow * c);
             const WG gu = wg_alloc(c, 0, c, 9, c, c, oh, ow);
             if (!buf.ok()) return oom();
-            CS_TRY(norm_bwd(u.norm_u, lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow));
+            CS_TRY(norm_bwd(u.norm_u, T.rt_upu[d], lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow));
             CS_TRY(bias_grad(dV, c, c, (int64_t)n * oh * ow, u.unit0.p_b[0], true));
             if (!dry) {
                 CS_TRY(launch_wgrad(s, 3, 1, dV, c, c, lu, nullptr, gu.part, gu.k, c, c, 0, 0, n, oh, ow, oh, ow));
@@ -643,7 +667,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dV, c, c), ConvSrc(), u.unit0.wd, nullptr, d_au, c, c, nullptr, n, oh, ow, &ex));
             }
         }
-        CS_TRY(norm_bwd(u.norm_t, lu, d_au, c, dU, c, (int64_t)oh * ow));
+        CS_TRY(norm_bwd(u.norm_t, T.rt_upt[d], lu, d_au, c, dU, c, (int64_t)oh * ow));
         CS_TRY(bias_grad(dU, c, c, (int64_t)n * oh * ow, u.convt.p_b[0], true));
         if (!dry) {
             if (u.top) {
@@ -687,7 +711,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const WG ga = wg_alloc(c, 0, su == 0 ? cin : c, 9, c, su == 0 ? cin : c, ph, pw);
             float* da_new = su > 0 ? buf.take<float>((size_t)n * npix * c) : nullptr;
             if (!buf.ok()) return oom();
-            CS_TRY(norm_bwd(u.norms[su], lazy_src(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c), da, c, dY, c, npix));
+            CS_TRY(norm_bwd(u.norms[su], T.rt_bottom[su], lazy_src(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c), da, c, dY, c, npix));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (dry) { da = da_new; continue; }
             if (su > 0) {
@@ -730,7 +754,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             float* da_new = buf.take<float>((size_t)n * npix * c);
             const WG ga = wg_alloc(c, 0, c, 9, c, c, oh, ow);
             if (!buf.ok()) return oom();
-            CS_TRY(norm_bwd(u.norms[su], lazy_src(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c), da, c, dY, c, npix));
+            CS_TRY(norm_bwd(u.norms[su], T.rt_down[d][su], lazy_src(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c), da, c, dY, c, npix));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (!dry) {
                 const ConvSrc prev = su - 1 == 0 ? lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0)
@@ -744,7 +768,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         float* dY0 = buf.take<float>((size_t)n * npix * c);
         const WG gf = wg_alloc(c, 0, cin, 9, c0, cin, oh, ow);
         if (!buf.ok()) return oom();
-        CS_TRY(norm_bwd(u.norms[0], lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0), da, c, dY0, c, npix));
+        CS_TRY(norm_bwd(u.norms[0], T.rt_down[d][0], lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0), da, c, dY0, c, npix));
         CS_TRY(bias_grad(dY0, c, c, n * npix, u.unit0.p_b[0], true));
         if (dry) continue;
         if (!u.first) {
@@ -849,6 +873,13 @@ int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* 
         off += (p.numel() + 3) / 4 * 4;          // keep every gradient 16-byte aligned inside the flat bucket
     }
     net->grad_floats = off;
+    (void)hipGetDevice(&net->device);
+    net->pack = cs::pack_ctx_create(4 * (int)net->params.size() + 16);
+    if (!net->pack) {
+        cs::set_error("unet_create: allocating the weight-packing tables failed");
+        cs_unet_destroy(net);
+        return CS_ERR_HIP;
+    }
     *out = net;
     return CS_OK;
 }
@@ -861,19 +892,39 @@ int cs_unet_set_precision(cs_unet* net, int planes) {
 
 int cs_unet_load_begin(cs_unet* net) {
     CS_REQUIRE(net, "load_begin: null handle");
-    cs::pack_batch_begin();
+    cs::pack_batch_begin(net->pack);
     return CS_OK;
 }
 
 int cs_unet_load_end(cs_unet* net, void* stream) {
     CS_REQUIRE(net, "load_end: null handle");
-    return cs::pack_batch_flush((hipStream_t)stream);
+    return cs::pack_batch_flush(net->pack, (hipStream_t)stream);
 }
 
 int cs_unet_set_training(cs_unet* net, int on) {
     CS_REQUIRE(net, "set_training: null handle");
     net->training = on != 0;
     return CS_OK;
+}
+
+int cs_unet_set_batch_stats(cs_unet* net, int on) {
+    CS_REQUIRE(net, "set_batch_stats: null handle");
+    CS_REQUIRE(!on || net->norm == CS_NORM_BATCH, "set_batch_stats: the network has no BatchNorm layers");
+    net->batch_stats = on != 0;
+    return CS_OK;
+}
+
+int cs_unet_read_param(cs_unet* net, const char* key_host, float* dst, int64_t numel, void* stream) {
+    CS_REQUIRE(net && key_host && dst, "read_param: null argument");
+    for (auto& p : net->params) {
+        if (p.key == key_host) {
+            CS_REQUIRE(p.raw != nullptr, "read_param: '%s' is kept in a packed layout only (readable: BatchNorm tensors, PReLU slopes)", key_host);
+            CS_REQUIRE(numel == p.numel(), "read_param: '%s' holds %lld elements, got %lld", key_host, (long long)p.numel(), (long long)numel);
+            return cs::pack_copy(net->pack, (hipStream_t)stream, p.raw, dst, (size_t)numel);
+        }
+    }
+    cs::set_error("read_param: unknown key '%s'", key_host);
+    return CS_ERR_UNKNOWN_KEY;
 }
 
 int cs_unet_set_streams(cs_unet* net, int n) {
@@ -895,6 +946,7 @@ int cs_unet_destroy(cs_unet* net) {
     }
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     if (net->arena) (void)hipFree(net->arena);
+    cs::pack_ctx_destroy(net->pack);
     delete net;
     return CS_OK;
 }
@@ -1083,7 +1135,7 @@ int cs_swi_infer(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_
     // chunks of `engine_batch` windows; with side streams the chunks are dealt round-robin to them, each stream owning
     // its own slice of the activation workspace (stream order serialises the chunks that share a slice).  Per-kernel
     // profiling (cs_prof_enable) forces one stream so that event-timed durations are not inflated by overlap.
-    const int ns = (net->n_streams > 1 && !cs::g_prof_on && nwin > engine_batch) ? net->n_streams : 1;
+    const int ns = (net->n_streams > 1 && !cs::prof_enabled() && nwin > engine_batch) ? net->n_streams : 1;
     const size_t mark = b.off;
     const size_t slice = ns > 1 ? ((workspace_bytes - mark) / ns) / 256 * 256 : 0;
     if (ns > 1) {
@@ -1187,31 +1239,34 @@ int cs_ccl_label(const uint8_t* mask, int h, int w, int connectivity, int32_t* l
 }
 
 int cs_prof_enable(int on) {
-    cs::g_prof_on = on != 0;
+    cs::prof_state().on = on != 0;
+    if (on) cs::g_prof_any = true;
     return CS_OK;
 }
 
 int cs_prof_reset(void) {
-    cs::prof_drain();
+    cs::ProfState& ps = cs::prof_state();
+    cs::prof_drain(ps);
     for (int i = 0; i < K_NUM_IDS; ++i) {
-        cs::g_prof_flops[i] = cs::g_prof_bytes[i] = cs::g_prof_ms[i] = 0.0;
-        cs::g_prof_launches[i] = 0;
+        ps.flops[i] = ps.bytes[i] = ps.ms[i] = 0.0;
+        ps.launches[i] = 0;
     }
     return CS_OK;
 }
 
 int cs_prof_collect(char* names_out_host, double* ms_out_host, int64_t* launches_out_host, double* flops_out_host,
                     double* bytes_out_host) {
-    cs::prof_drain();
+    cs::ProfState& ps = cs::prof_state();
+    cs::prof_drain(ps);
     for (int i = 0; i < K_NUM_IDS; ++i) {
         if (names_out_host) {
             strncpy(names_out_host + 48 * i, cs::kernel_name(i), 47);
             names_out_host[48 * i + 47] = 0;
         }
-        if (ms_out_host) ms_out_host[i] = cs::g_prof_ms[i];
-        if (launches_out_host) launches_out_host[i] = cs::g_prof_launches[i];
-        if (flops_out_host) flops_out_host[i] = cs::g_prof_flops[i];
-        if (bytes_out_host) bytes_out_host[i] = cs::g_prof_bytes[i];
+        if (ms_out_host) ms_out_host[i] = ps.ms[i];
+        if (launches_out_host) launches_out_host[i] = ps.launches[i];
+        if (flops_out_host) flops_out_host[i] = ps.flops[i];
+        if (bytes_out_host) bytes_out_host[i] = ps.bytes[i];
     }
     return K_NUM_IDS;
 }

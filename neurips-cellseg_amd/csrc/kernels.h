@@ -20,18 +20,25 @@ struct ConvSrc {
 // packed[chunk][tap][ntile_total][64 lanes][4] with cout = ntile*16 + (lane & 15), cin = chunk*16 + 4*(lane>>4) + j.
 // `cout_off`/`cout_total` let two convs (unit0 || residual) share one packed tensor; `cin_total` is the
 // concatenated input width.
-// `flip` reverses the taps (data gradient of a stride-1 conv); `cin_off` places this tensor's chunks at input-channel
-// offset cin_off of a wider packed conv (data gradient of the fused [unit0 || residual] conv).
-int pack_conv_weights(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
-                      float* packed, int cout_off, int cout_total, bool flip = false, int cin_off = 0);
+// `dgrad` (optional): the same tensor packed a second time for the DATA-GRADIENT launch, i.e. with the roles of the two channel
+// axes swapped (a conv's data gradient contracts over its output channels): chunk = output-channel tile (+ dgrad_chunk_off
+// tiles: the second half of a fused [unit0 || residual] pair), tile = input-channel tile (of cin/16), taps reversed when
+// dgrad_flip (data gradient of a stride-1 conv).  One block reads a 16 x 16 x taps weight tile once (coalesced rows) and
+// writes both layouts as whole 1 KB fragments.
+struct PackCtx;
+PackCtx* pack_ctx_create(int max_jobs);                    // allocates the job tables on the current device
+void pack_ctx_destroy(PackCtx* pc);
+int pack_conv_weights(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
+                      float* packed, int cout_off, int cout_total, float* dgrad = nullptr, bool dgrad_flip = false,
+                      int dgrad_chunk_off = 0);
 // first layer (cin < 16): packed[kstep][ntile_total][64], k = 4*kstep + (lane>>4) = tap*cin + c, zero padded
-int pack_first_weights(hipStream_t s, const float* w, int cout, int cin, float* packed, int cout_off, int cout_total);
-// batched packing: between begin and flush the pack_* entry points only record jobs; flush runs them in one kernel
-void pack_batch_begin();
-int pack_batch_flush(hipStream_t s);
-int pack_copy(hipStream_t s, const float* src, float* dst, size_t n);
-int pack_bf16_submit(hipStream_t s, const float* w, bool transposed, int cout, int cin, int taps, unsigned short* packed, int cout_off,
-                     int ntile_total, int cin_split, int chunks_total, bool f16);
+int pack_first_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed, int cout_off, int cout_total);
+// batched packing: between begin and flush the pack_* entry points only record jobs; flush runs them in (at most) two kernels
+void pack_batch_begin(PackCtx* pc);
+int pack_batch_flush(PackCtx* pc, hipStream_t s);
+int pack_copy(PackCtx* pc, hipStream_t s, const float* src, float* dst, size_t n);
+int pack_bf16_submit(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int taps, unsigned short* packed,
+                     int cout_off, int ntile_total, int cin_split, int chunks_total, bool f16);
 size_t packed_conv_floats(int cout_total, int cin_total, int ksize);
 size_t packed_first_floats(int cout_total, int cin);
 
@@ -62,8 +69,8 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
 int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSrc& b, const unsigned short* wpack, const float* bias,
                        float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
 size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize);
-int pack_conv_weights_bf16(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, unsigned short* packed,
-                           int cout_off, int cout_total, int cin_split, bool f16 = false);
+int pack_conv_weights_bf16(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
+                           unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16 = false);
 
 // first layer: cin < 16 (3), 3x3 pad 1, reads windows straight out of the image (tiler gather fused).
 // image element strides (sc, sh, sw); per-window origins (y0, x0) in image coordinates (may be negative when the
@@ -97,16 +104,25 @@ int launch_norm_finalize(hipStream_t s, const double* stats, float2* tab, int n,
 // eval-mode BatchNorm: tab[n][c] from running stats and affine parameters
 int launch_bn_table(hipStream_t s, const float* weight, const float* bias, const float* mean, const float* var,
                     float2* tab, int n, int c, int c_total, float eps);
+// training-mode BatchNorm: per-image sums [n][c_total][2] -> batch statistics; tab / xtab [n][c_total] (xtab may be null);
+// running statistics (may be null) updated in place with `momentum` and the unbiased variance
+int launch_bn_train_finalize(hipStream_t s, const double* stats, const float* weight, const float* bias, float* run_mean,
+                             float* run_var, float2* tab, float2* xtab, int n, int c, int c_total, int count, float eps,
+                             float momentum);
 // out = T_y(y) + T_r(r)   (T = lazy norm/act or identity), all NHWC with channel count c
 int launch_norm_act_add(hipStream_t s, const ConvSrc& y, const ConvSrc& r, float* out, int pitch_out, int64_t npix_per_image, int n);
 
 // ---- backward pass (kernels_bwd.hip) -----------------------------------------------------------
 // InstanceNorm + PReLU backward of `y` (raw conv output + forward table/slope): da -> dy; red [n][c][2] and dslope
 // are fp64 accumulators that must be zero on entry.
+// BatchNorm (batch statistics): pass the forward's `xtab` (x_hat table) and batch = true - the two sums are then reduced over
+// the whole batch, and d(gamma) = sum dz*x_hat / d(beta) = sum dz are written to dgamma / dbeta (fp32, may be null).
 int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch, double* red,
-                    double* dslope, int64_t npix, int n);
-// dst[c] += sum over pixels (fp64 accumulators)
-int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npix_total, double* dst);
+                    double* dslope, int64_t npix, int n, const float2* xtab = nullptr, bool batch = false, float* dgamma = nullptr,
+                    float* dbeta = nullptr);
+// dst[c] = sum over pixels (fp32 out, fp64 final accumulation); partial: colsum_blocks(npix_total) * c floats of scratch
+int colsum_blocks(int64_t npix_total);
+int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npix_total, float* partial, float* dst);
 struct WgradNarrow {          // "x-like" operand with <= 4 channels addressed by element strides
     const float* ptr = nullptr;
     int c = 0;

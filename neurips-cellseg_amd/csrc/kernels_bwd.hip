@@ -37,6 +37,8 @@ struct NormBwdParams {
     float* dy;         int dy_pitch;
     int c, npix;       // channels, pixels per image
     int pix_per_block;
+    const float2* xtab;   // BatchNorm: (rstd, -mean*rstd) so that x_hat = y*rstd - mean*rstd; null: x_hat == z (InstanceNorm, no affine)
+    double inv_m;         // 1 / (elements behind each pair of sums): npix (InstanceNorm) or n*npix (BatchNorm, sums reduced over n)
 };
 
 // wide: c % 4 == 0 and 256 % (c/4) == 0
@@ -50,6 +52,13 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
     const f32x4* t = reinterpret_cast<const f32x4*>(p.tab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
     const f32x4 t0 = t[0], t1 = t[1];
     const float sc[4] = {t0.x, t0.z, t1.x, t1.z}, sf[4] = {t0.y, t0.w, t1.y, t1.w};
+    float xs[4] = {sc[0], sc[1], sc[2], sc[3]}, xf[4] = {sf[0], sf[1], sf[2], sf[3]};     // x_hat table (== the z table without affine)
+    if (p.xtab) {
+        const f32x4* xt = reinterpret_cast<const f32x4*>(p.xtab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
+        const f32x4 x0 = xt[0], x1 = xt[1];
+        xs[0] = x0.x; xs[1] = x0.z; xs[2] = x1.x; xs[3] = x1.z;
+        xf[0] = x0.y; xf[1] = x0.w; xf[2] = x1.y; xf[3] = x1.w;
+    }
     const float slope = p.slope ? *p.slope : 0.f;
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, ds = 0.f;
     for (int64_t px = pix0 + pl; px < pix1; px += lanes) {
@@ -59,10 +68,11 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float z = y[j] * sc[j] + sf[j];
+            const float xh = y[j] * xs[j] + xf[j];
             const float dz = z >= 0.f ? da[j] : da[j] * slope;
             if (z < 0.f) ds += da[j] * z;
             s1[j] += dz;
-            s2[j] += dz * z;
+            s2[j] += dz * xh;
         }
     }
     // reduce over the `lanes` threads that share a channel quad
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
 
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p, int64_t total) {
     const int c4n = p.c >> 2;
-    const double inv_m = 1.0 / (double)p.npix;
+    const double inv_m = p.inv_m;
     const float slope = p.slope ? *p.slope : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t g = i / c4n;
@@ -112,6 +122,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p, in
         const f32x4* t = reinterpret_cast<const f32x4*>(p.tab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
         const f32x4 t0 = t[0], t1 = t[1];
         const float sc[4] = {t0.x, t0.z, t1.x, t1.z}, sf[4] = {t0.y, t0.w, t1.y, t1.w};
+        float xs[4] = {sc[0], sc[1], sc[2], sc[3]}, xf[4] = {sf[0], sf[1], sf[2], sf[3]};
+        if (p.xtab) {
+            const f32x4* xt = reinterpret_cast<const f32x4*>(p.xtab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
+            const f32x4 x0 = xt[0], x1 = xt[1];
+            xs[0] = x0.x; xs[1] = x0.z; xs[2] = x1.x; xs[3] = x1.z;
+            xf[0] = x0.y; xf[1] = x0.w; xf[2] = x1.y; xf[3] = x1.w;
+        }
         const double* red = p.red + ((size_t)img * p.c + 4 * quad) * 2;
         const f32x4 da = *reinterpret_cast<const f32x4*>(p.da + g * p.da_pitch + 4 * quad);
         const f32x4 y = *reinterpret_cast<const f32x4*>(p.y + g * p.y_pitch + 4 * quad);
@@ -119,9 +136,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p, in
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float z = y[j] * sc[j] + sf[j];
+            const float xh = y[j] * xs[j] + xf[j];
             const float dz = z >= 0.f ? da[j] : da[j] * slope;
             const float m1 = (float)(red[2 * j] * inv_m), m2 = (float)(red[2 * j + 1] * inv_m);
-            o[j] = sc[j] * (dz - m1 - z * m2);
+            o[j] = sc[j] * (dz - m1 - xh * m2);
         }
         *reinterpret_cast<f32x4*>(p.dy + g * p.dy_pitch + 4 * quad) = o;
     }
@@ -132,22 +150,24 @@ template <int C>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_small_kernel(NormBwdParams p) {
     const int img = blockIdx.y;
     const float slope = p.slope ? *p.slope : 0.f;
-    float s1[C], s2[C], ds = 0.f, sc[C], sf[C];
+    float s1[C], s2[C], ds = 0.f, sc[C], sf[C], xs[C], xf[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const float2 t = p.tab[(size_t)img * p.tab_c + p.tab_off + c];
-        sc[c] = t.x; sf[c] = t.y; s1[c] = 0.f; s2[c] = 0.f;
+        const float2 x = p.xtab ? p.xtab[(size_t)img * p.tab_c + p.tab_off + c] : t;
+        sc[c] = t.x; sf[c] = t.y; xs[c] = x.x; xf[c] = x.y; s1[c] = 0.f; s2[c] = 0.f;
     }
     for (int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; px < p.npix; px += (int64_t)gridDim.x * blockDim.x) {
         const int64_t g = (int64_t)img * p.npix + px;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float da = p.da[g * p.da_pitch + c];
-            const float z = p.y[g * p.y_pitch + c] * sc[c] + sf[c];
+            const float yv = p.y[g * p.y_pitch + c];
+            const float z = yv * sc[c] + sf[c];
             const float dz = z >= 0.f ? da : da * slope;
             if (z < 0.f) ds += da * z;
             s1[c] += dz;
-            s2[c] += dz * z;
+            s2[c] += dz * (yv * xs[c] + xf[c]);
         }
     }
 #pragma unroll
@@ -173,30 +193,57 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_small_kernel(NormBwdParams
     const int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (px >= p.npix) return;
     const float slope = p.slope ? *p.slope : 0.f;
-    const double inv_m = 1.0 / (double)p.npix;
+    const double inv_m = p.inv_m;
     const int64_t g = (int64_t)img * p.npix + px;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const float2 t = p.tab[(size_t)img * p.tab_c + p.tab_off + c];
+        const float2 x = p.xtab ? p.xtab[(size_t)img * p.tab_c + p.tab_off + c] : t;
         const float da = p.da[g * p.da_pitch + c];
-        const float z = p.y[g * p.y_pitch + c] * t.x + t.y;
+        const float yv = p.y[g * p.y_pitch + c];
+        const float z = yv * t.x + t.y;
         const float dz = z >= 0.f ? da : da * slope;
         const double* red = p.red + ((size_t)img * C + c) * 2;
-        p.dy[g * p.dy_pitch + c] = t.x * (dz - (float)(red[0] * inv_m) - z * (float)(red[1] * inv_m));
+        p.dy[g * p.dy_pitch + c] = t.x * (dz - (float)(red[0] * inv_m) - (yv * x.x + x.y) * (float)(red[1] * inv_m));
     }
 }
 
+// BatchNorm: the per-image sums are reduced over the batch (every image's slot receives the batch total, which is what the
+// apply pass then reads with inv_m = 1 / (n * npix)); d(gamma) = sum dz * x_hat, d(beta) = sum dz fall out of the same sums.
+__global__ void bn_bwd_finalize_kernel(double* red, int n, int c, float* dgamma, float* dbeta) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        s1 += red[((size_t)i * c + ch) * 2];
+        s2 += red[((size_t)i * c + ch) * 2 + 1];
+    }
+    for (int i = 0; i < n; ++i) {
+        red[((size_t)i * c + ch) * 2] = s1;
+        red[((size_t)i * c + ch) * 2 + 1] = s2;
+    }
+    if (dbeta) dbeta[ch] = (float)s1;
+    if (dgamma) dgamma[ch] = (float)s2;
+}
+
 int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch, double* red,
-                    double* dslope, int64_t npix, int n) {
+                    double* dslope, int64_t npix, int n, const float2* xtab, bool batch, float* dgamma, float* dbeta) {
     CS_REQUIRE(y.tab != nullptr, "norm_bwd: the forward table is required");
+    CS_REQUIRE(!batch || xtab, "norm_bwd: BatchNorm needs the forward's x_hat table");
     NormBwdParams p{};
     p.da = da; p.da_pitch = da_pitch; p.y = y.ptr; p.y_pitch = y.pitch;
     p.tab = y.tab; p.tab_c = y.tab_c ? y.tab_c : y.c; p.tab_off = y.tab_off; p.slope = y.slope;
     p.red = red; p.dslope = y.slope ? dslope : nullptr; p.dy = dy; p.dy_pitch = dy_pitch; p.c = y.c; p.npix = (int)npix;
+    p.xtab = xtab;
+    p.inv_m = 1.0 / ((double)npix * (batch ? (double)n : 1.0));
     ProfScope prof(K_NORM_BWD, s, 0, 4.0 * n * npix * y.c * 5);
+    auto bn_finalize = [&]() {
+        if (batch) hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(y.c, 64)), dim3(64), 0, s, red, n, y.c, dgamma, dbeta);
+    };
     if (y.c == 3) {
         dim3 grid((unsigned)(ceil_div((int)npix, 256) < 64 ? ceil_div((int)npix, 256) : 64), (unsigned)n);
         hipLaunchKernelGGL((norm_bwd_reduce_small_kernel<3>), grid, dim3(256), 0, s, p);
+        bn_finalize();
         hipLaunchKernelGGL((norm_bwd_apply_small_kernel<3>), dim3((unsigned)ceil_div((int)npix, 256), (unsigned)n), dim3(256), 0, s, p);
     } else {
         const int c4n = y.c / 4;
@@ -204,6 +251,7 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
         p.pix_per_block = npix >= 4096 ? 1024 : (npix >= 256 ? 256 : (int)npix);
         dim3 grid((unsigned)ceil_div((int)npix, p.pix_per_block), (unsigned)n);
         hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(256), 0, s, p);
+        bn_finalize();
         const int64_t total = (int64_t)n * npix * c4n;
         const int64_t blocks = (total + 255) / 256;
         hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, p, total);
@@ -213,38 +261,55 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
 }
 
 // ------------------------------------------------------------------------------------------------
-// column sums: dst[c] += sum over pixels of src[pix][c]   (bias gradients); fp64 atomics
+// column sums: dst[c] = sum over pixels of src[pix][c]   (bias gradients of the convs that do not feed a norm).
+// Two stages without atomics: every block reduces its pixel range to one fp32 row of `partial`, a second kernel sums the
+// rows in fp64.  (Round 1 added every block's row into the same c doubles with global atomics: 512 blocks serialised on
+// 32..512 addresses and the pass ran at ~110 GB/s.)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const float* src, int pitch, int c, int64_t npix, int64_t pix_per_block,
-                                                     double* dst) {
-    __shared__ float sh[256];
-    const int lanes = 256 / c > 0 ? 256 / c : 1;
-    const int ch = threadIdx.x % c, pl = threadIdx.x / c;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* src, int pitch, int c, int64_t npix, int64_t pix_per_block,
+                                                             float* partial) {
+    __shared__ f32x4 sh[256];
+    const int c4n = c >> 2;
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
-    for (int cb = 0; cb < c; cb += 256) {          // channels handled 256 at a time when c > 256
-        const int cc = c > 256 ? cb + threadIdx.x : ch;
-        float acc = 0.f;
-        if (cc < c && (c > 256 || pl < lanes))
-            for (int64_t px = p0 + (c > 256 ? 0 : pl); px < p1; px += (c > 256 ? 1 : lanes)) acc += src[px * pitch + cc];
+    for (int q0 = 0; q0 < c4n; q0 += 256) {                   // channel quads handled 256 at a time (c <= 1024: one trip)
+        const int cq = c4n - q0 < 256 ? c4n - q0 : 256;       // quads in this trip
+        const int lanes = 256 / cq;
+        const int quad = threadIdx.x % cq, pl = threadIdx.x / cq;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pl < lanes)
+            for (int64_t px = p0 + pl; px < p1; px += lanes) acc += *reinterpret_cast<const f32x4*>(src + px * pitch + 4 * (q0 + quad));
         sh[threadIdx.x] = acc;
         __syncthreads();
-        if (c > 256) {
-            if (cc < c) atomicAdd(dst + cc, (double)acc);
-        } else if (threadIdx.x < c) {
-            float t = 0.f;
-            for (int l = 0; l < lanes; ++l) t += sh[l * c + threadIdx.x];
-            atomicAdd(dst + threadIdx.x, (double)t);
+        if (threadIdx.x < cq) {
+            f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int l = 0; l < lanes; ++l) t += sh[l * cq + threadIdx.x];
+            *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * c + 4 * (q0 + threadIdx.x)) = t;
         }
         __syncthreads();
-        if (c <= 256) break;
     }
 }
 
-int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npix_total, double* dst) {
-    const int64_t ppb = npix_total >= (1 << 20) ? 1024 : 256;   // >= 512 blocks on the large tensors
+__global__ void colsum_final_kernel(const float* partial, int rows, int c, float* dst) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double acc = 0.0;
+    for (int r = 0; r < rows; ++r) acc += (double)partial[(size_t)r * c + ch];
+    dst[ch] = (float)acc;
+}
+
+int colsum_blocks(int64_t npix_total) {
+    const int64_t b = (npix_total + 255) / 256;
+    return (int)(b < 1024 ? (b < 1 ? 1 : b) : 1024);
+}
+
+int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npix_total, float* partial, float* dst) {
+    CS_REQUIRE(c % 4 == 0 && pitch % 4 == 0, "colsum: %d channels / pitch %d must be multiples of 4", c, pitch);
+    const int blocks = colsum_blocks(npix_total);
+    const int64_t ppb = (npix_total + blocks - 1) / blocks;
     ProfScope prof(K_COLSUM, s, 0, 4.0 * npix_total * c);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((npix_total + ppb - 1) / ppb)), dim3(256), 0, s, src, pitch, c, npix_total, ppb, dst);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, pitch, c, npix_total, ppb, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, s, partial, blocks, c, dst);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

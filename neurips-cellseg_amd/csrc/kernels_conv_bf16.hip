@@ -644,12 +644,12 @@ size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize) {
     return chunks * ksize * ksize * (cout_total / 16) * 3 * 512;
 }
 
-int pack_conv_weights_bf16(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, unsigned short* packed,
-                           int cout_off, int cout_total, int cin_split, bool f16) {
+int pack_conv_weights_bf16(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
+                           unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16) {
     CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack(bf16): bad channel counts");
     const int taps = ksize * ksize;
     const int chunks_total = cin_split > 0 ? (cin_split + 31) / 32 + (cin - cin_split + 31) / 32 : (cin + 31) / 32;
-    return pack_bf16_submit(s, w, transposed, cout, cin, taps, packed, cout_off, cout_total / 16, cin_split, chunks_total, f16);
+    return pack_bf16_submit(pc, s, w, transposed, cout, cin, taps, packed, cout_off, cout_total / 16, cin_split, chunks_total, f16);
 }
 
 }  // namespace cs

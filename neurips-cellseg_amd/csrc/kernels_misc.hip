@@ -52,6 +52,50 @@ int launch_bn_table(hipStream_t s, const float* weight, const float* bias, const
     return CS_OK;
 }
 
+// BatchNorm with BATCH statistics (training mode; torch.nn.BatchNorm2d.forward with self.training): the conv epilogues
+// leave per-(image, channel) fp64 sums, one thread per channel reduces them over the batch - mean / biased variance over
+// n*count elements, "wavefront reductions for BatchNorm statistics" of the north star happen in the producers - and writes
+//   tab  [n][c_total]  (gamma*rstd, beta - mean*gamma*rstd)   what every consumer applies lazily (same for all images)
+//   xtab [n][c_total]  (rstd, -mean*rstd)                     x_hat = y*rstd - mean*rstd, needed by the backward pass
+// and updates the running statistics in place: momentum 0.1, UNBIASED variance (torch semantics).
+__global__ void bn_train_finalize_kernel(const double* stats, const float* weight, const float* bias, float* run_mean, float* run_var,
+                                         float2* tab, float2* xtab, int n, int c, int c_total, double inv_m, double unbias, double eps,
+                                         float momentum) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < n; ++i) {
+        s += stats[((size_t)i * c_total + ch) * 2];
+        q += stats[((size_t)i * c_total + ch) * 2 + 1];
+    }
+    const double mean = s * inv_m;
+    double var = q * inv_m - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + eps);
+    const double g = weight ? (double)weight[ch] : 1.0, b = bias ? (double)bias[ch] : 0.0;
+    const float2 t = make_float2((float)(rstd * g), (float)(b - mean * rstd * g));
+    const float2 x = make_float2((float)rstd, (float)(-mean * rstd));
+    for (int i = 0; i < n; ++i) {
+        tab[(size_t)i * c_total + ch] = t;
+        if (xtab) xtab[(size_t)i * c_total + ch] = x;
+    }
+    if (run_mean) {
+        run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * (float)mean;
+        run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (float)(var * unbias);
+    }
+}
+
+int launch_bn_train_finalize(hipStream_t s, const double* stats, const float* weight, const float* bias, float* run_mean,
+                             float* run_var, float2* tab, float2* xtab, int n, int c, int c_total, int count, float eps,
+                             float momentum) {
+    const double m = (double)n * (double)count;
+    ProfScope prof(K_NORM_FINALIZE, s, 0, 16.0 * n * c + 16.0 * n * c);
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, s, stats, weight, bias, run_mean, run_var,
+                       tab, xtab, n, c, c_total, 1.0 / m, m > 1.0 ? m / (m - 1.0) : 1.0, (double)eps, momentum);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // out = T_y(y) + T_r(r): materialises a ResidualUnit output (cx + res).  float4 per thread.
 // ------------------------------------------------------------------------------------------------

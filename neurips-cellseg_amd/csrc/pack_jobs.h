@@ -1,5 +1,7 @@
 // Weight-packing jobs: element functions of every packed layout, run by ONE batched kernel (kernels_conv.hip).
 #pragma once
+#include <vector>
+
 #include "cs_common.h"
 
 namespace cs {
@@ -8,24 +10,26 @@ enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3 };
 struct PackJob {
     const float* src;
     void* dst;
-    long long begin;            // first flattened element of this job
-    int kind, transposed, cout, cin, taps, cout_off, ntile_total, flip, chunk_off, cin_split, chunks_total, f16, ksteps, pad_;
+    void* dst2;                 // PK_CONV: second packing of the same tensor for the data-gradient launch (roles of the two channel
+                                // axes swapped), or null
+    long long begin;            // first flattened element (element-wise kinds) / first block (PK_CONV) of this job
+    int kind, transposed, cout, cin, taps, cout_off, ntile_total, flip, chunk_off, cin_split, chunks_total, f16, ksteps;
+    int flip2, chunk_off2, ntile_total2;
 };
 
-__device__ __forceinline__ void pack_conv_elem(const PackJob& jb, int64_t e) {
-    const int cout = jb.cout, cin = jb.cin, taps = jb.taps;
-    const int j = e & 3, lane = (e >> 2) & 63;
-    int64_t r = e >> 8;
-    const int ntl = r % (cout / 16);
-    r /= (cout / 16);
-    const int tap = r % taps;
-    const int chunk = r / taps;
-    const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
-    const int st = jb.flip ? taps - 1 - tap : tap;
-    const float v = jb.transposed ? jb.src[((size_t)ci * cout + co) * taps + st] : jb.src[((size_t)co * cin + ci) * taps + st];
-    const int nt = jb.cout_off / 16 + ntl;
-    reinterpret_cast<float*>(jb.dst)[(((size_t)(chunk + jb.chunk_off) * taps + tap) * jb.ntile_total + nt) * 256 + lane * 4 + j] = v;
-}
+// Per-handle packing state (no process-global state): the job list of the batch being recorded, the pinned staging
+// copy of the job table and its device twin.  Both tables are allocated ONCE, when the handle is created, on the handle's device.
+struct PackCtx {
+    std::vector<PackJob> jobs;
+    bool recording = false;
+    PackJob* host = nullptr;
+    PackJob* dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t copied = nullptr;   // the last H2D copy out of `host` (the next flush rewrites it)
+    bool copied_pending = false;
+    int device = -1;
+};
+
 __device__ __forceinline__ void pack_first_elem(const PackJob& jb, int64_t e) {
     const int cout = jb.cout, cin = jb.cin;
     const int lane = e & 63;

@@ -331,8 +331,87 @@ def test_training_cli_two_ranks_early_stop_is_collective(tmp_path):
              "--val_interval", "2", "--batch_size", "4", "--num_workers", "0", "--epoch_tolerance", "-2", "--work_dir", str(tmp_path)],
             env=_env(RANK=r, LOCAL_RANK=r, WORLD_SIZE=2, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, CELLSEG_DEVICE=0, CELLSEG_BACKEND="gloo"),
             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
+    try:
+        outs = [p.communicate(timeout=400) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     assert [p.returncode for p in procs] == [0, 0], outs[0][1][-1500:] + outs[1][1][-1500:]
     assert "does not improve" in outs[0][0] and "epoch 3 average loss" not in outs[0][0]
     ck = torch.load(os.path.join(tmp_path, "unet_3class", "final_model.pth"), map_location="cpu")
     assert ck["epoch"] == 2
+
+
+# ------------------------------------------------------------------------------------------- BatchNorm with batch statistics
+@pytest.mark.parametrize("act", ["relu", "prelu"])
+@pytest.mark.parametrize("channels,shape", [((16, 32, 64), (4, 3, 64, 64)), ((32, 64, 128, 256, 512), (3, 3, 64, 96))])
+def test_batchnorm_train_mode_forward_and_running_stats(channels, shape, act):
+    """nn.BatchNorm2d in train mode (north_star: "wavefront reductions for BatchNorm statistics"): logits from the batch
+    statistics, running_mean / running_var (momentum 0.1, unbiased variance) and num_batches_tracked updated like torch does."""
+    ref, hip = _pair(channels, train=True, norm="batch", act=act)
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        for step in range(2):                                  # second step: the running stats of the first are the starting point
+            want = ref(x + step)
+            got = hip((x + step).to(_dev())).cpu()
+            assert (got - want).abs().max().item() <= LOGIT_TOL
+    sd_ref, sd_hip = ref.state_dict(), hip.state_dict()
+    for k, v in sd_ref.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd_hip[k]) == int(v) == 2
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            assert (sd_hip[k].cpu() - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+    # eval mode now normalises with those running statistics
+    ref.eval(), hip.eval()
+    with torch.no_grad():
+        assert (hip(x.to(_dev())).cpu() - ref(x)).abs().max().item() <= LOGIT_TOL
+
+
+@pytest.mark.parametrize("act,slope", [("prelu", 1.0), ("prelu", None), ("relu", None)])
+def test_batchnorm_backward_vs_fp64_oracle(act, slope):
+    """Gradients of every parameter (conv weights / biases, BatchNorm weight / bias, PReLU slopes) through train-mode BatchNorm
+    against fp64 autograd, torch-fp32 autograd as the yardstick: per tensor on the kink-free net (slope 1.0), at the net level
+    where ReLU / PReLU kinks flip individual elements in any fp32 implementation."""
+    res = _grads_fp64_yardstick((16, 32, 64, 128), (4, 3, 64, 64), slope=slope, norm="batch", act=act)
+    assert any(".N.weight" in k for k in res) and any(".N.bias" in k for k in res)
+    scale = max(m for _, _, m in res.values())
+    if slope == 1.0:
+        for k, (eh, et, m) in res.items():
+            assert eh <= 3 * et + 2e-6 * scale, (k, eh, et, m, scale)
+    else:
+        worst_hip = max(eh / max(m, 1e-3 * scale) for eh, _, m in res.values())
+        worst_t32 = max(et / max(m, 1e-3 * scale) for _, et, m in res.values())
+        assert worst_hip <= 3 * worst_t32 + 1e-2, (worst_hip, worst_t32)
+
+
+def test_batchnorm_ten_training_steps_match_oracle_loss_curve():
+    import cellseg_amd as ca
+    from oracle.train_ref import train_steps_ref
+    ref, hip = _pair((16, 32, 64, 128), train=True, norm="batch", act="relu")
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(8, 3, 64, 64, generator=g)
+    y = torch.randint(0, 3, (8, 1, 64, 64), generator=g)
+    want = train_steps_ref(ref, x, y, 10, lr=6e-4)
+    opt = torch.optim.AdamW(hip.parameters(), 6e-4)
+    loss_fn = ca.DiceCELoss(softmax=True)
+    xd, yd = x.to(_dev()), ca.one_hot(y.to(_dev()), 3)
+    got = []
+    for _ in range(10):
+        opt.zero_grad()
+        loss = loss_fn(hip(xd), yd)
+        loss.backward()
+        opt.step()
+        got.append(loss.item())
+    assert got[-1] < got[0]
+    assert max(abs(a - b) for a, b in zip(got, want)) <= 2e-3, (got, want)
+    for k, v in ref.state_dict().items():                      # ten steps of running-statistic updates
+        if k.endswith("running_var"):
+            assert (hip.state_dict()[k].cpu() - v).abs().max().item() <= 1e-3 * max(1.0, v.abs().max().item()), k
+
+
+def test_batchnorm_eval_mode_backward_is_refused():
+    import cellseg_amd as ca
+    _, hip = _pair((16, 32), norm="batch", act="relu")
+    with pytest.raises(ca.CellSegHipError, match="eval-mode BatchNorm"):
+        hip(torch.rand(1, 3, 32, 32, device=_dev()))

@@ -53,17 +53,22 @@ typedef struct cs_unet cs_unet;
 int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* channels_host, int n_channels,
                    int num_res_units, int norm_kind, int act_kind);
 int cs_unet_destroy(cs_unet* net);
-/* Arithmetic of the 3x3 / 1x1 convolutions on the matrix cores (activations stay fp32 in HBM either way):
+/* Arithmetic of the 3x3 / 1x1 convolutions on the matrix cores:
  *   0  v_mfma_f32_16x16x4_f32, exact fp32 (default; the 1e-4 logit-parity path)
  *   3  split-bf16, 3 planes / 6 MFMA terms on v_mfma_f32_16x16x32_bf16: fp32-grade results (~1e-5 logit error)
- *   2  split-bf16, 2 planes / 3 terms (~1e-4)        1  plain bf16 (throughput mode; judged by F1, not by logits)
+ *   2  split-bf16, 2 planes / 3 terms (~1e-4)
+ *   1  the bf16 DATAPATH (throughput mode; judged by F1 / argmax, not by logits): bf16 weights, fp32 accumulate, and - outside
+ *      training mode - every activation tensor between the first conv and the 3-channel top layers is bf16 IN HBM
+ *      (statistics still come from the fp32 accumulators); BASELINE.json configs[1]
  *   4  split-fp16: planes h0 = fp16(x'), h1 = fp16(x' - h0) (22 mantissa bits) of the power-of-two pre-scaled operands
  *      (weights * 2^8, staged activations * 2^4, sum * 2^-12), 3 terms on v_mfma_f32_16x16x32_f16 in one accumulator:
  *      fp32-grade results at half the MFMAs of mode 3; operands must lie inside fp16's range after scaling
  *      (|x| < 4094, |w| < 255: normalised activations and trained weights do).
+ * Modes 0, 2, 3, 4 keep activations fp32 in HBM.
  * Parameters must be (re)loaded after switching between the fp32 / bf16 (1..3) / fp16 (4) families. */
 int cs_unet_set_precision(cs_unet* net, int planes);
-/* on != 0: every cs_unet_load_param also packs the data-gradient layout of the tensor (needed by cs_unet_backward).
+/* on != 0: every cs_unet_load_param also packs the data-gradient layout of the tensor, and cs_unet_forward records the
+ * activation tape cs_unet_backward replays (activations then stay fp32 in every precision mode).
  * Parameters loaded under the wrong mode / precision are refused at forward / backward time (CS_ERR_NOT_LOADED). */
 int cs_unet_set_training(cs_unet* net, int on);
 /* BatchNorm networks (norm_kind CS_NORM_BATCH), replaces `model.train()` / `model.eval()` for nn.BatchNorm2d inside

@@ -52,4 +52,22 @@ struct View {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// bf16 <-> fp32 on 4 packed values (activations of the bf16 datapath live in HBM as bf16, round-to-nearest-even on the way out)
+typedef float cs_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cs_f32x4 bf16x4_to_f32(uint2 v) {
+    cs_f32x4 r;
+    r.x = __builtin_bit_cast(float, v.x << 16);
+    r.y = __builtin_bit_cast(float, v.x & 0xffff0000u);
+    r.z = __builtin_bit_cast(float, v.y << 16);
+    r.w = __builtin_bit_cast(float, v.y & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;            // RNE (NaN payloads are not expected on this path)
+}
+__device__ __forceinline__ uint2 f32x4_to_bf16(cs_f32x4 v) {
+    return make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16), f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
+}
+
 }  // namespace cs

@@ -399,22 +399,27 @@ static int finish_norm(hipStream_t s, const cs_unet* net, const NormSite& ns, No
     return launch_norm_finalize(s, rt.stats, rt.tab, n, c_total, count, 1e-5f);
 }
 
-static ConvSrc lazy_src(const float* ptr, int c, int pitch, const NormRt& rt, const NormSite& ns, int tab_c) {
+static ConvSrc lazy_src(const float* ptr, int c, int pitch, const NormRt& rt, const NormSite& ns, int tab_c, bool h16 = false) {
     ConvSrc s;
-    s.ptr = ptr; s.c = c; s.pitch = pitch; s.tab = rt.tab; s.slope = ns.slope; s.tab_c = tab_c; s.tab_off = 0;
+    s.ptr = ptr; s.c = c; s.pitch = pitch; s.tab = rt.tab; s.slope = ns.slope; s.tab_c = tab_c; s.tab_off = 0; s.h16 = h16;
     return s;
 }
-static ConvSrc raw_src(const float* ptr, int c, int pitch) {
+static ConvSrc raw_src(const float* ptr, int c, int pitch, bool h16 = false) {
     ConvSrc s;
-    s.ptr = ptr; s.c = c; s.pitch = pitch;
+    s.ptr = ptr; s.c = c; s.pitch = pitch; s.h16 = h16;
     return s;
+}
+// element offset into an activation tensor whose elements are fp32 or (bf16 datapath) 16 bits wide
+static const float* act_off(const float* p, size_t elems, bool h16) {
+    return h16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p) + elems) : p + elems;
 }
 
 // forward conv on the matrix cores: fp32 MFMA or split-bf16, by net->planes
 static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, const ConvSrc& a, const ConvW& cw, float* out,
                     int pitch_out, int cout, double* stats, int n, int hin, int win) {
     if (net->planes > 0 && cw.wb)
-        return launch_conv_bf16s(s, ksize, stride, net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin, win);
+        return launch_conv_bf16s(s, ksize, stride, net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin, win, a.h16);
+    CS_REQUIRE(!a.h16, "conv: a layer without 16-bit weights met bf16 activations");
     return launch_conv_mfma(s, ksize, stride, a, ConvSrc(), cw.w, cw.bias, out, pitch_out, cout, stats, n, hin, win);
 }
 
@@ -433,6 +438,13 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                1 << nl);
     const bool inst = net->norm == CS_NORM_INSTANCE || net->batch_stats;   // statistics of the running batch are needed
     const bool want_xtab = net->norm == CS_NORM_BATCH && net->batch_stats;
+    // bf16 datapath (plain-bf16 mode, cs_unet_set_training(0)): every activation tensor between the first conv and the 3-channel
+    // top layers is bf16 in HBM - half the traffic of every HBM-bound kernel and of the conv inputs / outputs.  A handle in
+    // training mode keeps fp32 activations: the backward kernels read them.
+    const bool a16 = net->planes == 1 && !net->training;
+    auto take_act = [&](size_t count) -> float* {
+        return a16 ? reinterpret_cast<float*>(ws.take<unsigned short>(count)) : ws.take<float>(count);
+    };
     if (tape) {
         tape->valid = false;
         tape->E.assign(nl, nullptr); tape->Y.assign(nl, {}); tape->U.assign(nl, nullptr); tape->V.assign(nl, nullptr);
@@ -476,23 +488,23 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     for (int d = 0; d < nl; ++d) {
         const DownUnit& u = net->down[d];
         const int oh = ph / 2, ow = pw / 2, c = u.c, c0 = u.unit0.cout;
-        float* E = ws.take<float>((size_t)n * oh * ow * c0);          // [y0 || r]
+        float* E = take_act((size_t)n * oh * ow * c0);          // [y0 || r]
         std::vector<float*> Y(u.subunits, nullptr);
-        for (int su = 1; su < u.subunits; ++su) Y[su] = ws.take<float>((size_t)n * oh * ow * c);
-        X[d] = ws.take<float>((size_t)n * oh * ow * c);
+        for (int su = 1; su < u.subunits; ++su) Y[su] = take_act((size_t)n * oh * ow * c);
+        X[d] = take_act((size_t)n * oh * ow * c);
         for (int su = 0; su < u.subunits; ++su) new_tab(rt_down[d][su], su == 0 ? c0 : c);
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
             if (u.first) {
-                CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n));
+                CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, a16));
             } else {
-                CS_TRY(conv_fwd(s, net, 3, 2, raw_src(prev, pc, pc), u.unit0, E, c0, c0, rt_down[d][0].stats, n, ph, pw));
+                CS_TRY(conv_fwd(s, net, 3, 2, raw_src(prev, pc, pc, a16), u.unit0, E, c0, c0, rt_down[d][0].stats, n, ph, pw));
             }
             CS_TRY(finish_norm(s, net, u.norms[0], rt_down[d][0], n, c0, oh * ow, dry));
             const float* cur = E;
             int cur_pitch = c0, cur_tabc = c0;
             for (int su = 1; su < u.subunits; ++su) {
-                CS_TRY(conv_fwd(s, net, 3, 1, lazy_src(cur, c, cur_pitch, rt_down[d][su - 1], u.norms[su - 1], cur_tabc),
+                CS_TRY(conv_fwd(s, net, 3, 1, lazy_src(cur, c, cur_pitch, rt_down[d][su - 1], u.norms[su - 1], cur_tabc, a16),
                                 u.units[su - 1], Y[su], c, c, rt_down[d][su].stats, n, oh, ow));
                 CS_TRY(finish_norm(s, net, u.norms[su], rt_down[d][su], n, c, oh * ow, dry));
                 cur = Y[su];
@@ -500,8 +512,8 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 cur_tabc = c;
             }
             const int last = u.subunits - 1;
-            CS_TRY(launch_norm_act_add(s, lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc),
-                                       raw_src(E + c, c, c0), X[d], c, (int64_t)oh * ow, n));
+            CS_TRY(launch_norm_act_add(s, lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc, a16),
+                                       raw_src(act_off(E, c, a16), c, c0, a16), X[d], c, (int64_t)oh * ow, n, a16));
         }
         prev = X[d];
         ph = oh; pw = ow; pc = c;
@@ -513,24 +525,24 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         const DownUnit& u = net->bottom;
         const int c = u.c;
         std::vector<float*> Y(u.subunits);
-        for (int su = 0; su < u.subunits; ++su) Y[su] = ws.take<float>((size_t)n * ph * pw * c);
-        float* R = u.res_conv ? ws.take<float>((size_t)n * ph * pw * c) : nullptr;
-        S = ws.take<float>((size_t)n * ph * pw * c);
+        for (int su = 0; su < u.subunits; ++su) Y[su] = take_act((size_t)n * ph * pw * c);
+        float* R = u.res_conv ? take_act((size_t)n * ph * pw * c) : nullptr;
+        S = take_act((size_t)n * ph * pw * c);
         for (int su = 0; su < u.subunits; ++su) new_tab(rt_bottom[su], c);
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
-            CS_TRY(conv_fwd(s, net, 3, 1, raw_src(prev, pc, pc), u.unit0, Y[0], c, c, rt_bottom[0].stats, n, ph, pw));
+            CS_TRY(conv_fwd(s, net, 3, 1, raw_src(prev, pc, pc, a16), u.unit0, Y[0], c, c, rt_bottom[0].stats, n, ph, pw));
             CS_TRY(finish_norm(s, net, u.norms[0], rt_bottom[0], n, c, ph * pw, dry));
             if (u.res_conv)
-                CS_TRY(conv_fwd(s, net, 1, 1, raw_src(prev, pc, pc), u.res1x1, R, c, c, nullptr, n, ph, pw));
+                CS_TRY(conv_fwd(s, net, 1, 1, raw_src(prev, pc, pc, a16), u.res1x1, R, c, c, nullptr, n, ph, pw));
             for (int su = 1; su < u.subunits; ++su) {
-                CS_TRY(conv_fwd(s, net, 3, 1, lazy_src(Y[su - 1], c, c, rt_bottom[su - 1], u.norms[su - 1], c), u.units[su - 1],
+                CS_TRY(conv_fwd(s, net, 3, 1, lazy_src(Y[su - 1], c, c, rt_bottom[su - 1], u.norms[su - 1], c, a16), u.units[su - 1],
                                 Y[su], c, c, rt_bottom[su].stats, n, ph, pw));
                 CS_TRY(finish_norm(s, net, u.norms[su], rt_bottom[su], n, c, ph * pw, dry));
             }
             const int last = u.subunits - 1;
-            CS_TRY(launch_norm_act_add(s, lazy_src(Y[last], c, c, rt_bottom[last], u.norms[last], c),
-                                       u.res_conv ? raw_src(R, c, c) : raw_src(prev, c, pc), S, c, (int64_t)ph * pw, n));
+            CS_TRY(launch_norm_act_add(s, lazy_src(Y[last], c, c, rt_bottom[last], u.norms[last], c, a16),
+                                       u.res_conv ? raw_src(R, c, c, a16) : raw_src(prev, c, pc, a16), S, c, (int64_t)ph * pw, n, a16));
         }
         if (tape) { tape->Yb = Y; tape->Rb = R; tape->Sb = S; }
     }
@@ -539,32 +551,34 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     for (int d = nl - 1; d >= 0; --d) {
         const UpUnit& u = net->up[d];
         const int oh = ph * 2, ow = pw * 2, c = u.cout;
-        float* U = ws.take<float>((size_t)n * oh * ow * c);
+        const bool u16 = a16 && !u.top;                           // the 3-channel top tensors stay fp32
+        float* U = u16 ? take_act((size_t)n * oh * ow * c) : ws.take<float>((size_t)n * oh * ow * c);
         new_tab(rt_upt[d], c);
         float *V = nullptr, *D = nullptr;
         if (!u.top) {
-            V = ws.take<float>((size_t)n * oh * ow * c);
-            D = ws.take<float>((size_t)n * oh * ow * c);
+            V = take_act((size_t)n * oh * ow * c);
+            D = take_act((size_t)n * oh * ow * c);
             new_tab(rt_upu[d], c);
         }
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
-            const ConvSrc a = raw_src(X[d], u.cin_skip, u.cin_skip), b = raw_src(S, sc, sc);
+            const ConvSrc a = raw_src(X[d], u.cin_skip, u.cin_skip, a16), b = raw_src(S, sc, sc, a16);
             if (c % 16 == 0 && net->planes > 0 && u.convt.wb) {
-                CS_TRY(launch_convt_bf16s(s, net->planes, a, b, u.convt.wb, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
+                CS_TRY(launch_convt_bf16s(s, net->planes, a, b, u.convt.wb, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw, a16));
             } else if (c % 16 == 0) {
+                CS_REQUIRE(!a16, "convT: a layer without 16-bit weights met bf16 activations");
                 CS_TRY(launch_convt_mfma(s, a, b, u.convt.w, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
             } else {
                 CS_TRY(launch_convt_small(s, a, b, u.convt.w, u.convt.bias, U, c, rt_upt[d].stats, n, ph, pw));
             }
             CS_TRY(finish_norm(s, net, u.norm_t, rt_upt[d], n, c, oh * ow, dry));
-            const ConvSrc lu = lazy_src(U, c, c, rt_upt[d], u.norm_t, c);
+            const ConvSrc lu = lazy_src(U, c, c, rt_upt[d], u.norm_t, c, u16);
             if (u.top) {
                 CS_TRY(launch_conv_last(s, lu, u.unit0.w, u.unit0.bias, logits, c, n, oh, ow));
             } else {
                 CS_TRY(conv_fwd(s, net, 3, 1, lu, u.unit0, V, c, c, rt_upu[d].stats, n, oh, ow));
                 CS_TRY(finish_norm(s, net, u.norm_u, rt_upu[d], n, c, oh * ow, dry));
-                CS_TRY(launch_norm_act_add(s, lazy_src(V, c, c, rt_upu[d], u.norm_u, c), lu, D, c, (int64_t)oh * ow, n));
+                CS_TRY(launch_norm_act_add(s, lazy_src(V, c, c, rt_upu[d], u.norm_u, c, a16), lu, D, c, (int64_t)oh * ow, n, a16));
             }
         }
         S = D;
@@ -1002,7 +1016,9 @@ int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_
     src.image = x; src.sn = sn; src.sc = sc; src.sh = sh; src.sw = sw;
     src.origins = nullptr; src.img_h = h; src.img_w = w; src.roi_h = h; src.roi_w = w;
     Bump b(workspace, workspace_bytes);
-    return unet_forward_impl(net, src, n, h, w, logits_nhwc, b, (hipStream_t)stream, &net->tape);
+    // the activation tape is recorded for cs_unet_backward only in training mode (cs_unet_set_training)
+    net->tape.valid = false;
+    return unet_forward_impl(net, src, n, h, w, logits_nhwc, b, (hipStream_t)stream, net->training ? &net->tape : nullptr);
 }
 
 int64_t cs_unet_grad_numel(const cs_unet* net) { return net ? net->grad_floats : CS_ERR_INVALID; }
@@ -1037,7 +1053,7 @@ size_t cs_unet_backward_workspace_bytes(const cs_unet* net, int n, int h, int w)
 int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspace, size_t workspace_bytes, float* flat_grad,
                      void* stream) {
     CS_REQUIRE(net && grad_logits_nhwc && workspace && flat_grad, "unet_backward: null argument");
-    CS_REQUIRE(net->tape.valid, "unet_backward: no forward has been recorded (call cs_unet_forward first and keep its workspace intact)");
+    CS_REQUIRE(net->tape.valid, "unet_backward: no forward has been recorded (cs_unet_set_training(1), then cs_unet_forward, and keep its workspace intact)");
     if (int rc0 = check_loaded(net, true)) return rc0;
     hipStream_t s = (hipStream_t)stream;
     size_t acc_bytes = 0, buf_bytes = 0;

@@ -13,6 +13,8 @@ struct ConvSrc {
     const float* slope = nullptr;  // PReLU slope (device scalar); nullptr with tab set = ReLU
     int tab_c = 0;                 // channels per image in `tab` (>= c when this source is a channel sub-range)
     int tab_off = 0;               // channel offset of this source inside `tab`
+    bool h16 = false;              // `ptr` really points at bf16 elements (the bf16 datapath keeps activations as bf16 in HBM);
+                                   // pitch / c still count elements
 };
 
 // ---- weight packing (PyTorch layout -> MFMA fragment order) -----------------------------------
@@ -63,11 +65,13 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
 
 // split-bf16 variant (kernels_conv_bf16.hip): `planes` = 1 (plain bf16), 2 (3 MFMA terms) or 3 (6 terms, fp32-grade).
 // Weights come from pack_conv_weights_bf16 (always 3 planes; the kernel reads the first `planes`).
+// act16: inputs (a.h16 / b.h16) and the output are bf16 tensors in HBM (plain-bf16 mode only: planes == 1); statistics still
+// come from the fp32 accumulators.
 int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
                       const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
-                      int hin, int win);
+                      int hin, int win, bool act16 = false);
 int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSrc& b, const unsigned short* wpack, const float* bias,
-                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
+                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win, bool act16 = false);
 size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize);
 int pack_conv_weights_bf16(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
                            unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16 = false);
@@ -83,7 +87,7 @@ struct WindowSrc {
     int roi_h = 0, roi_w = 0;                // window size = conv input size
 };
 int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
-                      float* out, int pitch_out, int cout, double* stats, int n);
+                      float* out, int pitch_out, int cout, double* stats, int n, bool out16 = false);
 
 // transposed 3x3 stride 2 pad 1 output_padding 1 (MFMA), input = concat(a, b); out is [n, 2h, 2w, cout]
 int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* wpack, const float* bias,
@@ -110,7 +114,8 @@ int launch_bn_train_finalize(hipStream_t s, const double* stats, const float* we
                              float* run_var, float2* tab, float2* xtab, int n, int c, int c_total, int count, float eps,
                              float momentum);
 // out = T_y(y) + T_r(r)   (T = lazy norm/act or identity), all NHWC with channel count c
-int launch_norm_act_add(hipStream_t s, const ConvSrc& y, const ConvSrc& r, float* out, int pitch_out, int64_t npix_per_image, int n);
+int launch_norm_act_add(hipStream_t s, const ConvSrc& y, const ConvSrc& r, float* out, int pitch_out, int64_t npix_per_image, int n,
+                        bool act16 = false);
 
 // ---- backward pass (kernels_bwd.hip) -----------------------------------------------------------
 // InstanceNorm + PReLU backward of `y` (raw conv output + forward table/slope): da -> dy; red [n][c][2] and dslope

@@ -111,10 +111,10 @@ __device__ __forceinline__ void stats_commit(double s, double q, double* dst, in
 // go through a wave-private LDS slab so that the global stores are 16 B per lane with consecutive lanes on
 // consecutive channels of one pixel (whole 64*NT-byte pixel records, full cache lines) instead of 64-byte fragments.
 // `ep` points at this wave's slab of ROWS*16 pixels x (16*NT + 4) floats.  Returns nothing; stats are separate.
-template <int NT, int ROWS>
+template <int NT, int ROWS, bool OUT16 = false>
 __device__ __forceinline__ void epilogue_store(float* ep, const f32x4 (&vals)[ROWS][NT], int lane, float* out_row0, int64_t row_stride,
                                                int pitch, int n_rows_valid, int n_cols_valid, const float* add_row0 = nullptr,
-                                               int64_t add_row_stride = 0, int add_pitch = 0) {
+                                               int64_t add_row_stride = 0, int add_pitch = 0, int64_t out_elem0 = 0) {
     constexpr int EPS = 16 * NT + 4;
     const int pl = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -133,7 +133,10 @@ __device__ __forceinline__ void epilogue_store(float* ep, const f32x4 (&vals)[RO
         if (m < n_rows_valid && x < n_cols_valid) {
             f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
             if (add_row0) v += *reinterpret_cast<const f32x4*>(add_row0 + m * add_row_stride + (int64_t)x * add_pitch + c4 * 4);
-            *reinterpret_cast<f32x4*>(out_row0 + m * row_stride + (int64_t)x * pitch + c4 * 4) = v;
+            if constexpr (OUT16)      // out_row0 = tensor base, out_elem0 = element offset of the tile (bf16 elements)
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out_row0) + out_elem0 + m * row_stride + (int64_t)x * pitch + c4 * 4) = f32x4_to_bf16(v);
+            else
+                *reinterpret_cast<f32x4*>(out_row0 + out_elem0 + m * row_stride + (int64_t)x * pitch + c4 * 4) = v;
         }
     }
 }
@@ -619,7 +622,7 @@ struct FirstParams {
     int pitch_out, cout, ntile_total, n, hout, wout, tiles_x, tiles_y;
 };
 
-template <int S, int CIN, int NT, int MT>
+template <int S, int CIN, int NT, int MT, bool OUT16>
 __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
     constexpr int TH = 4 * MT, TW = 16;
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
@@ -734,9 +737,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
     }
     {
         const int oy = oy0 + wave * MT;
-        float* out_row0 = p.out + (((size_t)img * p.hout + oy) * p.wout + ox0) * p.pitch_out;
-        epilogue_store<NT, MT>(smem + wave * EPW, acc, lane, out_row0, (int64_t)p.wout * p.pitch_out, p.pitch_out,
-                               p.hout - oy, p.wout - ox0);
+        const int64_t elem0 = (((int64_t)img * p.hout + oy) * p.wout + ox0) * p.pitch_out;
+        epilogue_store<NT, MT, OUT16>(smem + wave * EPW, acc, lane, p.out, (int64_t)p.wout * p.pitch_out, p.pitch_out,
+                                      p.hout - oy, p.wout - ox0, nullptr, 0, 0, elem0);
     }
     if (p.stats) {
         __syncthreads();
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
 }
 
 int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
-                      float* out, int pitch_out, int cout, double* stats, int n) {
+                      float* out, int pitch_out, int cout, double* stats, int n, bool out16) {
     CS_REQUIRE(cin == 3, "first conv: in_channels %d unsupported (the reference always feeds 3)", cin);
     CS_REQUIRE(stride == 2, "first conv: stride %d unsupported", stride);
     CS_REQUIRE(cout == 16 || cout == 32 || cout == 64 || cout == 128, "first conv: fused cout %d unsupported", cout);
@@ -768,14 +771,18 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
     p.tiles_y = ceil_div(p.hout, 4 * MT);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * n));
     const double flops = 2.0 * n * p.hout * p.wout * (double)cout * cin * 9;
-    const double bytes = 4.0 * n * ((double)src.roi_h * src.roi_w * cin + (double)p.hout * p.wout * cout);
+    const double bytes = n * (4.0 * src.roi_h * src.roi_w * cin + (out16 ? 2.0 : 4.0) * p.hout * p.wout * cout);
     ProfScope prof(K_CONV_FIRST, s, flops, bytes);
+#define CS_FIRST(NT_)                                                                                          \
+    if (out16) hipLaunchKernelGGL((conv_first_kernel<2, 3, NT_, MT, true>), grid, dim3(256), 0, s, p);         \
+    else hipLaunchKernelGGL((conv_first_kernel<2, 3, NT_, MT, false>), grid, dim3(256), 0, s, p);
     switch (cout / 16) {
-        case 1: hipLaunchKernelGGL((conv_first_kernel<2, 3, 1, MT>), grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((conv_first_kernel<2, 3, 2, MT>), grid, dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((conv_first_kernel<2, 3, 4, MT>), grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((conv_first_kernel<2, 3, 8, MT>), grid, dim3(256), 0, s, p); break;
+        case 1: CS_FIRST(1) break;
+        case 2: CS_FIRST(2) break;
+        case 4: CS_FIRST(4) break;
+        default: CS_FIRST(8) break;
     }
+#undef CS_FIRST
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -15,6 +15,8 @@
 //     so its B fragments are private: they go L2 -> registers as lane-linear 16-byte loads, a whole chunk ahead of
 //     their use (ring of taps x planes fragments) and never touch LDS;
 //   * epilogue as in the fp32 kernel (bias, fp64 statistics, full-line stores through an LDS slab).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace cs {
@@ -71,6 +73,12 @@ __device__ __forceinline__ bf16x4 split_plane(f32x4& v, int pn) {
     }
 }
 typedef __attribute__((address_space(3))) void lds_void;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));   // 4 bf16 activations as loaded from HBM (bf16 datapath)
+__device__ __forceinline__ f32x4 bf16x4_to_f32(u32x2 v) { return cs::bf16x4_to_f32(make_uint2(v.x, v.y)); }
+__device__ __forceinline__ u32x2 f32x4_to_bf16v(f32x4 v) {
+    const uint2 r = cs::f32x4_to_bf16(v);
+    return u32x2{r.x, r.y};
+}
 
 struct SrcDevB {
     const float* ptr;
@@ -122,8 +130,11 @@ __device__ __forceinline__ void stats_commit_b(double s, double q, double* dst, 
 // block = 4 waves arranged WN (along output channels) x WM = 4 / WN (along pixel rows); each wave owns NTW 16-channel
 // tiles and MTW pixel rows.  A (pixels) comes from the LDS planes shared by the block; B (weights) is private to the wave
 // and goes global -> registers, one tap ROW ahead (ring of KS x NTW x NP fragments), so no weight ever touches LDS.
-template <int S, int KS, int WN, int NTW, int NP, int THX>
+// A16: the bf16 datapath - inputs and output are bf16 tensors in HBM (half the activation traffic); only with NP == 1.
+template <int S, int KS, int WN, int NTW, int NP, int THX, bool A16>
 __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
+    static_assert(!A16 || NP == 1, "bf16 activations in HBM only make sense for the plain-bf16 mode");
+    typedef typename std::conditional<A16, u32x2, f32x4>::type raw4;
     constexpr bool F16 = SplitCfg<NP>::f16;
     constexpr int NPL = SplitCfg<NP>::planes, NTERM = SplitCfg<NP>::terms;
     constexpr int WM = 4 / WN;
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     }
 
     const int chunks_a = (p.a.c + 31) >> 5, chunks = chunks_a + ((p.b.c + 31) >> 5);
-    f32x4 rin[IN_ITERS];
+    raw4 rin[IN_ITERS];
     f32x4 t0, t1;
     float slope = 0.f;
     bool lazy = false, qvalid = false;
@@ -198,11 +209,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
         const float* sp = (lazy && src.slope) ? src.slope : p.dummy;
         slope = *sp;
         if (!(lazy && src.slope)) slope = 0.f;
-        const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + cq;
+        const size_t base_el = (size_t)img * p.hin * p.win * src.pitch + cq;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) {
             const int o = goff[it] >= 0 ? goff[it] : 0;
-            rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * src.pitch);
+            if constexpr (A16) rin[it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(src.ptr) + base_el + (size_t)o * src.pitch);
+            else rin[it] = *reinterpret_cast<const f32x4*>(src.ptr + base_el + (size_t)o * src.pitch);
         }
     };
     auto store_input = [&](char* in_s) {
@@ -210,7 +222,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
         for (int it = 0; it < IN_ITERS; ++it) {
             const int pix = (tid >> 3) + 32 * it;
             if (IN_ITEMS % 256 == 0 || pix < IH * IW) {
-                f32x4 v = rin[it];
+                f32x4 v;
+                if constexpr (A16) v = bf16x4_to_f32(rin[it]);
+                else v = rin[it];
                 if (lazy) {
                     v.x = prelu_h(v.x * t0.x + t0.y, slope);
                     v.y = prelu_h(v.y * t0.z + t0.w, slope);
@@ -325,34 +339,39 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     __syncthreads();
     {
         constexpr int F4 = NTB * 4;                          // float4 per pixel record of this block
-        float* out0 = p.out + (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + wk.ct * NTB * 16;
+        const size_t el0 = (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + wk.ct * NTB * 16;
         for (int i = tid; i < TH * 16 * F4; i += 256) {
             const int pix = i / F4, c4 = i - pix * F4;
             const int row = pix >> 4, x = pix & 15;
-            if (oy0 + row < p.hout && ox0 + x < p.wout)
-                *reinterpret_cast<f32x4*>(out0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) =
-                    *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+            if (oy0 + row < p.hout && ox0 + x < p.wout) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                const size_t el = el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4;
+                if constexpr (A16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el) = f32x4_to_bf16v(v);
+                else *reinterpret_cast<f32x4*>(p.out + el) = v;
+            }
         }
     }
 }
 
 static SrcDevB to_devb(const ConvSrc& s) { return SrcDevB{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
 
-template <int S, int KS, int WN, int NTW, int NP, int THX = 1>
+template <int S, int KS, int WN, int NTW, int NP, int THX = 1, bool A16 = false>
 static int launch_b(hipStream_t s, ConvBParams p) {
     constexpr int TH = THX * ((S == 1) ? 8 : 4);
     p.tiles_x = ceil_div(p.wout, 16);
     p.tiles_y = ceil_div(p.hout, TH);
     dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
-    hipLaunchKernelGGL((conv_bf16s_kernel<S, KS, WN, NTW, NP, THX>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_bf16s_kernel<S, KS, WN, NTW, NP, THX, A16>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
 int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
                       const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
-                      int hin, int win) {
+                      int hin, int win, bool act16) {
     CS_REQUIRE(ksize == 3 || ksize == 1, "conv(bf16): ksize %d unsupported", ksize);
+    CS_REQUIRE(!act16 || planes == 1, "conv(bf16): bf16 activations in HBM go with the plain-bf16 mode only");
+    CS_REQUIRE(a.h16 == act16 && (b.c == 0 || b.h16 == act16), "conv(bf16): activation element type does not match the mode");
     CS_REQUIRE((stride == 1 || stride == 2) && !(ksize == 1 && stride != 1), "conv(bf16): stride %d unsupported", stride);
     CS_REQUIRE(planes >= 1 && planes <= 4, "conv(bf16): %d planes", planes);
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "conv(bf16): channels must be multiples of 16");
@@ -373,23 +392,25 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     const bool tall = (tall_env & 1) && stride == 1 && p.hout >= 16;
     const bool wide128 = (tall_env & 2) && cout % 128 == 0;
     const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
-    const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
+    const double esz = act16 ? 2.0 : 4.0;
+    const double bytes = esz * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
-#define CS_B3(S_, KS_, NP_)                                                         \
+#define CS_B3(S_, KS_, NP_, A16_)                                                   \
     switch (wn) {                                                                   \
-        case 4: if ((tall_env & 4) && S_ == 1 && KS_ == 3 && NP_ != 3 && cout % 128 == 0) return launch_b<S_, KS_, 4, 2, (NP_ == 3 ? 4 : NP_)>(s, p); \
-                if (tall && (NP_ == 4 || NP_ <= 2) && KS_ == 3) return launch_b<S_, KS_, 2, 2, (NP_ == 3 ? 4 : NP_), 2>(s, p); \
-                if (wide128 && S_ == 2) return launch_b<S_, KS_, 4, 2, NP_>(s, p);    \
-                return launch_b<S_, KS_, 2, 2, NP_>(s, p);                          \
-        case 2: return launch_b<S_, KS_, 2, 1, NP_>(s, p);                          \
-        default: return launch_b<S_, KS_, 1, 1, NP_>(s, p);                         \
+        case 4: if ((tall_env & 4) && S_ == 1 && KS_ == 3 && NP_ != 3 && cout % 128 == 0) return launch_b<S_, KS_, 4, 2, (NP_ == 3 ? 4 : NP_), 1, A16_>(s, p); \
+                if (tall && (NP_ == 4 || NP_ <= 2) && KS_ == 3) return launch_b<S_, KS_, 2, 2, (NP_ == 3 ? 4 : NP_), 2, A16_>(s, p); \
+                if (wide128 && S_ == 2) return launch_b<S_, KS_, 4, 2, NP_, 1, A16_>(s, p);    \
+                return launch_b<S_, KS_, 2, 2, NP_, 1, A16_>(s, p);                 \
+        case 2: return launch_b<S_, KS_, 2, 1, NP_, 1, A16_>(s, p);                 \
+        default: return launch_b<S_, KS_, 1, 1, NP_, 1, A16_>(s, p);                \
     }
 #define CS_B2(S_, KS_)                                                              \
+    if (act16) { CS_B3(S_, KS_, 1, true) }                                          \
     switch (planes) {                                                               \
-        case 4: CS_B3(S_, KS_, 4)                                                   \
-        case 3: CS_B3(S_, KS_, 3)                                                   \
-        case 2: CS_B3(S_, KS_, 2)                                                   \
-        default: CS_B3(S_, KS_, 1)                                                  \
+        case 4: CS_B3(S_, KS_, 4, false)                                            \
+        case 3: CS_B3(S_, KS_, 3, false)                                            \
+        case 2: CS_B3(S_, KS_, 2, false)                                            \
+        default: CS_B3(S_, KS_, 1, false)                                           \
     }
     if (ksize == 1) { CS_B2(1, 1) }
     if (stride == 1) { CS_B2(1, 3) }
@@ -402,8 +423,10 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
 // transposed conv k3 s2 p1 op1, split-bf16: same operand handling as above, 4 output phases per input pixel
 //   out[2i+a][2j+b] += in[i+di][j+dj] * W[ky][kx],  ky: 0->(a=1,di=1) 1->(a=0,di=0) 2->(a=1,di=0); same for kx.
 // ------------------------------------------------------------------------------------------------
-template <int WN, int NTW, int NP>
+template <int WN, int NTW, int NP, bool A16>
 __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
+    static_assert(!A16 || NP == 1, "bf16 activations in HBM only make sense for the plain-bf16 mode");
+    typedef typename std::conditional<A16, u32x2, f32x4>::type raw4;
     constexpr bool F16 = SplitCfg<NP>::f16;
     constexpr int NPL = SplitCfg<NP>::planes, NTERM = SplitCfg<NP>::terms, NACC = 1;
     constexpr int WM = 4 / WN, TH = 4, TW = 16, MTW = TH / WM, NTB = WN * NTW;
@@ -453,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
         goff[it] = (pix < IH * IW && gy < p.hin && gx < p.win) ? gy * p.win + gx : -1;
     }
     const int chunks_a = (p.a.c + 31) >> 5, chunks = chunks_a + ((p.b.c + 31) >> 5);
-    f32x4 rin[IN_ITERS];
+    raw4 rin[IN_ITERS];
     f32x4 t0, t1;
     float slope = 0.f;
     bool lazy = false, qvalid = false;
@@ -471,11 +494,12 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
         const float* sp = (lazy && src.slope) ? src.slope : p.dummy;
         slope = *sp;
         if (!(lazy && src.slope)) slope = 0.f;
-        const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + cq;
+        const size_t base_el = (size_t)img * p.hin * p.win * src.pitch + cq;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) {
             const int o = goff[it] >= 0 ? goff[it] : 0;
-            rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * src.pitch);
+            if constexpr (A16) rin[it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(src.ptr) + base_el + (size_t)o * src.pitch);
+            else rin[it] = *reinterpret_cast<const f32x4*>(src.ptr + base_el + (size_t)o * src.pitch);
         }
     };
     auto store_input = [&]() {
@@ -483,7 +507,9 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
         for (int it = 0; it < IN_ITERS; ++it) {
             const int pix = (tid >> 3) + 32 * it;
             if (IN_ITEMS % 256 == 0 || pix < IH * IW) {
-                f32x4 v = rin[it];
+                f32x4 v;
+                if constexpr (A16) v = bf16x4_to_f32(rin[it]);
+                else v = rin[it];
                 if (lazy) {
                     v.x = prelu_h(v.x * t0.x + t0.y, slope);
                     v.y = prelu_h(v.y * t0.z + t0.w, slope);
@@ -588,28 +614,33 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     __syncthreads();
     {
         constexpr int F4 = NTB * 4;
-        float* out0 = p.out + (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;
+        const size_t el0 = (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;
         for (int i = tid; i < 2 * TH * 32 * F4; i += 256) {
             const int pix = i / F4, c4 = i - pix * F4;
             const int row = pix >> 5, x = pix & 31;
-            if (2 * iy0 + row < p.hout && 2 * ix0 + x < p.wout)
-                *reinterpret_cast<f32x4*>(out0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) =
-                    *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+            if (2 * iy0 + row < p.hout && 2 * ix0 + x < p.wout) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                const size_t el = el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4;
+                if constexpr (A16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el) = f32x4_to_bf16v(v);
+                else *reinterpret_cast<f32x4*>(p.out + el) = v;
+            }
         }
     }
 }
 
-template <int WN, int NTW, int NP>
+template <int WN, int NTW, int NP, bool A16 = false>
 static int launch_tb(hipStream_t s, ConvBParams p) {
     dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
-    hipLaunchKernelGGL((convt_bf16s_kernel<WN, NTW, NP>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((convt_bf16s_kernel<WN, NTW, NP, A16>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
 
 int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSrc& b, const unsigned short* wpack, const float* bias,
-                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
+                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win, bool act16) {
     CS_REQUIRE(planes >= 1 && planes <= 4, "convT(bf16): %d planes", planes);
+    CS_REQUIRE(!act16 || planes == 1, "convT(bf16): bf16 activations in HBM go with the plain-bf16 mode only");
+    CS_REQUIRE(a.h16 == act16 && (b.c == 0 || b.h16 == act16), "convT(bf16): activation element type does not match the mode");
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "convT(bf16): channels must be multiples of 16");
     ConvBParams p{};
     p.a = to_devb(a);
@@ -621,19 +652,20 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
     p.tiles_y = ceil_div(hin, 4);
     const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
     const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
-    const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
+    const double bytes = (act16 ? 2.0 : 4.0) * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
     ProfScope prof(K_CONVT, s, flops, bytes);
-#define CS_TB(NP_)                                                   \
+#define CS_TB(NP_, A16_)                                             \
     switch (wn) {                                                    \
-        case 4: return launch_tb<2, 2, NP_>(s, p);                   \
-        case 2: return launch_tb<2, 1, NP_>(s, p);                   \
-        default: return launch_tb<1, 1, NP_>(s, p);                  \
+        case 4: return launch_tb<2, 2, NP_, A16_>(s, p);             \
+        case 2: return launch_tb<2, 1, NP_, A16_>(s, p);             \
+        default: return launch_tb<1, 1, NP_, A16_>(s, p);            \
     }
+    if (act16) { CS_TB(1, true) }
     switch (planes) {
-        case 4: CS_TB(4)
-        case 3: CS_TB(3)
-        case 2: CS_TB(2)
-        default: CS_TB(1)
+        case 4: CS_TB(4, false)
+        case 3: CS_TB(3, false)
+        case 2: CS_TB(2, false)
+        default: CS_TB(1, false)
     }
 #undef CS_TB
 }

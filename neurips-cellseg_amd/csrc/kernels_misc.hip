@@ -3,6 +3,8 @@
 //
 // Reference rows: M (instance_norm / prelu / residual add inside monai UNet),
 // T step 6 (out / count map, crop), S (softmax(dim=1)[0,1], predict.py:110-111), P1 (> 0.5, predict.py:113).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace cs {
@@ -106,8 +108,11 @@ struct AddSrc {
     int pitch, tab_c, tab_off;
 };
 
+template <bool A16>
 __device__ __forceinline__ f32x4 load_lazy4(const AddSrc& s, int img, int64_t pix, int c4) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(s.ptr + pix * s.pitch + 4 * c4);
+    f32x4 v;
+    if constexpr (A16) v = bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(s.ptr) + pix * s.pitch + 4 * c4));
+    else v = *reinterpret_cast<const f32x4*>(s.ptr + pix * s.pitch + 4 * c4);
     if (s.tab) {
         const f32x4* t = reinterpret_cast<const f32x4*>(s.tab + (size_t)img * s.tab_c + s.tab_off + 4 * c4);
         const f32x4 t0 = t[0], t1 = t[1];
@@ -120,27 +125,34 @@ __device__ __forceinline__ f32x4 load_lazy4(const AddSrc& s, int img, int64_t pi
     return v;
 }
 
+template <bool A16>
 __global__ void norm_act_add_kernel(AddSrc y, AddSrc r, float* out, int pitch_out, int c4n, int64_t npix, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pix = i / c4n;
         const int c4 = (int)(i - pix * c4n);
         const int img = (int)(pix / npix);
-        const f32x4 a = load_lazy4(y, img, pix, c4);
-        const f32x4 b = load_lazy4(r, img, pix, c4);
-        *reinterpret_cast<f32x4*>(out + pix * pitch_out + 4 * c4) = a + b;
+        const f32x4 a = load_lazy4<A16>(y, img, pix, c4);
+        const f32x4 b = load_lazy4<A16>(r, img, pix, c4);
+        if constexpr (A16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + pix * pitch_out + 4 * c4) = f32x4_to_bf16(a + b);
+        else *reinterpret_cast<f32x4*>(out + pix * pitch_out + 4 * c4) = a + b;
     }
 }
 
 static AddSrc to_add(const ConvSrc& s) { return AddSrc{s.ptr, s.tab, s.slope, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
 
 int launch_norm_act_add(hipStream_t s, const ConvSrc& y, const ConvSrc& r, float* out, int pitch_out, int64_t npix_per_image,
-                        int n) {
+                        int n, bool act16) {
     CS_REQUIRE(y.c == r.c && y.c % 4 == 0, "norm_act_add: channel mismatch %d vs %d", y.c, r.c);
+    CS_REQUIRE(y.h16 == act16 && r.h16 == act16, "norm_act_add: mixed activation element types");
     const int c4n = y.c / 4;
     const int64_t total = (int64_t)n * npix_per_image * c4n;
     const int64_t blocks = (total + 255) / 256;
-    ProfScope prof(K_NORM_ACT_ADD, s, 0, 48.0 * total);
-    hipLaunchKernelGGL(norm_act_add_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, to_add(y),
+    ProfScope prof(K_NORM_ACT_ADD, s, 0, (act16 ? 24.0 : 48.0) * total);
+    if (act16)
+        hipLaunchKernelGGL(norm_act_add_kernel<true>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, to_add(y),
+                           to_add(r), out, pitch_out, c4n, npix_per_image, total);
+    else
+        hipLaunchKernelGGL(norm_act_add_kernel<false>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, to_add(y),
                        to_add(r), out, pitch_out, c4n, npix_per_image, total);
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -254,7 +266,7 @@ struct __attribute__((packed, aligned(4))) Px3 {             // one 3-channel pi
     float c0, c1, c2;
 };
 
-template <int CIN>
+template <int CIN, bool IN16>
 __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSrc b, const float* __restrict__ w, const float* bias,
                                                              float* out, double* stats, int hin, int win, int tiles_x, int tiles_y,
                                                              int n_tiles) {
@@ -283,8 +295,9 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
         w_s[i] = nn < 27 ? w[(size_t)k * 27 + nn] : 0.f;
     }
     constexpr int c4n = CIN / 4, ITERS = MPAD * c4n / 256;   // unconditional, fully unrolled loads: all in flight at once
-    f32x4m rx[ITERS];
-    // tile-invariant part of the staging addresses
+    typedef typename std::conditional<IN16, uint2, f32x4m>::type raw4;   // 4 channels as loaded (bf16 bits or fp32)
+    raw4 rx[ITERS];
+    // tile-invariant part of the staging addresses (element offsets; bf16 sources are addressed through a 16-bit pointer)
     const float* sptr[ITERS];
     int rel[ITERS], spitch[ITERS], liy[ITERS], lix[ITERS];
 #pragma unroll
@@ -294,7 +307,8 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
         const int iy = pix / IW, ix = pix - iy * IW;
         const int c = 4 * c4;
         const bool in_a = c < a.c;
-        sptr[it] = in_a ? a.ptr + c : b.ptr + (c - a.c);
+        sptr[it] = IN16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(in_a ? a.ptr : b.ptr) + (in_a ? c : c - a.c))
+                        : (in_a ? a.ptr + c : b.ptr + (c - a.c));
         spitch[it] = in_a ? a.pitch : b.pitch;
         rel[it] = (iy * win + ix) * spitch[it];
         liy[it] = pix < NPIX ? iy : (1 << 20);               // rows beyond the patch are never valid
@@ -309,7 +323,8 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
         for (int it = 0; it < ITERS; ++it) {
             const bool ok = iy0 + liy[it] < hin && ix0 + lix[it] < win;
             const int off = ok ? base_px * spitch[it] + rel[it] : 0;
-            rx[it] = *reinterpret_cast<const f32x4m*>(sptr[it] + off);
+            if constexpr (IN16) rx[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(sptr[it]) + off);
+            else rx[it] = *reinterpret_cast<const f32x4m*>(sptr[it] + off);
             okmask |= ok ? (1u << it) : 0u;
         }
     };
@@ -377,7 +392,10 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
         for (int it = 0; it < ITERS; ++it) {
             const int i = tid + 256 * it;
             const int pix = i / c4n, c4 = i - pix * c4n;
-            *reinterpret_cast<f32x4m*>(&x_s[pix * XP + 4 * c4]) = ((okmask >> it) & 1u) ? rx[it] : f32x4m{0.f, 0.f, 0.f, 0.f};
+            f32x4m xv;
+            if constexpr (IN16) xv = bf16x4_to_f32(rx[it]);
+            else xv = rx[it];
+            *reinterpret_cast<f32x4m*>(&x_s[pix * XP + 4 * c4]) = ((okmask >> it) & 1u) ? xv : f32x4m{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
         // advance to the next tile (the last trip re-reads its own tile from L2: the loads stay unconditional)
@@ -450,11 +468,13 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
     CS_REQUIRE(cout == 3, "convT(small): cout %d unsupported (3-class contract)", cout);
     CS_REQUIRE(a.tab == nullptr && b.tab == nullptr, "convT(small): lazy inputs unsupported");
     CS_REQUIRE(a.c % 4 == 0 && b.c % 4 == 0, "convT(small): channels must be multiples of 4");
+    CS_REQUIRE(a.h16 == b.h16 || b.c == 0, "convT(small): mixed activation element types");
     const int cin = a.c + b.c;
     const size_t lds = (size_t)cin * 28 * sizeof(float);
     const double flops = 2.0 * n * hin * win * (double)cout * cin * 9;
-    const double bytes = 4.0 * n * ((double)hin * win * cin + 4.0 * hin * win * cout);
+    const double bytes = n * ((a.h16 ? 2.0 : 4.0) * hin * win * cin + 4.0 * 4.0 * hin * win * cout);
     ProfScope prof(K_CONVT_TOP, s, flops, bytes);
+    CS_REQUIRE(!a.h16 || cin == 32 || cin == 64 || cin == 128, "convT(small): bf16 activations need 32 / 64 / 128 input channels (got %d)", cin);
     if ((cin == 32 || cin == 64 || cin == 128) && a.c % 4 == 0) {      // GEMM + gather on the matrix cores
         const int tiles_x = ceil_div(win, 16), tiles_y = ceil_div(hin, 8);
         const size_t sm = ((size_t)160 * (cin + 4) + (size_t)cin * 32) * sizeof(float);
@@ -462,9 +482,13 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
         const int resident = 256 * (int)((160 * 1024) / (sm + 64));           // persistent blocks: as many as the LDS lets live at once
         const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
         const SmallSrc sa{a.ptr, a.c, a.pitch}, sb{b.ptr, b.c, b.pitch};
-        if (cin == 32) hipLaunchKernelGGL((convt_top_gemm_kernel<32>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles);
-        else if (cin == 64) hipLaunchKernelGGL((convt_top_gemm_kernel<64>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles);
-        else hipLaunchKernelGGL((convt_top_gemm_kernel<128>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles);
+#define CS_TOP(CIN_, H_) hipLaunchKernelGGL((convt_top_gemm_kernel<CIN_, H_>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles)
+        if (a.h16) {
+            if (cin == 32) CS_TOP(32, true); else if (cin == 64) CS_TOP(64, true); else CS_TOP(128, true);
+        } else {
+            if (cin == 32) CS_TOP(32, false); else if (cin == 64) CS_TOP(64, false); else CS_TOP(128, false);
+        }
+#undef CS_TOP
         CS_HIP(hipGetLastError());
         return CS_OK;
     }

@@ -43,9 +43,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfm
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA peak; a split-bf16 product costs 6 / 3 / 1 bf16 MFMA terms
 PEAK_FP8_MFMA_TFLOPS = 5000.0    # dense fp8 MFMA peak
 MFMA_PEAK = {"fp32": PEAK_F32_MFMA_TFLOPS, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3,
-             "bf16": PEAK_BF16_MFMA_TFLOPS}
+             "bf16": PEAK_BF16_MFMA_TFLOPS, "fp8": PEAK_FP8_MFMA_TFLOPS}
 DTYPE = {"fp32": "f32", "fp16x3": "f32 (split-fp16, 2 planes x 3 MFMA terms, fp32 accumulate)", "bf16x6": "f32 (split-bf16, 3 planes x 6 MFMA terms, fp32 accumulate)",
-         "bf16x3": "split-bf16 (2 planes x 3 terms)", "bf16": "bf16"}
+         "bf16x3": "split-bf16 (2 planes x 3 terms)", "bf16": "bf16 (weights, activations in HBM; fp32 accumulate)",
+         "fp8": "fp8 e4m3 (weights with per-channel scales, activations converted from bf16 while staged; fp32 accumulate)"}
 PEAK_HBM_GBS = 8000.0
 WIDTHS = {"baseline32": (32, 64, 128, 256, 512), "reference16": (16, 32, 64, 128, 256),
           "deep64": (64, 128, 256, 512, 1024)}          # BASELINE.json configs[4] width (use with --roi 512)

@@ -64,8 +64,12 @@ int cs_unet_destroy(cs_unet* net);
  *      (weights * 2^8, staged activations * 2^4, sum * 2^-12), 3 terms on v_mfma_f32_16x16x32_f16 in one accumulator:
  *      fp32-grade results at half the MFMAs of mode 3; operands must lie inside fp16's range after scaling
  *      (|x| < 4094, |w| < 255: normalised activations and trained weights do).
+ *   5  fp8 (BASELINE.json configs[4]): weights stored as OCP e4m3 with one fp32 scale per output channel (amax / 448, computed
+ *      when the parameter is loaded), activations bf16 in HBM and converted to e4m3 while they are staged (after the lazy
+ *      InstanceNorm + PReLU), v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 rate), fp32 accumulate,
+ *      weight scale applied in the epilogue, bf16 out.  Inference only; judged by argmax / F1 like mode 1.
  * Modes 0, 2, 3, 4 keep activations fp32 in HBM.
- * Parameters must be (re)loaded after switching between the fp32 / bf16 (1..3) / fp16 (4) families. */
+ * Parameters must be (re)loaded after switching between the fp32 / bf16 (1..3) / fp16 (4) / fp8 (5) families. */
 int cs_unet_set_precision(cs_unet* net, int planes);
 /* on != 0: every cs_unet_load_param also packs the data-gradient layout of the tensor, and cs_unet_forward records the
  * activation tape cs_unet_backward replays (activations then stay fp32 in every precision mode).

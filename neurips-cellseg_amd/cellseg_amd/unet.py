@@ -176,7 +176,7 @@ class UNet(nn.Module):
         self._grad_slots: Dict[str, Tuple[int, int, Tuple[int, ...]]] = {}
         self._generation = 0           # id of the grad-enabled forward that owns the engine's activation tape
         self.flat_grad = None          # the flat gradient bucket of the last backward (what data parallel all-reduces)
-        self.precision = "fp32"        # "fp32" | "fp16x3", "bf16x6" (fp32-grade) | "bf16x3" | "bf16": matrix-core arithmetic of the convs
+        self.precision = "fp32"        # "fp32" | "fp16x3", "bf16x6" (fp32-grade) | "bf16x3" | "bf16" (bf16 datapath) | "fp8": arithmetic of the convs
 
     # ---- parameter registration under MONAI's dotted names -------------------------------------------
     def _register(self, key: str, shape) -> None:
@@ -238,9 +238,11 @@ class UNet(nn.Module):
                 for d in shape:
                     numel *= d
                 self._grad_slots[key] = (int(off), numel, tuple(shape))
-        planes = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "fp16x3": 4}.get(self.precision)
+        planes = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "fp16x3": 4, "fp8": 5}.get(self.precision)
         if planes is None:
-            raise ValueError(f"precision '{self.precision}' (fp32 | fp16x3 | bf16x6 | bf16x3 | bf16)")
+            raise ValueError(f"precision '{self.precision}' (fp32 | fp16x3 | bf16x6 | bf16x3 | bf16 | fp8)")
+        if planes == 5 and train:
+            raise _lib.CellSegHipError("precision 'fp8' is an inference mode: training runs in fp32 / bf16")
         check(lib.cs_unet_set_precision(self._engine.handle, planes), "cs_unet_set_precision")
         want_train = bool(train)
         check(lib.cs_unet_set_training(self._engine.handle, int(want_train)), "cs_unet_set_training")
@@ -248,7 +250,7 @@ class UNet(nn.Module):
             check(lib.cs_unet_set_batch_stats(self._engine.handle, int(self.training)), "cs_unet_set_batch_stats")
         # The engine packs the split-bf16 / data-gradient weight layouts only when asked.  `_pack_state` says which of them
         # EVERY uploaded tensor currently has; a missing one forces a full re-upload under the new flags.
-        fmt = 2 if planes == 4 else 1 if planes > 0 else 0       # 16-bit plane packing the kernels will read (bf16 / fp16 family)
+        fmt = 3 if planes == 5 else 2 if planes == 4 else 1 if planes > 0 else 0    # low-precision packing the kernels will read
         need = (fmt, want_train)
         state = getattr(self, "_pack_state", (0, False))
         if (need[0] and state[0] != need[0]) or (need[1] and not state[1]):

@@ -129,6 +129,8 @@ struct ConvW {             // packed weights + bias of one (possibly fused) conv
     float* w = nullptr;    // packed (MFMA kernels) or PyTorch layout (small VALU kernels)
     float* wd = nullptr;   // the same weights packed for the DATA-GRADIENT launch (see kernels_bwd.hip header)
     unsigned short* wb = nullptr;   // 3 bf16 planes in 16x16x32 fragment order (split-bf16 forward kernels)
+    unsigned char* w8 = nullptr;    // e4m3 weights in 16x16x128 fragment order (fp8 forward kernels)
+    float* wscale = nullptr;        // their per-output-channel scales [cout]
     float* bias = nullptr;
     int cin = 0, cout = 0; // cout = total (fused) output channels
     int p_w[2] = {-1, -1}, p_b[2] = {-1, -1};   // parameter indices (slot 1 = fused residual conv)
@@ -165,7 +167,7 @@ struct ParamEntry {
     float* raw = nullptr;                         // tensors the engine keeps verbatim (BatchNorm affine / running statistics, PReLU slope)
     bool has_dgrad = false, has_bf16 = false;     // tensor takes part in the data-gradient / split-bf16 packings
     bool dgrad_packed = false;
-    int wb_format = 0;                            // 16-bit plane packing present: 0 none, 1 split-bf16, 2 split-fp16
+    int wb_format = 0;                            // low-precision packing present: 0 none, 1 split-bf16, 2 split-fp16, 3 fp8
     int64_t grad_off = 0;      // float offset of this parameter's gradient in the flat gradient buffer
     int64_t numel() const {
         int64_t n = 1;
@@ -211,7 +213,8 @@ struct cs_unet {
     float* arena = nullptr;
     size_t arena_floats = 0;
     int64_t grad_floats = 0;
-    int planes = 0;   // 0: fp32 MFMA kernels; 1..3: split-bf16 kernels with that many planes (3 = fp32-grade); 4: split-fp16 (fp32-grade)
+    int planes = 0;   // 0: fp32 MFMA kernels; 1..3: split-bf16 kernels with that many planes (3 = fp32-grade); 4: split-fp16 (fp32-grade);
+                      // 5: fp8 weights + fp8-staged activations on the block-scaled matrix instruction (bf16 datapath)
     bool training = false;   // pack the data-gradient weight layouts on every parameter load
     bool batch_stats = false;   // BatchNorm networks: normalise with the statistics of the current batch and update the running ones
                                 // (nn.BatchNorm2d in train mode); false = running statistics (eval mode)
@@ -278,6 +281,8 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     float* wdst = cw.w;
     float* wd = cw.wd;
     unsigned short* wb = cw.wb;
+    unsigned char* w8 = cw.w8;
+    float* wsc = cw.wscale;
     float* bdst = cw.bias + cout_off;
     const int cout_total = cw.cout;
     // the data-gradient layout of the same tensor (channel axes swapped; see pack_conv_weights) is written by the same tile
@@ -289,16 +294,20 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     if (transposed) {
         cw.p_w[slot] = add_param(net, conv + ".weight", {cin, cout, ksize, ksize}, [=](const float* d, hipStream_t s) {
             if (mode == 2) return copy_param(net, wdst, d, (size_t)cin * cout * ksize * ksize, s);
-            if (wb && net->planes > 0)
+            if (wb && net->planes > 0 && net->planes <= 4)
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, true, cout, cin, ksize, wb, cout_off, cout_total, cin_split, net->planes == 4)) return rc;
+            if (w8 && net->planes == 5)
+                if (int rc = pack_conv_weights_fp8(s, d, true, cout, cin, ksize, w8, wsc, cout_off, cout_total, cin_split)) return rc;
             return pack_conv_weights(net->pack, s, d, true, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off);
         });
     } else {
         cw.p_w[slot] = add_param(net, conv + ".weight", {cout, cin, ksize, ksize}, [=](const float* d, hipStream_t s) {
             if (mode == 2) return copy_param(net, wdst, d, (size_t)cin * cout * ksize * ksize, s);
             if (mode == 1) return pack_first_weights(net->pack, s, d, cout, cin, wdst, cout_off, cout_total);
-            if (wb && net->planes > 0)
+            if (wb && net->planes > 0 && net->planes <= 4)
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0, net->planes == 4)) return rc;
+            if (w8 && net->planes == 5)
+                if (int rc = pack_conv_weights_fp8(s, d, false, cout, cin, ksize, w8, wsc, cout_off, cout_total, 0)) return rc;
             return pack_conv_weights(net->pack, s, d, false, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off);
         });
     }
@@ -324,6 +333,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     const int dg0 = u.first ? DG_NONE : (stride == 2 ? DG_S2_AS_CONVT : DG_S1);
     if (dg0 != DG_NONE) u.unit0.wd = ar.take(packed_conv_floats(cin, u.unit0.cout, 3));
     if (!u.first) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(u.unit0.cout, cin, 0, 3) + 1) / 2);
+    if (!u.first) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(u.unit0.cout, cin, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(u.unit0.cout); }
     add_conv_params(net, pfx + ".conv.unit0.conv", u.unit0, c, cin, 3, 0, false, u.first ? 1 : 0, dg0, 0);
     add_norm_params(net, ar, pfx + ".conv.unit0.adn", u.norms[0], c);
     for (int su = 1; su < u.subunits; ++su) {
@@ -333,6 +343,8 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         cw.bias = ar.take(c);
         cw.wd = ar.take(packed_conv_floats(c, c, 3));
         cw.wb = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
+        cw.w8 = (unsigned char*)ar.take((packed_fp8_bytes(c, c, 0, 3) + 3) / 4);
+        cw.wscale = ar.take(c);
         const std::string un = pfx + ".conv.unit" + std::to_string(su);
         add_conv_params(net, un + ".conv", cw, c, c, 3, 0, false, 0, DG_S1, 0);
         add_norm_params(net, ar, un + ".adn", u.norms[su], c);
@@ -344,6 +356,8 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         u.res1x1.w = ar.take(packed_conv_floats(c, cin, 1));
         u.res1x1.wd = ar.take(packed_conv_floats(cin, c, 1));
         u.res1x1.wb = (unsigned short*)ar.take((packed_bf16_elems(c, cin, 0, 1) + 1) / 2);
+        u.res1x1.w8 = (unsigned char*)ar.take((packed_fp8_bytes(c, cin, 0, 1) + 3) / 4);
+        u.res1x1.wscale = ar.take(c);
         u.res1x1.bias = ar.take(c);
         add_conv_params(net, pfx + ".residual", u.res1x1, c, cin, 1, 0, false, 0, DG_1X1, 0);
     }
@@ -358,6 +372,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     u.convt.bias = ar.take(cout);
     if (!small) u.convt.wd = ar.take(packed_conv_floats(cin, cout, 3));
     if (!small) u.convt.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cin_skip, cin_sub, 3) + 1) / 2);
+    if (!small) { u.convt.w8 = (unsigned char*)ar.take((packed_fp8_bytes(cout, cin_skip, cin_sub, 3) + 3) / 4); u.convt.wscale = ar.take(cout); }
     add_conv_params(net, pfx + ".0.conv", u.convt, cout, cin, 3, 0, true, small ? 2 : 0, small ? DG_NONE : DG_CONVT_AS_S2, 0, cin_skip);
     add_norm_params(net, ar, pfx + ".0.adn", u.norm_t, cout);
     u.unit0.cin = cout; u.unit0.cout = cout;
@@ -365,6 +380,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     u.unit0.bias = ar.take(cout);
     if (!small) u.unit0.wd = ar.take(packed_conv_floats(cout, cout, 3));
     if (!small) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
+    if (!small) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(cout, cout, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(cout); }
     add_conv_params(net, pfx + ".1.conv.unit0.conv", u.unit0, cout, cout, 3, 0, false, small ? 2 : 0, small ? DG_NONE : DG_S1, 0);
     if (!top) add_norm_params(net, ar, pfx + ".1.conv.unit0.adn", u.norm_u, cout);
 }
@@ -417,7 +433,9 @@ static const float* act_off(const float* p, size_t elems, bool h16) {
 // forward conv on the matrix cores: fp32 MFMA or split-bf16, by net->planes
 static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, const ConvSrc& a, const ConvW& cw, float* out,
                     int pitch_out, int cout, double* stats, int n, int hin, int win) {
-    if (net->planes > 0 && cw.wb)
+    if (net->planes == 5 && cw.w8)
+        return launch_conv_fp8(s, ksize, stride, a, ConvSrc(), cw.w8, cw.wscale, cw.bias, out, pitch_out, cout, stats, n, hin, win);
+    if (net->planes > 0 && net->planes <= 4 && cw.wb)
         return launch_conv_bf16s(s, ksize, stride, net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin, win, a.h16);
     CS_REQUIRE(!a.h16, "conv: a layer without 16-bit weights met bf16 activations");
     return launch_conv_mfma(s, ksize, stride, a, ConvSrc(), cw.w, cw.bias, out, pitch_out, cout, stats, n, hin, win);
@@ -441,7 +459,8 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     // bf16 datapath (plain-bf16 mode, cs_unet_set_training(0)): every activation tensor between the first conv and the 3-channel
     // top layers is bf16 in HBM - half the traffic of every HBM-bound kernel and of the conv inputs / outputs.  A handle in
     // training mode keeps fp32 activations: the backward kernels read them.
-    const bool a16 = net->planes == 1 && !net->training;
+    const bool a16 = (net->planes == 1 || net->planes == 5) && !net->training;
+    CS_REQUIRE(!(net->planes == 5 && net->training), "unet: the fp8 mode is an inference mode (cs_unet_set_training(0))");
     auto take_act = [&](size_t count) -> float* {
         return a16 ? reinterpret_cast<float*>(ws.take<unsigned short>(count)) : ws.take<float>(count);
     };
@@ -563,7 +582,9 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
             const ConvSrc a = raw_src(X[d], u.cin_skip, u.cin_skip, a16), b = raw_src(S, sc, sc, a16);
-            if (c % 16 == 0 && net->planes > 0 && u.convt.wb) {
+            if (c % 16 == 0 && net->planes == 5 && u.convt.w8) {
+                CS_TRY(launch_convt_fp8(s, a, b, u.convt.w8, u.convt.wscale, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
+            } else if (c % 16 == 0 && net->planes > 0 && net->planes <= 4 && u.convt.wb) {
                 CS_TRY(launch_convt_bf16s(s, net->planes, a, b, u.convt.wb, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw, a16));
             } else if (c % 16 == 0) {
                 CS_REQUIRE(!a16, "convT: a layer without 16-bit weights met bf16 activations");
@@ -810,7 +831,7 @@ static int check_loaded(const cs_unet* net, bool for_backward = false) {
             set_error("parameter '%s' was never loaded", p.key.c_str());
             return CS_ERR_NOT_LOADED;
         }
-        if (net->planes > 0 && p.has_bf16 && p.wb_format != (net->planes == 4 ? 2 : 1)) {
+        if (net->planes > 0 && p.has_bf16 && p.wb_format != (net->planes == 5 ? 3 : net->planes == 4 ? 2 : 1)) {
             set_error("parameter '%s' was loaded under a different cs_unet_set_precision family: load it again", p.key.c_str());
             return CS_ERR_NOT_LOADED;
         }
@@ -899,7 +920,7 @@ int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* 
 }
 
 int cs_unet_set_precision(cs_unet* net, int planes) {
-    CS_REQUIRE(net && planes >= 0 && planes <= 4, "set_precision: 0 (fp32 MFMA), 1..3 (split-bf16 planes) or 4 (split-fp16, 3 terms)");
+    CS_REQUIRE(net && planes >= 0 && planes <= 5, "set_precision: 0 (fp32 MFMA), 1..3 (split-bf16 planes), 4 (split-fp16, 3 terms) or 5 (fp8)");
     net->planes = planes;
     return CS_OK;
 }
@@ -989,7 +1010,7 @@ int cs_unet_load_param(cs_unet* net, const char* key_host, const float* data, in
             if (rc == CS_OK) {
                 p.loaded = true;
                 p.dgrad_packed = net->training;
-                p.wb_format = net->planes == 4 ? 2 : net->planes > 0 ? 1 : 0;
+                p.wb_format = net->planes == 5 ? 3 : net->planes == 4 ? 2 : net->planes > 0 ? 1 : 0;
             }
             return rc;
         }

@@ -76,6 +76,16 @@ size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize);
 int pack_conv_weights_bf16(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
                            unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16 = false);
 
+// fp8 variant (kernels_conv_fp8.hip): e4m3 weights with one fp32 scale per output channel, bf16 activations in HBM converted
+// to e4m3 while staging, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, fp32 accumulate, bf16 out.
+int launch_conv_fp8(hipStream_t s, int ksize, int stride, const ConvSrc& a, const ConvSrc& b, const unsigned char* wpack,
+                    const float* wscale, const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
+int launch_convt_fp8(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const unsigned char* wpack, const float* wscale, const float* bias,
+                     float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
+size_t packed_fp8_bytes(int cout_total, int cin_a, int cin_b, int ksize);
+int pack_conv_weights_fp8(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, unsigned char* packed, float* wscale,
+                          int cout_off, int cout_total, int cin_split);
+
 // first layer: cin < 16 (3), 3x3 pad 1, reads windows straight out of the image (tiler gather fused).
 // image element strides (sc, sh, sw); per-window origins (y0, x0) in image coordinates (may be negative when the
 // image is smaller than the roi); pixels outside the window or the image read as 0.

@@ -1,0 +1,647 @@
+// gfx950 fp8 convolution kernels: BASELINE.json configs[4] ("mixed fp8 weights ... on CDNA4 MFMA").
+//
+// Weights are stored as OCP fp8 (e4m3fn) with ONE fp32 scale per output channel (computed at pack time: amax / 448);
+// activations live in HBM as bf16 (the bf16 datapath) and are converted to e4m3 while the input patch is staged into LDS
+// (after the producer's lazy InstanceNorm + PReLU, so the values are O(1) and need no scale).  The contraction runs on the
+// block-scaled matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 0x7f): K = 128 channels per
+// instruction at twice the bf16 rate (~5 PFLOP/s dense), fp32 accumulate.  The per-channel weight scale is applied to the
+// fp32 accumulator in the epilogue; statistics for the next InstanceNorm come from those fp32 values; the output is bf16.
+//
+// Operand layout (probed with exact integer data, tests/diagnostics/mfma_fp8_layout_probe.hip): lane l holds
+// A[row l & 15][k = 32 (l >> 4) + j] and B[k = 32 (l >> 4) + j][col l & 15] in byte j = 0..31 of its 8-VGPR fragment;
+// C/D as every 16x16 MFMA (col = l & 15, row = 4 (l >> 4) + reg).
+//
+// Kernel frame = conv_bf16s_kernel (kernels_conv_bf16.hip): 4 waves as WN x WM, weights L2 -> registers one tap row ahead
+// (never through LDS), input patch double-buffered in LDS, unconditional clamped loads pinned with sched_barriers.
+#include <type_traits>
+
+#include "kernels.h"
+#include "pack_jobs.h"
+
+namespace cs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int FP8_UNIT_SCALE = 0x7f7f7f7f;      // E8M0 1.0 in every byte
+
+__device__ __forceinline__ f32x4 mfma_fp8(i32x8 a, i32x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, FP8_UNIT_SCALE, 0, FP8_UNIT_SCALE);
+}
+__device__ __forceinline__ float prelu_8(float v, float slope) { return v >= 0.f ? v : v * slope; }
+__device__ __forceinline__ float bf16lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf16hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+// two floats -> two e4m3 bytes in the low / high half of a dword (saturating: v_cvt_pk_fp8_f32 clamps to +-448)
+template <bool HIGH>
+__device__ __forceinline__ unsigned pk_fp8(float a, float b, unsigned old) {
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, HIGH);
+}
+
+struct SrcDev8 {
+    const float* ptr;            // bf16 elements (bf16 datapath)
+    const float2* tab;
+    const float* slope;
+    int c, pitch, tab_c, tab_off;
+};
+
+struct Conv8Params {
+    SrcDev8 a, b;
+    const unsigned char* wpack;  // [chunk][tap][ntile_total][64 lanes][32] e4m3
+    const float* wscale;         // [cout] per-output-channel weight scale
+    const float* bias;
+    float* out;                  // bf16 elements
+    double* stats;
+    const float* dummy;
+    int pitch_out, cout, ntile_total;
+    int n, hin, win, hout, wout, tiles_x, tiles_y;
+};
+
+struct WorkId8 {
+    int spatial, ct;
+    bool valid;
+};
+__device__ __forceinline__ WorkId8 decode_work8(int n_spatial, int n_ct) {   // XCD-aware: see kernels_conv.hip
+    const int id = blockIdx.x, lane8 = id & 7, rest = id >> 3;
+    const int ct = rest % n_ct, sg = rest / n_ct;
+    const int spatial = sg * 8 + lane8;
+    return WorkId8{spatial, ct, spatial < n_spatial};
+}
+static inline unsigned xcd_grid8(int n_spatial, int n_ct) { return (unsigned)(((n_spatial + 7) / 8) * 8 * n_ct); }
+
+__device__ __forceinline__ void stats_commit8(double s, double q, double* dst, int lane) {
+    s += __shfl_xor(s, 16);
+    q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (lane < 16) {
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, q);
+    }
+}
+
+// Staging of one 128-channel chunk: item = (pixel, 8 channels) = one 16-byte load of bf16, lazy norm / act, 8 e4m3 bytes to LDS.
+// Every thread keeps the same channel octet `q` for all its items, so its 8 (scale, shift) pairs are loaded once per chunk.
+struct Lazy8 {
+    f32x4 t[4];
+    float slope;
+    bool on;
+};
+
+// MODE 0: conv (S in {1,2}, KS in {3,1});  the transposed conv has its own kernel below.
+template <int S, int KS, int WN, int NTW, int THX>
+__global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
+    constexpr int WM = 4 / WN;
+    constexpr int TH = THX * ((S == 1) ? 8 : 4), TW = 16;
+    constexpr int MTW = TH / WM;
+    constexpr int NTB = WN * NTW;
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int PITCH = 144;                              // bytes per staged pixel: 128 e4m3 + 16 pad (conflict-free b128 reads at S = 1)
+    constexpr int PAD = KS / 2, TAPS = KS * KS;
+    constexpr int IN_ITEMS = IH * IW * 16;
+    constexpr int IN_ITERS = (IN_ITEMS + 255) / 256;
+    constexpr int IN_BYTES = (IH * IW * PITCH + 15) / 16 * 16;
+    constexpr int EPS = 16 * NTB + 4;
+    constexpr int EP_BYTES = TH * 16 * EPS * 4;
+    constexpr int SM_BYTES = 2 * IN_BYTES > EP_BYTES ? 2 * IN_BYTES : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+
+    // MODE.FP16_OVFL (bit 23): an activation beyond +-448 saturates in the e4m3 conversion instead of turning into NaN
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    const int wn = wave % WN, wm = wave / WN;
+    const WorkId8 wk = decode_work8(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NTB);
+    if (!wk.valid) return;
+    int bid = wk.spatial;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int nt_w = wk.ct * NTB + wn * NTW;
+    const int q = tid & 15;                                  // channel octet of this thread inside the 128-channel chunk
+
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int goff[IN_ITERS];
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (tid >> 4) + 16 * it;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
+        goff[it] = (pix < IH * IW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win) ? gy * p.win + gx : -1;
+    }
+
+    const int chunks_a = (p.a.c + 127) >> 7, chunks = chunks_a + ((p.b.c + 127) >> 7);
+    u32x4 rin[IN_ITERS];
+    Lazy8 lz;
+    bool qvalid = false;
+
+    auto load_input = [&](int ch) {
+        const bool from_a = ch < chunks_a;
+        const SrcDev8& src = from_a ? p.a : p.b;
+        const int c0 = (from_a ? ch : ch - chunks_a) << 7;
+        qvalid = c0 + 8 * q < src.c;                        // channel tails (cin % 128 != 0) are zero-filled
+        const int cq = qvalid ? c0 + 8 * q : 0;
+        lz.on = src.tab != nullptr;
+        const f32x4* t = lz.on ? reinterpret_cast<const f32x4*>(src.tab + (size_t)img * src.tab_c + src.tab_off + cq)
+                               : reinterpret_cast<const f32x4*>(p.dummy);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lz.t[k] = t[k];
+        const float* sp = (lz.on && src.slope) ? src.slope : p.dummy;
+        lz.slope = *sp;
+        if (!(lz.on && src.slope)) lz.slope = 0.f;
+        const unsigned short* base = reinterpret_cast<const unsigned short*>(src.ptr) + (size_t)img * p.hin * p.win * src.pitch + cq;
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int o = goff[it] >= 0 ? goff[it] : 0;
+            rin[it] = *reinterpret_cast<const u32x4*>(base + (size_t)o * src.pitch);
+        }
+    };
+    auto store_input = [&](char* in_s) {
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int pix = (tid >> 4) + 16 * it;
+            if (IN_ITEMS % 256 == 0 || pix < IH * IW) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[2 * k] = bf16lo(rin[it][k]);
+                    v[2 * k + 1] = bf16hi(rin[it][k]);
+                }
+                if (lz.on) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] = prelu_8(v[2 * k] * lz.t[k].x + lz.t[k].y, lz.slope);
+                        v[2 * k + 1] = prelu_8(v[2 * k + 1] * lz.t[k].z + lz.t[k].w, lz.slope);
+                    }
+                }
+                u32x2 o{0u, 0u};
+                if (goff[it] >= 0 && qvalid) {
+                    o.x = pk_fp8<false>(v[0], v[1], 0u);
+                    o.x = pk_fp8<true>(v[2], v[3], o.x);
+                    o.y = pk_fp8<false>(v[4], v[5], 0u);
+                    o.y = pk_fp8<true>(v[6], v[7], o.y);
+                }
+                *reinterpret_cast<u32x2*>(in_s + pix * PITCH + q * 8) = o;
+            }
+        }
+    };
+    // weight fragments of one tap row: KS x NTW fragments of 32 bytes per lane (two lane-linear 16-byte loads each, from L2)
+    i32x8 bq[KS][NTW];
+    const i32x4* wbase = reinterpret_cast<const i32x4*>(p.wpack) + ((size_t)nt_w * 64 + lane) * 2;
+    auto load_b = [&](int ch, int ky, int kx) {
+        const i32x4* w = wbase + ((size_t)ch * TAPS + ky * KS + kx) * p.ntile_total * 128;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const i32x4 lo = w[t * 128], hi = w[t * 128 + 1];
+            bq[kx][t] = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+    };
+
+    load_input(0);
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) load_b(0, 0, kx);
+    store_input(smem);
+    __syncthreads();
+
+    const int last_row = chunks * KS - 1;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        load_input(more ? ch + 1 : ch);                     // unconditional (see conv_bf16s_kernel)
+        __builtin_amdgcn_sched_barrier(0);
+        const char* in_s = smem + (ch & 1) * IN_BYTES;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int row_next = ch * KS + ky + 1 < last_row ? ch * KS + ky + 1 : last_row;
+            const int ch_n = row_next / KS, ky_n = row_next - ch_n * KS;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                i32x8 b[NTW];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) b[t] = bq[kx][t];
+                load_b(ch_n, ky_n, kx);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int MG = (MTW % 2 == 0) ? 2 : 1;
+#pragma unroll
+                for (int m0 = 0; m0 < MTW; m0 += MG) {
+                    i32x8 a[MG];
+#pragma unroll
+                    for (int mm = 0; mm < MG; ++mm) {
+                        const char* ap = in_s + (((wm * MTW + m0 + mm) * S + ky) * IW + pl * S + kx) * PITCH + g * 32;
+                        const i32x4 lo = *reinterpret_cast<const i32x4*>(ap), hi = *reinterpret_cast<const i32x4*>(ap + 16);
+                        a[mm] = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
+#pragma unroll
+                    for (int mm = 0; mm < MG; ++mm)
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) acc[m0 + mm][t] = mfma_fp8(a[mm], b[t], acc[m0 + mm][t]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) asm volatile("" ::"v"(rin[it]));
+        if (more) store_input(smem + ((ch + 1) & 1) * IN_BYTES);
+        __syncthreads();
+    }
+
+    // ---- epilogue: weight scale, bias, fp64 statistics, bf16 stores through a block-wide LDS slab ----
+    float* ep = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int co = (nt_w + t) * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        const float ws = p.wscale[co];
+        double s = 0.0, qq = 0.0;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int row = wm * MTW + m, oy = oy0 + row;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + g * 4 + r;
+                const float v = acc[m][t][r] * ws + bias;
+                ep[(row * 16 + g * 4 + r) * EPS + (wn * NTW + t) * 16 + pl] = v;
+                if (oy < p.hout && ox < p.wout) {
+                    s += (double)v;
+                    qq += (double)v * (double)v;
+                }
+            }
+        }
+        if (p.stats) stats_commit8(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+    __syncthreads();
+    {
+        constexpr int F4 = NTB * 4;
+        const size_t el0 = (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + wk.ct * NTB * 16;
+        for (int i = tid; i < TH * 16 * F4; i += 256) {
+            const int pix = i / F4, c4 = i - pix * F4;
+            const int row = pix >> 4, x = pix & 15;
+            if (oy0 + row < p.hout && ox0 + x < p.wout) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                const uint2 o = f32x4_to_bf16(v);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) =
+                    u32x2{o.x, o.y};
+            }
+        }
+    }
+}
+
+static SrcDev8 to_dev8(const ConvSrc& s) { return SrcDev8{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
+
+template <int S, int KS, int WN, int NTW, int THX = 1>
+static int launch_8(hipStream_t s, Conv8Params p) {
+    constexpr int TH = THX * ((S == 1) ? 8 : 4);
+    p.tiles_x = ceil_div(p.wout, 16);
+    p.tiles_y = ceil_div(p.hout, TH);
+    dim3 grid(xcd_grid8(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
+    hipLaunchKernelGGL((conv_fp8_kernel<S, KS, WN, NTW, THX>), grid, dim3(256), 0, s, p);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int launch_conv_fp8(hipStream_t s, int ksize, int stride, const ConvSrc& a, const ConvSrc& b, const unsigned char* wpack,
+                    const float* wscale, const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
+    CS_REQUIRE(ksize == 3 || ksize == 1, "conv(fp8): ksize %d unsupported", ksize);
+    CS_REQUIRE((stride == 1 || stride == 2) && !(ksize == 1 && stride != 1), "conv(fp8): stride %d unsupported", stride);
+    CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "conv(fp8): channels must be multiples of 16");
+    CS_REQUIRE(a.h16 && (b.c == 0 || b.h16), "conv(fp8): activations must be bf16 tensors (bf16 datapath)");
+    CS_REQUIRE(a.pitch % 8 == 0 && (b.c == 0 || b.pitch % 8 == 0), "conv(fp8): pixel pitch must be a multiple of 8 elements");
+    Conv8Params p{};
+    p.a = to_dev8(a);
+    p.b = to_dev8(b);
+    p.wpack = wpack; p.wscale = wscale; p.bias = bias; p.out = out; p.stats = stats; p.dummy = wscale;
+    p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16;
+    p.n = n; p.hin = hin; p.win = win;
+    const int pad = ksize / 2;
+    p.hout = (hin + 2 * pad - ksize) / stride + 1;
+    p.wout = (win + 2 * pad - ksize) / stride + 1;
+    const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    // FLOPs are the ALGORITHMIC ones (2 * cin * ...), not the zero-padded K the matrix pipe executes
+    const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
+    const double bytes = 2.0 * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
+    ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
+    const bool tall = stride == 1 && p.hout >= 16;
+#define CS_8(S_, KS_)                                                               \
+    switch (wn) {                                                                   \
+        case 4: if (S_ == 1 && KS_ == 3 && cout % 128 == 0) return launch_8<S_, KS_, 4, 2>(s, p);  \
+                if (tall && KS_ == 3) return launch_8<S_, KS_, 2, 2, 2>(s, p);      \
+                if (S_ == 2 && cout % 128 == 0) return launch_8<S_, KS_, 4, 2>(s, p);  \
+                return launch_8<S_, KS_, 2, 2>(s, p);                               \
+        case 2: return launch_8<S_, KS_, 2, 1>(s, p);                               \
+        default: return launch_8<S_, KS_, 1, 1>(s, p);                              \
+    }
+    if (ksize == 1) { CS_8(1, 1) }
+    if (stride == 1) { CS_8(1, 3) }
+    CS_8(2, 3)
+#undef CS_8
+}
+
+// ------------------------------------------------------------------------------------------------
+// transposed conv k3 s2 p1 op1 in fp8: 4 output phases per input pixel (see convt_mfma_kernel)
+// ------------------------------------------------------------------------------------------------
+template <int WN, int NTW>
+__global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
+    constexpr int WM = 4 / WN, TH = 4, TW = 16, MTW = TH / WM, NTB = WN * NTW;
+    constexpr int IH = TH + 1, IW = TW + 1, PITCH = 144;
+    constexpr int IN_ITEMS = IH * IW * 16, IN_ITERS = (IN_ITEMS + 255) / 256;
+    constexpr int IN_BYTES = (IH * IW * PITCH + 15) / 16 * 16;
+    constexpr int EPS = 16 * NTB + 4;
+    constexpr int EP_BYTES = 2 * TH * 32 * EPS * 4;
+    constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    char* const in_s = smem;
+
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // saturating e4m3 conversion (see conv_fp8_kernel)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    const int wn = wave % WN, wm = wave / WN;
+    const WorkId8 wk = decode_work8(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NTB);
+    if (!wk.valid) return;
+    int bid = wk.spatial;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int iy0 = ty * TH, ix0 = tx * TW;
+    const int nt_w = wk.ct * NTB + wn * NTW;
+    const int q = tid & 15;
+
+    f32x4 acc[MTW][4][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[m][ph][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int goff[IN_ITERS];
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (tid >> 4) + 16 * it;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        goff[it] = (pix < IH * IW && gy < p.hin && gx < p.win) ? gy * p.win + gx : -1;
+    }
+    const int chunks_a = (p.a.c + 127) >> 7, chunks = chunks_a + ((p.b.c + 127) >> 7);
+    u32x4 rin[IN_ITERS];
+    Lazy8 lz;
+    bool qvalid = false;
+    auto load_input = [&](int ch) {
+        const bool from_a = ch < chunks_a;
+        const SrcDev8& src = from_a ? p.a : p.b;
+        const int c0 = (from_a ? ch : ch - chunks_a) << 7;
+        qvalid = c0 + 8 * q < src.c;
+        const int cq = qvalid ? c0 + 8 * q : 0;
+        lz.on = src.tab != nullptr;
+        const f32x4* t = lz.on ? reinterpret_cast<const f32x4*>(src.tab + (size_t)img * src.tab_c + src.tab_off + cq)
+                               : reinterpret_cast<const f32x4*>(p.dummy);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lz.t[k] = t[k];
+        const float* sp = (lz.on && src.slope) ? src.slope : p.dummy;
+        lz.slope = *sp;
+        if (!(lz.on && src.slope)) lz.slope = 0.f;
+        const unsigned short* base = reinterpret_cast<const unsigned short*>(src.ptr) + (size_t)img * p.hin * p.win * src.pitch + cq;
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int o = goff[it] >= 0 ? goff[it] : 0;
+            rin[it] = *reinterpret_cast<const u32x4*>(base + (size_t)o * src.pitch);
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int pix = (tid >> 4) + 16 * it;
+            if (IN_ITEMS % 256 == 0 || pix < IH * IW) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[2 * k] = bf16lo(rin[it][k]);
+                    v[2 * k + 1] = bf16hi(rin[it][k]);
+                }
+                if (lz.on) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] = prelu_8(v[2 * k] * lz.t[k].x + lz.t[k].y, lz.slope);
+                        v[2 * k + 1] = prelu_8(v[2 * k + 1] * lz.t[k].z + lz.t[k].w, lz.slope);
+                    }
+                }
+                u32x2 o{0u, 0u};
+                if (goff[it] >= 0 && qvalid) {
+                    o.x = pk_fp8<false>(v[0], v[1], 0u);
+                    o.x = pk_fp8<true>(v[2], v[3], o.x);
+                    o.y = pk_fp8<false>(v[4], v[5], 0u);
+                    o.y = pk_fp8<true>(v[6], v[7], o.y);
+                }
+                *reinterpret_cast<u32x2*>(in_s + pix * PITCH + q * 8) = o;
+            }
+        }
+    };
+    i32x8 bq[3][NTW];
+    const i32x4* wbase = reinterpret_cast<const i32x4*>(p.wpack) + ((size_t)nt_w * 64 + lane) * 2;
+    auto load_b = [&](int ch, int tap, int slot) {
+        const i32x4* w = wbase + ((size_t)ch * 9 + tap) * p.ntile_total * 128;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const i32x4 lo = w[t * 128], hi = w[t * 128 + 1];
+            bq[slot][t] = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+    };
+
+    load_input(0);
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) load_b(0, tap, tap);
+    store_input();
+    __syncthreads();
+    const int last_tap = chunks * 9 - 1;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        load_input(more ? ch + 1 : ch);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int pa = (ky == 1) ? 0 : 1, di = (ky == 0) ? 1 : 0;
+            const int pb = (kx == 1) ? 0 : 1, dj = (kx == 0) ? 1 : 0;
+            const int ph = pa * 2 + pb;
+            i32x8 b[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) b[t] = bq[tap % 3][t];
+            {
+                const int nxt = ch * 9 + tap + 3 < last_tap ? ch * 9 + tap + 3 : last_tap;
+                load_b(nxt / 9, nxt % 9, tap % 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int r = wm * MTW + m;
+                const char* ap = in_s + ((r + di) * IW + pl + dj) * PITCH + g * 32;
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(ap), hi = *reinterpret_cast<const i32x4*>(ap + 16);
+                const i32x8 a = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[m][ph][t] = mfma_fp8(a, b[t], acc[m][ph][t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) asm volatile("" ::"v"(rin[it]));
+        __syncthreads();
+        if (more) {
+            store_input();
+            __syncthreads();
+        }
+    }
+
+    float* ep = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int co = (nt_w + t) * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        const float ws = p.wscale[co];
+        double s = 0.0, qq = 0.0;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int row = wm * MTW + m, iy = iy0 + row;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ix = ix0 + g * 4 + r;
+                    const float v = acc[m][ph][t][r] * ws + bias;
+                    ep[((2 * row + (ph >> 1)) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + (wn * NTW + t) * 16 + pl] = v;
+                    if (iy < p.hin && ix < p.win) {
+                        s += (double)v;
+                        qq += (double)v * (double)v;
+                    }
+                }
+        }
+        if (p.stats) stats_commit8(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+    }
+    __syncthreads();
+    {
+        constexpr int F4 = NTB * 4;
+        const size_t el0 = (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;
+        for (int i = tid; i < 2 * TH * 32 * F4; i += 256) {
+            const int pix = i / F4, c4 = i - pix * F4;
+            const int row = pix >> 5, x = pix & 31;
+            if (2 * iy0 + row < p.hout && 2 * ix0 + x < p.wout) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                const uint2 o = f32x4_to_bf16(v);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) =
+                    u32x2{o.x, o.y};
+            }
+        }
+    }
+}
+
+template <int WN, int NTW>
+static int launch_t8(hipStream_t s, Conv8Params p) {
+    dim3 grid(xcd_grid8(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
+    hipLaunchKernelGGL((convt_fp8_kernel<WN, NTW>), grid, dim3(256), 0, s, p);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int launch_convt_fp8(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const unsigned char* wpack, const float* wscale, const float* bias,
+                     float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
+    CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "convT(fp8): channels must be multiples of 16");
+    CS_REQUIRE(a.h16 && (b.c == 0 || b.h16), "convT(fp8): activations must be bf16 tensors (bf16 datapath)");
+    CS_REQUIRE(a.pitch % 8 == 0 && (b.c == 0 || b.pitch % 8 == 0), "convT(fp8): pixel pitch must be a multiple of 8 elements");
+    Conv8Params p{};
+    p.a = to_dev8(a);
+    p.b = to_dev8(b);
+    p.wpack = wpack; p.wscale = wscale; p.bias = bias; p.out = out; p.stats = stats; p.dummy = wscale;
+    p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16;
+    p.n = n; p.hin = hin; p.win = win; p.hout = 2 * hin; p.wout = 2 * win;
+    p.tiles_x = ceil_div(win, 16);
+    p.tiles_y = ceil_div(hin, 4);
+    const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
+    const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
+    const double bytes = 2.0 * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
+    ProfScope prof(K_CONVT, s, flops, bytes);
+    switch (wn) {
+        case 4: return launch_t8<2, 2>(s, p);
+        case 2: return launch_t8<2, 1>(s, p);
+        default: return launch_t8<1, 1>(s, p);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 PyTorch layout -> per-output-channel scale + e4m3 fragments
+//   packed[chunk][tap][ntile_total][lane][32]: cout = ntile*16 + (lane & 15), cin = chunk*128 + 32 (lane >> 4) + j
+//   input channels >= cin_split (second concat source) start a fresh 128-channel chunk, as the kernels stage them
+// ------------------------------------------------------------------------------------------------
+size_t packed_fp8_bytes(int cout_total, int cin_a, int cin_b, int ksize) {
+    const size_t chunks = (size_t)(cin_a + 127) / 128 + (size_t)(cin_b + 127) / 128;
+    return chunks * ksize * ksize * (cout_total / 16) * 2048;
+}
+
+// one block per output channel: amax over (cin, taps) -> scale = amax / 448 (1 for an all-zero channel)
+__global__ __launch_bounds__(256) void fp8_wscale_kernel(const float* w, int transposed, int cout, int cin, int taps, float* wscale) {
+    __shared__ float red[4];
+    const int co = blockIdx.x;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < cin * taps; i += 256) {
+        const int ci = i / taps, tp = i - ci * taps;
+        const float v = transposed ? w[((size_t)ci * cout + co) * taps + tp] : w[((size_t)co * cin + ci) * taps + tp];
+        m = fmaxf(m, fabsf(v));
+    }
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float a = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        wscale[co] = a > 0.f ? a * (1.f / 448.f) : 1.f;
+    }
+}
+
+// one thread per packed dword (4 consecutive k of one lane)
+__global__ __launch_bounds__(256) void fp8_pack_kernel(const float* w, int transposed, int cout, int cin, int taps, int cin_split, int chunks_total,
+                                                       const float* wscale, unsigned* packed, int cout_off, int ntile_total, long long total) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int jd = e & 7, lane = (e >> 3) & 63;
+    long long r = e >> 9;
+    const int ntl = r % (cout / 16);
+    r /= (cout / 16);
+    const int tap = r % taps;
+    const int chunk = (int)(r / taps);
+    const int chunks_a = cin_split > 0 ? (cin_split + 127) / 128 : chunks_total;
+    const int co = ntl * 16 + (lane & 15);
+    const float inv = 1.f / wscale[cout_off + co];
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = (chunk < chunks_a ? chunk * 128 : (chunk - chunks_a) * 128) + 32 * (lane >> 4) + 4 * jd + j;
+        const int ci = chunk < chunks_a ? k : cin_split + k;
+        const bool valid = chunk < chunks_a ? k < (cin_split > 0 ? cin_split : cin) : ci < cin;
+        v[j] = valid ? (transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap]) * inv : 0.f;
+    }
+    unsigned o = pk_fp8<false>(v[0], v[1], 0u);
+    o = pk_fp8<true>(v[2], v[3], o);
+    packed[((((size_t)chunk * taps + tap) * ntile_total + cout_off / 16 + ntl) * 64 + lane) * 8 + jd] = o;
+}
+
+// Not batched: the fp8 packing is a load-time (inference) step, two small kernels per tensor on the caller's stream.
+int pack_conv_weights_fp8(hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, unsigned char* packed, float* wscale,
+                          int cout_off, int cout_total, int cin_split) {
+    CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack(fp8): bad channel counts");
+    const int taps = ksize * ksize;
+    const int chunks_total = cin_split > 0 ? (cin_split + 127) / 128 + (cin - cin_split + 127) / 128 : (cin + 127) / 128;
+    const long long total = (long long)chunks_total * taps * (cout / 16) * 512;
+    ProfScope prof(K_PACK, s, 0, 4.0 * cout * cin * taps + 4.0 * total);
+    hipLaunchKernelGGL(fp8_wscale_kernel, dim3((unsigned)cout), dim3(256), 0, s, w, transposed ? 1 : 0, cout, cin, taps, wscale + cout_off);
+    hipLaunchKernelGGL(fp8_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, transposed ? 1 : 0, cout, cin, taps, cin_split,
+                       chunks_total, wscale, reinterpret_cast<unsigned*>(packed), cout_off, cout_total / 16, total);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

@@ -416,3 +416,68 @@ def test_batchnorm_eval_mode_backward_is_refused():
     _, hip = _pair((16, 32), norm="batch", act="relu")
     with pytest.raises(ca.CellSegHipError, match="eval-mode BatchNorm"):
         hip(torch.rand(1, 3, 32, 32, device=_dev()))
+
+
+# ------------------------------------------------------------------------------------------- low-precision datapaths on a TRAINED net
+@pytest.fixture(scope="module")
+def trained_pair():
+    """A 32-base net trained for 150 steps on seeded synthetic cells (fp32 engine): low-precision modes are judged on a network
+    whose logits are decisive, not on random-init logits that sit at the 0.5 threshold."""
+    import cellseg_amd as ca
+    from cellseg_amd import data
+    torch.manual_seed(7)
+    model = ca.UNet(channels=(32, 64, 128, 256, 512), strides=(2, 2, 2, 2), num_res_units=2).to(_dev()).train()
+    ds = data.SyntheticCells(64, 256, 2022)
+    batches = [(torch.stack([ds[i]["img"] for i in range(b, b + 8)]).to(_dev()),
+                torch.stack([ds[i]["label"] for i in range(b, b + 8)]).to(_dev())) for b in range(0, 64, 8)]
+    opt = torch.optim.AdamW(model.parameters(), 6e-4)
+    loss_fn = ca.DiceCELoss(softmax=True)
+    first = last = None
+    for step in range(150):
+        x, y = batches[step % len(batches)]
+        opt.zero_grad()
+        loss = loss_fn(model(x), ca.one_hot(y, 3))
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+        last = loss.item()
+    assert last < 0.6 * first, (first, last)
+    return model.eval()
+
+
+@pytest.mark.parametrize("precision,f1_min,agree_min", [("bf16", 0.97, 0.995), ("fp8", 0.90, 0.98)])
+def test_low_precision_datapaths_keep_instances_of_a_trained_net(trained_pair, precision, f1_min, agree_min):
+    """BASELINE configs[1] / configs[4] datapaths (bf16 activations in HBM; fp8 weights + fp8-staged activations) on the trained
+    net: the instance masks of a 1024^2 synthetic image against the fp32 path's - F1@0.5 (compute_metric semantics) and pixel
+    agreement of the interior mask."""
+    import cellseg_amd as ca
+    from cellseg_amd import data, metrics
+    model = trained_pair
+    big = data.SyntheticCells(1, 1024, 99)[0]["img"].to(_dev())
+    out = {}
+    with torch.no_grad():
+        for prec in ("fp32", precision):
+            model.precision = prec
+            _, _, mask = ca.swi_infer_image(model, big, (256, 256), 0.5, want_logits=False, want_mask=True)
+            out[prec] = (mask.clone(), ca.mask_to_instances(mask))
+    model.precision = "fp32"
+    assert int(out["fp32"][1].max()) > 20                                     # the trained net does find cells
+    agree = float((out["fp32"][0] == out[precision][0]).float().mean())
+    f1 = metrics.f1_score(out["fp32"][1], out[precision][1])[5]
+    assert agree >= agree_min and f1 >= f1_min, (precision, agree, f1)
+
+
+def test_fp8_deep64_forward_error_bound():
+    """configs[4] net (64...1024) in the fp8 mode against the fp32 torch-CPU oracle on 512-pixel-window-shaped input (one 128^2
+    crop keeps the CPU side short): bounded logit error, class decision mostly unchanged."""
+    ref, hip = _pair((64, 128, 256, 512, 1024))
+    hip.precision = "fp8"
+    x = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        want = ref(x)
+        got = hip(x.to(_dev())).cpu()
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert torch.isfinite(got).all()
+    assert err <= 0.35 * scale + 0.1, (err, scale)
+    assert (got.argmax(1) == want.argmax(1)).float().mean().item() > 0.85

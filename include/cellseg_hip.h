@@ -213,7 +213,8 @@ int cs_remove_boundary_cells(const int32_t* labels, int h, int w, int border, in
 /* ------------------------------------------------------------------------------------------------
  * Per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.
  * cs_prof_enable(1) brackets every kernel launch with events; cs_prof_collect synchronises and
- * returns per-kernel-id totals.  Disabled (default) costs nothing.
+ * returns per-kernel-id totals.  Disabled (default) costs nothing.  The state is kept per device: the calls act on the
+ * device that is current when they are made.
  * ---------------------------------------------------------------------------------------------- */
 enum { CS_PROF_MAX_KERNELS = 32 };
 int cs_prof_enable(int on);

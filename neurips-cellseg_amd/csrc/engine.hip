@@ -33,7 +33,7 @@ static const char* kNames[K_NUM_IDS] = {
     "conv3x3_s1_mfma", "conv3x3_s2_mfma", "conv1x1_mfma", "conv_first_mfma", "convT3x3s2_mfma", "convT_top_mfma",
     "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
     "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset", "norm_bwd",
-    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric"};
+    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric", "wgrad_unpack"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
 
 struct ProfRecord {

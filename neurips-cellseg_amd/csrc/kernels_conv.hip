@@ -600,6 +600,9 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
         const bool wide = (g_conv_variant & 4) && cout % 128 == 0;
         return wide ? launch_conv_wreg<2, 3, 4, 4, 3, 2>(s, p) : launch_conv_wreg<2, 3, 4, 4, 3, 1>(s, p);
     }
+    // 32-channel stride-1 layers (bit 8): register weights with a 16-row tile - every wave owns one channel tile and 8 rows, so a
+    // B fragment feeds 32 MFMAs (the LDS-weights kernel re-reads its weights from LDS for every 2 rows)
+    if ((g_conv_variant & 8) && nt == 2 && ksize == 3 && stride == 1 && p.hout >= 16) return launch_conv_wreg<1, 3, 2, 16, 2, 1>(s, p);
     if (ksize == 1) { CS_DISPATCH_NT(1, 1, 2) }
     if (stride == 1) { CS_DISPATCH_NT(1, 3, 2) }
     CS_DISPATCH_NT(2, 3, 1)

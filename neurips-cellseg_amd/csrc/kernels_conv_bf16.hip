@@ -401,7 +401,8 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
                 if (tall && (NP_ == 4 || NP_ <= 2) && KS_ == 3) return launch_b<S_, KS_, 2, 2, (NP_ == 3 ? 4 : NP_), 2, A16_>(s, p); \
                 if (wide128 && S_ == 2) return launch_b<S_, KS_, 4, 2, NP_, 1, A16_>(s, p);    \
                 return launch_b<S_, KS_, 2, 2, NP_, 1, A16_>(s, p);                 \
-        case 2: return launch_b<S_, KS_, 2, 1, NP_, 1, A16_>(s, p);                 \
+        case 2: if (tall && KS_ == 3 && (NP_ == 1 || NP_ == 4)) return launch_b<S_, KS_, 1, 2, NP_, 2, A16_>(s, p); /* 32-channel layers: each A fragment feeds both tiles */ \
+                return launch_b<S_, KS_, 2, 1, NP_, 1, A16_>(s, p);                 \
         default: return launch_b<S_, KS_, 1, 1, NP_, 1, A16_>(s, p);                \
     }
 #define CS_B2(S_, KS_)                                                              \

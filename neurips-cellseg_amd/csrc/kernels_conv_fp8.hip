@@ -335,7 +335,8 @@ int launch_conv_fp8(hipStream_t s, int ksize, int stride, const ConvSrc& a, cons
                 if (tall && KS_ == 3) return launch_8<S_, KS_, 2, 2, 2>(s, p);      \
                 if (S_ == 2 && cout % 128 == 0) return launch_8<S_, KS_, 4, 2>(s, p);  \
                 return launch_8<S_, KS_, 2, 2>(s, p);                               \
-        case 2: return launch_8<S_, KS_, 2, 1>(s, p);                               \
+        case 2: if (tall && KS_ == 3) return launch_8<S_, KS_, 1, 2, 2>(s, p);      \
+                return launch_8<S_, KS_, 2, 1>(s, p);                               \
         default: return launch_8<S_, KS_, 1, 1>(s, p);                              \
     }
     if (ksize == 1) { CS_8(1, 1) }

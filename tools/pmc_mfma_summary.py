@@ -18,6 +18,7 @@ import sys
 
 def main():
     tag, path = sys.argv[1:3]
+    extra = " ".join(sys.argv[3:])
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     secs = collections.defaultdict(float)
     calls = collections.Counter()
@@ -32,7 +33,7 @@ def main():
             secs[name] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
             calls[name] += 1
     out = {"source": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES "
-                     "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary",
+                     "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-secondary " + extra,
            "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); clock = GRBM_GUI_ACTIVE/8 / kernel time",
            "kernels": {}}
     for name in sorted(agg, key=lambda k: -secs[k]):

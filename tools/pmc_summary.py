@@ -14,9 +14,9 @@ import json
 import re
 import sys
 
-GROUPS = [(r"conv_(mfma|wreg)_kernel<1, 3,", "conv3x3_s1_mfma"), (r"conv_(mfma|wreg)_kernel<2, 3,", "conv3x3_s2_mfma"),
-          (r"conv_mfma_kernel<1, 1,", "conv1x1_mfma"), (r"conv_first_kernel", "conv_first_mfma"),
-          (r"convt_mfma_kernel", "convT3x3s2_mfma"), (r"convt_small_kernel|convt_top_gemm_kernel", "convT_top_mfma"),
+GROUPS = [(r"conv_(mfma|wreg|bf16s|fp8)_kernel<1, 3,", "conv3x3_s1_mfma"), (r"conv_(mfma|wreg|bf16s|fp8)_kernel<2, 3,", "conv3x3_s2_mfma"),
+          (r"conv_(mfma|bf16s|fp8)_kernel<1, 1,", "conv1x1_mfma"), (r"conv_first_kernel", "conv_first_mfma"),
+          (r"convt_(mfma|bf16s|fp8)_kernel", "convT3x3s2_mfma"), (r"convt_small_kernel|convt_top_gemm_kernel", "convT_top_mfma"),
           (r"conv_last_kernel", "conv_last_valu"), (r"norm_finalize_kernel", "norm_finalize"),
           (r"norm_act_add_kernel", "norm_act_add"), (r"swi_finalize_kernel", "swi_finalize"),
           (r"ccl_(\w+)_kernel", None)]
@@ -42,8 +42,10 @@ def counters(path):
 
 def main():
     tag, stats, fetch, write = sys.argv[1:5]
+    extra = " ".join(sys.argv[5:])
     out = {"source": "rocprofv3 --kernel-trace --stats and separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
-                     "`python3 bench.py --no-cpu-baseline --no-secondary` (default workload)", "kernels": {}}
+                     f"`python3 bench.py --streams 1 --no-cpu-baseline --no-secondary {extra}`".rstrip() + (" (default workload)" if not extra else ""),
+           "kernels": {}}
     t = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(stats)):
         g = group(r["Name"])
@@ -60,7 +62,8 @@ def main():
                       "hbm_bytes_per_launch": round(fetch_b + write_b)})
         out["kernels"][g] = e
     json.dump(out, open(f"profiles/pmc_traffic_{tag}.json", "w"), indent=1)
-    json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+    if re.fullmatch(r"r\d+", tag):                      # the default (fp32) workload's summary is what bench.py quotes as `traffic`
+        json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
     for g, e in out["kernels"].items():
         print(f"{g:20s} calls {e['calls']:5d} avg {e['avg_duration_us']:9.2f} us  hbm/launch {e.get('hbm_bytes_per_launch', 0)/1e6:9.1f} MB")
 

@@ -252,6 +252,7 @@ def main():
     n_windows = plan.n_h * plan.n_w
     mpix = args.size * args.size / 1e6
     host = torch.empty((args.size, args.size), dtype=torch.int32, pin_memory=True)    # where "labels on host" land
+    copy_stream, done = torch.cuda.Stream(dev), torch.cuda.Event()
 
     # ------------------------------------------------------------------------------------------------------------------
     # inference legs
@@ -291,8 +292,15 @@ def main():
             return inner
 
         def step_d2h():
+            """The label copy runs on its own stream (ordered after this slide's CC by an event), so the PCIe transfer of slide k
+            overlaps the inference of slide k + 1 - what the predict CLI does with its writer thread.  Every timed step's labels
+            are on the host when the timed region ends (torch.cuda.synchronize() drains both streams)."""
             lab, num = inner()
-            host.copy_(lab, non_blocking=True)
+            done.record()
+            copy_stream.wait_event(done)
+            with torch.cuda.stream(copy_stream):
+                host.copy_(lab, non_blocking=True)
+            lab.record_stream(copy_stream)
             return lab, num
         return step_d2h
 

@@ -61,18 +61,28 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
     }
     const float slope = p.slope ? *p.slope : 0.f;
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, ds = 0.f;
-    for (int64_t px = pix0 + pl; px < pix1; px += lanes) {
-        const int64_t g = (int64_t)img * p.npix + px;
-        const f32x4 da = *reinterpret_cast<const f32x4*>(p.da + g * p.da_pitch + 4 * quad);
-        const f32x4 y = *reinterpret_cast<const f32x4*>(p.y + g * p.y_pitch + 4 * quad);
+    // 4 pixels per trip, all 8 loads issued before the first use: the pass is bound by loads in flight, not by arithmetic
+    for (int64_t px = pix0 + pl; px < pix1; px += 4 * lanes) {
+        f32x4 da[4], y[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float z = y[j] * sc[j] + sf[j];
-            const float xh = y[j] * xs[j] + xf[j];
-            const float dz = z >= 0.f ? da[j] : da[j] * slope;
-            if (z < 0.f) ds += da[j] * z;
-            s1[j] += dz;
-            s2[j] += dz * xh;
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pu = px + u * lanes < pix1 ? px + u * lanes : px;       // clamped: the tail re-reads a valid pixel
+            const int64_t g = (int64_t)img * p.npix + pu;
+            da[u] = *reinterpret_cast<const f32x4*>(p.da + g * p.da_pitch + 4 * quad);
+            y[u] = *reinterpret_cast<const f32x4*>(p.y + g * p.y_pitch + 4 * quad);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (px + u * lanes >= pix1) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = y[u][j] * sc[j] + sf[j];
+                const float xh = y[u][j] * xs[j] + xf[j];
+                const float dz = z >= 0.f ? da[u][j] : da[u][j] * slope;
+                if (z < 0.f) ds += da[u][j] * z;
+                s1[j] += dz;
+                s2[j] += dz * xh;
+            }
         }
     }
     // reduce over the `lanes` threads that share a channel quad
@@ -111,37 +121,57 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p, int64_t total) {
-    const int c4n = p.c >> 2;
-    const double inv_m = p.inv_m;
-    const float slope = p.slope ? *p.slope : 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t g = i / c4n;
-        const int quad = (int)(i - g * c4n);
-        const int img = (int)(g / p.npix);
-        const f32x4* t = reinterpret_cast<const f32x4*>(p.tab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
-        const f32x4 t0 = t[0], t1 = t[1];
-        const float sc[4] = {t0.x, t0.z, t1.x, t1.z}, sf[4] = {t0.y, t0.w, t1.y, t1.w};
-        float xs[4] = {sc[0], sc[1], sc[2], sc[3]}, xf[4] = {sf[0], sf[1], sf[2], sf[3]};
-        if (p.xtab) {
-            const f32x4* xt = reinterpret_cast<const f32x4*>(p.xtab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
-            const f32x4 x0 = xt[0], x1 = xt[1];
-            xs[0] = x0.x; xs[1] = x0.z; xs[2] = x1.x; xs[3] = x1.z;
-            xf[0] = x0.y; xf[1] = x0.w; xf[2] = x1.y; xf[3] = x1.w;
-        }
-        const double* red = p.red + ((size_t)img * p.c + 4 * quad) * 2;
-        const f32x4 da = *reinterpret_cast<const f32x4*>(p.da + g * p.da_pitch + 4 * quad);
-        const f32x4 y = *reinterpret_cast<const f32x4*>(p.y + g * p.y_pitch + 4 * quad);
-        f32x4 o;
+// apply pass: dy = sc * (dz - mean(dz) - x_hat * mean(dz * x_hat)).  Same thread layout as the reduce pass (a thread keeps its
+// channel quad for all its pixels, blockIdx.y = image), so the tables and the two means are loaded and converted ONCE per
+// thread; the round-1 version was a flat grid-stride loop that paid two 64-bit divisions and eight fp64 loads per element quad.
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p) {
+    const int c4n = p.c >> 2, lanes = 256 / c4n;
+    const int quad = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+    const int img = blockIdx.y;
+    const int64_t pix0 = (int64_t)blockIdx.x * p.pix_per_block;
+    const int64_t pix1 = pix0 + p.pix_per_block < p.npix ? pix0 + p.pix_per_block : p.npix;
+    const f32x4* t = reinterpret_cast<const f32x4*>(p.tab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
+    const f32x4 t0 = t[0], t1 = t[1];
+    const float sc[4] = {t0.x, t0.z, t1.x, t1.z}, sf[4] = {t0.y, t0.w, t1.y, t1.w};
+    float xs[4] = {sc[0], sc[1], sc[2], sc[3]}, xf[4] = {sf[0], sf[1], sf[2], sf[3]};
+    if (p.xtab) {
+        const f32x4* xt = reinterpret_cast<const f32x4*>(p.xtab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
+        const f32x4 x0 = xt[0], x1 = xt[1];
+        xs[0] = x0.x; xs[1] = x0.z; xs[2] = x1.x; xs[3] = x1.z;
+        xf[0] = x0.y; xf[1] = x0.w; xf[2] = x1.y; xf[3] = x1.w;
+    }
+    const double* red = p.red + ((size_t)img * p.c + 4 * quad) * 2;
+    float m1[4], m2[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float z = y[j] * sc[j] + sf[j];
-            const float xh = y[j] * xs[j] + xf[j];
-            const float dz = z >= 0.f ? da[j] : da[j] * slope;
-            const float m1 = (float)(red[2 * j] * inv_m), m2 = (float)(red[2 * j + 1] * inv_m);
-            o[j] = sc[j] * (dz - m1 - xh * m2);
+    for (int j = 0; j < 4; ++j) {
+        m1[j] = (float)(red[2 * j] * p.inv_m);
+        m2[j] = (float)(red[2 * j + 1] * p.inv_m);
+    }
+    const float slope = p.slope ? *p.slope : 0.f;
+    if (pl >= lanes) return;
+    for (int64_t px = pix0 + pl; px < pix1; px += 4 * lanes) {
+        f32x4 da[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pu = px + u * lanes < pix1 ? px + u * lanes : px;
+            const int64_t g = (int64_t)img * p.npix + pu;
+            da[u] = *reinterpret_cast<const f32x4*>(p.da + g * p.da_pitch + 4 * quad);
+            y[u] = *reinterpret_cast<const f32x4*>(p.y + g * p.y_pitch + 4 * quad);
         }
-        *reinterpret_cast<f32x4*>(p.dy + g * p.dy_pitch + 4 * quad) = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (px + u * lanes >= pix1) continue;
+            const int64_t g = (int64_t)img * p.npix + px + u * lanes;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = y[u][j] * sc[j] + sf[j];
+                const float xh = y[u][j] * xs[j] + xf[j];
+                const float dz = z >= 0.f ? da[u][j] : da[u][j] * slope;
+                o[j] = sc[j] * (dz - m1[j] - xh * m2[j]);
+            }
+            *reinterpret_cast<f32x4*>(p.dy + g * p.dy_pitch + 4 * quad) = o;
+        }
     }
 }
 
@@ -170,6 +200,9 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_small_kernel(NormBwdParam
             s2[c] += dz * (yv * xs[c] + xf[c]);
         }
     }
+    // wave shuffle -> block LDS -> ONE fp64 atomic per block and sum (per-wave atomics on the same 2C words of an image serialise
+    // at the memory side: 8192 waves x 6 atomics made this pass 107 us)
+    __shared__ float blk[4][2 * C + 1];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         for (int off = 32; off >= 1; off >>= 1) {
@@ -177,14 +210,18 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_small_kernel(NormBwdParam
             s2[c] += __shfl_xor(s2[c], off);
         }
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(p.red + ((size_t)img * C + c) * 2, (double)s1[c]);
-            atomicAdd(p.red + ((size_t)img * C + c) * 2 + 1, (double)s2[c]);
+            blk[threadIdx.x >> 6][2 * c] = s1[c];
+            blk[threadIdx.x >> 6][2 * c + 1] = s2[c];
         }
     }
-    if (p.dslope) {
-        for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off);
-        if ((threadIdx.x & 63) == 0) atomicAdd(p.dslope, (double)ds);
-    }
+    for (int off = 32; off >= 1; off >>= 1) ds += __shfl_xor(ds, off);
+    if ((threadIdx.x & 63) == 0) blk[threadIdx.x >> 6][2 * C] = ds;
+    __syncthreads();
+    if (threadIdx.x < 2 * C)
+        atomicAdd(p.red + (size_t)img * C * 2 + threadIdx.x,
+                  (double)blk[0][threadIdx.x] + (double)blk[1][threadIdx.x] + (double)blk[2][threadIdx.x] + (double)blk[3][threadIdx.x]);
+    if (p.dslope && threadIdx.x == 2 * C)
+        atomicAdd(p.dslope, (double)blk[0][2 * C] + (double)blk[1][2 * C] + (double)blk[2][2 * C] + (double)blk[3][2 * C]);
 }
 
 template <int C>
@@ -248,13 +285,21 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
     } else {
         const int c4n = y.c / 4;
         CS_REQUIRE(y.c % 4 == 0 && c4n <= 256 && 256 % c4n == 0, "norm_bwd: %d channels unsupported (need a power of two in 16..1024)", y.c);
-        p.pix_per_block = npix >= 4096 ? 1024 : (npix >= 256 ? 256 : (int)npix);
+        // enough blocks to keep ~30 KB of loads in flight per CU: ~4096 blocks over the batch (the round-1 choice of 1024 pixels
+        // per block left 2 blocks per CU on the large tensors and ran the pass at 1 TB/s)
+        auto chunk = [&](int64_t target_blocks) {
+            int64_t ppb = (npix * n + target_blocks - 1) / target_blocks;
+            ppb = ppb < 64 ? 64 : ppb;
+            ppb = (ppb + 63) / 64 * 64;
+            return (int)(ppb < npix ? ppb : npix);
+        };
+        p.pix_per_block = chunk(2048);
         dim3 grid((unsigned)ceil_div((int)npix, p.pix_per_block), (unsigned)n);
         hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(256), 0, s, p);
         bn_finalize();
-        const int64_t total = (int64_t)n * npix * c4n;
-        const int64_t blocks = (total + 255) / 256;
-        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, p, total);
+        NormBwdParams pa = p;                                // finer pixel chunks: the apply pass has no per-block reduction to amortise
+        pa.pix_per_block = chunk(4096);
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)ceil_div((int)npix, pa.pix_per_block), (unsigned)n), dim3(256), 0, s, pa);
     }
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -566,37 +611,58 @@ int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pit
 }
 
 // sum of the split_k partials [k][taps][rows_total][cols_total] (rows row_off.., cols col_off..) -> PyTorch layout
-// dst[row][col][tap].  Block = 32 consecutive partial elements (one tap) x 8 split-K lanes, LDS tree over the lanes.
+// dst[row][col][tap].  Block = EL consecutive elements x KL split-K lanes (KL = 256 / EL): every thread sums ALL taps of its
+// element over its share of the split-K slices (loads coalesced over the elements), the lanes are merged through LDS and the
+// block writes its EL * taps outputs as one contiguous run.  KL = 4 for short split-K, 32 for the high-resolution layers whose
+// split-K is in the hundreds (round 1: 32 elements x 8 lanes, one tap per block, 22 us per launch on average).
+template <int EL, int TAPS>
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* part, int split_k, int rows_total, int cols_total, int row_off,
-                                                           int col_off, int rows, int cols, int taps, float* dst) {
-    __shared__ float sh[256];
-    const int el = threadIdx.x & 31, kl = threadIdx.x >> 5;
+                                                           int col_off, int rows, int cols, float* dst) {
+    constexpr int KL = 256 / EL;
+    __shared__ float sh[KL][EL * TAPS + 1];
+    const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
     const int per_tap = rows * cols;
-    const int tap = blockIdx.y;
-    const int e = blockIdx.x * 32 + el;                 // element inside this conv's [rows][cols] block
-    float acc = 0.f;
+    const int e = blockIdx.x * EL + el;
+    float acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = 0.f;
     if (e < per_tap) {
         const int row = e / cols, col = e - row * cols;
-        const size_t off = ((size_t)tap * rows_total + row_off + row) * cols_total + col_off + col;
-        const size_t stride = (size_t)taps * rows_total * cols_total;
-        for (int k = kl; k < split_k; k += 8) acc += part[(size_t)k * stride + off];
+        const size_t off = ((size_t)row_off + row) * cols_total + col_off + col;
+        const size_t tap_stride = (size_t)rows_total * cols_total, k_stride = (size_t)TAPS * tap_stride;
+        for (int k = kl; k < split_k; k += KL) {
+            const float* pk = part + (size_t)k * k_stride + off;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[t] += pk[(size_t)t * tap_stride];
+        }
     }
-    sh[threadIdx.x] = acc;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) sh[kl][el * TAPS + t] = acc[t];
     __syncthreads();
-    if (kl == 0 && e < per_tap) {
+    const int e0 = blockIdx.x * EL;
+    const int n_out = (per_tap - e0 < EL ? per_tap - e0 : EL) * TAPS;
+    for (int i = threadIdx.x; i < n_out; i += 256) {
         float t = 0.f;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) t += sh[l * 32 + el];
-        dst[(size_t)e * taps + tap] = t;
+        for (int l = 0; l < KL; ++l) t += sh[l][i];
+        dst[(size_t)e0 * TAPS + i] = t;
     }
 }
 
 int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_total, int cols_total, int row_off, int col_off,
                         int rows, int cols, int taps, float* dst) {
     const int total = rows * cols * taps;
+    CS_REQUIRE(taps == 9 || taps == 1, "unpack_wgrad: %d taps", taps);
     ProfScope prof(K_UNPACK, s, 0, 4.0 * total * (split_k + 1));
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)ceil_div(rows * cols, 32), (unsigned)taps), dim3(256), 0, s, part, split_k,
-                       rows_total, cols_total, row_off, col_off, rows, cols, taps, dst);
+#define CS_UNPACK(EL_, T_)                                                                                                       \
+    hipLaunchKernelGGL((unpack_wgrad_kernel<EL_, T_>), dim3((unsigned)ceil_div(rows * cols, EL_)), dim3(256), 0, s, part, split_k, \
+                       rows_total, cols_total, row_off, col_off, rows, cols, dst)
+    if (split_k > 16) {
+        if (taps == 9) CS_UNPACK(8, 9); else CS_UNPACK(8, 1);
+    } else {
+        if (taps == 9) CS_UNPACK(64, 9); else CS_UNPACK(64, 1);
+    }
+#undef CS_UNPACK
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -693,24 +759,35 @@ __global__ __launch_bounds__(256) void conv_last_bwd_kernel(const float* dl, con
             red_s[0][threadIdx.x] + red_s[1][threadIdx.x] + red_s[2][threadIdx.x] + red_s[3][threadIdx.x];
 }
 
-// sum of the per-block partial rows in fp64
-__global__ void rows_sum_kernel(const float* partial, int rows, int cols, double* dst) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// sum of the per-block partial rows in fp64: block = 8 columns x 32 row lanes (one thread walking all the rows of a column was
+// 119 us of pure latency)
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* partial, int rows, int cols, double* dst) {
+    __shared__ double sh[256];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double acc = 0.0;
-    for (int r = 0; r < rows; ++r) acc += (double)partial[(size_t)r * cols + c];
-    dst[c] = acc;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 32) acc += (double)partial[(size_t)r * cols + c];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 32; ++l) t += sh[l * 8 + cl];
+        dst[c] = t;
+    }
 }
 
-size_t conv_last_bwd_partial_floats(int n) { return (size_t)n * 16 * 84; }
+constexpr int LAST_BWD_BLOCKS = 64;      // blocks per image of the last-layer backward
+size_t conv_last_bwd_partial_floats(int n) { return (size_t)n * LAST_BWD_BLOCKS * 84; }
 
 int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw_db,
                          float* partial, int n, int h, int w) {
     CS_REQUIRE(u.c == 3 && u.pitch == 3 && u.tab, "conv_last_bwd: 3-class contract");
     ProfScope prof(K_TOP_BWD, s, 4.0 * n * h * w * 81.0, 4.0 * n * (double)h * w * 9);
-    dim3 grid(16, (unsigned)n);
+    dim3 grid(LAST_BWD_BLOCKS, (unsigned)n);
     hipLaunchKernelGGL((conv_last_bwd_kernel<3>), grid, dim3(256), 0, s, dlogits, u.ptr, u.tab, u.slope, w_torch, d_au, partial, h, w);
-    hipLaunchKernelGGL(rows_sum_kernel, dim3(1), dim3(128), 0, s, partial, n * 16, 84, dw_db);   // [81 weights | 3 biases]
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(84, 8)), dim3(256), 0, s, partial, n * LAST_BWD_BLOCKS, 84, dw_db);   // [81 weights | 3 biases]
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -744,6 +821,22 @@ __global__ __launch_bounds__(256) void convt_small_bwd_data_kernel(const float* 
             for (int co = 0; co < COUT; ++co) g[ky * 3 + kx][co] = ok ? du[(((size_t)img * hout + oy) * wout + ox) * COUT + co] : 0.f;
         }
     float* o = dst + ((size_t)img * hin * win + pix) * dst_pitch;
+    if ((c_count & 3) == 0 && (dst_pitch & 3) == 0) {          // 16-byte stores: 4 channels at a time
+        for (int ci = 0; ci < c_count; ci += 4) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* wr = &w_s[(ci + j) * WROW];
+#pragma unroll
+                for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) acc[j] += g[k][co] * wr[co * 9 + k];
+            }
+            if (accumulate) acc += *reinterpret_cast<const f32x4*>(o + ci);
+            *reinterpret_cast<f32x4*>(o + ci) = acc;
+        }
+        return;
+    }
     for (int ci = 0; ci < c_count; ++ci) {
         const float* wr = &w_s[ci * WROW];
         float acc = 0.f;

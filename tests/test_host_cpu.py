@@ -167,3 +167,89 @@ def test_cell_dataset_train_pipeline(tmp_path):
         item = ds[rep % 3]
         assert item["img"].shape == (3, 64, 64) and item["label"].shape == (1, 64, 64)
         assert item["img"].dtype == torch.float32 and set(item["label"].unique().tolist()) <= {0, 1, 2}
+
+
+# ---- deterministic parts of the augmentations against independent restatements written down here (MONAI is absent:
+# ---- model_training_3class.py:119-162 is anchored on what MONAI's transforms are documented to compute)
+def test_gaussian_smooth_equals_direct_erf_convolution():
+    """RandGaussianSmoothd's deterministic part: separable correlation with pixel-integrated Gaussian taps
+    0.5 (erf((x + 0.5) / (sigma sqrt 2)) - erf((x - 0.5) / (sigma sqrt 2))), tail int(max(4 sigma, 0.5) + 0.5), zero padding."""
+    import math
+    from cellseg_amd import data
+    rng = np.random.default_rng(5)
+    img = rng.random((2, 19, 23)).astype(np.float32)
+    sy, sx = 1.3, 0.6
+
+    def taps(sigma):
+        tail = int(max(sigma * 4.0, 0.5) + 0.5)
+        return tail, [0.5 * (math.erf((x + 0.5) / (sigma * math.sqrt(2))) - math.erf((x - 0.5) / (sigma * math.sqrt(2)))) for x in range(-tail, tail + 1)]
+    ty, ky = taps(sy)
+    tx, kx = taps(sx)
+    want = np.zeros_like(img, dtype=np.float64)
+    tmp = np.zeros_like(img, dtype=np.float64)
+    c, h, w = img.shape
+    for y in range(h):
+        for j, wgt in enumerate(ky):
+            yy = y + j - ty
+            if 0 <= yy < h:
+                tmp[:, y] += wgt * img[:, yy]
+    for x in range(w):
+        for j, wgt in enumerate(kx):
+            xx = x + j - tx
+            if 0 <= xx < w:
+                want[:, :, x] += wgt * tmp[:, :, xx]
+    got = data.gaussian_smooth(img, sy, sx)
+    assert np.abs(got - want).max() <= 5e-6
+
+
+def test_histogram_shift_equals_piecewise_linear_formula():
+    """RandHistogramShiftd's deterministic part with 3 control points: x in [lo, mid] maps linearly onto [lo, f], x in [mid, hi]
+    onto [f, hi] where f = lo + fl[1] (hi - lo)."""
+    from cellseg_amd import data
+    rng = np.random.default_rng(6)
+    img = (rng.random((3, 17, 11)) * 3 - 1).astype(np.float32)
+    fl = np.array([0.0, 0.73, 1.0])
+    lo, hi = float(img.min()), float(img.max())
+    mid, f = 0.5 * (lo + hi), lo + 0.73 * (hi - lo)
+    want = np.where(img <= mid, lo + (img - lo) / (mid - lo) * (f - lo), f + (img - mid) / (hi - mid) * (hi - f))
+    assert np.abs(data.histogram_shift(img, fl) - want).max() <= 1e-5
+
+
+def test_zoom_keep_size_equals_block_average_and_nearest():
+    """RandZoomd(mode=("area", "nearest"), keep_size=True, padding_mode="edge") for zoom factors with integer ratios: zoom 0.5
+    is a 2x2 block average (image) / the top-left sample of each block (label: nearest picks floor(i / zoom)), edge-padded back to
+    the input size; zoom 2.0 replicates every pixel 2x2 and crops the centre."""
+    from cellseg_amd import data
+    rng = np.random.default_rng(7)
+    img = rng.random((3, 16, 24)).astype(np.float32)
+    lab = rng.integers(0, 3, (1, 16, 24)).astype(np.uint8)
+    zi, zl = data.zoom_keep_size(img, lab, 0.5)
+    small = img.reshape(3, 8, 2, 12, 2).mean((2, 4))
+    small_l = lab[:, ::2, ::2]
+    assert np.abs(zi[:, 4:12, 6:18] - small).max() <= 1e-6 and np.array_equal(zl[:, 4:12, 6:18], small_l)
+    assert np.allclose(zi[:, 0, 6:18], small[:, 0]) and np.allclose(zi[:, 15, 6:18], small[:, -1])      # edge padding, rows
+    assert np.allclose(zi[:, 4:12, 0], small[:, :, 0]) and np.array_equal(zl[:, 4:12, 23], small_l[:, :, -1])
+    zi, zl = data.zoom_keep_size(img, lab, 2.0)
+    big = np.repeat(np.repeat(img, 2, 1), 2, 2)
+    big_l = np.repeat(np.repeat(lab, 2, 1), 2, 2)
+    assert np.abs(zi - big[:, 8:24, 12:36]).max() <= 1e-6 and np.array_equal(zl, big_l[:, 8:24, 12:36])
+
+
+def test_worker_seeding_gives_distinct_streams():
+    """forked DataLoader workers all replayed the parent's generator state."""
+    from cellseg_amd import data
+    ds = data.CellDataset([], 64, True, seed=3)
+
+    class Info:
+        def __init__(self, seed, ds):
+            self.seed, self.dataset = seed, ds
+    draws = []
+    for wid, seed in ((0, 1000), (1, 1001), (0, 2000)):
+        real = torch.utils.data.get_worker_info
+        torch.utils.data.get_worker_info = lambda s=seed: Info(s, ds)
+        try:
+            data.seed_worker(wid)
+        finally:
+            torch.utils.data.get_worker_info = real
+        draws.append(ds.rng.random(4).tolist())
+    assert draws[0] != draws[1] and draws[0] != draws[2] and draws[1] != draws[2]

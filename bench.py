@@ -403,7 +403,7 @@ def main():
             if world == 1 and args.width != "reference16":
                 sec_res = measure_infer("reference16", args.precision, False, True)
             if world == 1 and args.precision == "fp32":
-                for prec in ("fp16x3", "bf16x6", "bf16"):
+                for prec in ("fp16x3", "bf16x6", "bf16", "fp8"):
                     r = measure_infer(args.width, prec, False, False)
                     modes[prec] = dict(infer_summary(r, False), foreground_agreement_vs_primary=round(
                         float(((r["labels"] > 0) == (main_res["labels"] > 0)).float().mean().item()), 6))
@@ -507,8 +507,10 @@ def main():
     if modes:
         out["other_precisions"] = {"note": "same workload, convolutions on the 16-bit matrix pipe (v_mfma_f32_16x16x32_{f16,bf16}, fp32 "
                                            "accumulate): fp16x3 = 2 fp16 planes (22 mantissa bits) x 3 terms and bf16x6 = 3 bf16 planes x "
-                                           "6 terms are fp32-grade (logits within 1e-4 of the oracle in the GPU tests), bf16 = plain bf16 "
-                                           "products", **modes}
+                                           "6 terms are fp32-grade (logits within 1e-4 of the oracle in the GPU tests); bf16 = the bf16 datapath "
+                                           "(bf16 weights, bf16 activations in HBM); fp8 = e4m3 weights with per-channel scales, e4m3-staged "
+                                           "activations, v_mfma_scale_f32_16x16x128_f8f6f4 (built for the 64...1024 net of configs[4]: at this "
+                                           "width most layers fill a fraction of its K = 128)", **modes}
     if train_res:
         out["train_step"] = train_res
     if world == 1 and not args.no_cpu_baseline:

@@ -66,6 +66,14 @@ __device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
     const unsigned u = __builtin_bit_cast(unsigned, f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;            // RNE (NaN payloads are not expected on this path)
 }
+// 8 floats -> 8 e4m3 bytes (v_cvt_pk_fp8_f32; saturating when the kernel has set MODE.FP16_OVFL)
+__device__ __forceinline__ uint2 f32x8_to_fp8(const float (&v)[8]) {
+    unsigned lo = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    lo = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], (int)lo, true);
+    unsigned hi = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    hi = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], (int)hi, true);
+    return make_uint2(lo, hi);
+}
 __device__ __forceinline__ uint2 f32x4_to_bf16(cs_f32x4 v) {
     return make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16), f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
 }

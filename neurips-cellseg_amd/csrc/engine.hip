@@ -437,7 +437,7 @@ static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, co
         return launch_conv_fp8(s, ksize, stride, a, ConvSrc(), cw.w8, cw.wscale, cw.bias, out, pitch_out, cout, stats, n, hin, win);
     if (net->planes > 0 && net->planes <= 4 && cw.wb)
         return launch_conv_bf16s(s, ksize, stride, net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin, win, a.h16);
-    CS_REQUIRE(!a.h16, "conv: a layer without 16-bit weights met bf16 activations");
+    CS_REQUIRE(!a.h16 && !a.q8, "conv: a layer without low-precision weights met bf16 / e4m3 activations");
     return launch_conv_mfma(s, ksize, stride, a, ConvSrc(), cw.w, cw.bias, out, pitch_out, cout, stats, n, hin, win);
 }
 
@@ -500,9 +500,21 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         rt.xtab = want_xtab ? ws.take<float2>((size_t)n * c_total) : nullptr;
     };
 
+    // fp8 mode: conv outputs stay bf16 (raw, pre-norm); every tensor a conv READS is materialised once as activated e4m3
+    // (launch_act_quant for the lazily normalised ones, the residual add writes its sum as e4m3), so the fp8 convs stage plain bytes
+    const bool q8 = a16 && net->planes == 5;
+    auto take_q8 = [&](size_t count) -> unsigned char* { return q8 ? ws.take<unsigned char>(count) : nullptr; };
+    auto raw8_src = [&](const unsigned char* ptr, int c) {
+        ConvSrc r;
+        r.ptr = reinterpret_cast<const float*>(ptr); r.c = c; r.pitch = c; r.q8 = true;
+        return r;
+    };
+
     // ---- encoder ----
     std::vector<float*> X(nl);   // materialised ResidualUnit outputs (skip connections)
+    std::vector<unsigned char*> Xq(nl, nullptr);
     const float* prev = nullptr;
+    const unsigned char* prevq = nullptr;
     int ph = h, pw = w, pc = net->in_ch;
     for (int d = 0; d < nl; ++d) {
         const DownUnit& u = net->down[d];
@@ -510,21 +522,25 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         float* E = take_act((size_t)n * oh * ow * c0);          // [y0 || r]
         std::vector<float*> Y(u.subunits, nullptr);
         for (int su = 1; su < u.subunits; ++su) Y[su] = take_act((size_t)n * oh * ow * c);
-        X[d] = take_act((size_t)n * oh * ow * c);
+        // X[d] as bf16 / fp32: everywhere except the fp8 mode, where only the top transposed conv (level 0) still reads it as bf16
+        X[d] = (!q8 || d == 0) ? take_act((size_t)n * oh * ow * c) : nullptr;
+        Xq[d] = take_q8((size_t)n * oh * ow * c);
+        unsigned char* Aq = (q8 && u.subunits > 1) ? take_q8((size_t)n * oh * ow * c) : nullptr;   // activated input of the next subunit
         for (int su = 0; su < u.subunits; ++su) new_tab(rt_down[d][su], su == 0 ? c0 : c);
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
             if (u.first) {
                 CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, a16));
             } else {
-                CS_TRY(conv_fwd(s, net, 3, 2, raw_src(prev, pc, pc, a16), u.unit0, E, c0, c0, rt_down[d][0].stats, n, ph, pw));
+                CS_TRY(conv_fwd(s, net, 3, 2, q8 ? raw8_src(prevq, pc) : raw_src(prev, pc, pc, a16), u.unit0, E, c0, c0, rt_down[d][0].stats, n, ph, pw));
             }
             CS_TRY(finish_norm(s, net, u.norms[0], rt_down[d][0], n, c0, oh * ow, dry));
             const float* cur = E;
             int cur_pitch = c0, cur_tabc = c0;
             for (int su = 1; su < u.subunits; ++su) {
-                CS_TRY(conv_fwd(s, net, 3, 1, lazy_src(cur, c, cur_pitch, rt_down[d][su - 1], u.norms[su - 1], cur_tabc, a16),
-                                u.units[su - 1], Y[su], c, c, rt_down[d][su].stats, n, oh, ow));
+                const ConvSrc lz = lazy_src(cur, c, cur_pitch, rt_down[d][su - 1], u.norms[su - 1], cur_tabc, a16);
+                if (q8) CS_TRY(launch_act_quant(s, lz, Aq, c, (int64_t)oh * ow, n));
+                CS_TRY(conv_fwd(s, net, 3, 1, q8 ? raw8_src(Aq, c) : lz, u.units[su - 1], Y[su], c, c, rt_down[d][su].stats, n, oh, ow));
                 CS_TRY(finish_norm(s, net, u.norms[su], rt_down[d][su], n, c, oh * ow, dry));
                 cur = Y[su];
                 cur_pitch = c;
@@ -532,36 +548,43 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             }
             const int last = u.subunits - 1;
             CS_TRY(launch_norm_act_add(s, lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc, a16),
-                                       raw_src(act_off(E, c, a16), c, c0, a16), X[d], c, (int64_t)oh * ow, n, a16));
+                                       raw_src(act_off(E, c, a16), c, c0, a16), X[d], c, (int64_t)oh * ow, n, a16, Xq[d], c));
         }
         prev = X[d];
+        prevq = Xq[d];
         ph = oh; pw = ow; pc = c;
         if (tape) { tape->E[d] = E; tape->Y[d] = Y; }
     }
     // ---- bottom ----
     float* S = nullptr;   // "sub" input of the next up layer
+    unsigned char* Sq = nullptr;
     {
         const DownUnit& u = net->bottom;
         const int c = u.c;
         std::vector<float*> Y(u.subunits);
         for (int su = 0; su < u.subunits; ++su) Y[su] = take_act((size_t)n * ph * pw * c);
         float* R = u.res_conv ? take_act((size_t)n * ph * pw * c) : nullptr;
-        S = take_act((size_t)n * ph * pw * c);
+        S = (!q8 || nl == 1) ? take_act((size_t)n * ph * pw * c) : nullptr;     // bf16 form only where the top transposed conv reads it
+        Sq = (q8 && nl > 1) ? take_q8((size_t)n * ph * pw * c) : nullptr;
+        unsigned char* Aq = (q8 && u.subunits > 1) ? take_q8((size_t)n * ph * pw * c) : nullptr;
         for (int su = 0; su < u.subunits; ++su) new_tab(rt_bottom[su], c);
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
+        CS_REQUIRE(!q8 || u.res_conv, "unet(fp8): an identity residual at the bottom is not supported");
         if (!dry) {
-            CS_TRY(conv_fwd(s, net, 3, 1, raw_src(prev, pc, pc, a16), u.unit0, Y[0], c, c, rt_bottom[0].stats, n, ph, pw));
+            const ConvSrc in = q8 ? raw8_src(prevq, pc) : raw_src(prev, pc, pc, a16);
+            CS_TRY(conv_fwd(s, net, 3, 1, in, u.unit0, Y[0], c, c, rt_bottom[0].stats, n, ph, pw));
             CS_TRY(finish_norm(s, net, u.norms[0], rt_bottom[0], n, c, ph * pw, dry));
             if (u.res_conv)
-                CS_TRY(conv_fwd(s, net, 1, 1, raw_src(prev, pc, pc, a16), u.res1x1, R, c, c, nullptr, n, ph, pw));
+                CS_TRY(conv_fwd(s, net, 1, 1, in, u.res1x1, R, c, c, nullptr, n, ph, pw));
             for (int su = 1; su < u.subunits; ++su) {
-                CS_TRY(conv_fwd(s, net, 3, 1, lazy_src(Y[su - 1], c, c, rt_bottom[su - 1], u.norms[su - 1], c, a16), u.units[su - 1],
-                                Y[su], c, c, rt_bottom[su].stats, n, ph, pw));
+                const ConvSrc lz = lazy_src(Y[su - 1], c, c, rt_bottom[su - 1], u.norms[su - 1], c, a16);
+                if (q8) CS_TRY(launch_act_quant(s, lz, Aq, c, (int64_t)ph * pw, n));
+                CS_TRY(conv_fwd(s, net, 3, 1, q8 ? raw8_src(Aq, c) : lz, u.units[su - 1], Y[su], c, c, rt_bottom[su].stats, n, ph, pw));
                 CS_TRY(finish_norm(s, net, u.norms[su], rt_bottom[su], n, c, ph * pw, dry));
             }
             const int last = u.subunits - 1;
             CS_TRY(launch_norm_act_add(s, lazy_src(Y[last], c, c, rt_bottom[last], u.norms[last], c, a16),
-                                       u.res_conv ? raw_src(R, c, c, a16) : raw_src(prev, c, pc, a16), S, c, (int64_t)ph * pw, n, a16));
+                                       u.res_conv ? raw_src(R, c, c, a16) : raw_src(prev, c, pc, a16), S, c, (int64_t)ph * pw, n, a16, Sq, c));
         }
         if (tape) { tape->Yb = Y; tape->Rb = R; tape->Sb = S; }
     }
@@ -574,14 +597,19 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         float* U = u16 ? take_act((size_t)n * oh * ow * c) : ws.take<float>((size_t)n * oh * ow * c);
         new_tab(rt_upt[d], c);
         float *V = nullptr, *D = nullptr;
+        unsigned char *Dq = nullptr, *Uq = nullptr;
         if (!u.top) {
             V = take_act((size_t)n * oh * ow * c);
-            D = take_act((size_t)n * oh * ow * c);
+            D = (!q8 || d == 1) ? take_act((size_t)n * oh * ow * c) : nullptr;   // fp8 mode: bf16 only for the level the top conv reads
+            Dq = (q8 && d > 1) ? take_q8((size_t)n * oh * ow * c) : nullptr;
+            Uq = take_q8((size_t)n * oh * ow * c);
             new_tab(rt_upu[d], c);
         }
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
-            const ConvSrc a = raw_src(X[d], u.cin_skip, u.cin_skip, a16), b = raw_src(S, sc, sc, a16);
+            const bool in8 = q8 && !u.top;
+            const ConvSrc a = in8 ? raw8_src(Xq[d], u.cin_skip) : raw_src(X[d], u.cin_skip, u.cin_skip, a16);
+            const ConvSrc b = in8 ? raw8_src(Sq, sc) : raw_src(S, sc, sc, a16);
             if (c % 16 == 0 && net->planes == 5 && u.convt.w8) {
                 CS_TRY(launch_convt_fp8(s, a, b, u.convt.w8, u.convt.wscale, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
             } else if (c % 16 == 0 && net->planes > 0 && net->planes <= 4 && u.convt.wb) {
@@ -597,12 +625,14 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             if (u.top) {
                 CS_TRY(launch_conv_last(s, lu, u.unit0.w, u.unit0.bias, logits, c, n, oh, ow));
             } else {
-                CS_TRY(conv_fwd(s, net, 3, 1, lu, u.unit0, V, c, c, rt_upu[d].stats, n, oh, ow));
+                if (q8) CS_TRY(launch_act_quant(s, lu, Uq, c, (int64_t)oh * ow, n));
+                CS_TRY(conv_fwd(s, net, 3, 1, q8 ? raw8_src(Uq, c) : lu, u.unit0, V, c, c, rt_upu[d].stats, n, oh, ow));
                 CS_TRY(finish_norm(s, net, u.norm_u, rt_upu[d], n, c, oh * ow, dry));
-                CS_TRY(launch_norm_act_add(s, lazy_src(V, c, c, rt_upu[d], u.norm_u, c, a16), lu, D, c, (int64_t)oh * ow, n, a16));
+                CS_TRY(launch_norm_act_add(s, lazy_src(V, c, c, rt_upu[d], u.norm_u, c, a16), lu, D, c, (int64_t)oh * ow, n, a16, Dq, c));
             }
         }
         S = D;
+        Sq = Dq;
         sc = c;
         ph = oh; pw = ow;
         if (tape) { tape->U[d] = U; tape->V[d] = V; tape->D[d] = D; }

@@ -15,6 +15,7 @@ struct ConvSrc {
     int tab_off = 0;               // channel offset of this source inside `tab`
     bool h16 = false;              // `ptr` really points at bf16 elements (the bf16 datapath keeps activations as bf16 in HBM);
                                    // pitch / c still count elements
+    bool q8 = false;               // `ptr` points at e4m3 bytes: an ACTIVATED tensor materialised for the fp8 kernels (no table)
 };
 
 // ---- weight packing (PyTorch layout -> MFMA fragment order) -----------------------------------
@@ -76,8 +77,9 @@ size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize);
 int pack_conv_weights_bf16(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
                            unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16 = false);
 
-// fp8 variant (kernels_conv_fp8.hip): e4m3 weights with one fp32 scale per output channel, bf16 activations in HBM converted
-// to e4m3 while staging, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, fp32 accumulate, bf16 out.
+// fp8 variant (kernels_conv_fp8.hip): e4m3 weights with one fp32 scale per output channel, inputs = ACTIVATED e4m3 tensors
+// (ConvSrc::q8; launch_act_quant / launch_norm_act_add produce them) staged as plain 16-byte copies,
+// v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, fp32 accumulate, bf16 out (raw conv output for the next norm).
 int launch_conv_fp8(hipStream_t s, int ksize, int stride, const ConvSrc& a, const ConvSrc& b, const unsigned char* wpack,
                     const float* wscale, const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win);
 int launch_convt_fp8(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const unsigned char* wpack, const float* wscale, const float* bias,
@@ -124,8 +126,13 @@ int launch_bn_train_finalize(hipStream_t s, const double* stats, const float* we
                              float* run_var, float2* tab, float2* xtab, int n, int c, int c_total, int count, float eps,
                              float momentum);
 // out = T_y(y) + T_r(r)   (T = lazy norm/act or identity), all NHWC with channel count c
+// out8 (fp8 mode): the sum is ALSO (or, with out == nullptr, only) written as e4m3 bytes with pixel pitch pitch8 - the form the
+// fp8 convolutions stage without any arithmetic
 int launch_norm_act_add(hipStream_t s, const ConvSrc& y, const ConvSrc& r, float* out, int pitch_out, int64_t npix_per_image, int n,
-                        bool act16 = false);
+                        bool act16 = false, unsigned char* out8 = nullptr, int pitch8 = 0);
+// fp8 mode: dst8[pix][c] = e4m3(T(src)) - InstanceNorm / BatchNorm table + PReLU applied ONCE per element instead of by every
+// output-channel block of every consumer; src is a bf16 tensor with a lazy table
+int launch_act_quant(hipStream_t s, const ConvSrc& src, unsigned char* dst8, int pitch8, int64_t npix_per_image, int n);
 
 // ---- backward pass (kernels_bwd.hip) -----------------------------------------------------------
 // InstanceNorm + PReLU backward of `y` (raw conv output + forward table/slope): da -> dy; red [n][c][2] and dslope

@@ -299,6 +299,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
 #pragma unroll
                             for (int t = 0; t < NTW; ++t)
                                 acc[ka][m0 + mm][t] = mfma_split<F16>(a[mm][ia], b[t][ib], acc[ka][m0 + mm][t]);
+                        // pin the chains here: LLVM may otherwise sink the (side-effect free) MFMAs below the staging code
+                        // (kernels_conv_fp8.hip: 2.7 KB of spills per lane when that happened)
+#pragma unroll
+                        for (int mm = 0; mm < MG; ++mm)
+#pragma unroll
+                            for (int t = 0; t < NTW; ++t) asm volatile("" : "+v"(acc[0][m0 + mm][t]));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -1,8 +1,12 @@
 // gfx950 fp8 convolution kernels: BASELINE.json configs[4] ("mixed fp8 weights ... on CDNA4 MFMA").
 //
-// Weights are stored as OCP fp8 (e4m3fn) with ONE fp32 scale per output channel (computed at pack time: amax / 448);
-// activations live in HBM as bf16 (the bf16 datapath) and are converted to e4m3 while the input patch is staged into LDS
-// (after the producer's lazy InstanceNorm + PReLU, so the values are O(1) and need no scale).  The contraction runs on the
+// Weights are stored as OCP fp8 (e4m3fn) with ONE fp32 scale per output channel (computed at pack time: amax / 448).
+// Conv OUTPUTS are bf16 (raw, pre-norm); every conv INPUT is an activated e4m3 tensor that was materialised once - by
+// launch_act_quant (norm table + PReLU + conversion, 2 bytes in / 1 byte out per element) or by the residual add - so the
+// values are O(1) and need no scale, and a conv stages its input patch with plain 16-byte copies: no arithmetic, one byte per
+// element and channel-tile block.  (The first version converted bf16 -> e4m3 while staging: ~45 VALU instructions per 8 channels,
+// repeated by each of the up to 8 output-channel blocks that read a pixel - the conversion, not the matrix pipe, set the pace,
+// and the bf16 kernels were faster on the configs[4] net.)  The contraction runs on the
 // block-scaled matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 0x7f): K = 128 channels per
 // instruction at twice the bf16 rate (~5 PFLOP/s dense), fp32 accumulate.  The per-channel weight scale is applied to the
 // fp32 accumulator in the epilogue; statistics for the next InstanceNorm come from those fp32 values; the output is bf16.
@@ -41,10 +45,8 @@ __device__ __forceinline__ unsigned pk_fp8(float a, float b, unsigned old) {
 }
 
 struct SrcDev8 {
-    const float* ptr;            // bf16 elements (bf16 datapath)
-    const float2* tab;
-    const float* slope;
-    int c, pitch, tab_c, tab_off;
+    const unsigned char* ptr;    // activated e4m3 elements
+    int c, pitch;
 };
 
 struct Conv8Params {
@@ -54,7 +56,6 @@ struct Conv8Params {
     const float* bias;
     float* out;                  // bf16 elements
     double* stats;
-    const float* dummy;
     int pitch_out, cout, ntile_total;
     int n, hin, win, hout, wout, tiles_x, tiles_y;
 };
@@ -82,13 +83,7 @@ __device__ __forceinline__ void stats_commit8(double s, double q, double* dst, i
     }
 }
 
-// Staging of one 128-channel chunk: item = (pixel, 8 channels) = one 16-byte load of bf16, lazy norm / act, 8 e4m3 bytes to LDS.
-// Every thread keeps the same channel octet `q` for all its items, so its 8 (scale, shift) pairs are loaded once per chunk.
-struct Lazy8 {
-    f32x4 t[4];
-    float slope;
-    bool on;
-};
+// Staging of one 128-channel chunk: item = (pixel, 16 channels) = one 16-byte load and one 16-byte LDS store.
 
 // MODE 0: conv (S in {1,2}, KS in {3,1});  the transposed conv has its own kernel below.
 template <int S, int KS, int WN, int NTW, int THX>
@@ -100,16 +95,17 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
     constexpr int PITCH = 144;                              // bytes per staged pixel: 128 e4m3 + 16 pad (conflict-free b128 reads at S = 1)
     constexpr int PAD = KS / 2, TAPS = KS * KS;
-    constexpr int IN_ITEMS = IH * IW * 16;
+    constexpr int IN_ITEMS = IH * IW * 8;
     constexpr int IN_ITERS = (IN_ITEMS + 255) / 256;
     constexpr int IN_BYTES = (IH * IW * PITCH + 15) / 16 * 16;
     constexpr int EPS = 16 * NTB + 4;
     constexpr int EP_BYTES = TH * 16 * EPS * 4;
-    constexpr int SM_BYTES = 2 * IN_BYTES > EP_BYTES ? 2 * IN_BYTES : EP_BYTES;
+    // the input patch is double-buffered only where the epilogue slab already pays for the LDS: a 2 x 43 KB patch (stride 2) left
+    // ONE block per CU - one wave per SIMD, every load / barrier latency exposed: 20 us per block for 1 us of matrix work
+    constexpr bool DB = 2 * IN_BYTES <= EP_BYTES + 4096;
+    constexpr int SM_BYTES = (DB ? 2 : 1) * IN_BYTES > EP_BYTES ? (DB ? 2 : 1) * IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
 
-    // MODE.FP16_OVFL (bit 23): an activation beyond +-448 saturates in the e4m3 conversion instead of turning into NaN
-    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
     const int wn = wave % WN, wm = wave / WN;
@@ -122,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
     const int img = bid / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int nt_w = wk.ct * NTB + wn * NTW;
-    const int q = tid & 15;                                  // channel octet of this thread inside the 128-channel chunk
+    const int q = tid & 7;                                   // 16-channel group of this thread inside the 128-channel chunk
 
     f32x4 acc[MTW][NTW];
 #pragma unroll
@@ -133,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
     int goff[IN_ITERS];
 #pragma unroll
     for (int it = 0; it < IN_ITERS; ++it) {
-        const int pix = (tid >> 4) + 16 * it;
+        const int pix = (tid >> 3) + 32 * it;
         const int iy = pix / IW, ix = pix - iy * IW;
         const int gy = oy0 * S - PAD + iy, gx = ox0 * S - PAD + ix;
         goff[it] = (pix < IH * IW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win) ? gy * p.win + gx : -1;
@@ -141,24 +137,15 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
 
     const int chunks_a = (p.a.c + 127) >> 7, chunks = chunks_a + ((p.b.c + 127) >> 7);
     u32x4 rin[IN_ITERS];
-    Lazy8 lz;
     bool qvalid = false;
 
     auto load_input = [&](int ch) {
         const bool from_a = ch < chunks_a;
         const SrcDev8& src = from_a ? p.a : p.b;
         const int c0 = (from_a ? ch : ch - chunks_a) << 7;
-        qvalid = c0 + 8 * q < src.c;                        // channel tails (cin % 128 != 0) are zero-filled
-        const int cq = qvalid ? c0 + 8 * q : 0;
-        lz.on = src.tab != nullptr;
-        const f32x4* t = lz.on ? reinterpret_cast<const f32x4*>(src.tab + (size_t)img * src.tab_c + src.tab_off + cq)
-                               : reinterpret_cast<const f32x4*>(p.dummy);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lz.t[k] = t[k];
-        const float* sp = (lz.on && src.slope) ? src.slope : p.dummy;
-        lz.slope = *sp;
-        if (!(lz.on && src.slope)) lz.slope = 0.f;
-        const unsigned short* base = reinterpret_cast<const unsigned short*>(src.ptr) + (size_t)img * p.hin * p.win * src.pitch + cq;
+        qvalid = c0 + 16 * q < src.c;                       // channel tails (cin % 128 != 0) are zero-filled
+        const int cq = qvalid ? c0 + 16 * q : 0;
+        const unsigned char* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + cq;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) {
             const int o = goff[it] >= 0 ? goff[it] : 0;
@@ -168,30 +155,9 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
     auto store_input = [&](char* in_s) {
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) {
-            const int pix = (tid >> 4) + 16 * it;
-            if (IN_ITEMS % 256 == 0 || pix < IH * IW) {
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[2 * k] = bf16lo(rin[it][k]);
-                    v[2 * k + 1] = bf16hi(rin[it][k]);
-                }
-                if (lz.on) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v[2 * k] = prelu_8(v[2 * k] * lz.t[k].x + lz.t[k].y, lz.slope);
-                        v[2 * k + 1] = prelu_8(v[2 * k + 1] * lz.t[k].z + lz.t[k].w, lz.slope);
-                    }
-                }
-                u32x2 o{0u, 0u};
-                if (goff[it] >= 0 && qvalid) {
-                    o.x = pk_fp8<false>(v[0], v[1], 0u);
-                    o.x = pk_fp8<true>(v[2], v[3], o.x);
-                    o.y = pk_fp8<false>(v[4], v[5], 0u);
-                    o.y = pk_fp8<true>(v[6], v[7], o.y);
-                }
-                *reinterpret_cast<u32x2*>(in_s + pix * PITCH + q * 8) = o;
-            }
+            const int pix = (tid >> 3) + 32 * it;
+            if (IN_ITEMS % 256 == 0 || pix < IH * IW)
+                *reinterpret_cast<u32x4*>(in_s + pix * PITCH + q * 16) = (goff[it] >= 0 && qvalid) ? rin[it] : u32x4{0u, 0u, 0u, 0u};
         }
     };
     // weight fragments of one tap row: KS x NTW fragments of 32 bytes per lane (two lane-linear 16-byte loads each, from L2)
@@ -217,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
         const bool more = ch + 1 < chunks;
         load_input(more ? ch + 1 : ch);                     // unconditional (see conv_bf16s_kernel)
         __builtin_amdgcn_sched_barrier(0);
-        const char* in_s = smem + (ch & 1) * IN_BYTES;
+        const char* in_s = smem + (DB ? (ch & 1) * IN_BYTES : 0);
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
             const int row_next = ch * KS + ky + 1 < last_row ? ch * KS + ky + 1 : last_row;
@@ -242,14 +208,21 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
 #pragma unroll
                     for (int mm = 0; mm < MG; ++mm)
 #pragma unroll
-                        for (int t = 0; t < NTW; ++t) acc[m0 + mm][t] = mfma_fp8(a[mm], b[t], acc[m0 + mm][t]);
+                        for (int t = 0; t < NTW; ++t) {
+                            acc[m0 + mm][t] = mfma_fp8(a[mm], b[t], acc[m0 + mm][t]);
+                            // pins the MFMA at this point of the program: without it LLVM sinks the whole (side-effect free)
+                            // accumulation chain below the staging code, first loads the A fragments of all 9 taps (144+
+                            // registers) and spills 2.7 KB per lane
+                            asm volatile("" : "+v"(acc[m0 + mm][t]));
+                        }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) asm volatile("" ::"v"(rin[it]));
-        if (more) store_input(smem + ((ch + 1) & 1) * IN_BYTES);
+        if (!DB) __syncthreads();
+        if (more) store_input(smem + (DB ? ((ch + 1) & 1) * IN_BYTES : 0));
         __syncthreads();
     }
 
@@ -294,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
     }
 }
 
-static SrcDev8 to_dev8(const ConvSrc& s) { return SrcDev8{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
+static SrcDev8 to_dev8(const ConvSrc& s) { return SrcDev8{reinterpret_cast<const unsigned char*>(s.ptr), s.c, s.pitch}; }
 
 template <int S, int KS, int WN, int NTW, int THX = 1>
 static int launch_8(hipStream_t s, Conv8Params p) {
@@ -312,12 +285,12 @@ int launch_conv_fp8(hipStream_t s, int ksize, int stride, const ConvSrc& a, cons
     CS_REQUIRE(ksize == 3 || ksize == 1, "conv(fp8): ksize %d unsupported", ksize);
     CS_REQUIRE((stride == 1 || stride == 2) && !(ksize == 1 && stride != 1), "conv(fp8): stride %d unsupported", stride);
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "conv(fp8): channels must be multiples of 16");
-    CS_REQUIRE(a.h16 && (b.c == 0 || b.h16), "conv(fp8): activations must be bf16 tensors (bf16 datapath)");
-    CS_REQUIRE(a.pitch % 8 == 0 && (b.c == 0 || b.pitch % 8 == 0), "conv(fp8): pixel pitch must be a multiple of 8 elements");
+    CS_REQUIRE(a.q8 && !a.tab && (b.c == 0 || (b.q8 && !b.tab)), "conv(fp8): inputs must be activated e4m3 tensors (launch_act_quant)");
+    CS_REQUIRE(a.pitch % 16 == 0 && (b.c == 0 || b.pitch % 16 == 0), "conv(fp8): pixel pitch must be a multiple of 16 bytes");
     Conv8Params p{};
     p.a = to_dev8(a);
     p.b = to_dev8(b);
-    p.wpack = wpack; p.wscale = wscale; p.bias = bias; p.out = out; p.stats = stats; p.dummy = wscale;
+    p.wpack = wpack; p.wscale = wscale; p.bias = bias; p.out = out; p.stats = stats;
     p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16;
     p.n = n; p.hin = hin; p.win = win;
     const int pad = ksize / 2;
@@ -326,7 +299,7 @@ int launch_conv_fp8(hipStream_t s, int ksize, int stride, const ConvSrc& a, cons
     const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
     // FLOPs are the ALGORITHMIC ones (2 * cin * ...), not the zero-padded K the matrix pipe executes
     const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
-    const double bytes = 2.0 * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
+    const double bytes = n * (1.0 * hin * win * (a.c + b.c) + 2.0 * p.hout * p.wout * cout);
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
     const bool tall = stride == 1 && p.hout >= 16;
 #define CS_8(S_, KS_)                                                               \
@@ -352,7 +325,7 @@ template <int WN, int NTW>
 __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
     constexpr int WM = 4 / WN, TH = 4, TW = 16, MTW = TH / WM, NTB = WN * NTW;
     constexpr int IH = TH + 1, IW = TW + 1, PITCH = 144;
-    constexpr int IN_ITEMS = IH * IW * 16, IN_ITERS = (IN_ITEMS + 255) / 256;
+    constexpr int IN_ITEMS = IH * IW * 8, IN_ITERS = (IN_ITEMS + 255) / 256;
     constexpr int IN_BYTES = (IH * IW * PITCH + 15) / 16 * 16;
     constexpr int EPS = 16 * NTB + 4;
     constexpr int EP_BYTES = 2 * TH * 32 * EPS * 4;
@@ -360,7 +333,6 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
     char* const in_s = smem;
 
-    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // saturating e4m3 conversion (see conv_fp8_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
     const int wn = wave % WN, wm = wave / WN;
@@ -373,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
     const int img = bid / p.tiles_y;
     const int iy0 = ty * TH, ix0 = tx * TW;
     const int nt_w = wk.ct * NTB + wn * NTW;
-    const int q = tid & 15;
+    const int q = tid & 7;
 
     f32x4 acc[MTW][4][NTW];
 #pragma unroll
@@ -386,30 +358,21 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
     int goff[IN_ITERS];
 #pragma unroll
     for (int it = 0; it < IN_ITERS; ++it) {
-        const int pix = (tid >> 4) + 16 * it;
+        const int pix = (tid >> 3) + 32 * it;
         const int iy = pix / IW, ix = pix - iy * IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
         goff[it] = (pix < IH * IW && gy < p.hin && gx < p.win) ? gy * p.win + gx : -1;
     }
     const int chunks_a = (p.a.c + 127) >> 7, chunks = chunks_a + ((p.b.c + 127) >> 7);
     u32x4 rin[IN_ITERS];
-    Lazy8 lz;
     bool qvalid = false;
     auto load_input = [&](int ch) {
         const bool from_a = ch < chunks_a;
         const SrcDev8& src = from_a ? p.a : p.b;
         const int c0 = (from_a ? ch : ch - chunks_a) << 7;
-        qvalid = c0 + 8 * q < src.c;
-        const int cq = qvalid ? c0 + 8 * q : 0;
-        lz.on = src.tab != nullptr;
-        const f32x4* t = lz.on ? reinterpret_cast<const f32x4*>(src.tab + (size_t)img * src.tab_c + src.tab_off + cq)
-                               : reinterpret_cast<const f32x4*>(p.dummy);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lz.t[k] = t[k];
-        const float* sp = (lz.on && src.slope) ? src.slope : p.dummy;
-        lz.slope = *sp;
-        if (!(lz.on && src.slope)) lz.slope = 0.f;
-        const unsigned short* base = reinterpret_cast<const unsigned short*>(src.ptr) + (size_t)img * p.hin * p.win * src.pitch + cq;
+        qvalid = c0 + 16 * q < src.c;
+        const int cq = qvalid ? c0 + 16 * q : 0;
+        const unsigned char* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + cq;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) {
             const int o = goff[it] >= 0 ? goff[it] : 0;
@@ -419,30 +382,9 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
     auto store_input = [&]() {
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) {
-            const int pix = (tid >> 4) + 16 * it;
-            if (IN_ITEMS % 256 == 0 || pix < IH * IW) {
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[2 * k] = bf16lo(rin[it][k]);
-                    v[2 * k + 1] = bf16hi(rin[it][k]);
-                }
-                if (lz.on) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v[2 * k] = prelu_8(v[2 * k] * lz.t[k].x + lz.t[k].y, lz.slope);
-                        v[2 * k + 1] = prelu_8(v[2 * k + 1] * lz.t[k].z + lz.t[k].w, lz.slope);
-                    }
-                }
-                u32x2 o{0u, 0u};
-                if (goff[it] >= 0 && qvalid) {
-                    o.x = pk_fp8<false>(v[0], v[1], 0u);
-                    o.x = pk_fp8<true>(v[2], v[3], o.x);
-                    o.y = pk_fp8<false>(v[4], v[5], 0u);
-                    o.y = pk_fp8<true>(v[6], v[7], o.y);
-                }
-                *reinterpret_cast<u32x2*>(in_s + pix * PITCH + q * 8) = o;
-            }
+            const int pix = (tid >> 3) + 32 * it;
+            if (IN_ITEMS % 256 == 0 || pix < IH * IW)
+                *reinterpret_cast<u32x4*>(in_s + pix * PITCH + q * 16) = (goff[it] >= 0 && qvalid) ? rin[it] : u32x4{0u, 0u, 0u, 0u};
         }
     };
     i32x8 bq[3][NTW];
@@ -487,7 +429,10 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
                 const i32x4 lo = *reinterpret_cast<const i32x4*>(ap), hi = *reinterpret_cast<const i32x4*>(ap + 16);
                 const i32x8 a = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[m][ph][t] = mfma_fp8(a, b[t], acc[m][ph][t]);
+                for (int t = 0; t < NTW; ++t) {
+                    acc[m][ph][t] = mfma_fp8(a, b[t], acc[m][ph][t]);
+                    asm volatile("" : "+v"(acc[m][ph][t]));   // pinned: see conv_fp8_kernel
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -553,19 +498,19 @@ static int launch_t8(hipStream_t s, Conv8Params p) {
 int launch_convt_fp8(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const unsigned char* wpack, const float* wscale, const float* bias,
                      float* out, int pitch_out, int cout, double* stats, int n, int hin, int win) {
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "convT(fp8): channels must be multiples of 16");
-    CS_REQUIRE(a.h16 && (b.c == 0 || b.h16), "convT(fp8): activations must be bf16 tensors (bf16 datapath)");
-    CS_REQUIRE(a.pitch % 8 == 0 && (b.c == 0 || b.pitch % 8 == 0), "convT(fp8): pixel pitch must be a multiple of 8 elements");
+    CS_REQUIRE(a.q8 && !a.tab && (b.c == 0 || (b.q8 && !b.tab)), "convT(fp8): inputs must be activated e4m3 tensors (launch_act_quant)");
+    CS_REQUIRE(a.pitch % 16 == 0 && (b.c == 0 || b.pitch % 16 == 0), "convT(fp8): pixel pitch must be a multiple of 16 bytes");
     Conv8Params p{};
     p.a = to_dev8(a);
     p.b = to_dev8(b);
-    p.wpack = wpack; p.wscale = wscale; p.bias = bias; p.out = out; p.stats = stats; p.dummy = wscale;
+    p.wpack = wpack; p.wscale = wscale; p.bias = bias; p.out = out; p.stats = stats;
     p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16;
     p.n = n; p.hin = hin; p.win = win; p.hout = 2 * hin; p.wout = 2 * win;
     p.tiles_x = ceil_div(win, 16);
     p.tiles_y = ceil_div(hin, 4);
     const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
     const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
-    const double bytes = 2.0 * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
+    const double bytes = n * (1.0 * hin * win * (a.c + b.c) + 2.0 * 4.0 * hin * win * cout);
     ProfScope prof(K_CONVT, s, flops, bytes);
     switch (wn) {
         case 4: return launch_t8<2, 2>(s, p);

@@ -158,7 +158,9 @@ __device__ __forceinline__ void load_lazy8(const AddSrc& s, int img, int64_t pix
         }
     }
 }
-__global__ void norm_act_add16x8_kernel(AddSrc y, AddSrc r, float* out, int pitch_out, int c8n, int64_t npix, int64_t total) {
+__global__ void norm_act_add16x8_kernel(AddSrc y, AddSrc r, float* out, int pitch_out, int c8n, int64_t npix, int64_t total,
+                                        unsigned char* out8, int pitch8) {
+    if (out8) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);     // saturating e4m3 conversion (MODE.FP16_OVFL)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pix = i / c8n;
         const int c8 = (int)(i - pix * c8n);
@@ -166,27 +168,60 @@ __global__ void norm_act_add16x8_kernel(AddSrc y, AddSrc r, float* out, int pitc
         float a[8], b[8];
         load_lazy8(y, img, pix, c8, a);
         load_lazy8(r, img, pix, c8, b);
-        u32x4m o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16_bits(a[2 * k] + b[2 * k]) | (f32_to_bf16_bits(a[2 * k + 1] + b[2 * k + 1]) << 16);
-        *reinterpret_cast<u32x4m*>(reinterpret_cast<unsigned short*>(out) + pix * pitch_out + 8 * c8) = o;
+        for (int k = 0; k < 8; ++k) a[k] += b[k];
+        if (out) {
+            u32x4m o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16_bits(a[2 * k]) | (f32_to_bf16_bits(a[2 * k + 1]) << 16);
+            *reinterpret_cast<u32x4m*>(reinterpret_cast<unsigned short*>(out) + pix * pitch_out + 8 * c8) = o;
+        }
+        if (out8) *reinterpret_cast<uint2*>(out8 + pix * pitch8 + 8 * c8) = f32x8_to_fp8(a);
+    }
+}
+
+// fp8 mode: one pass that applies the producer's norm table + activation and stores e4m3 (2 bytes in, 1 byte out per element)
+__global__ void act_quant_kernel(AddSrc src, unsigned char* dst8, int pitch8, int c8n, int64_t npix, int64_t total) {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / c8n;
+        const int c8 = (int)(i - pix * c8n);
+        const int img = (int)(pix / npix);
+        float a[8];
+        load_lazy8(src, img, pix, c8, a);
+        *reinterpret_cast<uint2*>(dst8 + pix * pitch8 + 8 * c8) = f32x8_to_fp8(a);
     }
 }
 
 static AddSrc to_add(const ConvSrc& s) { return AddSrc{s.ptr, s.tab, s.slope, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
 
+int launch_act_quant(hipStream_t s, const ConvSrc& src, unsigned char* dst8, int pitch8, int64_t npix_per_image, int n) {
+    CS_REQUIRE(src.h16 && src.c % 8 == 0 && src.pitch % 8 == 0 && pitch8 % 8 == 0 && src.tab_off % 8 == 0,
+               "act_quant: a bf16 source with channels / pitches in multiples of 8 is required");
+    const int c8n = src.c / 8;
+    const int64_t total = (int64_t)n * npix_per_image * c8n, blocks = (total + 255) / 256;
+    ProfScope prof(K_NORM_ACT_ADD, s, 0, 24.0 * total);
+    hipLaunchKernelGGL(act_quant_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, to_add(src), dst8, pitch8, c8n,
+                       npix_per_image, total);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 int launch_norm_act_add(hipStream_t s, const ConvSrc& y, const ConvSrc& r, float* out, int pitch_out, int64_t npix_per_image,
-                        int n, bool act16) {
+                        int n, bool act16, unsigned char* out8, int pitch8) {
     CS_REQUIRE(y.c == r.c && y.c % 4 == 0, "norm_act_add: channel mismatch %d vs %d", y.c, r.c);
+    CS_REQUIRE(out || out8, "norm_act_add: no output");
     CS_REQUIRE(y.h16 == act16 && r.h16 == act16, "norm_act_add: mixed activation element types");
     const int c4n = y.c / 4;
     const int64_t total = (int64_t)n * npix_per_image * c4n;
     const int64_t blocks = (total + 255) / 256;
-    ProfScope prof(K_NORM_ACT_ADD, s, 0, (act16 ? 24.0 : 48.0) * total);
-    if (act16 && y.c % 8 == 0 && y.pitch % 8 == 0 && r.pitch % 8 == 0 && pitch_out % 8 == 0 && y.tab_off % 8 == 0 && r.tab_off % 8 == 0) {
+    ProfScope prof(K_NORM_ACT_ADD, s, 0, (act16 ? (16.0 + (out ? 8.0 : 0.0) + (out8 ? 4.0 : 0.0)) : 48.0) * total);
+    const bool wide = act16 && y.c % 8 == 0 && y.pitch % 8 == 0 && r.pitch % 8 == 0 && pitch_out % 8 == 0 && y.tab_off % 8 == 0 && r.tab_off % 8 == 0;
+    CS_REQUIRE(!out8 || (wide && pitch8 % 8 == 0), "norm_act_add: the e4m3 output needs the bf16 datapath with channels in multiples of 8");
+    if (wide) {
         const int64_t total8 = total / 2, blocks8 = (total8 + 255) / 256;
         hipLaunchKernelGGL(norm_act_add16x8_kernel, dim3((unsigned)(blocks8 < 65536 ? blocks8 : 65536)), dim3(256), 0, s, to_add(y),
-                           to_add(r), out, pitch_out, c4n / 2, npix_per_image, total8);
+                           to_add(r), out, pitch_out, c4n / 2, npix_per_image, total8, out8, pitch8);
     } else if (act16)
         hipLaunchKernelGGL(norm_act_add_kernel<true>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, to_add(y),
                            to_add(r), out, pitch_out, c4n, npix_per_image, total);

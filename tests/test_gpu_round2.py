@@ -481,3 +481,12 @@ def test_fp8_deep64_forward_error_bound():
     assert torch.isfinite(got).all()
     assert err <= 0.35 * scale + 0.1, (err, scale)
     assert (got.argmax(1) == want.argmax(1)).float().mean().item() > 0.85
+
+
+def test_c5_workload_runs_on_one_gpu():
+    """BASELINE configs[4] end to end on ONE GPU: 64...1024 net, 512-pixel windows at stride 256 (961 windows), 3x8192x8192 slide, fp8
+    mode, connected components and the label copy included (the 8-GPU form deals such slides - or row strips of one - to the ranks)."""
+    line = _bench("--precision", "fp8", "--width", "deep64", "--roi", "512", "--size", "8192", "--steps", "1", "--warmup", "1",
+                  "--no-secondary", "--no-cpu-baseline")
+    assert line["config"]["windows"] == 961 and line["config"]["precision"] == "fp8" and line["value"] > 50
+    assert line["roofline"]["kernel"].startswith("conv3x3") and line["roofline"]["peak"] == 5000.0

@@ -303,7 +303,11 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     } else {
         cw.p_w[slot] = add_param(net, conv + ".weight", {cout, cin, ksize, ksize}, [=](const float* d, hipStream_t s) {
             if (mode == 2) return copy_param(net, wdst, d, (size_t)cin * cout * ksize * ksize, s);
-            if (mode == 1) return pack_first_weights(net->pack, s, d, cout, cin, wdst, cout_off, cout_total);
+            if (mode == 1) {
+                if (wb && (net->planes == 5 || (net->planes >= 1 && net->planes <= 3)))   // every mode of the bf16 / fp8 upload families
+                    if (int rc = pack_first_weights16(net->pack, s, d, cout, cin, wb, cout_off)) return rc;
+                return pack_first_weights(net->pack, s, d, cout, cin, wdst, cout_off, cout_total);
+            }
             if (wb && net->planes > 0 && net->planes <= 4)
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0, net->planes == 4)) return rc;
             if (w8 && net->planes == 5)
@@ -312,7 +316,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
         });
     }
     net->params[cw.p_w[slot]].has_dgrad = dg != DG_NONE;
-    net->params[cw.p_w[slot]].has_bf16 = wb != nullptr && mode == 0;
+    net->params[cw.p_w[slot]].has_bf16 = wb != nullptr && (mode == 0 || mode == 1);
     cw.p_b[slot] = add_param(net, conv + ".bias", {cout}, [=](const float* d, hipStream_t s) { return copy_param(net, bdst, d, cout, s); });
 }
 
@@ -333,6 +337,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     const int dg0 = u.first ? DG_NONE : (stride == 2 ? DG_S2_AS_CONVT : DG_S1);
     if (dg0 != DG_NONE) u.unit0.wd = ar.take(packed_conv_floats(cin, u.unit0.cout, 3));
     if (!u.first) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(u.unit0.cout, cin, 0, 3) + 1) / 2);
+    if (u.first) u.unit0.wb = (unsigned short*)ar.take((size_t)(u.unit0.cout / 16) * 512 / 2);      // one bf16 K-step (bf16 / fp8 datapaths)
     if (!u.first) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(u.unit0.cout, cin, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(u.unit0.cout); }
     add_conv_params(net, pfx + ".conv.unit0.conv", u.unit0, c, cin, 3, 0, false, u.first ? 1 : 0, dg0, 0);
     add_norm_params(net, ar, pfx + ".conv.unit0.adn", u.norms[0], c);
@@ -530,7 +535,10 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
             if (u.first) {
-                CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, a16));
+                if (a16 && u.unit0.wb)
+                    CS_TRY(launch_conv_first16(s, src, pc, u.unit0.wb, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n));
+                else
+                    CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, a16));
             } else {
                 CS_TRY(conv_fwd(s, net, 3, 2, q8 ? raw8_src(prevq, pc) : raw_src(prev, pc, pc, a16), u.unit0, E, c0, c0, rt_down[d][0].stats, n, ph, pw));
             }

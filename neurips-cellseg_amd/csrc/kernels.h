@@ -36,6 +36,8 @@ int pack_conv_weights(PackCtx* pc, hipStream_t s, const float* w, bool transpose
                       int dgrad_chunk_off = 0);
 // first layer (cin < 16): packed[kstep][ntile_total][64], k = 4*kstep + (lane>>4) = tap*cin + c, zero padded
 int pack_first_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed, int cout_off, int cout_total);
+// the same layer as ONE bf16 K-step (9 * cin <= 32): packed16[ntile_total][64][8] bf16 (bf16 / fp8 datapaths)
+int pack_first_weights16(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, unsigned short* packed16, int cout_off);
 // batched packing: between begin and flush the pack_* entry points only record jobs; flush runs them in (at most) two kernels
 void pack_batch_begin(PackCtx* pc);
 int pack_batch_flush(PackCtx* pc, hipStream_t s);
@@ -100,6 +102,10 @@ struct WindowSrc {
 };
 int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
                       float* out, int pitch_out, int cout, double* stats, int n, bool out16 = false);
+// bf16 / fp8 datapaths: the image is converted to bf16 while it is staged, one v_mfma_f32_16x16x32_bf16 per 16 x 16 output tile
+// (the fp32 form needs seven 16x16x4 steps = 14x the matrix-pipe cycles), bf16 out
+int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsigned short* wpack16, const float* bias, float* out,
+                        int pitch_out, int cout, double* stats, int n);
 
 // transposed 3x3 stride 2 pad 1 output_padding 1 (MFMA), input = concat(a, b); out is [n, 2h, 2w, cout]
 int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* wpack, const float* bias,

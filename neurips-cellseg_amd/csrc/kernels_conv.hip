@@ -791,6 +791,180 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// first layer on the bf16 matrix pipe (bf16 / fp8 datapaths): K = 27 fits ONE v_mfma_f32_16x16x32_bf16 step.
+//   phase 1  the 17 x 33 x 3 window patch goes image -> bf16 -> LDS (the tiler's gather, as in conv_first_kernel)
+//   phase 2  im2col in LDS: a_s[128 pixels][32 k] bf16 (k = tap * 3 + c), 80-byte rows: A fragments are conflict-free b128 reads
+//   phase 3  MT x NT MFMAs per wave, weights (NT fragments of 16 bytes per lane) straight from L2 into registers
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8f __attribute__((ext_vector_type(8)));
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void conv_first16_kernel(FirstParams p) {
+    constexpr int S = 2, CIN = 3, TH = 4 * MT, TW = 16;
+    constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+    constexpr int PATCH = IH * IW * CIN;                     // bf16 elements
+    constexpr int PA = 40;                                   // a_s row pitch in bf16 elements (80 bytes)
+    constexpr int IN_BYTES = (PATCH * 2 + 15) / 16 * 16, A_BYTES = TH * TW * PA * 2;
+    constexpr int EPW = MT * 16 * (16 * NT + 4);             // floats per wave slab
+    constexpr int EP_BYTES = (4 * EPW + 4 * 16 * NT * 2 * 2) * 4;
+    constexpr int SM_BYTES = (IN_BYTES + A_BYTES) > EP_BYTES ? (IN_BYTES + A_BYTES) : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem_c[SM_BYTES];
+    unsigned short* const in_s = reinterpret_cast<unsigned short*>(smem_c);
+    unsigned short* const a_s = reinterpret_cast<unsigned short*>(smem_c + IN_BYTES);
+    float* const smem = reinterpret_cast<float*>(smem_c);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    int y0 = 0, x0 = 0;
+    const float* image = p.image;
+    if (p.origins) {
+        const int2 o = p.origins[img];
+        y0 = o.x;
+        x0 = o.y;
+    } else {
+        image += (size_t)img * p.sn;
+    }
+    // weights: NT fragments, issued first so that they are in flight under the patch gather
+    bf16x8f b[NT];
+    const bf16x8f* wsrc = reinterpret_cast<const bf16x8f*>(p.wpack) + lane;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = wsrc[nt * 64];
+    constexpr int ST_ITERS = (PATCH + 255) / 256;
+    float rv[ST_ITERS];
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; ++it) {                  // unconditional (clamped) loads, all in flight together
+        const int i = tid + 256 * it;
+        const int c = i % CIN, pix = i / CIN;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int wy = oy0 * S - 1 + iy, wx = ox0 * S - 1 + ix;
+        const int gy = y0 + wy, gx = x0 + wx;
+        const bool ok = i < PATCH && wy >= 0 && wy < p.roi_h && wx >= 0 && wx < p.roi_w && gy >= 0 && gy < p.img_h && gx >= 0 && gx < p.img_w;
+        const float v = image[ok ? c * p.sc + gy * p.sh + gx * p.sw : 0];
+        rv[it] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; ++it) {
+        const int i = tid + 256 * it;
+        if (i < PATCH) in_s[i] = (unsigned short)f32_to_bf16_bits(rv[it]);
+    }
+    __syncthreads();
+    // im2col: thread (pixel, half) writes 16 of the pixel's 32 k values
+    for (int item = tid; item < TH * TW * 2; item += 256) {
+        const int px = item >> 1, h = item & 1;
+        const int row = px >> 4, col = px & 15;
+        unsigned w[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            unsigned pair = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 16 * h + 2 * jj + e;
+                const int tap = k / CIN, c = k - tap * CIN, ky = tap / 3, kx = tap - ky * 3;
+                const unsigned v = k < 9 * CIN ? in_s[((row * S + ky) * IW + col * S + kx) * CIN + c] : 0u;
+                pair |= v << (16 * e);
+            }
+            w[jj] = pair;
+        }
+        uint4* dst = reinterpret_cast<uint4*>(a_s + px * PA + 16 * h);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    __syncthreads();
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const bf16x8f a = *reinterpret_cast<const bf16x8f*>(a_s + ((wave * MT + m) * 16 + pl) * PA + 8 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    __syncthreads();   // every wave has read its A fragments before statistics / slabs overwrite the staging memory
+    double* st_s = reinterpret_cast<double*>(smem + 4 * EPW);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        double s = 0.0, qq = 0.0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = oy0 + wave * MT + m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + g * 4 + r;
+                const float v = acc[m][nt][r] + bias;
+                acc[m][nt][r] = v;
+                if (oy < p.hout && ox < p.wout) {
+                    s += (double)v;
+                    qq += (double)v * (double)v;
+                }
+            }
+        }
+        if (p.stats) {
+            s += __shfl_xor(s, 16);
+            qq += __shfl_xor(qq, 16);
+            s += __shfl_xor(s, 32);
+            qq += __shfl_xor(qq, 32);
+            if (lane < 16) {
+                st_s[(wave * 16 * NT + nt * 16 + pl) * 2] = s;
+                st_s[(wave * 16 * NT + nt * 16 + pl) * 2 + 1] = qq;
+            }
+        }
+    }
+    {
+        const int oy = oy0 + wave * MT;
+        const int64_t elem0 = (((int64_t)img * p.hout + oy) * p.wout + ox0) * p.pitch_out;
+        epilogue_store<NT, MT, true>(smem + wave * EPW, acc, lane, p.out, (int64_t)p.wout * p.pitch_out, p.pitch_out,
+                                     p.hout - oy, p.wout - ox0, nullptr, 0, 0, elem0);
+    }
+    if (p.stats) {
+        __syncthreads();
+        if (tid < 32 * NT) {
+            const int c = tid >> 1, k = tid & 1;
+            const double v = st_s[(0 * 16 * NT + c) * 2 + k] + st_s[(1 * 16 * NT + c) * 2 + k] + st_s[(2 * 16 * NT + c) * 2 + k] +
+                             st_s[(3 * 16 * NT + c) * 2 + k];
+            atomicAdd(p.stats + ((size_t)img * p.cout + c) * 2 + k, v);
+        }
+    }
+}
+
+int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsigned short* wpack16, const float* bias, float* out,
+                        int pitch_out, int cout, double* stats, int n) {
+    CS_REQUIRE(cin == 3, "first conv: in_channels %d unsupported (the reference always feeds 3)", cin);
+    CS_REQUIRE(cout == 16 || cout == 32 || cout == 64 || cout == 128, "first conv: fused cout %d unsupported", cout);
+    FirstParams p{};
+    p.image = src.image;
+    p.sn = src.sn; p.sc = src.sc; p.sh = src.sh; p.sw = src.sw;
+    p.origins = src.origins;
+    p.img_h = src.img_h; p.img_w = src.img_w; p.roi_h = src.roi_h; p.roi_w = src.roi_w;
+    p.wpack = reinterpret_cast<const float*>(wpack16); p.bias = bias; p.out = out; p.stats = stats;
+    p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16; p.n = n;
+    p.hout = (src.roi_h + 2 - 3) / 2 + 1;
+    p.wout = (src.roi_w + 2 - 3) / 2 + 1;
+    constexpr int MT = 2;
+    p.tiles_x = ceil_div(p.wout, 16);
+    p.tiles_y = ceil_div(p.hout, 4 * MT);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * n));
+    const double flops = 2.0 * n * p.hout * p.wout * (double)cout * cin * 9;
+    const double bytes = n * (4.0 * src.roi_h * src.roi_w * cin + 2.0 * p.hout * p.wout * cout);
+    ProfScope prof(K_CONV_FIRST, s, flops, bytes);
+    switch (cout / 16) {
+        case 1: hipLaunchKernelGGL((conv_first16_kernel<1, MT>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_first16_kernel<2, MT>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((conv_first16_kernel<4, MT>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv_first16_kernel<8, MT>), grid, dim3(256), 0, s, p); break;
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // transposed conv k3 s2 p1 op1 as 4 output phases over a 2x2 input neighbourhood:
 //   out[2i+a][2j+b] += in[i+di][j+dj] * W[ky][kx],  ky: 0->(a=1,di=1) 1->(a=0,di=0) 2->(a=1,di=0); same for kx.
 // M tile = 16 input pixels of one row; each wave owns one input row of the block's 4-row tile.
@@ -1025,6 +1199,7 @@ static inline int64_t pack_job_elems(const PackJob& jb) {
     switch (jb.kind) {
         case PK_CONV: return (int64_t)(jb.cin / 16) * (jb.cout / 16);       // BLOCKS: one per (chunk, channel tile)
         case PK_FIRST: return (int64_t)jb.ksteps * (jb.cout / 16) * 64;
+        case PK_FIRST16: return (int64_t)(jb.cout / 16) * 512;
         case PK_BF16: return (int64_t)jb.chunks_total * jb.taps * (jb.cout / 16) * 512;
         default: return jb.cout;                              // PK_COPY: cout = element count
     }
@@ -1048,6 +1223,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* jobs, int
     const int64_t le = e - jb.begin;
     switch (jb.kind) {
         case PK_FIRST: pack_first_elem(jb, le); break;
+        case PK_FIRST16: pack_first16_elem(jb, le); break;
         case PK_BF16: pack_bf16_elem(jb, le); break;
         default: reinterpret_cast<float*>(jb.dst)[le] = jb.src[le]; break;
     }
@@ -1185,6 +1361,13 @@ int pack_first_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int
     PackJob jb{};
     jb.src = w; jb.dst = packed; jb.kind = PK_FIRST; jb.cout = cout; jb.cin = cin; jb.cout_off = cout_off; jb.ntile_total = cout_total / 16;
     jb.ksteps = (9 * cin + 3) / 4;
+    return pack_submit(pc, s, jb);
+}
+
+int pack_first_weights16(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, unsigned short* packed16, int cout_off) {
+    CS_REQUIRE(9 * cin <= 32, "pack(first16): %d input channels do not fit one K-step", cin);
+    PackJob jb{};
+    jb.src = w; jb.dst = packed16; jb.kind = PK_FIRST16; jb.cout = cout; jb.cin = cin; jb.cout_off = cout_off;
     return pack_submit(pc, s, jb);
 }
 

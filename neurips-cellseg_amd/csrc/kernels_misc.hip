@@ -537,6 +537,189 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// the same layer for the bf16 / fp8 datapaths: the inputs ARE bf16, so the patch is staged as a plain copy and the 27-column
+// GEMM runs on v_mfma_f32_16x16x32_bf16 (CIN / 32 instructions per tile instead of CIN / 4 fp32 ones); weights are converted to
+// bf16 fragments once per (persistent) block.  Gather, bias, statistics and the fp32 3-channel output as above.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8m __attribute__((ext_vector_type(8)));
+template <int CIN>
+__global__ __launch_bounds__(256) void convt_top_gemm16_kernel(SmallSrc a, SmallSrc b, const float* __restrict__ w, const float* bias,
+                                                               float* out, double* stats, int hin, int win, int tiles_x, int tiles_y,
+                                                               int n_tiles) {
+    constexpr int TH = 8, TW = 16, IH = TH + 1, IW = TW + 1, NPIX = IH * IW, MPAD = 160;
+    constexpr int PP = 33;                                   // P pitch in floats
+    constexpr int XP = CIN + 8;                              // x pitch in bf16 elements: 16-byte A-fragment reads are conflict-free
+    constexpr int X_BYTES = MPAD * XP * 2, P_BYTES = MPAD * PP * 4;
+    constexpr int XP_BYTES = X_BYTES > P_BYTES ? X_BYTES : P_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char sm16[];
+    unsigned short* x_s = reinterpret_cast<unsigned short*>(sm16);             // [MPAD][XP] bf16
+    float* p_s = reinterpret_cast<float*>(sm16);                               // [MPAD][PP] (reuses x_s after the GEMM)
+    unsigned short* w_s = reinterpret_cast<unsigned short*>(sm16 + XP_BYTES);  // [CIN/32][2][64 lanes][8] bf16 fragments
+    __shared__ double red[4][6];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kk = lane >> 4;
+    const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(n_tiles, t_begin + per);
+    if (t_begin >= t_end) return;
+
+    // weights W[cin][27] fp32 -> bf16 fragments: element (c32, nn, lane, j) = W[c32*32 + 8 (lane >> 4) + j][nn*16 + (lane & 15)]
+    for (int i = tid; i < CIN * 32; i += 256) {
+        const int j = i & 7, ln = (i >> 3) & 63, nn = (i >> 9) & 1, c32 = i >> 10;
+        const int k = c32 * 32 + 8 * (ln >> 4) + j, col = nn * 16 + (ln & 15);
+        w_s[i] = (unsigned short)f32_to_bf16_bits(col < 27 ? w[(size_t)k * 27 + col] : 0.f);
+    }
+    constexpr int c8n = CIN / 8, ITERS = (MPAD * c8n + 255) / 256;   // 16-byte items
+    typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+    u32x4t rx[ITERS];
+    const unsigned short* sptr[ITERS];
+    int rel[ITERS], spitch[ITERS], liy[ITERS], lix[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = tid + 256 * it;
+        const int pix = i / c8n, c8 = i - pix * c8n;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int c = 8 * c8;
+        const bool in_a = c < a.c;
+        sptr[it] = reinterpret_cast<const unsigned short*>(in_a ? a.ptr : b.ptr) + (in_a ? c : c - a.c);
+        spitch[it] = in_a ? a.pitch : b.pitch;
+        rel[it] = (iy * win + ix) * spitch[it];
+        liy[it] = (pix < NPIX && i < MPAD * c8n) ? iy : (1 << 20);
+        lix[it] = ix;
+    }
+    unsigned okmask = 0;
+    auto prefetch = [&](int img, int iy0, int ix0) {
+        okmask = 0;
+        const int base_px = (img * hin + iy0) * win + ix0;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const bool ok = iy0 + liy[it] < hin && ix0 + lix[it] < win;
+            const int off = ok ? base_px * spitch[it] + rel[it] : 0;
+            rx[it] = *reinterpret_cast<const u32x4t*>(sptr[it] + off);
+            okmask |= ok ? (1u << it) : 0u;
+        }
+    };
+    int xo[5], wo[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int t = wave + 4 * i, m = t >> 1, nn = t & 1;
+        xo[i] = (m * 16 + li) * XP + 8 * kk;                 // bf16 elements
+        wo[i] = (nn * 64 + lane) * 8;
+    }
+    const int hout = 2 * hin, wout = 2 * win;
+    float bv[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) bv[co] = bias ? bias[co] : 0.f;
+    int g_oyl[2], g_oxl[2], g_p[2][4];
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int o = tid + 256 * rep;
+        const int oyl = o >> 5, oxl = o & 31;
+        const int i = oyl >> 1, pa = oyl & 1, j = oxl >> 1, pb = oxl & 1;
+        g_oyl[rep] = oyl;
+        g_oxl[rep] = oxl;
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+#pragma unroll
+            for (int rxx = 0; rxx < 2; ++rxx) {
+                const bool use = !(pa == 0 && ry == 1) && !(pb == 0 && rxx == 1);
+                const int ky = pa == 0 ? 1 : (ry == 0 ? 0 : 2), di = (pa == 1 && ry == 0) ? 1 : 0;
+                const int kx = pb == 0 ? 1 : (rxx == 0 ? 0 : 2), dj = (pb == 1 && rxx == 0) ? 1 : 0;
+                g_p[rep][ry * 2 + rxx] = use ? ((i + di) * IW + j + dj) * PP + ky * 3 + kx : -1;
+            }
+        }
+    }
+
+    int tx = t_begin % tiles_x, ty = (t_begin / tiles_x) % tiles_y, img = t_begin / (tiles_x * tiles_y);
+    prefetch(img, ty * TH, tx * TW);
+    double s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+    auto flush_stats = [&](int im) {
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                s[co] += __shfl_xor(s[co], off);
+                q[co] += __shfl_xor(q[co], off);
+            }
+            if (lane == 0) {
+                red[wave][2 * co] = s[co];
+                red[wave][2 * co + 1] = q[co];
+            }
+            s[co] = 0.0;
+            q[co] = 0.0;
+        }
+        __syncthreads();
+        if (tid < 6) atomicAdd(stats + (size_t)im * 6 + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+        __syncthreads();
+    };
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int iy0 = ty * TH, ix0 = tx * TW, cur_img = img;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + 256 * it;
+            const int pix = i / c8n, c8 = i - pix * c8n;
+            if (ITERS * 256 == MPAD * c8n || i < MPAD * c8n)
+                *reinterpret_cast<u32x4t*>(&x_s[pix * XP + 8 * c8]) = ((okmask >> it) & 1u) ? rx[it] : u32x4t{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+        const bool more = tile + 1 < t_end;
+        if (more && ++tx == tiles_x) {
+            tx = 0;
+            if (++ty == tiles_y) {
+                ty = 0;
+                ++img;
+            }
+        }
+        prefetch(img, ty * TH, tx * TW);
+
+        f32x4m acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c32 = 0; c32 < CIN / 32; ++c32) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const bf16x8m xa = *reinterpret_cast<const bf16x8m*>(&x_s[xo[i] + c32 * 32]);
+                const bf16x8m wb = *reinterpret_cast<const bf16x8m*>(&w_s[wo[i] + c32 * 1024]);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, wb, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int t = wave + 4 * i, m = t >> 1, nn = t & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p_s[(m * 16 + kk * 4 + r) * PP + nn * 16 + li] = acc[i][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int oy = 2 * iy0 + g_oyl[rep], ox = 2 * ix0 + g_oxl[rep];
+            if (oy < hout && ox < wout) {
+                float v[3];
+#pragma unroll
+                for (int co = 0; co < 3; ++co) v[co] = bv[co];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (g_p[rep][t] >= 0) {
+                        const float* pp = &p_s[g_p[rep][t]];
+#pragma unroll
+                        for (int co = 0; co < 3; ++co) v[co] += pp[co * 9];
+                    }
+                }
+                *reinterpret_cast<Px3*>(out + (((size_t)cur_img * hout + oy) * wout + ox) * 3) = Px3{v[0], v[1], v[2]};
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    s[co] += (double)v[co];
+                    q[co] += (double)v[co] * (double)v[co];
+                }
+            }
+        }
+        __syncthreads();
+        if (stats && (img != cur_img || !more)) flush_stats(cur_img);
+    }
+}
+
 int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* w_torch, const float* bias, float* out,
                        int cout, double* stats, int n, int hin, int win) {
     CS_REQUIRE(cout == 3, "convT(small): cout %d unsupported (3-class contract)", cout);
@@ -557,7 +740,15 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
         const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
         const SmallSrc sa{a.ptr, a.c, a.pitch}, sb{b.ptr, b.c, b.pitch};
 #define CS_TOP(CIN_, H_) hipLaunchKernelGGL((convt_top_gemm_kernel<CIN_, H_>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles)
-        if (a.h16) {
+        if (a.h16 && a.c % 8 == 0 && b.c % 8 == 0) {           // bf16 inputs: bf16 matrix pipe, plain-copy staging
+            const size_t xb = (size_t)160 * (cin + 8) * 2, pb = (size_t)160 * 33 * 4;
+            const size_t sm16 = (xb > pb ? xb : pb) + (size_t)cin * 32 * 2;
+            const int resident16 = 256 * (int)((160 * 1024) / (sm16 + 64));
+            const dim3 grid16((unsigned)(n_tiles < resident16 ? n_tiles : resident16));
+#define CS_TOP16(CIN_) hipLaunchKernelGGL((convt_top_gemm16_kernel<CIN_>), grid16, dim3(256), sm16, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles)
+            if (cin == 32) CS_TOP16(32); else if (cin == 64) CS_TOP16(64); else CS_TOP16(128);
+#undef CS_TOP16
+        } else if (a.h16) {
             if (cin == 32) CS_TOP(32, true); else if (cin == 64) CS_TOP(64, true); else CS_TOP(128, true);
         } else {
             if (cin == 32) CS_TOP(32, false); else if (cin == 64) CS_TOP(64, false); else CS_TOP(128, false);

@@ -6,7 +6,7 @@
 
 namespace cs {
 
-enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3 };
+enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3, PK_FIRST16 = 4 };
 struct PackJob {
     const float* src;
     void* dst;
@@ -45,6 +45,21 @@ __device__ __forceinline__ void pack_first_elem(const PackJob& jb, int64_t e) {
     reinterpret_cast<float*>(jb.dst)[((size_t)ks * jb.ntile_total + jb.cout_off / 16 + ntl) * 64 + lane] = v;
 }
 
+
+// first layer for the bf16 / fp8 datapaths: ONE 16x16x32 bf16 K-step holds all 9 * cin (27) products, zero padded to 32.
+// packed[ntile_total][lane][8]: cout = ntile*16 + (lane & 15), k = 8 (lane >> 4) + j = tap * cin + c
+__device__ __forceinline__ void pack_first16_elem(const PackJob& jb, int64_t e) {
+    const int cin = jb.cin;
+    const int j = e & 7, lane = (e >> 3) & 63, ntl = (int)(e >> 9);
+    const int k = 8 * (lane >> 4) + j;
+    float v = 0.f;
+    if (k < 9 * cin) {
+        const int tap = k / cin, c = k - tap * cin, co = ntl * 16 + (lane & 15);
+        v = jb.src[((size_t)co * cin + c) * 9 + tap];
+    }
+    const __bf16 h = (__bf16)v;
+    reinterpret_cast<unsigned short*>(jb.dst)[((size_t)(jb.cout_off / 16 + ntl) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h);
+}
 
 // split-bf16 / split-fp16 weight planes in 16x16x32 fragment order:
 // packed[chunk][tap][ntile_total][plane][lane][j]: cout = ntile*16 + (lane & 15), k = chunk*32 + 8*(lane>>4) + j.

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace cs {
@@ -854,26 +855,34 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(FirstParams p) {
         if (i < PATCH) in_s[i] = (unsigned short)f32_to_bf16_bits(rv[it]);
     }
     __syncthreads();
-    // im2col: thread (pixel, half) writes 16 of the pixel's 32 k values
-    for (int item = tid; item < TH * TW * 2; item += 256) {
-        const int px = item >> 1, h = item & 1;
+    // im2col: thread (pixel, half) writes 16 of the pixel's 32 k values; the half is resolved at compile time (two code paths) so
+    // that every (tap, channel) offset of the patch is an immediate
+    auto build = [&](int px, auto half) {
+        constexpr int H = decltype(half)::value;
         const int row = px >> 4, col = px & 15;
+        const unsigned short* src = in_s + ((row * S) * IW + col * S) * CIN;
         unsigned w[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             unsigned pair = 0;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int k = 16 * h + 2 * jj + e;
+                constexpr int dummy = 0;
+                const int k = 16 * H + 2 * jj + e;
                 const int tap = k / CIN, c = k - tap * CIN, ky = tap / 3, kx = tap - ky * 3;
-                const unsigned v = k < 9 * CIN ? in_s[((row * S + ky) * IW + col * S + kx) * CIN + c] : 0u;
+                const unsigned v = k < 9 * CIN ? src[(ky * IW + kx) * CIN + c] : 0u;
                 pair |= v << (16 * e);
+                (void)dummy;
             }
             w[jj] = pair;
         }
-        uint4* dst = reinterpret_cast<uint4*>(a_s + px * PA + 16 * h);
+        uint4* dst = reinterpret_cast<uint4*>(a_s + px * PA + 16 * H);
         dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
         dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    };
+    for (int item = tid; item < TH * TW * 2; item += 256) {
+        if (item & 1) build(item >> 1, std::integral_constant<int, 1>());
+        else build(item >> 1, std::integral_constant<int, 0>());
     }
     __syncthreads();
 

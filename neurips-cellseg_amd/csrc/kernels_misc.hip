@@ -241,7 +241,13 @@ struct SmallSrc {
     int c, pitch;
 };
 
-template <int COUT>
+template <bool IN16>
+__device__ __forceinline__ f32x4 load4_act(const float* base, size_t elem) {     // 4 channels of an fp32 or a bf16 activation tensor
+    if constexpr (IN16) return bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem));
+    else return *reinterpret_cast<const f32x4*>(base + elem);
+}
+
+template <int COUT, bool IN16>
 __global__ __launch_bounds__(256) void convt_small_kernel(SmallSrc a, SmallSrc b, const float* w, const float* bias, float* out,
                                                           double* stats, int hin, int win) {
     constexpr int WROW = ((COUT * 9 + 3) / 4) * 4;
@@ -267,16 +273,14 @@ __global__ __launch_bounds__(256) void convt_small_kernel(SmallSrc a, SmallSrc b
         const SmallSrc& s = part == 0 ? a : b;
         if (s.c == 0) continue;
         const int cbase = part == 0 ? 0 : a.c;
-        const float* p00 = s.ptr + (((size_t)img * hin + iy) * win + ix) * s.pitch;
-        const float* p01 = p00 + s.pitch;
-        const float* p10 = p00 + (size_t)win * s.pitch;
-        const float* p11 = p10 + s.pitch;
+        const size_t e00 = (((size_t)img * hin + iy) * win + ix) * s.pitch;          // element offsets (fp32 or bf16 elements)
+        const size_t e01 = e00 + s.pitch, e10 = e00 + (size_t)win * s.pitch, e11 = e10 + s.pitch;
         for (int c = 0; c < s.c; c += 4) {
             const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 x00 = *reinterpret_cast<const f32x4*>(p00 + c);
-            const f32x4 x01 = has_r ? *reinterpret_cast<const f32x4*>(p01 + c) : z;
-            const f32x4 x10 = has_d ? *reinterpret_cast<const f32x4*>(p10 + c) : z;
-            const f32x4 x11 = (has_r && has_d) ? *reinterpret_cast<const f32x4*>(p11 + c) : z;
+            const f32x4 x00 = load4_act<IN16>(s.ptr, e00 + c);
+            const f32x4 x01 = has_r ? load4_act<IN16>(s.ptr, e01 + c) : z;
+            const f32x4 x10 = has_d ? load4_act<IN16>(s.ptr, e10 + c) : z;
+            const f32x4 x11 = (has_r && has_d) ? load4_act<IN16>(s.ptr, e11 + c) : z;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float* wr = &w_s[(cbase + c + j) * WROW];
@@ -731,7 +735,6 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
     const double flops = 2.0 * n * hin * win * (double)cout * cin * 9;
     const double bytes = n * ((a.h16 ? 2.0 : 4.0) * hin * win * cin + 4.0 * 4.0 * hin * win * cout);
     ProfScope prof(K_CONVT_TOP, s, flops, bytes);
-    CS_REQUIRE(!a.h16 || cin == 32 || cin == 64 || cin == 128, "convT(small): bf16 activations need 32 / 64 / 128 input channels (got %d)", cin);
     if ((cin == 32 || cin == 64 || cin == 128) && a.c % 4 == 0) {      // GEMM + gather on the matrix cores
         const int tiles_x = ceil_div(win, 16), tiles_y = ceil_div(hin, 8);
         const size_t sm = ((size_t)160 * (cin + 4) + (size_t)cin * 32) * sizeof(float);
@@ -758,7 +761,11 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
         return CS_OK;
     }
     dim3 grid((unsigned)ceil_div(hin * win, 256), (unsigned)n);
-    hipLaunchKernelGGL((convt_small_kernel<3>), grid, dim3(256), lds, s, SmallSrc{a.ptr, a.c, a.pitch},
+    if (a.h16)
+        hipLaunchKernelGGL((convt_small_kernel<3, true>), grid, dim3(256), lds, s, SmallSrc{a.ptr, a.c, a.pitch},
+                           SmallSrc{b.ptr, b.c, b.pitch}, w_torch, bias, out, stats, hin, win);
+    else
+        hipLaunchKernelGGL((convt_small_kernel<3, false>), grid, dim3(256), lds, s, SmallSrc{a.ptr, a.c, a.pitch},
                        SmallSrc{b.ptr, b.c, b.pitch}, w_torch, bias, out, stats, hin, win);
     CS_HIP(hipGetLastError());
     return CS_OK;

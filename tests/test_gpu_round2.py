@@ -490,3 +490,27 @@ def test_c5_workload_runs_on_one_gpu():
                   "--no-secondary", "--no-cpu-baseline")
     assert line["config"]["windows"] == 961 and line["config"]["precision"] == "fp8" and line["value"] > 50
     assert line["roofline"]["kernel"].startswith("conv3x3") and line["roofline"]["peak"] == 5000.0
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+@pytest.mark.parametrize("channels,nru,norm,act,shape", [
+    ((16, 32, 64, 128, 256), 2, "instance", "prelu", (2, 3, 64, 96)),
+    ((16, 32), 1, "instance", "prelu", (1, 3, 32, 48)),
+    ((16, 32, 64), 3, "instance", "prelu", (2, 3, 64, 64)),
+    ((32, 64, 128, 256, 512), 2, "batch", "relu", (1, 3, 64, 64)),          # eval-mode BatchNorm through the low-precision datapaths
+])
+def test_low_precision_datapaths_other_topologies(precision, channels, nru, norm, act, shape):
+    """The bf16 / fp8 datapaths (bf16 tensors in HBM, e4m3 materialisation) on the topologies the fp32 parity tests cover: finite,
+    close to the engine's own fp32 result, class decision mostly unchanged."""
+    import cellseg_amd as ca
+    torch.manual_seed(3)
+    hip = ca.UNet(channels=channels, strides=(2,) * (len(channels) - 1), num_res_units=nru, norm=norm, act=act).to(_dev()).eval()
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(1)).to(_dev())
+    with torch.no_grad():
+        want = hip(x).clone()
+        hip.precision = precision
+        got = hip(x)
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= (0.12 if precision == "bf16" else 0.4) * scale + 0.05
+    assert (got.argmax(1) == want.argmax(1)).float().mean().item() > (0.93 if precision == "bf16" else 0.8)

@@ -336,9 +336,10 @@ def main():
     # ------------------------------------------------------------------------------------------------------------------
     # training leg (BASELINE.json configs[1] at N=1, configs[3] at N=8): the reference loop, model_training_3class.py:247-267
     # ------------------------------------------------------------------------------------------------------------------
-    def measure_train(width, with_prof=True):
+    def measure_train(width, with_prof=True, precision="fp32"):
         torch.manual_seed(seed)                                   # identical replicas on every rank
         model = ca.UNet(channels=WIDTHS[width], strides=(2, 2, 2, 2), num_res_units=2).to(dev)
+        model.precision = precision                               # forward arithmetic; activations stay fp32 and the backward runs in fp32
         g = torch.Generator(device="cpu").manual_seed(seed + 1 + rank)      # every rank its own shard of the global batch
         b = args.train_batch
         x = torch.rand(b, 3, 256, 256, generator=g).to(dev)
@@ -380,7 +381,8 @@ def main():
         out = {"images_per_s": round(world * b * k / dt, 1), "ms_per_step": round(ms, 3),
                "tflops": round(world * 3 * b * WINDOW_GFLOP[width] / ms, 2),
                "frac_of_fp32_mfma_peak": round(3 * b * WINDOW_GFLOP[width] / ms / PEAK_F32_MFMA_TFLOPS, 4),
-               "global_batch": world * b, "per_gpu_batch": b, "width": list(WIDTHS[width]), "dtype": "f32",
+               "global_batch": world * b, "per_gpu_batch": b, "width": list(WIDTHS[width]),
+               "dtype": "f32" if precision == "fp32" else f"{precision} forward convolutions (fp32 activations), f32 backward",
                "loss": round(float(loss.item()), 5), "grad_bucket_bytes": int(model.flat_grad.numel() * 4),
                "allreduce_ms": allreduce_ms,
                "engine_gpu_ms_per_step": round(tot / k, 3) if prof else None,
@@ -407,9 +409,13 @@ def main():
                     r = measure_infer(args.width, prec, False, False)
                     modes[prec] = dict(infer_summary(r, False), foreground_agreement_vs_primary=round(
                         float(((r["labels"] > 0) == (main_res["labels"] > 0)).float().mean().item()), 6))
-            train_res = measure_train(args.width if args.width in WINDOW_GFLOP and args.roi == 256 else "baseline32")
+            tw = args.width if args.width in WINDOW_GFLOP and args.roi == 256 else "baseline32"
+            train_res = measure_train(tw)
+            if world == 1:                                        # configs[1]: the same step with the forward convolutions on the bf16 pipe
+                t16 = measure_train(tw, with_prof=False, precision="bf16")
+                train_res["bf16_forward"] = {k: t16[k] for k in ("images_per_s", "ms_per_step", "loss", "dtype")}
     else:
-        train_res = measure_train(args.width)
+        train_res = measure_train(args.width, precision=args.precision if args.precision in ("fp32", "bf16", "fp16x3", "bf16x6") else "fp32")
 
     if rank != 0:
         if dist:

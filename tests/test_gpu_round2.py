@@ -514,3 +514,29 @@ def test_low_precision_datapaths_other_topologies(precision, channels, nru, norm
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= (0.12 if precision == "bf16" else 0.4) * scale + 0.05
     assert (got.argmax(1) == want.argmax(1)).float().mean().item() > (0.93 if precision == "bf16" else 0.8)
+
+
+def test_training_with_bf16_forward_tracks_the_fp32_curve():
+    """configs[1]'s training flavour: forward convolutions on the bf16 matrix pipe (fp32 activations kept for the backward, which
+    runs in fp32): ten AdamW steps must learn and stay close to the all-fp32 engine's loss curve."""
+    import cellseg_amd as ca
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(11)
+        m = ca.UNet(channels=(32, 64, 128, 256, 512), strides=(2, 2, 2, 2), num_res_units=2).to(_dev()).train()
+        m.precision = prec
+        g = torch.Generator().manual_seed(12)
+        x = torch.rand(8, 3, 128, 128, generator=g).to(_dev())
+        y = ca.one_hot(torch.randint(0, 3, (8, 1, 128, 128), generator=g).to(_dev()), 3)
+        opt = torch.optim.AdamW(m.parameters(), 6e-4)
+        loss_fn = ca.DiceCELoss(softmax=True)
+        out = []
+        for _ in range(10):
+            opt.zero_grad()
+            loss = loss_fn(m(x), y)
+            loss.backward()
+            opt.step()
+            out.append(loss.item())
+        curves[prec] = out
+    assert curves["bf16"][-1] < curves["bf16"][0]
+    assert max(abs(a - b) for a, b in zip(curves["fp32"], curves["bf16"])) <= 0.03, curves

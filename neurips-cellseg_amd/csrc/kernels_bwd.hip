@@ -561,7 +561,10 @@ int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo) {
     const int mt = (a_c % 64 == 0) ? 4 : (a_c % 32 == 0) ? 2 : 1;
     const int combos = (a_c / (16 * mt)) * (b_c >= 16 ? b_c / 16 : 1);
     const int total_tiles = n * ceil_div(wo, 16) * ceil_div(ho, 4);
-    int k = ceil_div(1024, combos);
+    // blocks per launch: measured on the 32-base step (wgrad + unpack ms): 1024 -> 2.46 + 0.50, 768 -> 2.67 + 0.40, 512 -> 2.53 + 0.30,
+    // 384 -> 3.17 + 0.25: fewer slices halve the partial slabs the unpack pass has to sum
+    static const int target_blocks = getenv("CS_WGRAD_BLOCKS") ? atoi(getenv("CS_WGRAD_BLOCKS")) : 512;
+    int k = ceil_div(target_blocks, combos);
     if (k > total_tiles) k = total_tiles;
     return k < 1 ? 1 : k;
 }

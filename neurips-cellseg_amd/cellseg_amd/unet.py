@@ -257,26 +257,27 @@ class UNet(nn.Module):
             self._uploaded.clear()
             state = need
         uploaded_any = False
-        stream = _lib.stream_ptr()
         alive = []                                                   # sources must outlive the batched pack kernel's enqueue
-        check(lib.cs_unet_load_begin(self._engine.handle), "cs_unet_load_begin")
-        try:
-            for key in self._keys:
-                if key.endswith("num_batches_tracked"):
-                    continue
-                t = self._tensor(key)
-                tag = (t.data_ptr(), t._version)
-                if self._uploaded.get(key) != tag:
-                    src = t.detach()
-                    if src.dtype != torch.float32 or not src.is_contiguous():
-                        src = src.float().contiguous()
-                    alive.append(src)
-                    check(lib.cs_unet_load_param(self._engine.handle, key.encode(), C.c_void_p(src.data_ptr()), src.numel(),
-                                                 stream), f"cs_unet_load_param({key})")
-                    self._uploaded[key] = tag
-                    uploaded_any = True
-        finally:
-            check(lib.cs_unet_load_end(self._engine.handle, stream), "cs_unet_load_end")   # one kernel packs everything recorded
+        with torch.cuda.device(p0.device):                          # the handle lives on the parameters' device, whatever is current
+            stream = _lib.stream_ptr()
+            check(lib.cs_unet_load_begin(self._engine.handle), "cs_unet_load_begin")
+            try:
+                for key in self._keys:
+                    if key.endswith("num_batches_tracked"):
+                        continue
+                    t = self._tensor(key)
+                    tag = (t.data_ptr(), t._version)
+                    if self._uploaded.get(key) != tag:
+                        src = t.detach()
+                        if src.dtype != torch.float32 or not src.is_contiguous():
+                            src = src.float().contiguous()
+                        alive.append(src)
+                        check(lib.cs_unet_load_param(self._engine.handle, key.encode(), C.c_void_p(src.data_ptr()), src.numel(),
+                                                     stream), f"cs_unet_load_param({key})")
+                        self._uploaded[key] = tag
+                        uploaded_any = True
+            finally:
+                check(lib.cs_unet_load_end(self._engine.handle, stream), "cs_unet_load_end")   # one kernel packs everything recorded
         del alive
         self._pack_state = (state[0] and need[0], state[1] and need[1]) if uploaded_any else state
         return self._engine

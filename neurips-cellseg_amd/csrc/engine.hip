@@ -863,6 +863,14 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     return CS_OK;
 }
 
+// a handle's weight arena, packing tables and side streams live on the device that was current when it was created
+static int check_device(const cs_unet* net) {
+    int dev = -1;
+    CS_HIP(hipGetDevice(&dev));
+    CS_REQUIRE(dev == net->device, "this cs_unet handle belongs to device %d but device %d is current (hipSetDevice / torch.cuda.device)", net->device, dev);
+    return CS_OK;
+}
+
 static int check_loaded(const cs_unet* net, bool for_backward = false) {
     for (const auto& p : net->params) {
         if (!p.loaded) {
@@ -1040,6 +1048,7 @@ int cs_unet_param_info(const cs_unet* net, int index, char* key_out_host, int64_
 
 int cs_unet_load_param(cs_unet* net, const char* key_host, const float* data, int64_t numel, void* stream) {
     CS_REQUIRE(net && key_host && data, "load_param: null argument");
+    if (int rcd = check_device(net)) return rcd;
     for (auto& p : net->params) {
         if (p.key == key_host) {
             CS_REQUIRE(numel == p.numel(), "load_param: '%s' expects %lld elements, got %lld", key_host, (long long)p.numel(),
@@ -1069,6 +1078,7 @@ int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_
                     float* logits_nhwc, void* workspace, size_t workspace_bytes, void* stream) {
     CS_REQUIRE(net && x && logits_nhwc && workspace, "unet_forward: null argument");
     CS_REQUIRE(n > 0, "unet_forward: n = %d", n);
+    if (int rcd = check_device(net)) return rcd;
     int rc = check_loaded(net);
     if (rc) return rc;
     WindowSrc src;
@@ -1113,6 +1123,7 @@ int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspac
                      void* stream) {
     CS_REQUIRE(net && grad_logits_nhwc && workspace && flat_grad, "unet_backward: null argument");
     CS_REQUIRE(net->tape.valid, "unet_backward: no forward has been recorded (cs_unet_set_training(1), then cs_unet_forward, and keep its workspace intact)");
+    if (int rcd = check_device(net)) return rcd;
     if (int rc0 = check_loaded(net, true)) return rc0;
     hipStream_t s = (hipStream_t)stream;
     size_t acc_bytes = 0, buf_bytes = 0;
@@ -1190,6 +1201,7 @@ int cs_swi_infer(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_
     CS_REQUIRE(net && pl && image && workspace, "swi_infer: null argument");
     CS_REQUIRE(engine_batch > 0, "swi_infer: engine_batch %d", engine_batch);
     CS_REQUIRE(row_begin >= 0 && row_end <= pl->img_h && row_begin < row_end, "swi_infer: bad row range [%d, %d)", row_begin, row_end);
+    if (int rcd = check_device(net)) return rcd;
     int rc = check_loaded(net);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -45,6 +45,11 @@ int pack_copy(PackCtx* pc, hipStream_t s, const float* src, float* dst, size_t n
 int pack_bf16_submit(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int taps, unsigned short* packed,
                      int cout_off, int ntile_total, int cin_split, int chunks_total, bool f16);
 size_t packed_conv_floats(int cout_total, int cin_total, int ksize);
+// Winograd F(2x2, 3x3) weights of a 3x3 stride-1 conv W[cout][cin][3][3] (kernels_conv_wino.hip): U = G g G^T in fragment order
+// packed[cin/16][16 positions][cout/16][64 lanes][4].  dgrad: the weights of the data-gradient convolution of the same tensor
+// (cout = the forward conv's cin and vice versa, taps reversed).
+size_t packed_wino_floats(int cout_total, int cin_total);
+int pack_wino_weights(PackCtx* pc, hipStream_t s, const float* w, bool dgrad, int cout, int cin, float* packed);
 size_t packed_first_floats(int cout_total, int cin);
 
 // Extras used by the backward pass when a forward kernel computes a data gradient:
@@ -65,6 +70,12 @@ struct ConvOutExtra {
 int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, const ConvSrc& b, const float* wpack,
                      const float* bias, float* out, int pitch_out, int cout, double* stats, int n, int hin, int win,
                      const ConvOutExtra* ex = nullptr);
+
+// 3x3 stride-1 pad-1 convolution as Winograd F(2x2, 3x3) on the fp32 matrix pipe (kernels_conv_wino.hip): 16 instead of 36
+// multiplies per 2x2 output tile; fp32 throughout, same outputs / statistics contract as launch_conv_mfma.  cout % 32 == 0.
+bool wino_enabled();           // CS_WINO=0 disables it (A/B against the direct kernels)
+int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, const float* bias, float* out, int pitch_out, int cout,
+                     double* stats, int n, int h, int w);
 
 // split-bf16 variant (kernels_conv_bf16.hip): `planes` = 1 (plain bf16), 2 (3 MFMA terms) or 3 (6 terms, fp32-grade).
 // Weights come from pack_conv_weights_bf16 (always 3 planes; the kernel reads the first `planes`).

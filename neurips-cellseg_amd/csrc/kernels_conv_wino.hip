@@ -1,0 +1,304 @@
+// gfx950 (MI355X): the 3x3 stride-1 convolutions of the U-Net in Winograd form F(2x2, 3x3) on the fp32 matrix pipe.
+//
+// Replaces the same torch conv2d dispatches as kernels_conv.hip (reference call sites baseline/predict.py:109 -> :45-52:
+// the stride-1 subunits of every monai ResidualUnit); all arithmetic is fp32 (v_mfma_f32_16x16x4_f32 + fp32 VALU
+// transforms), the logits stay inside the 1e-4 budget (tests/diagnostics/winograd_precision.py: 6.7e-6 vs fp64, the
+// direct fp32 form 7.0e-6).
+//
+// Why: the fp32 matrix pipe runs at the fp32 VECTOR rate (157 TFLOP/s), so the direct kernels are bound by the number of
+// multiplies.  Y = A^T [ (G g G^T) . (B^T d B) ] A needs 16 multiplies per 2x2 output tile and (cin, cout) pair instead of
+// 36: 2.25x fewer matrix-pipe cycles for the layers that hold 65 % of the network's FLOPs.
+//
+// Shape of the kernel (one block = 256 threads = 4 waves, 8 x 16 output pixels = 4 x 8 Winograd tiles, 16*NTW channels):
+//   * K loop over 16-channel chunks.  The halo'd 10 x 18 input patch of the chunk goes global -> registers one chunk
+//     ahead (lazy InstanceNorm + PReLU of the producer applied on the way, zero padding after the activation) -> LDS
+//     `raw` [180 px][20]; then every thread transforms one (tile, 2 channels) 4x4 patch (B^T d B: 64 adds) and writes
+//     the 16 transform-domain values to `V` [16 positions][4 k-groups][32 tiles][4], the A-fragment order of the MFMA
+//     (ds_read_b128, bank-conflict free without padding).
+//   * wave xi owns the 4 positions (xi, nu = 0..3) for all 32 tiles (2 M-tiles) and all NTW channel tiles: per chunk and nu
+//     2 A fragments from LDS, NTW B fragments L2 -> registers one nu ahead (the transformed weights never touch LDS),
+//     2 * NTW * 4 MFMAs; 32 * NTW accumulator registers.
+//   * epilogue: the nu half of A^T M A is taken in registers (the wave holds a whole row of positions), the xi half after
+//     an exchange through LDS; bias, fp64 InstanceNorm statistics, whole 64 * NTW byte pixel records to HBM.
+#include "conv_common.h"
+#include "pack_jobs.h"
+
+#include <stdlib.h>
+
+namespace cs {
+
+namespace {
+constexpr int WIH = 10, WIW = 18;                  // input patch of a block
+constexpr int WPS = 20;                            // floats per staged raw pixel (16 + 4: conflict-free transform reads)
+constexpr int RAW_FLOATS = WIH * WIW * WPS;        // 3600
+constexpr int V_FLOATS = 16 * 4 * 32 * 4;          // 8192
+}  // namespace
+
+template <int NTW, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p) {
+    constexpr int IN_ITERS = (WIH * WIW + 63) / 64;            // 3
+    constexpr int RS = 16 * NTW + 4;                           // floats per (xi, j, tile) record of the epilogue exchange
+    constexpr int R_FLOATS = 4 * 2 * 32 * RS;
+    constexpr int MAIN_FLOATS = RAW_FLOATS + V_FLOATS;
+    constexpr int BODY_FLOATS = MAIN_FLOATS > R_FLOATS ? MAIN_FLOATS : R_FLOATS;
+    constexpr int ST_FLOATS = 4 * 16 * NTW * 2 * 2;            // fp64 statistics of the 4 waves
+    __shared__ __attribute__((aligned(16))) float smem[BODY_FLOATS + ST_FLOATS];
+    float* const raw = smem;
+    float* const vs = smem + RAW_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NTW);
+    if (!wk.valid) return;
+    int bid = wk.spatial;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int oy0 = ty * 8, ox0 = tx * 16;
+    const int nt0 = wk.ct * NTW;
+    const int q = tid & 3;
+
+    f32x4 acc[4][2][NTW];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[nu][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int goff[IN_ITERS];
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (tid >> 2) + 64 * it;
+        const int iy = pix / WIW, ix = pix - iy * WIW;
+        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+        goff[it] = (pix < WIH * WIW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win) ? gy * p.win + gx : -1;
+    }
+
+    const int chunks = p.a.c >> 4;
+    f32x4 rin[IN_ITERS];
+    Lazy4 lz;
+    auto load_in = [&](int ch) {
+        const int c0 = ch << 4;
+        lz.load(p.a, img, c0 + 4 * q, p.wpack);
+        const float* base = p.a.ptr + (size_t)img * p.hin * p.win * p.a.pitch + c0 + 4 * q;
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {   // unconditional (clamped) loads; padding is zeroed at store time
+            const int o = goff[it] >= 0 ? goff[it] : 0;
+            rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * p.a.pitch);
+        }
+    };
+    auto store_raw = [&]() {
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int pix = (tid >> 2) + 64 * it;
+            if (pix < WIH * WIW) {
+                const f32x4 v = goff[it] >= 0 ? lz.apply(rin[it]) : f32x4{0.f, 0.f, 0.f, 0.f};   // padding stays 0 after the activation
+                *reinterpret_cast<f32x4*>(&raw[pix * WPS + 4 * q]) = v;
+            }
+        }
+    };
+    // input transform V = B^T d B of one (tile, channel pair): wave = tile row, lane = (k-group, channel pair, tile column)
+    const int t_tx = lane & 7, t_h = (lane >> 3) & 1, t_g = lane >> 4;
+    const float* const t_src = raw + ((2 * wave) * WIW + 2 * t_tx) * WPS + 4 * t_g + 2 * t_h;
+    float* const t_dst = vs + (t_g * 32 + wave * 8 + t_tx) * 4 + 2 * t_h;
+    auto transform = [&]() {
+        float2 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const float2*>(t_src + (i * WIW + j) * WPS);
+        float2 t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = make_float2(d[0][j].x - d[2][j].x, d[0][j].y - d[2][j].y);
+            t[1][j] = make_float2(d[1][j].x + d[2][j].x, d[1][j].y + d[2][j].y);
+            t[2][j] = make_float2(d[2][j].x - d[1][j].x, d[2][j].y - d[1][j].y);
+            t[3][j] = make_float2(d[1][j].x - d[3][j].x, d[1][j].y - d[3][j].y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 v0 = make_float2(t[i][0].x - t[i][2].x, t[i][0].y - t[i][2].y);
+            const float2 v1 = make_float2(t[i][1].x + t[i][2].x, t[i][1].y + t[i][2].y);
+            const float2 v2 = make_float2(t[i][2].x - t[i][1].x, t[i][2].y - t[i][1].y);
+            const float2 v3 = make_float2(t[i][1].x - t[i][3].x, t[i][1].y - t[i][3].y);
+            *reinterpret_cast<float2*>(t_dst + (i * 4 + 0) * 512) = v0;
+            *reinterpret_cast<float2*>(t_dst + (i * 4 + 1) * 512) = v1;
+            *reinterpret_cast<float2*>(t_dst + (i * 4 + 2) * 512) = v2;
+            *reinterpret_cast<float2*>(t_dst + (i * 4 + 3) * 512) = v3;
+        }
+    };
+
+    // B fragments: packed[chunk][position 16][ntile_total][64 lanes][4]; this wave reads positions 4*wave + nu
+    const f32x4* const wbase = reinterpret_cast<const f32x4*>(p.wpack) + (size_t)nt0 * 64 + lane;
+    const size_t wpos = (size_t)p.ntile_total * 64;
+    f32x4 wc[2][NTW];
+    const int last_step = chunks * 4 - 1;
+    auto wload = [&](int step, f32x4 (&dst)[NTW]) {
+        const f32x4* w = wbase + (size_t)((step >> 2) * 16 + wave * 4 + (step & 3)) * wpos;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) dst[t] = w[t * 64];
+    };
+
+    load_in(0);
+    wload(0, wc[0]);
+    store_raw();
+    __syncthreads();
+    transform();
+    __syncthreads();
+    const float* const a_src = vs + ((wave * 4 * 4 + g) * 32 + pl) * 4;   // + nu * 512 + m * 64
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        load_in(more ? ch + 1 : ch);           // unconditional: see conv_wreg_kernel
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            {
+                const int step = ch * 4 + nu + 1;
+                wload(step < last_step ? step : last_step, wc[(nu + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 a[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const f32x4*>(a_src + nu * 512 + m * 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) acc[nu][m][t] = mfma4(a[m][j], wc[nu & 1][t][j], acc[nu][m][t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) asm volatile("" ::"v"(rin[it]));   // keeps the loads above the MFMA section
+        if (more) store_raw();
+        __syncthreads();
+        if (more) {
+            transform();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----
+    // nu half of the output transform in registers: R[xi][j] = sum_nu M[xi][nu] A[nu][j]
+    float* const rs = smem;                                      // [xi 4][j 2][tile 32][RS]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const f32x4 r0 = (acc[0][m][t] + acc[1][m][t]) + acc[2][m][t];
+            const f32x4 r1 = (acc[1][m][t] - acc[2][m][t]) - acc[3][m][t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tile = m * 16 + g * 4 + r;
+                rs[((wave * 2 + 0) * 32 + tile) * RS + t * 16 + pl] = r0[r];
+                rs[((wave * 2 + 1) * 32 + tile) * RS + t * 16 + pl] = r1[r];
+            }
+        }
+    __syncthreads();
+    // xi half + bias + statistics + stores: thread = (pixel, channel quad)
+    constexpr int F4 = NTW * 4, PPP = 256 / F4, XS = 2 * 32 * RS;
+    const int c4 = tid % F4;
+    const int co = nt0 * 16 + c4 * 4;
+    const OutSel o = select_out(p, nt0 + c4 / 4);
+    const int cw = (c4 & 3) * 4;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, qsum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int it = 0; it < 128 / PPP; ++it) {
+        const int pix = tid / F4 + PPP * it;
+        const int oyl = pix >> 4, oxl = pix & 15;
+        const int tile = (oyl >> 1) * 8 + (oxl >> 1), ii = oyl & 1, jj = oxl & 1;
+        const float* rb = rs + (jj * 32 + tile) * RS + c4 * 4;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(rb + (ii ? 3 * XS : 0));
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(rb + XS);
+        const f32x4 x2 = *reinterpret_cast<const f32x4*>(rb + 2 * XS);
+        f32x4 y = ii ? (x1 - x2) - x0 : (x0 + x1) + x2;
+        y += bias4;
+        const int oy = oy0 + oyl, ox = ox0 + oxl;
+        if (oy < p.hout && ox < p.wout) {
+            const size_t gp = ((size_t)img * p.hout + oy) * p.wout + ox;
+            if (o.add) y += *reinterpret_cast<const f32x4*>(o.add + gp * o.pitch_add + o.ch0 + cw);
+            *reinterpret_cast<f32x4*>(o.out + gp * o.pitch + o.ch0 + cw) = y;
+            if (p.stats) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ssum[k] += (double)y[k];
+                    qsum[k] += (double)y[k] * (double)y[k];
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        // lanes with equal c4 (lane % F4) -> the waves of the block (LDS) -> ONE fp64 atomic pair per block and channel
+        double* st_s = reinterpret_cast<double*>(smem + BODY_FLOATS);      // [4 waves][16*NTW][2]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int sh = F4; sh < 64; sh <<= 1) {
+                ssum[k] += __shfl_xor(ssum[k], sh);
+                qsum[k] += __shfl_xor(qsum[k], sh);
+            }
+        }
+        if (lane < F4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2] = ssum[k];
+                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2 + 1] = qsum[k];
+            }
+        }
+        __syncthreads();
+        if (tid < 32 * NTW) {
+            const int c = tid >> 1, k = tid & 1;
+            const double v = st_s[(0 * 16 * NTW + c) * 2 + k] + st_s[(1 * 16 * NTW + c) * 2 + k] + st_s[(2 * 16 * NTW + c) * 2 + k] +
+                             st_s[(3 * 16 * NTW + c) * 2 + k];
+            atomicAdd(p.stats + ((size_t)img * p.cout + nt0 * 16 + c) * 2 + k, v);
+        }
+    }
+}
+
+int g_wino = 1;   // A/B switch: CS_WINO=0 sends the 3x3 stride-1 layers back to the direct kernels
+static const int g_wino_init = [] {
+    if (const char* e = getenv("CS_WINO")) g_wino = atoi(e);
+    return 0;
+}();
+bool wino_enabled() { return g_wino != 0; }
+
+size_t packed_wino_floats(int cout_total, int cin_total) { return (size_t)(cin_total / 16) * 16 * (cout_total / 16) * 256; }
+
+int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, const float* bias, float* out, int pitch_out, int cout,
+                     double* stats, int n, int h, int w) {
+    CS_REQUIRE(a.c % 16 == 0 && a.c > 0 && cout % 32 == 0, "conv(winograd): channels (%d -> %d) unsupported", a.c, cout);
+    CS_REQUIRE((a.pitch % 4) == 0 && (pitch_out % 4) == 0, "conv(winograd): pixel pitch must be a multiple of 4 floats");
+    CS_REQUIRE(!a.h16 && !a.q8, "conv(winograd): fp32 activations only");
+    ConvParams p{};
+    p.a = SrcDev{a.ptr, a.tab, a.slope, a.c, a.pitch, a.tab_c ? a.tab_c : a.c, a.tab_off};
+    p.wpack = wpack_wino;
+    p.bias = bias;
+    p.out = out;
+    p.stats = stats;
+    p.pitch_out = pitch_out;
+    p.cout = cout;
+    p.ntile_total = cout / 16;
+    p.n = n;
+    p.hin = p.hout = h;
+    p.win = p.wout = w;
+    p.tiles_x = ceil_div(w, 16);
+    p.tiles_y = ceil_div(h, 8);
+    // the multiplies this algorithm performs on the matrix pipe: 16 per 2x2 output tile and (cin, cout) pair (a direct 3x3 needs 36)
+    const double flops = 2.0 * n * (double)ceil_div(h, 2) * ceil_div(w, 2) * 16.0 * (double)cout * a.c;
+    const double bytes = 4.0 * n * (double)h * w * (a.c + cout);
+    ProfScope prof(K_CONV3_WINO, s, flops, bytes);
+    const int nsp = p.tiles_x * p.tiles_y * n;
+    if (cout % 64 == 0) {
+        hipLaunchKernelGGL((conv_wino_kernel<4, 2>), dim3(xcd_grid(nsp, p.ntile_total / 4)), dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_wino_kernel<2, 3>), dim3(xcd_grid(nsp, p.ntile_total / 2)), dim3(256), 0, s, p);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+}  // namespace cs

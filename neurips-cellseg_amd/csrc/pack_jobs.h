@@ -6,7 +6,7 @@
 
 namespace cs {
 
-enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3, PK_FIRST16 = 4 };
+enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3, PK_FIRST16 = 4, PK_WINO = 5 };
 struct PackJob {
     const float* src;
     void* dst;
@@ -97,6 +97,33 @@ __device__ __forceinline__ void pack_bf16_elem(const PackJob& jb, int64_t e) {
         v -= (float)h;
         packed[((base + pn) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h);
     }
+}
+
+// Winograd F(2x2, 3x3) weights U = G g G^T (fp64, rounded once) in fp32 MFMA fragment order (kernels_conv_wino.hip):
+// packed[chunk][position xi*4+nu][ntile_total][lane][j]: cout = ntile*16 + (lane & 15), cin = chunk*16 + 4*(lane>>4) + j.
+// transposed + flip = the data-gradient convolution of the same tensor (channel roles swapped, taps reversed).
+__device__ __forceinline__ void pack_wino_elem(const PackJob& jb, int64_t e) {
+    const int cout = jb.cout, cin = jb.cin;
+    const int j = e & 3, lane = (e >> 2) & 63;
+    int64_t r = e >> 8;
+    const int ntl = r % (cout / 16);
+    r /= (cout / 16);
+    const int pos = r & 15;
+    const int chunk = (int)(r >> 4);
+    const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
+    const float* src = jb.transposed ? jb.src + ((size_t)ci * cout + co) * 9 : jb.src + ((size_t)co * cin + ci) * 9;
+    double gk[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) gk[a][b] = (double)src[jb.flip ? 8 - (a * 3 + b) : a * 3 + b];
+    const int xi = pos >> 2, nu = pos & 3;
+    double col[3];                                            // (G g)[xi][b]
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+        col[b] = xi == 0 ? gk[0][b] : xi == 3 ? gk[2][b] : 0.5 * (xi == 1 ? gk[0][b] + gk[1][b] + gk[2][b] : gk[0][b] - gk[1][b] + gk[2][b]);
+    const double u = nu == 0 ? col[0] : nu == 3 ? col[2] : 0.5 * (nu == 1 ? col[0] + col[1] + col[2] : col[0] - col[1] + col[2]);
+    reinterpret_cast<float*>(jb.dst)[(((size_t)chunk * 16 + pos) * jb.ntile_total + ntl) * 256 + lane * 4 + j] = (float)u;
 }
 
 }  // namespace cs

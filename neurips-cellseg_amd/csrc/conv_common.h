@@ -48,7 +48,9 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float prelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+// PReLU without a compare / select pair (v_max, v_min, v_fma: no VCC round trip between dependent VALU instructions, which
+// matters on the fp32 path where every VALU cycle is taken from the MFMA stream); bit-identical to v >= 0 ? v : v * slope
+__device__ __forceinline__ float prelu(float v, float slope) { return __builtin_fmaf(slope, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f)); }
 
 // lazy norm + activation on 4 consecutive channels.  Branch-free on purpose: a conditional load makes hipcc wait
 // vmcnt(0) at the join, which would serialise the table fetch in front of the chunk's input loads.
@@ -73,6 +75,15 @@ struct Lazy4 {
         r.z = prelu(v.z * t1.x + t1.y, slope);
         r.w = prelu(v.w * t1.z + t1.w, slope);
         return on ? r : v;
+    }
+    // the same for a caller that KNOWS the table is present (no select)
+    __device__ __forceinline__ f32x4 apply_on(f32x4 v) const {
+        f32x4 r;
+        r.x = prelu(v.x * t0.x + t0.y, slope);
+        r.y = prelu(v.y * t0.z + t0.w, slope);
+        r.z = prelu(v.z * t1.x + t1.y, slope);
+        r.w = prelu(v.w * t1.z + t1.w, slope);
+        return r;
     }
 };
 

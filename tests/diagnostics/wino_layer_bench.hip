@@ -65,6 +65,18 @@ int main(int argc, char** argv) {
         }
         cs::ConvSrc a;
         a.ptr = x; a.c = L.cin; a.pitch = L.cin;
+        float2* tab = nullptr;
+        float* slope = nullptr;
+        if (!getenv("WINO_RAW")) {          // lazy InstanceNorm + PReLU of the producer, as in the network (WINO_RAW=1: raw input)
+            std::vector<float2> ht((size_t)n * L.cin);
+            for (auto& v : ht) v = make_float2(1.f + 0.25f * rnd(), 0.5f * rnd());
+            const float hs = 0.25f;
+            CK(hipMalloc(&tab, ht.size() * 8));
+            CK(hipMalloc(&slope, 4));
+            CK(hipMemcpy(tab, ht.data(), ht.size() * 8, hipMemcpyHostToDevice));
+            CK(hipMemcpy(slope, &hs, 4, hipMemcpyHostToDevice));
+            a.tab = tab; a.slope = slope; a.tab_c = L.cin;
+        }
         auto run_w = [&]() { return cs::launch_conv_wino(s, a, ww, b, y1, L.cout, L.cout, st1, n, L.hw, L.hw); };
         auto run_d = [&]() { return cs::launch_conv_mfma(s, 3, 1, a, cs::ConvSrc(), wd, b, y2, L.cout, L.cout, st2, n, L.hw, L.hw); };
         if (run_w() || run_d()) {
@@ -131,6 +143,7 @@ int main(int argc, char** argv) {
             }
             hipFree(sb);
         }
+        if (tab) { (void)hipFree(tab); (void)hipFree(slope); }
         hipFree(x); hipFree(w); hipFree(b); hipFree(ww); hipFree(wd); hipFree(y1); hipFree(y2); hipFree(st1); hipFree(st2);
     }
     cs::pack_ctx_destroy(pc);

@@ -427,7 +427,7 @@ def main():
         if not prof:
             return None
         name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        mfma = k["flops"] > 0 and "mfma" in name
+        mfma = k["flops"] > 0 and ("mfma" in name or "wino" in name)
         sec = k["ms"] / 1e3
         if mfma:
             achieved = k["flops"] / sec / 1e12
@@ -448,6 +448,12 @@ def main():
                 rl["algorithmic_bytes_per_launch"] = round(k["bytes"] / k["launches"])
         except (OSError, ValueError, KeyError):
             pass
+        if "wino" in name:
+            # Winograd F(2x2,3x3): `achieved` counts the multiplies the algorithm really issues on the matrix pipe (16 per 2x2 output
+            # tile and channel pair); the same launches expressed in direct-convolution FLOPs (36 per tile: SURVEY 8(d)'s figure)
+            rl["algorithm"] = "Winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per output tile and channel pair"
+            rl["direct_conv_equivalent"] = round(rl["achieved"] * 36 / 16, 3)
+            rl["frac_direct_conv_equivalent"] = round(rl["achieved"] * 36 / 16 / rl["peak"], 4)
         rl.update({"kernel": name, "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 5),
                    "algorithmic_per_launch": (k["flops"] if mfma else k["bytes"]) / k["launches"],
                    "share_of_gpu_time": round(k["ms"] / sum(v["ms"] for v in prof.values()), 4)})

@@ -129,6 +129,7 @@ struct ConvW {             // packed weights + bias of one (possibly fused) conv
     float* w = nullptr;    // packed (MFMA kernels) or PyTorch layout (small VALU kernels)
     float* wd = nullptr;   // the same weights packed for the DATA-GRADIENT launch (see kernels_bwd.hip header)
     float* ww = nullptr;   // 3x3 stride-1 layers: Winograd F(2x2,3x3) weights G g G^T in fragment order (kernels_conv_wino.hip)
+    float* wwd = nullptr;  // ... and those of the layer's DATA-GRADIENT convolution (channel roles swapped, taps reversed)
     unsigned short* wb = nullptr;   // 3 bf16 planes in 16x16x32 fragment order (split-bf16 forward kernels)
     unsigned char* w8 = nullptr;    // e4m3 weights in 16x16x128 fragment order (fp8 forward kernels)
     float* wscale = nullptr;        // their per-output-channel scales [cout]
@@ -282,6 +283,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     float* wdst = cw.w;
     float* wd = cw.wd;
     float* ww = cw.ww;
+    float* wwd = cw.wwd;
     unsigned short* wb = cw.wb;
     unsigned char* w8 = cw.w8;
     float* wsc = cw.wscale;
@@ -314,9 +316,11 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0, net->planes == 4)) return rc;
             if (w8 && net->planes == 5)
                 if (int rc = pack_conv_weights_fp8(s, d, false, cout, cin, ksize, w8, wsc, cout_off, cout_total, 0)) return rc;
-            if (ww && wino_enabled())
-                if (int rc = pack_wino_weights(net->pack, s, d, false, cout, cin, ww)) return rc;
-            return pack_conv_weights(net->pack, s, d, false, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off);
+            // 3x3 stride-1 layers: the tile kernel also writes the Winograd weights (forward; data gradient in training mode)
+            float* const wino_f = (ww && wino_enabled()) ? ww : nullptr;
+            float* const wino_d = (wwd && wino_enabled() && net->training && dg == DG_S1) ? wwd : nullptr;
+            return pack_conv_weights(net->pack, s, d, false, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off,
+                                     wino_f, wino_d);
         });
     }
     net->params[cw.p_w[slot]].has_dgrad = dg != DG_NONE;
@@ -341,6 +345,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     const int dg0 = u.first ? DG_NONE : (stride == 2 ? DG_S2_AS_CONVT : DG_S1);
     if (dg0 != DG_NONE) u.unit0.wd = ar.take(packed_conv_floats(cin, u.unit0.cout, 3));
     if (stride == 1 && !u.first && cin % 16 == 0 && c % 32 == 0) u.unit0.ww = ar.take(packed_wino_floats(c, cin));
+    if (stride == 1 && !u.first && c % 16 == 0 && cin % 32 == 0) u.unit0.wwd = ar.take(packed_wino_floats(cin, c));
     if (!u.first) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(u.unit0.cout, cin, 0, 3) + 1) / 2);
     if (u.first) u.unit0.wb = (unsigned short*)ar.take((size_t)(u.unit0.cout / 16) * 512 / 2);      // one bf16 K-step (bf16 / fp8 datapaths)
     if (!u.first) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(u.unit0.cout, cin, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(u.unit0.cout); }
@@ -353,6 +358,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         cw.bias = ar.take(c);
         cw.wd = ar.take(packed_conv_floats(c, c, 3));
         if (c % 32 == 0) cw.ww = ar.take(packed_wino_floats(c, c));
+        if (c % 32 == 0) cw.wwd = ar.take(packed_wino_floats(c, c));
         cw.wb = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
         cw.w8 = (unsigned char*)ar.take((packed_fp8_bytes(c, c, 0, 3) + 3) / 4);
         cw.wscale = ar.take(c);
@@ -391,6 +397,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     u.unit0.bias = ar.take(cout);
     if (!small) u.unit0.wd = ar.take(packed_conv_floats(cout, cout, 3));
     if (!small && cout % 32 == 0) u.unit0.ww = ar.take(packed_wino_floats(cout, cout));
+    if (!small && cout % 32 == 0) u.unit0.wwd = ar.take(packed_wino_floats(cout, cout));
     if (!small) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
     if (!small) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(cout, cout, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(cout); }
     add_conv_params(net, pfx + ".1.conv.unit0.conv", u.unit0, cout, cout, 3, 0, false, small ? 2 : 0, small ? DG_NONE : DG_S1, 0);
@@ -453,6 +460,17 @@ static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, co
     if (net->planes == 0 && cw.ww && ksize == 3 && stride == 1 && wino_enabled())      // fp32: Winograd F(2x2,3x3), 2.25x fewer multiplies
         return launch_conv_wino(s, a, cw.ww, cw.bias, out, pitch_out, cout, stats, n, hin, win);
     return launch_conv_mfma(s, ksize, stride, a, ConvSrc(), cw.w, cw.bias, out, pitch_out, cout, stats, n, hin, win);
+}
+
+// data gradient of a 3x3 stride-1 conv = a 3x3 stride-1 conv of dy with the channel-swapped, tap-reversed weights: Winograd form
+// when the layer has one (same kernel as the forward), else the direct kernel on cw.wd
+static int dgrad_s1(hipStream_t s, const ConvW& cw, const float* dy, int c_dy, float* out, int c_out, int n, int h, int w,
+                    const ConvOutExtra* ex = nullptr) {
+    ConvSrc src;
+    src.ptr = dy; src.c = c_dy; src.pitch = c_dy;
+    if (cw.wwd && wino_enabled() && !(ex && ex->out2))
+        return launch_conv_wino(s, src, cw.wwd, nullptr, out, c_out, c_out, nullptr, n, h, w, ex);
+    return launch_conv_mfma(s, 3, 1, src, ConvSrc(), cw.wd, nullptr, out, c_out, c_out, nullptr, n, h, w, ex);
 }
 
 #define CS_TRY(expr)            \
@@ -746,7 +764,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 CS_TRY(launch_unpack_wgrad(s, gu.part, gu.k, c, c, 0, 0, c, c, 9, gptr(u.unit0.p_w[0])));
                 ConvOutExtra ex;
                 ex.addend = dS; ex.pitch_add = c;          // identity residual of the up ResidualUnit
-                CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dV, c, c), ConvSrc(), u.unit0.wd, nullptr, d_au, c, c, nullptr, n, oh, ow, &ex));
+                CS_TRY(dgrad_s1(s, u.unit0, dV, c, d_au, c, n, oh, ow, &ex));
             }
         }
         CS_TRY(norm_bwd(u.norm_t, T.rt_upt[d], lu, d_au, c, dU, c, (int64_t)oh * ow));
@@ -800,14 +818,14 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 const ConvSrc prev = lazy_src(T.Yb[su - 1], c, c, T.rt_bottom[su - 1], u.norms[su - 1], c);
                 CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, ph, pw, ph, pw));
                 CS_TRY(launch_unpack_wgrad(s, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
-                CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dY, c, c), ConvSrc(), cw.wd, nullptr, da_new, c, c, nullptr, n, ph, pw));
+                CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, ph, pw));
                 da = da_new;
             } else {
                 CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, rsrc(Xin, cin, cin), nullptr, ga.part, ga.k, c, cin, 0, 0, n, ph, pw, ph, pw));
                 CS_TRY(launch_unpack_wgrad(s, ga.part, ga.k, c, cin, 0, 0, c, cin, 9, gptr(cw.p_w[0])));
                 ConvOutExtra ex;
                 ex.addend = dXin; ex.pitch_add = cin;
-                CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dY, c, c), ConvSrc(), cw.wd, nullptr, dXin, cin, cin, nullptr, n, ph, pw, &ex));
+                CS_TRY(dgrad_s1(s, cw, dY, c, dXin, cin, n, ph, pw, &ex));
             }
         }
         if (!dry) {
@@ -843,7 +861,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                                                  : lazy_src(T.Y[d][su - 1], c, c, T.rt_down[d][su - 1], u.norms[su - 1], c);
                 CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, oh, ow, oh, ow));
                 CS_TRY(launch_unpack_wgrad(s, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
-                CS_TRY(launch_conv_mfma(s, 3, 1, rsrc(dY, c, c), ConvSrc(), cw.wd, nullptr, da_new, c, c, nullptr, n, oh, ow));
+                CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, oh, ow));
             }
             da = da_new;
         }

@@ -33,7 +33,7 @@ PackCtx* pack_ctx_create(int max_jobs);                    // allocates the job 
 void pack_ctx_destroy(PackCtx* pc);
 int pack_conv_weights(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
                       float* packed, int cout_off, int cout_total, float* dgrad = nullptr, bool dgrad_flip = false,
-                      int dgrad_chunk_off = 0);
+                      int dgrad_chunk_off = 0, float* wino = nullptr, float* wino_dgrad = nullptr);   // wino*: see packed_wino_floats
 // first layer (cin < 16): packed[kstep][ntile_total][64], k = 4*kstep + (lane>>4) = tap*cin + c, zero padded
 int pack_first_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed, int cout_off, int cout_total);
 // the same layer as ONE bf16 K-step (9 * cin <= 32): packed16[ntile_total][64][8] bf16 (bf16 / fp8 datapaths)
@@ -76,7 +76,7 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
 bool wino_enabled();           // CS_WINO=0 disables it (A/B against the direct kernels)
 void wino_set_stamp_buffer(long long* dev);   // diagnostics: in-kernel cycle stamps of block 0 (null = off)
 int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, const float* bias, float* out, int pitch_out, int cout,
-                     double* stats, int n, int h, int w);
+                     double* stats, int n, int h, int w, const ConvOutExtra* ex = nullptr);   // ex: addend only
 
 // split-bf16 variant (kernels_conv_bf16.hip): `planes` = 1 (plain bf16), 2 (3 MFMA terms) or 3 (6 terms, fp32-grade).
 // Weights come from pack_conv_weights_bf16 (always 3 planes; the kernel reads the first `planes`).

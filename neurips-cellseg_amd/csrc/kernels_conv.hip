@@ -1180,6 +1180,26 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const PackJob* jobs, in
             const int st = jb.flip2 ? taps - 1 - tap : tap;
             dst[(((size_t)(ntl + jb.chunk_off2) * taps + tap) * jb.ntile_total2 + chunk) * 256 + tid] = tile[r * pitch + c * taps + st];
         }
+    }    // 3x3 stride-1 layers (conv, not transposed): the same tile as Winograd weights U = G g G^T, 16 fragments instead of 9,
+    // forward order and / or data-gradient order (channel roles swapped, taps reversed) - kernels_conv_wino.hip
+    if (jb.dstw) {
+        float g[9], u[16];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) g[tap] = tile[co_l * pitch + ci_l * 9 + tap];
+        wino_weight_transform(g, u);
+        float* dst = reinterpret_cast<float*>(jb.dstw);
+        const int nt = (jb.cout_off >> 4) + ntl;
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) dst[(((size_t)chunk * 16 + pos) * jb.ntile_total + nt) * 256 + tid] = u[pos];
+    }
+    if (jb.dstw2) {
+        float g[9], u[16];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) g[tap] = tile[ci_l * pitch + co_l * 9 + (8 - tap)];
+        wino_weight_transform(g, u);
+        float* dst = reinterpret_cast<float*>(jb.dstw2);
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) dst[(((size_t)ntl * 16 + pos) * jb.ntile_total2 + chunk) * 256 + tid] = u[pos];
     }
 }
 
@@ -1251,7 +1271,8 @@ int pack_batch_flush(PackCtx* pc, hipStream_t s) {
     CS_HIP(hipEventRecord(pc->copied, s));
     pc->copied_pending = true;
     double bytes = 8.0 * (double)total_elems;
-    for (size_t i = n_elem; i < n; ++i) bytes += 4.0 * 256 * jobs[i].taps * pack_job_elems(jobs[i]) * (jobs[i].dst2 ? 3 : 2);
+    for (size_t i = n_elem; i < n; ++i)
+        bytes += 4.0 * 256 * pack_job_elems(jobs[i]) * (jobs[i].taps * (jobs[i].dst2 ? 3 : 2) + 16 * ((jobs[i].dstw ? 1 : 0) + (jobs[i].dstw2 ? 1 : 0)));
     ProfScope prof(K_PACK, s, 0, bytes);
     if (total_elems > 0)
         hipLaunchKernelGGL(pack_jobs_kernel, dim3((unsigned)((total_elems + 255) / 256)), dim3(256), 0, s, pc->dev, (int)n_elem, total_elems);
@@ -1263,13 +1284,15 @@ int pack_batch_flush(PackCtx* pc, hipStream_t s) {
 }
 
 int pack_conv_weights(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, float* packed,
-                      int cout_off, int cout_total, float* dgrad, bool dgrad_flip, int dgrad_chunk_off) {
+                      int cout_off, int cout_total, float* dgrad, bool dgrad_flip, int dgrad_chunk_off, float* wino, float* wino_dgrad) {
     CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack: bad channel counts");
     CS_REQUIRE(ksize == 3 || ksize == 1, "pack: ksize %d", ksize);
     PackJob jb{};
     jb.src = w; jb.dst = packed; jb.kind = PK_CONV; jb.transposed = transposed ? 1 : 0; jb.cout = cout; jb.cin = cin;
     jb.taps = ksize * ksize; jb.cout_off = cout_off; jb.ntile_total = cout_total / 16;
     jb.dst2 = dgrad; jb.flip2 = dgrad_flip ? 1 : 0; jb.chunk_off2 = dgrad_chunk_off; jb.ntile_total2 = cin / 16;
+    CS_REQUIRE(!(wino || wino_dgrad) || (!transposed && ksize == 3 && cout_off == 0 && cout_total == cout), "pack: Winograd weights are for plain 3x3 convs");
+    jb.dstw = wino; jb.dstw2 = wino_dgrad;
     return pack_submit(pc, s, jb);
 }
 

@@ -313,7 +313,7 @@ bool wino_enabled() { return g_wino != 0; }
 size_t packed_wino_floats(int cout_total, int cin_total) { return (size_t)(cin_total / 16) * 16 * (cout_total / 16) * 256; }
 
 int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, const float* bias, float* out, int pitch_out, int cout,
-                     double* stats, int n, int h, int w) {
+                     double* stats, int n, int h, int w, const ConvOutExtra* ex) {
     CS_REQUIRE(a.c % 16 == 0 && a.c > 0 && cout % 32 == 0, "conv(winograd): channels (%d -> %d) unsupported", a.c, cout);
     CS_REQUIRE((a.pitch % 4) == 0 && (pitch_out % 4) == 0, "conv(winograd): pixel pitch must be a multiple of 4 floats");
     CS_REQUIRE(!a.h16 && !a.q8, "conv(winograd): fp32 activations only");
@@ -331,6 +331,11 @@ int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, c
     p.win = p.wout = w;
     p.tiles_x = ceil_div(w, 16);
     p.tiles_y = ceil_div(h, 8);
+    if (ex) {                                  // data-gradient launches: out = conv + addend (no (out, out2) split in this kernel)
+        CS_REQUIRE(!ex->out2, "conv(winograd): the output split is not supported");
+        p.addend = ex->addend;
+        p.pitch_add = ex->pitch_add;
+    }
     // the multiplies this algorithm performs on the matrix pipe: 16 per 2x2 output tile and (cin, cout) pair (a direct 3x3 needs 36)
     const double flops = 2.0 * n * (double)ceil_div(h, 2) * ceil_div(w, 2) * 16.0 * (double)cout * a.c;
     const double bytes = 4.0 * n * (double)h * w * (a.c + cout);

@@ -15,6 +15,8 @@ struct PackJob {
     long long begin;            // first flattened element (element-wise kinds) / first block (PK_CONV) of this job
     int kind, transposed, cout, cin, taps, cout_off, ntile_total, flip, chunk_off, cin_split, chunks_total, f16, ksteps;
     int flip2, chunk_off2, ntile_total2;
+    void* dstw;                 // PK_CONV, 3x3 stride-1 layers: the same tile also written as Winograd weights G g G^T (forward) ...
+    void* dstw2;                // ... and as the Winograd weights of the data-gradient convolution; either may be null
 };
 
 // Per-handle packing state (no process-global state): the job list of the batch being recorded, the pinned staging
@@ -96,6 +98,26 @@ __device__ __forceinline__ void pack_bf16_elem(const PackJob& jb, int64_t e) {
         const __bf16 h = (__bf16)v;
         v -= (float)h;
         packed[((base + pn) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
+// U = G g G^T of one 3x3 kernel (fp64, rounded once); g[a * 3 + b]
+__device__ __forceinline__ void wino_weight_transform(const float (&g)[9], float (&u)[16]) {
+    double col[4][3];                                         // (G g)[xi][b]
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const double g0 = g[b], g1 = g[3 + b], g2 = g[6 + b];
+        col[0][b] = g0;
+        col[1][b] = 0.5 * (g0 + g1 + g2);
+        col[2][b] = 0.5 * (g0 - g1 + g2);
+        col[3][b] = g2;
+    }
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+        u[xi * 4 + 0] = (float)col[xi][0];
+        u[xi * 4 + 1] = (float)(0.5 * (col[xi][0] + col[xi][1] + col[xi][2]));
+        u[xi * 4 + 2] = (float)(0.5 * (col[xi][0] - col[xi][1] + col[xi][2]));
+        u[xi * 4 + 3] = (float)col[xi][2];
     }
 }
 

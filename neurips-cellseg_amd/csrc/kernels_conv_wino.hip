@@ -298,268 +298,10 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
 // the fp32 VECTOR rate and, unlike the 16-bit MFMAs, does not execute beside another wave's VALU instructions on the same SIMD -
 // so on the fp32 path the only lever is the number of VALU instructions per MFMA and not stalling, and specialising waves buys
 // nothing.  Also measured without effect (+-1.5 %): a channel-tile-major block order (the blocks resident on an XCD stream ONE weight
-// slice) and a weight ring that runs a whole chunk ahead - the weight stream is not what this kernel waits for.
-
-// ------------------------------------------------------------------------------------------------
-// 128-channel form for the layers with cout % 128 == 0 (60 % of the Winograd FLOPs of the 32-base net).
-// On the fp32 path every staging instruction (norm, transform, LDS traffic) is taken out of the MFMA stream's cycles, and the
-// staging work of a block does not depend on how many output channels it computes - so this kernel doubles the channels per
-// block: 512 threads = 8 waves, wave = (xi, channel half); both halves contract the SAME V against their own 64 channels and
-// all 8 waves share the staging, i.e. half the staging instructions per MFMA.  One block per CU (the two waves of a SIMD belong
-// to the same block), so the K loop is software-pipelined around ONE barrier per chunk: raw patch and V are double-buffered,
-// and inside an interval a wave (1) transforms chunk c + 1 out of raw[(c + 1) & 1] into V[(c + 1) & 1], (2) runs the MFMAs of
-// chunk c out of V[c & 1], (3) parks chunk c + 2 (registers -> raw[c & 1]) and loads chunk c + 3 - three independent
-// activities the two waves of a SIMD interleave.  The transform is split over the halves by ROWS of B^T d B: a thread
-// needs 3 of the 4 patch rows and does half the adds.
-// LDS: 2 x (14 KB + 32 KB) in the loop; the epilogue exchange R [4][2][32][132] (132 KB) + statistics reuse it.
-// ------------------------------------------------------------------------------------------------
-template <bool LAZY>
-__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvParams p, long long* stamps) {
-    constexpr int NTW = 4, NB = 8;                             // channel tiles per wave / per block
-    constexpr int IN_ITERS = 2;                                // 720 (pixel, quad) items over 512 threads
-    constexpr int RS = 16 * NB + 4;
-    constexpr int R_FLOATS = 4 * 2 * 32 * RS;                  // 33792
-    constexpr int MAIN_FLOATS = 2 * (RAW_FLOATS + V_FLOATS);   // 23584
-    constexpr int BODY_FLOATS = MAIN_FLOATS > R_FLOATS ? MAIN_FLOATS : R_FLOATS;
-    constexpr int ST_FLOATS = 8 * 16 * NB * 2 * 2;             // fp64 statistics of the 8 waves
-    __shared__ __attribute__((aligned(16))) float smem[BODY_FLOATS + ST_FLOATS];
-    float* const raw0 = smem;                                  // raw[b] = raw0 + b * RAW_FLOATS
-    float* const vs0 = smem + 2 * RAW_FLOATS;                  // V[b]   = vs0 + b * V_FLOATS
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xi = wave & 3, nh = wave >> 2;
-    const int pl = lane & 15, g = lane >> 4;
-    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    auto stamp = [&](int k) {
-        if (stamps) {
-            __builtin_amdgcn_sched_barrier(0);
-            const long long t = (long long)__builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_sched_barrier(0);
-            tsum[k] += t - tlast;
-            tlast = t;
-        }
-    };
-    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NB);
-    if (!wk.valid) return;
-    int bid = wk.spatial;
-    const int tx = bid % p.tiles_x;
-    bid /= p.tiles_x;
-    const int ty = bid % p.tiles_y;
-    const int img = bid / p.tiles_y;
-    const int oy0 = ty * 8, ox0 = tx * 16;
-    const int nt0 = wk.ct * NB;
-    const int q = tid & 3;
-
-    f32x4 acc[4][2][NTW];
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[nu][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    unsigned boff[IN_ITERS], inb = 0;
-#pragma unroll
-    for (int it = 0; it < IN_ITERS; ++it) {
-        const int pix = (tid >> 2) + 128 * it;
-        const int iy = pix / WIW, ix = pix - iy * WIW;
-        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-        const bool ok = pix < WIH * WIW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win;
-        inb |= ok ? (1u << it) : 0u;
-        boff[it] = ok ? ((unsigned)(gy * p.win + gx) * (unsigned)p.a.pitch + 4u * q) * 4u : 16u * q;
-    }
-    const char* const img_base = reinterpret_cast<const char*>(p.a.ptr + (size_t)img * p.hin * p.win * p.a.pitch);
-    const int chunks = p.a.c >> 4;
-    f32x4 rin[IN_ITERS];
-    Lazy4 lz;
-    auto load_in = [&](int ch) {                               // unconditional (clamped past the end: re-reads the last chunk)
-        const int c0 = (ch < chunks ? ch : chunks - 1) << 4;
-        if (LAZY) lz.load(p.a, img, c0 + 4 * q, p.wpack);
-        const char* base = img_base + (size_t)c0 * 4;
-#pragma unroll
-        for (int it = 0; it < IN_ITERS; ++it) rin[it] = *reinterpret_cast<const f32x4*>(base + boff[it]);
-    };
-    auto park = [&](float* raw) {                              // registers -> raw patch (lazy norm + PReLU, zero padding after it)
-#pragma unroll
-        for (int it = 0; it < IN_ITERS; ++it) {
-            const int pix = (tid >> 2) + 128 * it;
-            if (pix < WIH * WIW) {
-                const f32x4 a = LAZY ? lz.apply_on(rin[it]) : rin[it];
-                const f32x4 v = (inb >> it) & 1u ? a : f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(&raw[pix * WPS + 4 * q]) = v;
-            }
-        }
-    };
-    // input transform, rows {2 nh, 2 nh + 1} of B^T d B for one (tile, channel pair): wave = (tile row xi, row half nh)
-    const int t_tx = lane & 7, t_h = (lane >> 3) & 1, t_g = lane >> 4;
-    const int t_src_off = ((2 * xi + nh) * WIW + 2 * t_tx) * WPS + 4 * t_g + 2 * t_h;          // patch rows nh .. nh + 2 of the tile
-    const int t_dst_off = (t_g * 32 + xi * 8 + t_tx) * 4 + 2 * t_h + (2 * nh) * 4 * 512;      // positions (2 nh + i) * 4 + j
-    auto transform = [&](const float* raw, float* vs) {
-        const float* src = raw + t_src_off;
-        float2 e[3][4];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) e[r][j] = *reinterpret_cast<const float2*>(src + (r * WIW + j) * WPS);
-        float2 ta[4], tb[4];                                   // rows 2 nh and 2 nh + 1 of B^T d
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (nh == 0) {                                     // t0 = d0 - d2, t1 = d1 + d2 (patch rows 0, 1, 2)
-                ta[j] = make_float2(e[0][j].x - e[2][j].x, e[0][j].y - e[2][j].y);
-                tb[j] = make_float2(e[1][j].x + e[2][j].x, e[1][j].y + e[2][j].y);
-            } else {                                           // t2 = d2 - d1, t3 = d1 - d3 (patch rows 1, 2, 3)
-                ta[j] = make_float2(e[1][j].x - e[0][j].x, e[1][j].y - e[0][j].y);
-                tb[j] = make_float2(e[0][j].x - e[2][j].x, e[0][j].y - e[2][j].y);
-            }
-        }
-        float* dst = vs + t_dst_off;
-        *reinterpret_cast<float2*>(dst + 0 * 512) = make_float2(ta[0].x - ta[2].x, ta[0].y - ta[2].y);
-        *reinterpret_cast<float2*>(dst + 1 * 512) = make_float2(ta[1].x + ta[2].x, ta[1].y + ta[2].y);
-        *reinterpret_cast<float2*>(dst + 2 * 512) = make_float2(ta[2].x - ta[1].x, ta[2].y - ta[1].y);
-        *reinterpret_cast<float2*>(dst + 3 * 512) = make_float2(ta[1].x - ta[3].x, ta[1].y - ta[3].y);
-        *reinterpret_cast<float2*>(dst + 4 * 512) = make_float2(tb[0].x - tb[2].x, tb[0].y - tb[2].y);
-        *reinterpret_cast<float2*>(dst + 5 * 512) = make_float2(tb[1].x + tb[2].x, tb[1].y + tb[2].y);
-        *reinterpret_cast<float2*>(dst + 6 * 512) = make_float2(tb[2].x - tb[1].x, tb[2].y - tb[1].y);
-        *reinterpret_cast<float2*>(dst + 7 * 512) = make_float2(tb[1].x - tb[3].x, tb[1].y - tb[3].y);
-    };
-
-    // B fragments of this wave: positions 4 xi + nu, channel tiles nt0 + 4 nh + t (scalar base + 32-bit lane offset)
-    const char* const wbase = reinterpret_cast<const char*>(p.wpack) + ((size_t)(nt0 + nh * NTW) * 64 + (size_t)xi * 4 * p.ntile_total * 64) * 16;
-    const size_t wpos = (size_t)p.ntile_total * 64 * 16;
-    const unsigned wlane = (unsigned)lane * 16u;
-    f32x4 wc[2][NTW];
-    const int last_step = chunks * 4 - 1;
-    auto wload = [&](int step, f32x4 (&dst)[NTW]) {
-        const char* w = wbase + (size_t)((step >> 2) * 16 + (step & 3)) * wpos;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) dst[t] = *reinterpret_cast<const f32x4*>(w + t * 1024 + wlane);
-    };
-
-    // prologue: chunk 0 -> raw[0] -> V[0]; chunk 1 -> raw[1]; chunk 2 in registers
-    load_in(0);
-    wload(0, wc[0]);
-    park(raw0);
-    load_in(1);
-    __syncthreads();
-    transform(raw0, vs0);
-    park(raw0 + RAW_FLOATS);
-    load_in(2);
-    __syncthreads();
-    stamp(0);                                  // [0] prologue
-    const int a_off = ((xi * 16 + g) * 32 + pl) * 4;           // + nu * 512 + m * 64
-    for (int ch = 0; ch < chunks; ++ch) {
-        const int b = ch & 1;
-        if (ch + 1 < chunks) transform(raw0 + (b ^ 1) * RAW_FLOATS, vs0 + (b ^ 1) * V_FLOATS);
-        stamp(1);                              // [1] transform of chunk c + 1
-        const float* const a_src = vs0 + b * V_FLOATS + a_off;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            {
-                const int step = ch * 4 + nu + 1;
-                wload(step < last_step ? step : last_step, wc[(nu + 1) & 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 a[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const f32x4*>(a_src + nu * 512 + m * 64);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int t = 0; t < NTW; ++t) acc[nu][m][t] = mfma4(a[m][j], wc[nu & 1][t][j], acc[nu][m][t]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stamp(2);                              // [2] MFMA phase
-        if (ch + 2 < chunks) park(raw0 + b * RAW_FLOATS);
-        load_in(ch + 3);
-        stamp(3);                              // [3] park chunk c + 2, load chunk c + 3
-        __syncthreads();
-        stamp(4);                              // [4] barrier
-    }
-
-    // ---- epilogue: nu half of A^T M A in registers, xi half after the exchange through LDS ----
-    float* const rs = smem;                                      // [xi 4][j 2][tile 32][RS]
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const f32x4 r0 = (acc[0][m][t] + acc[1][m][t]) + acc[2][m][t];
-            const f32x4 r1 = (acc[1][m][t] - acc[2][m][t]) - acc[3][m][t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tile = m * 16 + g * 4 + r;
-                rs[((xi * 2 + 0) * 32 + tile) * RS + (nh * NTW + t) * 16 + pl] = r0[r];
-                rs[((xi * 2 + 1) * 32 + tile) * RS + (nh * NTW + t) * 16 + pl] = r1[r];
-            }
-        }
-    __syncthreads();
-    constexpr int F4 = NB * 4, PPP = 512 / F4, XS = 2 * 32 * RS;
-    const int c4 = tid % F4;
-    const int co = nt0 * 16 + c4 * 4;
-    const OutSel o = OutSel{p.out, p.addend, p.pitch_out, p.pitch_add, (nt0 + c4 / 4) * 16};
-    const int cw = (c4 & 3) * 4;
-    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, qsum[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int it = 0; it < 128 / PPP; ++it) {
-        const int pix = tid / F4 + PPP * it;
-        const int oyl = pix >> 4, oxl = pix & 15;
-        const int tile = (oyl >> 1) * 8 + (oxl >> 1), ii = oyl & 1, jj = oxl & 1;
-        const float* rb = rs + (jj * 32 + tile) * RS + c4 * 4;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(rb + (ii ? 3 * XS : 0));
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(rb + XS);
-        const f32x4 x2 = *reinterpret_cast<const f32x4*>(rb + 2 * XS);
-        f32x4 y = ii ? (x1 - x2) - x0 : (x0 + x1) + x2;
-        y += bias4;
-        const int oy = oy0 + oyl, ox = ox0 + oxl;
-        if (oy < p.hout && ox < p.wout) {
-            const size_t gp = ((size_t)img * p.hout + oy) * p.wout + ox;
-            if (o.add) y += *reinterpret_cast<const f32x4*>(o.add + gp * o.pitch_add + o.ch0 + cw);
-            *reinterpret_cast<f32x4*>(o.out + gp * o.pitch + o.ch0 + cw) = y;
-            if (p.stats) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ssum[k] += (double)y[k];
-                    qsum[k] += (double)y[k] * (double)y[k];
-                }
-            }
-        }
-    }
-    if (p.stats) {
-        double* st_s = reinterpret_cast<double*>(smem + BODY_FLOATS);      // [8 waves][16*NB][2]
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int sh = F4; sh < 64; sh <<= 1) {
-                ssum[k] += __shfl_xor(ssum[k], sh);
-                qsum[k] += __shfl_xor(qsum[k], sh);
-            }
-        }
-        if (lane < F4) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                st_s[(wave * 16 * NB + c4 * 4 + k) * 2] = ssum[k];
-                st_s[(wave * 16 * NB + c4 * 4 + k) * 2 + 1] = qsum[k];
-            }
-        }
-        __syncthreads();
-        if (tid < 32 * NB) {
-            const int c = tid >> 1, k = tid & 1;
-            double v = 0.0;
-#pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) v += st_s[(w8 * 16 * NB + c) * 2 + k];
-            atomicAdd(p.stats + ((size_t)img * p.cout + nt0 * 16 + c) * 2 + k, v);
-        }
-    }
-    stamp(5);                                  // [5] epilogue
-    if (stamps && blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 8; ++k) stamps[wave * 8 + k] = tsum[k];
-}
+// slice), a weight ring that runs a whole chunk ahead - the weight stream is not what this kernel waits for - and a 128-channel form
+// (512 threads, both channel halves contracting the same V so that the staging work per MFMA halves, raw patch and V double-buffered
+// around ONE barrier per chunk, one block per CU): 512->512 in 1469 us against 1438 us - with both waves of a SIMD in the same block
+// the barrier skew ate what the shared staging saved (git history: "128-channel double-buffered kernel").
 
 long long* g_wino_stamps = nullptr;    // diagnostics: device buffer of 8 x 8 counters (tests/diagnostics/wino_layer_bench.hip)
 void wino_set_stamp_buffer(long long* dev) { g_wino_stamps = dev; }
@@ -606,12 +348,7 @@ int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, c
     const bool lazy = a.tab != nullptr;
 #define CS_WINO_LAUNCH(NTW_, OCC_, LAZY_)                                                                                       \
     hipLaunchKernelGGL((conv_wino_kernel<NTW_, OCC_, LAZY_>), dim3(xcd_grid(nsp, p.ntile_total / NTW_)), dim3(256), 0, s, p, g_wino_stamps)
-    static const int wide = getenv("CS_WINO_WIDE") ? atoi(getenv("CS_WINO_WIDE")) : 1;   // A/B: 0 = 64-channel blocks everywhere
-    if (cout % 128 == 0 && wide) {
-        const dim3 grid8(xcd_grid(nsp, p.ntile_total / 8));
-        if (lazy) hipLaunchKernelGGL((conv_wino8_kernel<true>), grid8, dim3(512), 0, s, p, g_wino_stamps);
-        else hipLaunchKernelGGL((conv_wino8_kernel<false>), grid8, dim3(512), 0, s, p, g_wino_stamps);
-    } else if (cout % 64 == 0) {
+    if (cout % 64 == 0) {
         if (lazy) CS_WINO_LAUNCH(4, 2, true);
         else CS_WINO_LAUNCH(4, 2, false);
     } else {

@@ -540,3 +540,61 @@ def test_training_with_bf16_forward_tracks_the_fp32_curve():
         curves[prec] = out
     assert curves["bf16"][-1] < curves["bf16"][0]
     assert max(abs(a - b) for a, b in zip(curves["fp32"], curves["bf16"])) <= 0.03, curves
+
+
+# ------------------------------------------------------------------------------------------- Winograd F(2x2,3x3) kernels (fp32)
+@pytest.mark.parametrize("channels,shape", [
+    ((32, 64), (2, 3, 20, 52)),                          # 10 x 26 at level 0: partial 8 x 16 block tiles in both directions
+    ((32, 64, 128), (1, 3, 24, 72)),                     # 12 x 36, 6 x 18, bottom 6 x 18: odd tile counts, 2-row remainders
+    ((32, 64, 128, 256, 512), (2, 3, 80, 48)),           # 5 x 3 pixels at the bottom: ODD heights and widths (half Winograd tiles)
+    ((64, 128, 256), (3, 3, 56, 40)),
+])
+def test_winograd_layers_on_partial_and_odd_tiles_match_oracle(channels, shape):
+    """Every 3x3 stride-1 layer of these nets runs in Winograd form (cout % 32 == 0); the shapes leave partial block tiles,
+    partial 2x2 output tiles and single-row / single-column remainders at some level.  Logit budget as everywhere: 1e-4."""
+    ref, hip = _pair(channels)
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = ref(x)
+        got = hip(x.to(_dev())).cpu()
+    assert (got - want).abs().max().item() <= LOGIT_TOL
+
+
+_WINO_AB = r"""
+import sys, torch
+sys.path[:0] = [{root!r}, {pkg!r}]
+import cellseg_amd as ca
+from oracle.unet_ref import UNetRef
+torch.manual_seed(7)
+ch = (32, 64, 128, 256, 512)
+ref = UNetRef(channels=ch, strides=(2, 2, 2, 2), num_res_units=2)
+hip = ca.UNet(channels=ch, strides=(2, 2, 2, 2), num_res_units=2)
+hip.load_state_dict(ref.state_dict())
+hip = hip.to("cuda:0").train()
+x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(1)).to("cuda:0")
+w = torch.randn(2, 3, 96, 128, generator=torch.Generator().manual_seed(2)).to("cuda:0")
+for k, p in hip.named_parameters():
+    if k.endswith(".A.weight"):
+        p.data.fill_(1.0)                                  # no PReLU kink: the comparison measures arithmetic only
+hip.invalidate_weights()
+y = hip(x)
+(y * w).sum().backward()
+torch.save({{"y": y.detach().cpu(), "g": {{k: p.grad.cpu() for k, p in hip.named_parameters()}}}}, sys.argv[1])
+"""
+
+
+def test_winograd_and_direct_kernels_agree_forward_and_backward(tmp_path):
+    """The same training-mode forward + backward in two processes: CS_WINO=0 (direct fp32 MFMA kernels for the 3x3 stride-1
+    layers and their data gradients) and the default (Winograd).  Both are fp32 throughout, so they differ by rounding only."""
+    outs = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"wino{mode}.pt")
+        env = dict(os.environ, CS_WINO=mode)
+        subprocess.run([sys.executable, "-c", _WINO_AB.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
+        outs[mode] = torch.load(path)
+    y0, y1 = outs["0"]["y"], outs["1"]["y"]
+    assert (y0 - y1).abs().max().item() <= 5e-5
+    scale = max(g.abs().max().item() for g in outs["0"]["g"].values())
+    for k, g0 in outs["0"]["g"].items():
+        g1 = outs["1"]["g"][k]
+        assert (g0 - g1).abs().max().item() <= 2e-4 * max(g0.abs().max().item(), 1e-3 * scale), k

@@ -457,7 +457,7 @@ static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, co
     if (net->planes > 0 && net->planes <= 4 && cw.wb)
         return launch_conv_bf16s(s, ksize, stride, net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin, win, a.h16);
     CS_REQUIRE(!a.h16 && !a.q8, "conv: a layer without low-precision weights met bf16 / e4m3 activations");
-    if (net->planes == 0 && cw.ww && ksize == 3 && stride == 1 && wino_enabled())      // fp32: Winograd F(2x2,3x3), 2.25x fewer multiplies
+    if (net->planes == 0 && cw.ww && ksize == 3 && stride == 1 && wino_enabled() && wino_fits(hin, win, a.pitch))   // fp32: Winograd F(2x2,3x3), 2.25x fewer multiplies
         return launch_conv_wino(s, a, cw.ww, cw.bias, out, pitch_out, cout, stats, n, hin, win);
     return launch_conv_mfma(s, ksize, stride, a, ConvSrc(), cw.w, cw.bias, out, pitch_out, cout, stats, n, hin, win);
 }
@@ -468,7 +468,7 @@ static int dgrad_s1(hipStream_t s, const ConvW& cw, const float* dy, int c_dy, f
                     const ConvOutExtra* ex = nullptr) {
     ConvSrc src;
     src.ptr = dy; src.c = c_dy; src.pitch = c_dy;
-    if (cw.wwd && wino_enabled() && !(ex && ex->out2))
+    if (cw.wwd && wino_enabled() && !(ex && ex->out2) && wino_fits(h, w, c_dy))
         return launch_conv_wino(s, src, cw.wwd, nullptr, out, c_out, c_out, nullptr, n, h, w, ex);
     return launch_conv_mfma(s, 3, 1, src, ConvSrc(), cw.wd, nullptr, out, c_out, c_out, nullptr, n, h, w, ex);
 }

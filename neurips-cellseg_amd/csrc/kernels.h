@@ -74,6 +74,9 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
 // 3x3 stride-1 pad-1 convolution as Winograd F(2x2, 3x3) on the fp32 matrix pipe (kernels_conv_wino.hip): 16 instead of 36
 // multiplies per 2x2 output tile; fp32 throughout, same outputs / statistics contract as launch_conv_mfma.  cout % 32 == 0.
 bool wino_enabled();           // CS_WINO=0 disables it (A/B against the direct kernels)
+// the kernel addresses one image's input tensor with 32-bit byte offsets; larger tensors (a plain forward over a > 4 GB image
+// level) take the direct kernels
+static inline bool wino_fits(int h, int w, int pitch) { return (size_t)h * w * pitch * 4 < ((size_t)1 << 32); }
 void wino_set_stamp_buffer(long long* dev);   // diagnostics: in-kernel cycle stamps of block 0 (null = off)
 int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, const float* bias, float* out, int pitch_out, int cout,
                      double* stats, int n, int h, int w, const ConvOutExtra* ex = nullptr);   // ex: addend only

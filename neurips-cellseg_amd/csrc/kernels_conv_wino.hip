@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
 // slice), a weight ring that runs a whole chunk ahead - the weight stream is not what this kernel waits for - and a 128-channel form
 // (512 threads, both channel halves contracting the same V so that the staging work per MFMA halves, raw patch and V double-buffered
 // around ONE barrier per chunk, one block per CU): 512->512 in 1469 us against 1438 us - with both waves of a SIMD in the same block
-// the barrier skew ate what the shared staging saved (git history: "128-channel double-buffered kernel").
+// the barrier skew ate what the shared staging saved (git history: "128-channel double-buffered kernel").  32-channel blocks at
+// three per CU for every layer (more waves to cover stalls, twice the staging per MFMA): 10 % slower.
 
 long long* g_wino_stamps = nullptr;    // diagnostics: device buffer of 8 x 8 counters (tests/diagnostics/wino_layer_bench.hip)
 void wino_set_stamp_buffer(long long* dev) { g_wino_stamps = dev; }

@@ -302,7 +302,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
 // (512 threads, both channel halves contracting the same V so that the staging work per MFMA halves, raw patch and V double-buffered
 // around ONE barrier per chunk, one block per CU): 512->512 in 1469 us against 1438 us - with both waves of a SIMD in the same block
 // the barrier skew ate what the shared staging saved (git history: "128-channel double-buffered kernel").  32-channel blocks at
-// three per CU for every layer (more waves to cover stalls, twice the staging per MFMA): 10 % slower.
+// three per CU for every layer (more waves to cover stalls, twice the staging per MFMA): 10 % slower.  Several tiles per block for the
+// short-K layers (the next tile's first patch requested before the epilogue of the current one): no change for 32->32 (683 us),
+// 2 % slower for the deep layers (registers) - the wait for the first patch is already covered by the other blocks of the CU.
 
 long long* g_wino_stamps = nullptr;    // diagnostics: device buffer of 8 x 8 counters (tests/diagnostics/wino_layer_bench.hip)
 void wino_set_stamp_buffer(long long* dev) { g_wino_stamps = dev; }

@@ -720,10 +720,10 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     auto rsrc = [&](const float* p, int c, int pitch) { return raw_src(p, c, pitch); };
     // weight-gradient partial sums: [split_k][taps][rows][cols] in the (un-zeroed) buffer arena
     struct WG { float* part; int k; };
-    auto wg_alloc = [&](int a_c1, int a_c2, int b_c, int taps, int rows, int cols, int ho, int wo) {
+    auto wg_alloc = [&](int a_c1, int a_c2, int b_c, int taps, int rows, int cols, int ho, int wo, int ks = 3, int st = 2) {
         WG g;
-        g.k = wgrad_split_k(a_c1, b_c, n, ho, wo);
-        if (a_c2 > 0) { const int k2 = wgrad_split_k(a_c2, b_c, n, ho, wo); g.k = k2 < g.k ? k2 : g.k; }
+        g.k = wgrad_split_k(a_c1, b_c, n, ho, wo, ks, st);
+        if (a_c2 > 0) { const int k2 = wgrad_split_k(a_c2, b_c, n, ho, wo, ks, st); g.k = k2 < g.k ? k2 : g.k; }
         g.part = buf.take<float>((size_t)g.k * taps * rows * cols);
         return g;
     };
@@ -755,7 +755,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             }
         } else {
             float* dV = buf.take<float>((size_t)n * oh * ow * c);
-            const WG gu = wg_alloc(c, 0, c, 9, c, c, oh, ow);
+            const WG gu = wg_alloc(c, 0, c, 9, c, c, oh, ow, 3, 1);
             if (!buf.ok()) return oom();
             CS_TRY(norm_bwd(u.norm_u, T.rt_upu[d], lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow));
             CS_TRY(bias_grad(dV, c, c, (int64_t)n * oh * ow, u.unit0.p_b[0], true));
@@ -797,7 +797,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         const float* Xin = T.X[nl - 1];
         float* dXin = dX[nl - 1];
         if (u.res_conv) {
-            const WG gr = wg_alloc(c, 0, cin, 1, c, cin, ph, pw);
+            const WG gr = wg_alloc(c, 0, cin, 1, c, cin, ph, pw, 1, 1);
             CS_TRY(bias_grad(dS, c, c, n * npix, u.res1x1.p_b[0]));
             if (!dry) {
                 CS_TRY(launch_wgrad(s, 1, 1, dS, c, c, rsrc(Xin, cin, cin), nullptr, gr.part, gr.k, c, cin, 0, 0, n, ph, pw, ph, pw));
@@ -808,7 +808,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         for (int su = u.subunits - 1; su >= 0; --su) {
             const ConvW& cw = su == 0 ? u.unit0 : u.units[su - 1];
             float* dY = buf.take<float>((size_t)n * npix * c);
-            const WG ga = wg_alloc(c, 0, su == 0 ? cin : c, 9, c, su == 0 ? cin : c, ph, pw);
+            const WG ga = wg_alloc(c, 0, su == 0 ? cin : c, 9, c, su == 0 ? cin : c, ph, pw, 3, 1);
             float* da_new = su > 0 ? buf.take<float>((size_t)n * npix * c) : nullptr;
             if (!buf.ok()) return oom();
             CS_TRY(norm_bwd(u.norms[su], T.rt_bottom[su], lazy_src(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c), da, c, dY, c, npix));
@@ -852,7 +852,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const ConvW& cw = u.units[su - 1];
             float* dY = buf.take<float>((size_t)n * npix * c);
             float* da_new = buf.take<float>((size_t)n * npix * c);
-            const WG ga = wg_alloc(c, 0, c, 9, c, c, oh, ow);
+            const WG ga = wg_alloc(c, 0, c, 9, c, c, oh, ow, 3, 1);
             if (!buf.ok()) return oom();
             CS_TRY(norm_bwd(u.norms[su], T.rt_down[d][su], lazy_src(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c), da, c, dY, c, npix));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));

@@ -174,7 +174,7 @@ struct WgradNarrow {          // "x-like" operand with <= 4 channels addressed b
 // part[k][tap][co_off + i][ci_off + j] = sum over split-K slice k of a[pix][i] * b[pix*stride + tap - pad][j]  (plain stores;
 // every element of the launch's [co_off, co_off+a_c) x [ci_off, ..) block is written, nothing needs zeroing).
 // split_k from wgrad_split_k(); launches that share one partial buffer (fused / concatenated operands) must use the same value.
-int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo);
+int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo, int ksize = 3, int stride = 2);   // (ksize, stride) of the launch that will use it
 int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pitch, int a_c, const ConvSrc& b, const WgradNarrow* nb,
                  float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi);
 // sums the split_k partials and converts to the PyTorch layout dst[row][col][tap]

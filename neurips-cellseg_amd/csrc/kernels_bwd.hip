@@ -397,9 +397,9 @@ struct WgradParams {
 // [taps][16*MT][16] slab; the unpack kernel sums the split_k partials while it converts to the PyTorch layout.  (A first
 // version committed every block with global float atomics: hundreds of blocks adding to the same few KB serialised at
 // the memory side and every launch took 110-260 us whatever its size.)
-template <int S, int KS, int MT, bool NARROW>
+template <int S, int KS, int MT, bool NARROW, int TH = 4>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradParams p) {
-    constexpr int TH = 4, TW = 16;
+    constexpr int TW = 16;
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
     constexpr int PAD = KS / 2, TAPS = KS * KS;
     constexpr int COP = (MT & 1) ? 16 * MT : 16 * MT + 16;   // dy pixel pitch: == 16 (mod 32) -> conflict-free A reads
@@ -524,16 +524,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradParams p) {
     for (int tile = t_begin; tile < t_end; ++tile) {
         const bool more = tile + 1 < t_end;
         if (more) load_tile(tile + 1);
-        for (int row = 0; row < TH; ++row) {
+        // 16 K-steps (4 pixel rows x 4 groups of 4 pixels).  All tiles of a wave share ONE dy channel tile ((wave + 4 i) % MT does
+        // not depend on i), so a step needs one A value and NACC B values; they are read from LDS one step AHEAD of their MFMAs
+        // (left to itself hipcc put every operand pair and an lgkmcnt(0) wait directly in front of its MFMA: each MFMA then paid a
+        // full LDS round trip and a wave reached about a quarter of the matrix rate)
+        float a_op[2], b_op[2][NACC];
+        auto read_ops = [&](int step, float& av, float (&bv)[NACC]) {
+            const int row = step >> 2, ks = step & 3;
+            av = a_s[(row * 16 + 4 * ks + kk) * COP + a_off[0]];
+            const int pb = (row * S * IW + (4 * ks + kk) * S) * CSX;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int pa = (row * 16 + 4 * ks + kk) * COP;
-                const int pb = (row * S * IW + (4 * ks + kk) * S) * CSX;
+            for (int i = 0; i < NACC; ++i) bv[i] = b_s[pb + b_off[i]];
+        };
+        read_ops(0, a_op[0], b_op[0]);
 #pragma unroll
-                for (int i = 0; i < NACC; ++i)
-                    if ((TAPS * MT) % 4 == 0 || wave + 4 * i < TAPS * MT)
-                        acc[i] = mfma4b(a_s[pa + a_off[i]], b_s[pb + b_off[i]], acc[i]);
-            }
+        for (int step = 0; step < 4 * TH; ++step) {
+            if (step + 1 < 4 * TH) read_ops(step + 1, a_op[(step + 1) & 1], b_op[(step + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);       // the reads stay in front of this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+                if ((TAPS * MT) % 4 == 0 || wave + 4 * i < TAPS * MT) acc[i] = mfma4b(a_op[step & 1], b_op[step & 1][i], acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         if (more) {
@@ -557,13 +568,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradParams p) {
 }
 
 // how many split-K slices a weight-gradient launch should use: enough blocks to fill the chip, never more than tiles
-int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo) {
+// pixel rows per K tile: 8 for the 3x3 stride-1 layers with 64-channel blocks (twice the MFMAs per barrier pair), else 4
+static int g_wgrad_th8 = getenv("CS_WGRAD_TH8") ? atoi(getenv("CS_WGRAD_TH8")) : 1;
+static inline int wgrad_th(int ksize, int stride, int a_c, int b_c, int ho) {
+    return (g_wgrad_th8 && ksize == 3 && stride == 1 && a_c % 64 == 0 && b_c >= 16 && ho >= 8) ? 8 : 4;
+}
+
+int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo, int ksize, int stride) {
     const int mt = (a_c % 64 == 0) ? 4 : (a_c % 32 == 0) ? 2 : 1;
     const int combos = (a_c / (16 * mt)) * (b_c >= 16 ? b_c / 16 : 1);
-    const int total_tiles = n * ceil_div(wo, 16) * ceil_div(ho, 4);
+    const int total_tiles = n * ceil_div(wo, 16) * ceil_div(ho, wgrad_th(ksize, stride, a_c, b_c, ho));
     // blocks per launch: measured on the 32-base step (wgrad + unpack ms): 1024 -> 2.46 + 0.50, 768 -> 2.67 + 0.40, 512 -> 2.53 + 0.30,
     // 384 -> 3.17 + 0.25: fewer slices halve the partial slabs the unpack pass has to sum
     static const int target_blocks = getenv("CS_WGRAD_BLOCKS") ? atoi(getenv("CS_WGRAD_BLOCKS")) : 512;
+    // (four times the blocks for the narrow launches - 3-channel operand, 70 us each, four per step - was measured: the launches got
+    // 5 us shorter and the unpack pass 15 us longer each)
     int k = ceil_div(target_blocks, combos);
     if (k > total_tiles) k = total_tiles;
     return k < 1 ? 1 : k;
@@ -589,8 +608,9 @@ int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pit
     p.dummy = a;
     p.part = part; p.co_total = co_total; p.ci_total = ci_total; p.co_off = co_off; p.ci_off = ci_off;
     p.n = n; p.ho = ho; p.wo = wo; p.hi = hi; p.wi = wi;
+    const int th = wgrad_th(ksize, stride, a_c, nb ? nb->c : b.c, ho);
     p.tiles_x = ceil_div(wo, 16);
-    p.tiles_y = ceil_div(ho, 4);
+    p.tiles_y = ceil_div(ho, th);
     p.total_tiles = n * p.tiles_x * p.tiles_y;
     CS_REQUIRE(split_k >= 1 && split_k <= p.total_tiles, "wgrad: split_k %d out of range", split_k);
     p.split_k = split_k;
@@ -607,7 +627,9 @@ int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pit
     if (nb) {
         CS_REQUIRE(ksize == 3 && stride == 2, "wgrad: the narrow operand is only used by stride-2 3x3 layers");
         CS_WG(2, 3, true)
-    } else if (ksize == 1) { CS_WG(1, 1, false) } else if (stride == 1) { CS_WG(1, 3, false) } else { CS_WG(2, 3, false) }
+    } else if (ksize == 1) { CS_WG(1, 1, false) } else if (stride == 1 && th == 8) {
+        hipLaunchKernelGGL((wgrad_mfma_kernel<1, 3, 4, false, 8>), grid, dim3(256), 0, s, p);
+    } else if (stride == 1) { CS_WG(1, 3, false) } else { CS_WG(2, 3, false) }
 #undef CS_WG
     CS_HIP(hipGetLastError());
     return CS_OK;

@@ -77,7 +77,8 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(slope, &hs, 4, hipMemcpyHostToDevice));
             a.tab = tab; a.slope = slope; a.tab_c = L.cin;
         }
-        auto run_w = [&]() { return cs::launch_conv_wino(s, a, ww, b, y1, L.cout, L.cout, st1, n, L.hw, L.hw); };
+        double* const st1_arg = getenv("WINO_NOSTATS") ? nullptr : st1;    // diagnostics: the epilogue without the fp64 statistics
+        auto run_w = [&]() { return cs::launch_conv_wino(s, a, ww, b, y1, L.cout, L.cout, st1_arg, n, L.hw, L.hw); };
         auto run_d = [&]() { return cs::launch_conv_mfma(s, 3, 1, a, cs::ConvSrc(), wd, b, y2, L.cout, L.cout, st2, n, L.hw, L.hw); };
         if (run_w() || run_d()) {
             printf("launch failed: %s\n", cs_last_error());

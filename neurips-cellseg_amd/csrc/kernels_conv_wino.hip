@@ -306,6 +306,289 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
 // short-K layers (the next tile's first patch requested before the epilogue of the current one): no change for 32->32 (683 us),
 // 2 % slower for the deep layers (registers) - the wait for the first patch is already covered by the other blocks of the CU.
 
+// ------------------------------------------------------------------------------------------------
+// 128-channel form for the layers with cout % 128 == 0 (60 % of the Winograd FLOPs of the 32-base net): ONE wave per SIMD.
+// Because an fp32 MFMA and another wave's VALU instruction do not execute together, a second wave on the SIMD buys overlap
+// only for WAITS - and those can be scheduled away by hand when a wave has the SIMD to itself.  So: 256 threads, every wave
+// owns its 4 positions for all 32 tiles and all 8 channel tiles (256 accumulator registers in the AGPR half of the file; every
+// staged value feeds twice the MFMAs of the 64-channel kernel), raw patch and V are double-buffered around ONE barrier per chunk,
+// and the staging of the next chunks is cut into pieces that sit BETWEEN the four nu steps of the running chunk:
+//     [LDS reads of the transform of chunk c+1] MFMA nu=0 [transform arithmetic + V stores] MFMA nu=1
+//     [norm + park of chunk c+2, global loads of chunk c+3] MFMA nu=2 MFMA nu=3 [barrier]
+// every LDS round trip and the global latency run under 64 MFMAs; what is left in the MFMA stream is the VALU work itself.
+// LDS: 2 x (14 KB + 32 KB) in the loop; the epilogue exchange R [4][2][32][132] (132 KB) + statistics reuse it: one block per CU.
+// ------------------------------------------------------------------------------------------------
+template <bool LAZY>
+__global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long long* stamps) {
+    constexpr int NTW = 8;
+    constexpr int IN_ITERS = (WIH * WIW + 63) / 64;            // 3
+    constexpr int RS = 16 * NTW + 4;
+    constexpr int R_FLOATS = 4 * 2 * 32 * RS;                  // 33792
+    constexpr int MAIN_FLOATS = 2 * (RAW_FLOATS + V_FLOATS);   // 23584
+    constexpr int BODY_FLOATS = MAIN_FLOATS > R_FLOATS ? MAIN_FLOATS : R_FLOATS;
+    constexpr int ST_FLOATS = 4 * 16 * NTW * 2 * 2;
+    __shared__ __attribute__((aligned(16))) float smem[BODY_FLOATS + ST_FLOATS];
+    float* const raw0 = smem;                                  // raw[b] = raw0 + b * RAW_FLOATS
+    float* const vs0 = smem + 2 * RAW_FLOATS;                  // V[b]   = vs0 + b * V_FLOATS
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    auto stamp = [&](int k) {
+        if (stamps) {
+            __builtin_amdgcn_sched_barrier(0);
+            const long long t = (long long)__builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            tsum[k] += t - tlast;
+            tlast = t;
+        }
+    };
+    const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NTW);
+    if (!wk.valid) return;
+    int bid = wk.spatial;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int oy0 = ty * 8, ox0 = tx * 16;
+    const int nt0 = wk.ct * NTW;
+    const int q = tid & 3;
+
+    f32x4 acc[4][2][NTW];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[nu][m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned boff[IN_ITERS], inb = 0;
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (tid >> 2) + 64 * it;
+        const int iy = pix / WIW, ix = pix - iy * WIW;
+        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+        const bool ok = pix < WIH * WIW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win;
+        inb |= ok ? (1u << it) : 0u;
+        boff[it] = ok ? ((unsigned)(gy * p.win + gx) * (unsigned)p.a.pitch + 4u * q) * 4u : 16u * q;
+    }
+    const char* const img_base = reinterpret_cast<const char*>(p.a.ptr + (size_t)img * p.hin * p.win * p.a.pitch);
+    const int chunks = p.a.c >> 4;
+    f32x4 rin[IN_ITERS];
+    Lazy4 lz;
+    auto load_in = [&](int ch) {                               // unconditional (clamped past the end: re-reads the last chunk)
+        const int c0 = (ch < chunks ? ch : chunks - 1) << 4;
+        if (LAZY) lz.load(p.a, img, c0 + 4 * q, p.wpack);
+        const char* base = img_base + (size_t)c0 * 4;
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) rin[it] = *reinterpret_cast<const f32x4*>(base + boff[it]);
+    };
+    auto park = [&](float* raw) {                              // registers -> raw patch (lazy norm + PReLU, zero padding after it)
+#pragma unroll
+        for (int it = 0; it < IN_ITERS; ++it) {
+            const int pix = (tid >> 2) + 64 * it;
+            if (pix < WIH * WIW) {
+                const f32x4 a = LAZY ? lz.apply_on(rin[it]) : rin[it];
+                const f32x4 v = (inb >> it) & 1u ? a : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&raw[pix * WPS + 4 * q]) = v;
+            }
+        }
+    };
+    // input transform of one (tile, channel pair), in two pieces: the LDS reads, then arithmetic + V stores
+    const int t_tx = lane & 7, t_h = (lane >> 3) & 1, t_g = lane >> 4;
+    const int t_src_off = ((2 * wave) * WIW + 2 * t_tx) * WPS + 4 * t_g + 2 * t_h;
+    const int t_dst_off = (t_g * 32 + wave * 8 + t_tx) * 4 + 2 * t_h;
+    float2 d[4][4];
+    auto transform_read = [&](const float* raw) {
+        const float* src = raw + t_src_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const float2*>(src + (i * WIW + j) * WPS);
+    };
+    auto transform_write = [&](float* vs) {
+        float2 t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = make_float2(d[0][j].x - d[2][j].x, d[0][j].y - d[2][j].y);
+            t[1][j] = make_float2(d[1][j].x + d[2][j].x, d[1][j].y + d[2][j].y);
+            t[2][j] = make_float2(d[2][j].x - d[1][j].x, d[2][j].y - d[1][j].y);
+            t[3][j] = make_float2(d[1][j].x - d[3][j].x, d[1][j].y - d[3][j].y);
+        }
+        float* dst = vs + t_dst_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float2*>(dst + (i * 4 + 0) * 512) = make_float2(t[i][0].x - t[i][2].x, t[i][0].y - t[i][2].y);
+            *reinterpret_cast<float2*>(dst + (i * 4 + 1) * 512) = make_float2(t[i][1].x + t[i][2].x, t[i][1].y + t[i][2].y);
+            *reinterpret_cast<float2*>(dst + (i * 4 + 2) * 512) = make_float2(t[i][2].x - t[i][1].x, t[i][2].y - t[i][1].y);
+            *reinterpret_cast<float2*>(dst + (i * 4 + 3) * 512) = make_float2(t[i][1].x - t[i][3].x, t[i][1].y - t[i][3].y);
+        }
+    };
+
+    // B fragments of this wave: positions 4 wave + nu, channel tiles nt0 + t (scalar base + 32-bit lane offset), one nu step ahead
+    const char* const wbase = reinterpret_cast<const char*>(p.wpack) + ((size_t)nt0 * 64 + (size_t)wave * 4 * p.ntile_total * 64) * 16;
+    const size_t wpos = (size_t)p.ntile_total * 64 * 16;
+    const unsigned wlane = (unsigned)lane * 16u;
+    // four slots: the fragments of a whole chunk, refilled one CHUNK ahead (a lone wave has nobody to cover a late fragment: one nu
+    // step = 2048 cycles of lead was not always enough for the L2 under the weight streams of 256 CUs)
+    f32x4 wc[4][NTW];
+    auto wload = [&](int step, f32x4 (&dst)[NTW]) {
+        const char* w = wbase + (size_t)((step >> 2) * 16 + (step & 3)) * wpos;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) dst[t] = *reinterpret_cast<const f32x4*>(w + t * 1024 + wlane);
+    };
+
+    // prologue: chunk 0 -> raw[0] -> V[0]; chunk 1 -> raw[1]; chunk 2 in registers
+    load_in(0);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) wload(nu, wc[nu]);
+    park(raw0);
+    load_in(1);
+    __syncthreads();
+    transform_read(raw0);
+    transform_write(vs0);
+    park(raw0 + RAW_FLOATS);
+    load_in(2);
+    __syncthreads();
+    stamp(0);                                  // [0] prologue
+    const int a_off = ((wave * 16 + g) * 32 + pl) * 4;            // + nu * 512 + m * 64
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int b = ch & 1;
+        const bool more1 = ch + 1 < chunks, more2 = ch + 2 < chunks;
+        const float* const a_src = vs0 + b * V_FLOATS + a_off;
+        f32x4 a[2][2];
+        // piece 1: the transform's LDS reads of chunk c + 1 and the first A fragments, all in flight under the first MFMAs
+        if (more1) transform_read(raw0 + (b ^ 1) * RAW_FLOATS);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(a_src + m * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            if (nu < 3) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[(nu + 1) & 1][m] = *reinterpret_cast<const f32x4*>(a_src + (nu + 1) * 512 + m * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) acc[nu][m][t] = mfma4(a[nu & 1][m][j], wc[nu][t][j], acc[nu][m][t]);
+            __builtin_amdgcn_sched_barrier(0);
+            // last k-step of the fragments: channel tile by channel tile, each slot refilled (same nu of the NEXT chunk; the last chunk
+            // re-reads its own) right behind its last two MFMAs - eight loads spread under sixteen MFMAs instead of one burst
+            {
+                const char* wn = wbase + (size_t)((more1 ? ch + 1 : ch) * 16 + nu) * wpos;
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    acc[nu][0][t] = mfma4(a[nu & 1][0][3], wc[nu][t][3], acc[nu][0][t]);
+                    acc[nu][1][t] = mfma4(a[nu & 1][1][3], wc[nu][t][3], acc[nu][1][t]);
+                    wc[nu][t] = *reinterpret_cast<const f32x4*>(wn + t * 1024 + wlane);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(1);                          // [1] MFMA steps (+ the reads issued in front of them)
+            if (nu == 0 && more1) {            // piece 2: transform arithmetic + V stores of chunk c + 1
+                transform_write(vs0 + (b ^ 1) * V_FLOATS);
+                __builtin_amdgcn_sched_barrier(0);
+                stamp(4);                      // [4] transform arithmetic + V stores
+            }
+            if (nu == 1) {                     // piece 3: park chunk c + 2 (its loads were issued an iteration ago), request chunk c + 3
+                if (more2) park(raw0 + b * RAW_FLOATS);
+                load_in(ch + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                stamp(5);                      // [5] park + loads
+            }
+        }
+        stamp(6);                              // [6] weight loads of the last step, loop overhead
+        __syncthreads();
+        stamp(2);                              // [2] barrier
+    }
+
+    // ---- epilogue: nu half of A^T M A in registers, xi half after the exchange through LDS ----
+    float* const rs = smem;                                      // [xi 4][j 2][tile 32][RS]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const f32x4 r0 = (acc[0][m][t] + acc[1][m][t]) + acc[2][m][t];
+            const f32x4 r1 = (acc[1][m][t] - acc[2][m][t]) - acc[3][m][t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tile = m * 16 + g * 4 + r;
+                rs[((wave * 2 + 0) * 32 + tile) * RS + t * 16 + pl] = r0[r];
+                rs[((wave * 2 + 1) * 32 + tile) * RS + t * 16 + pl] = r1[r];
+            }
+        }
+    __syncthreads();
+    constexpr int F4 = NTW * 4, PPP = 256 / F4, XS = 2 * 32 * RS;
+    const int c4 = tid % F4;
+    const int co = nt0 * 16 + c4 * 4;
+    const OutSel o = OutSel{p.out, p.addend, p.pitch_out, p.pitch_add, (nt0 + c4 / 4) * 16};
+    const int cw = (c4 & 3) * 4;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, qsum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int it = 0; it < 128 / PPP; ++it) {
+        const int pix = tid / F4 + PPP * it;
+        const int oyl = pix >> 4, oxl = pix & 15;
+        const int tile = (oyl >> 1) * 8 + (oxl >> 1), ii = oyl & 1, jj = oxl & 1;
+        const float* rb = rs + (jj * 32 + tile) * RS + c4 * 4;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(rb + (ii ? 3 * XS : 0));
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(rb + XS);
+        const f32x4 x2 = *reinterpret_cast<const f32x4*>(rb + 2 * XS);
+        f32x4 y = ii ? (x1 - x2) - x0 : (x0 + x1) + x2;
+        y += bias4;
+        const int oy = oy0 + oyl, ox = ox0 + oxl;
+        if (oy < p.hout && ox < p.wout) {
+            const size_t gp = ((size_t)img * p.hout + oy) * p.wout + ox;
+            if (o.add) y += *reinterpret_cast<const f32x4*>(o.add + gp * o.pitch_add + o.ch0 + cw);
+            *reinterpret_cast<f32x4*>(o.out + gp * o.pitch + o.ch0 + cw) = y;
+            if (p.stats) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ssum[k] += (double)y[k];
+                    qsum[k] += (double)y[k] * (double)y[k];
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        double* st_s = reinterpret_cast<double*>(smem + BODY_FLOATS);      // [4 waves][16*NTW][2]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int sh = F4; sh < 64; sh <<= 1) {
+                ssum[k] += __shfl_xor(ssum[k], sh);
+                qsum[k] += __shfl_xor(qsum[k], sh);
+            }
+        }
+        if (lane < F4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2] = ssum[k];
+                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2 + 1] = qsum[k];
+            }
+        }
+        __syncthreads();
+        if (tid < 32 * NTW) {
+            const int c = tid >> 1, k = tid & 1;
+            const double v = st_s[(0 * 16 * NTW + c) * 2 + k] + st_s[(1 * 16 * NTW + c) * 2 + k] + st_s[(2 * 16 * NTW + c) * 2 + k] +
+                             st_s[(3 * 16 * NTW + c) * 2 + k];
+            atomicAdd(p.stats + ((size_t)img * p.cout + nt0 * 16 + c) * 2 + k, v);
+        }
+    }
+    stamp(3);                                  // [3] epilogue
+    if (stamps && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 8; ++k) stamps[wave * 8 + k] = tsum[k];
+}
+
 long long* g_wino_stamps = nullptr;    // diagnostics: device buffer of 8 x 8 counters (tests/diagnostics/wino_layer_bench.hip)
 void wino_set_stamp_buffer(long long* dev) { g_wino_stamps = dev; }
 
@@ -351,7 +634,15 @@ int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, c
     const bool lazy = a.tab != nullptr;
 #define CS_WINO_LAUNCH(NTW_, OCC_, LAZY_)                                                                                       \
     hipLaunchKernelGGL((conv_wino_kernel<NTW_, OCC_, LAZY_>), dim3(xcd_grid(nsp, p.ntile_total / NTW_)), dim3(256), 0, s, p, g_wino_stamps)
-    if (cout % 64 == 0) {
+    // 128-channel blocks at one wave per SIMD (conv_wino1_kernel) where the grid still fills the chip twice over: measured 2-8 %
+    // faster than the 64-channel kernel on the 128...512-channel layers of the slide; small (training-sized) launches keep the
+    // 64-channel kernel and its twice as many blocks.  CS_WINO_WIDE=0 switches it off (A/B).
+    static const int wide = getenv("CS_WINO_WIDE") ? atoi(getenv("CS_WINO_WIDE")) : 1;
+    if (cout % 128 == 0 && wide && (long long)xcd_grid(nsp, p.ntile_total / 8) >= 512) {
+        const dim3 grid1(xcd_grid(nsp, p.ntile_total / 8));
+        if (lazy) hipLaunchKernelGGL((conv_wino1_kernel<true>), grid1, dim3(256), 0, s, p, g_wino_stamps);
+        else hipLaunchKernelGGL((conv_wino1_kernel<false>), grid1, dim3(256), 0, s, p, g_wino_stamps);
+    } else if (cout % 64 == 0) {
         if (lazy) CS_WINO_LAUNCH(4, 2, true);
         else CS_WINO_LAUNCH(4, 2, false);
     } else {

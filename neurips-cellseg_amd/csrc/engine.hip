@@ -226,6 +226,10 @@ struct cs_unet {
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     Tape tape;
+    // backward: the weight-gradient launches (off the critical chain dy -> data gradient -> norm backward -> dy) run on a side
+    // stream, forked from the caller's stream by an event once their dy is complete
+    hipStream_t bwd_side[2] = {nullptr, nullptr};
+    hipEvent_t bwd_ev[48] = {};
     int device = -1;                 // the device the weight arena and the packing tables live on
     cs::PackCtx* pack = nullptr;     // per-handle weight-packing state (job tables allocated once, at creation)
 };
@@ -686,7 +690,8 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
 // backward over the batch recorded in net->tape.  `acc` = fp64 / fp32 accumulators (zeroed by the caller's memset),
 // `buf` = gradient activations.  Gradients land in `flat` at params[i].grad_off, in PyTorch layouts.
 // ---------------------------------------------------------------------------------------------------
-static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& acc, Bump& buf, float* flat, hipStream_t s) {
+static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& acc, Bump& buf, float* flat, hipStream_t s,
+                              const hipStream_t* side = nullptr, int n_side = 0, const hipEvent_t* side_ev = nullptr, int n_side_ev = 0) {
     const bool dry = buf.dry();
     const Tape& T = net->tape;
     const int nl = net->nl, n = T.n, h = T.h, w = T.w;
@@ -696,6 +701,21 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     CS_REQUIRE(dry || T.src.origins == nullptr, "backward: the recorded forward must be a plain batched forward");
     auto gptr = [&](int pidx) { return flat + net->params[pidx].grad_off; };
     auto oom = [&]() { set_error("backward: workspace too small"); return CS_ERR_WORKSPACE; };
+    // weight gradients (+ their unpack passes) go to the side stream `sw`: wg_begin() makes it wait for everything issued on `s` so far
+    // (the dy the launches read).  They only read finished tensors and write their own partial slabs / gradient slots, and the
+    // workspace is a bump allocator (nothing is reused inside one backward), so the main chain never has to wait for them before
+    // the join at the end.  HBM-bound norm-backward kernels of the main chain then run beside matrix-bound weight gradients.
+    const bool side_on = side != nullptr && n_side > 0 && n_side_ev > 0 && !dry;
+    hipStream_t sw = s;                        // stream of the current weight-gradient group (the groups alternate over the side streams)
+    int side_used = 0, groups = 0;
+    auto wg_begin = [&]() -> int {
+        if (!side_on) return CS_OK;
+        sw = side[groups++ % n_side];
+        const hipEvent_t ev = side_ev[side_used++ % n_side_ev];
+        CS_HIP(hipEventRecord(ev, s));
+        CS_HIP(hipStreamWaitEvent(sw, ev, 0));
+        return CS_OK;
+    };
 
     // helpers -------------------------------------------------------------------------------------------
     // `before_norm`: the conv feeds an InstanceNorm, which removes any per-(image, channel) constant - the bias gradient is
@@ -760,8 +780,9 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             CS_TRY(norm_bwd(u.norm_u, T.rt_upu[d], lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow));
             CS_TRY(bias_grad(dV, c, c, (int64_t)n * oh * ow, u.unit0.p_b[0], true));
             if (!dry) {
-                CS_TRY(launch_wgrad(s, 3, 1, dV, c, c, lu, nullptr, gu.part, gu.k, c, c, 0, 0, n, oh, ow, oh, ow));
-                CS_TRY(launch_unpack_wgrad(s, gu.part, gu.k, c, c, 0, 0, c, c, 9, gptr(u.unit0.p_w[0])));
+                CS_TRY(wg_begin());
+                CS_TRY(launch_wgrad(sw, 3, 1, dV, c, c, lu, nullptr, gu.part, gu.k, c, c, 0, 0, n, oh, ow, oh, ow));
+                CS_TRY(launch_unpack_wgrad(sw, gu.part, gu.k, c, c, 0, 0, c, c, 9, gptr(u.unit0.p_w[0])));
                 ConvOutExtra ex;
                 ex.addend = dS; ex.pitch_add = c;          // identity residual of the up ResidualUnit
                 CS_TRY(dgrad_s1(s, u.unit0, dV, c, d_au, c, n, oh, ow, &ex));
@@ -775,16 +796,18 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 CS_TRY(launch_convt_small_bwd_data(s, dU, u.convt.w, cin_t, cs, cb, dSn, cb, false, n, ph, pw));
                 WgradNarrow nb;
                 nb.ptr = dU; nb.c = c; nb.sn = (int64_t)oh * ow * c; nb.sc = 1; nb.sh = (int64_t)ow * c; nb.sw = c;
-                CS_TRY(launch_wgrad(s, 3, 2, T.X[d], cs, cs, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, 0, 0, n, ph, pw, oh, ow));
-                CS_TRY(launch_wgrad(s, 3, 2, Ssub, cb, cb, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, cs, 0, n, ph, pw, oh, ow));
+                CS_TRY(wg_begin());
+                CS_TRY(launch_wgrad(sw, 3, 2, T.X[d], cs, cs, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, 0, 0, n, ph, pw, oh, ow));
+                CS_TRY(launch_wgrad(sw, 3, 2, Ssub, cb, cb, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, cs, 0, n, ph, pw, oh, ow));
             } else {
                 ConvOutExtra ex;
                 ex.out2 = dSn; ex.pitch_out2 = cb; ex.split = cs;
                 CS_TRY(launch_conv_mfma(s, 3, 2, rsrc(dU, c, c), ConvSrc(), u.convt.wd, nullptr, dX[d], cs, cin_t, nullptr, n, oh, ow, &ex));
-                CS_TRY(launch_wgrad(s, 3, 2, T.X[d], cs, cs, rsrc(dU, c, c), nullptr, gt.part, gt.k, cin_t, c, 0, 0, n, ph, pw, oh, ow));
-                CS_TRY(launch_wgrad(s, 3, 2, Ssub, cb, cb, rsrc(dU, c, c), nullptr, gt.part, gt.k, cin_t, c, cs, 0, n, ph, pw, oh, ow));
+                CS_TRY(wg_begin());
+                CS_TRY(launch_wgrad(sw, 3, 2, T.X[d], cs, cs, rsrc(dU, c, c), nullptr, gt.part, gt.k, cin_t, c, 0, 0, n, ph, pw, oh, ow));
+                CS_TRY(launch_wgrad(sw, 3, 2, Ssub, cb, cb, rsrc(dU, c, c), nullptr, gt.part, gt.k, cin_t, c, cs, 0, n, ph, pw, oh, ow));
             }
-            CS_TRY(launch_unpack_wgrad(s, gt.part, gt.k, cin_t, c, 0, 0, cin_t, c, 9, gptr(u.convt.p_w[0])));
+            CS_TRY(launch_unpack_wgrad(sw, gt.part, gt.k, cin_t, c, 0, 0, cin_t, c, 9, gptr(u.convt.p_w[0])));
         }
         dS = dSn;
     }
@@ -800,8 +823,9 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const WG gr = wg_alloc(c, 0, cin, 1, c, cin, ph, pw, 1, 1);
             CS_TRY(bias_grad(dS, c, c, n * npix, u.res1x1.p_b[0]));
             if (!dry) {
-                CS_TRY(launch_wgrad(s, 1, 1, dS, c, c, rsrc(Xin, cin, cin), nullptr, gr.part, gr.k, c, cin, 0, 0, n, ph, pw, ph, pw));
-                CS_TRY(launch_unpack_wgrad(s, gr.part, gr.k, c, cin, 0, 0, c, cin, 1, gptr(u.res1x1.p_w[0])));
+                CS_TRY(wg_begin());
+                CS_TRY(launch_wgrad(sw, 1, 1, dS, c, c, rsrc(Xin, cin, cin), nullptr, gr.part, gr.k, c, cin, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_unpack_wgrad(sw, gr.part, gr.k, c, cin, 0, 0, c, cin, 1, gptr(u.res1x1.p_w[0])));
             }
         }
         const float* da = dS;
@@ -816,13 +840,15 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             if (dry) { da = da_new; continue; }
             if (su > 0) {
                 const ConvSrc prev = lazy_src(T.Yb[su - 1], c, c, T.rt_bottom[su - 1], u.norms[su - 1], c);
-                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, ph, pw, ph, pw));
-                CS_TRY(launch_unpack_wgrad(s, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
+                CS_TRY(wg_begin());
+                CS_TRY(launch_wgrad(sw, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_unpack_wgrad(sw, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
                 CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, ph, pw));
                 da = da_new;
             } else {
-                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, rsrc(Xin, cin, cin), nullptr, ga.part, ga.k, c, cin, 0, 0, n, ph, pw, ph, pw));
-                CS_TRY(launch_unpack_wgrad(s, ga.part, ga.k, c, cin, 0, 0, c, cin, 9, gptr(cw.p_w[0])));
+                CS_TRY(wg_begin());
+                CS_TRY(launch_wgrad(sw, 3, 1, dY, c, c, rsrc(Xin, cin, cin), nullptr, ga.part, ga.k, c, cin, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_unpack_wgrad(sw, ga.part, ga.k, c, cin, 0, 0, c, cin, 9, gptr(cw.p_w[0])));
                 ConvOutExtra ex;
                 ex.addend = dXin; ex.pitch_add = cin;
                 CS_TRY(dgrad_s1(s, cw, dY, c, dXin, cin, n, ph, pw, &ex));
@@ -859,8 +885,9 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             if (!dry) {
                 const ConvSrc prev = su - 1 == 0 ? lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0)
                                                  : lazy_src(T.Y[d][su - 1], c, c, T.rt_down[d][su - 1], u.norms[su - 1], c);
-                CS_TRY(launch_wgrad(s, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, oh, ow, oh, ow));
-                CS_TRY(launch_unpack_wgrad(s, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
+                CS_TRY(wg_begin());
+                CS_TRY(launch_wgrad(sw, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, oh, ow, oh, ow));
+                CS_TRY(launch_unpack_wgrad(sw, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
                 CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, oh, ow));
             }
             da = da_new;
@@ -873,19 +900,28 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         if (dry) continue;
         if (!u.first) {
             const ConvSrc xin = rsrc(T.X[d - 1], cin, cin);
-            CS_TRY(launch_wgrad(s, 3, 2, dY0, c, c, xin, nullptr, gf.part, gf.k, c0, cin, 0, 0, n, oh, ow, ph, pw));
-            CS_TRY(launch_wgrad(s, 3, 2, dXd, c, c, xin, nullptr, gf.part, gf.k, c0, cin, c, 0, n, oh, ow, ph, pw));
+            CS_TRY(wg_begin());
+            CS_TRY(launch_wgrad(sw, 3, 2, dY0, c, c, xin, nullptr, gf.part, gf.k, c0, cin, 0, 0, n, oh, ow, ph, pw));
+            CS_TRY(launch_wgrad(sw, 3, 2, dXd, c, c, xin, nullptr, gf.part, gf.k, c0, cin, c, 0, n, oh, ow, ph, pw));
             ConvOutExtra ex;
             ex.addend = dX[d - 1]; ex.pitch_add = cin;
             CS_TRY(launch_convt_mfma(s, rsrc(dY0, c, c), rsrc(dXd, c, c), u.unit0.wd, nullptr, dX[d - 1], cin, cin, nullptr, n, oh, ow, &ex));
         } else {
             WgradNarrow nb;
             nb.ptr = T.src.image; nb.c = cin; nb.sn = T.src.sn; nb.sc = T.src.sc; nb.sh = T.src.sh; nb.sw = T.src.sw;
-            CS_TRY(launch_wgrad(s, 3, 2, dY0, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, 0, 0, n, oh, ow, ph, pw));
-            CS_TRY(launch_wgrad(s, 3, 2, dXd, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, c, 0, n, oh, ow, ph, pw));
+            CS_TRY(wg_begin());
+            CS_TRY(launch_wgrad(sw, 3, 2, dY0, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, 0, 0, n, oh, ow, ph, pw));
+            CS_TRY(launch_wgrad(sw, 3, 2, dXd, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, c, 0, n, oh, ow, ph, pw));
         }
-        CS_TRY(launch_unpack_wgrad(s, gf.part, gf.k, c0, cin, 0, 0, c, cin, 9, gptr(u.unit0.p_w[0])));
-        CS_TRY(launch_unpack_wgrad(s, gf.part, gf.k, c0, cin, c, 0, c, cin, 9, gptr(u.unit0.p_w[1])));
+        CS_TRY(launch_unpack_wgrad(sw, gf.part, gf.k, c0, cin, 0, 0, c, cin, 9, gptr(u.unit0.p_w[0])));
+        CS_TRY(launch_unpack_wgrad(sw, gf.part, gf.k, c0, cin, c, 0, c, cin, 9, gptr(u.unit0.p_w[1])));
+    }
+    if (side_on) {                             // join: the caller's stream continues behind the last weight gradients
+        for (int i = 0; i < n_side; ++i) {
+            const hipEvent_t ev = side_ev[side_used++ % n_side_ev];
+            CS_HIP(hipEventRecord(ev, side[i]));
+            CS_HIP(hipStreamWaitEvent(s, ev, 0));
+        }
     }
     return CS_OK;
 }
@@ -1053,6 +1089,13 @@ int cs_unet_destroy(cs_unet* net) {
         if (net->ev_join[i]) (void)hipEventDestroy(net->ev_join[i]);
     }
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    for (auto& st : net->bwd_side)
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (auto& ev : net->bwd_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (net->arena) (void)hipFree(net->arena);
     cs::pack_ctx_destroy(net->pack);
     delete net;
@@ -1164,7 +1207,14 @@ int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspac
     CS_HIP(hipMemsetAsync(workspace, 0, acc_bytes, s));
     CS_HIP(hipMemsetAsync(flat_grad, 0, (size_t)net->grad_floats * sizeof(float), s));
     Bump acc(workspace, acc_bytes), buf((char*)workspace + acc_bytes, workspace_bytes - acc_bytes);
-    rc = unet_backward_impl(net, grad_logits_nhwc, acc, buf, flat_grad, s);
+    static const bool side_env = !(getenv("CS_BWD_SIDE") && atoi(getenv("CS_BWD_SIDE")) == 0);     // A/B: CS_BWD_SIDE=0 = one stream
+    static const int n_side_env = getenv("CS_BWD_SIDE") ? atoi(getenv("CS_BWD_SIDE")) : 1;   // measured: 7.38 ms (0) / 6.90 (1) / 7.04 (2 alternating)
+    if (side_env && !prof_enabled() && !net->bwd_side[0]) {      // (per-kernel HIP-event profiling keeps everything on one stream)
+        for (auto& st : net->bwd_side) CS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (auto& ev : net->bwd_ev) CS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const bool use_side = side_env && !prof_enabled() && net->bwd_side[0];
+    rc = unet_backward_impl(net, grad_logits_nhwc, acc, buf, flat_grad, s, net->bwd_side, use_side ? (n_side_env >= 2 ? 2 : 1) : 0, net->bwd_ev, 48);
     net->tape.valid = false;      // the gradient buffers reused nothing of the tape, but one backward per forward
     return rc;
 }

@@ -208,6 +208,8 @@ def main():
                          "the other partition is reported as a secondary object")
     ap.add_argument("--train-batch", type=int, default=32, help="tiles per GPU of the training step (BASELINE configs[1]/[3]: 32)")
     ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--cc-stream", type=int, default=1, help="1: the connected-component pass of slide k runs on its own stream beside "
+                                                              "the convolutions of slide k + 1 (0: same stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (reference width, other precisions, "
                                                                 "the other partition, the training step)")
@@ -253,6 +255,7 @@ def main():
     mpix = args.size * args.size / 1e6
     host = torch.empty((args.size, args.size), dtype=torch.int32, pin_memory=True)    # where "labels on host" land
     copy_stream, done = torch.cuda.Stream(dev), torch.cuda.Event()
+    cc_stream, mask_ready = torch.cuda.Stream(dev), torch.cuda.Event()
 
     # ------------------------------------------------------------------------------------------------------------------
     # inference legs
@@ -266,14 +269,24 @@ def main():
             images[key] = torch.from_numpy(synthetic_wsi(args.size, key)).to(dev)      # resident in HBM before timing
         return images[key]
 
-    def make_step(model, strips, d2h):
+    def make_step(model, strips, d2h, cc_overlap=True):
         image = slide(strips)
         row_lo, row_hi = ca.rank_rows(args.size, rank, world) if strips else (0, args.size)
 
         def step_slide():
+            """The connected-component pass of slide k runs on its own stream (ordered after the slide's mask by an event), so its
+            latency-bound kernels execute beside the convolutions of slide k + 1 - the same software pipeline the label copy
+            already is part of.  Every timed slide is complete when the timed region ends (torch.cuda.synchronize())."""
             _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch, want_logits=False,
                                             want_mask=True, streams=args.streams)
-            return ca.mask_to_instances(mask, return_num=True)
+            if args.cc_stream == 0 or not cc_overlap:
+                return ca.mask_to_instances(mask, return_num=True)
+            mask_ready.record()
+            cc_stream.wait_event(mask_ready)
+            with torch.cuda.stream(cc_stream):
+                lab, num = ca.mask_to_instances(mask, return_num=True)
+            mask.record_stream(cc_stream)
+            return lab, num
 
         def step_strips():
             """One slide across ranks: every rank runs the windows that touch its row strip, finalises its rows, the uint8 mask
@@ -296,7 +309,7 @@ def main():
             overlaps the inference of slide k + 1 - what the predict CLI does with its writer thread.  Every timed step's labels
             are on the host when the timed region ends (torch.cuda.synchronize() drains both streams)."""
             lab, num = inner()
-            done.record()
+            done.record(cc_stream if (inner is step_slide and args.cc_stream and cc_overlap) else None)
             copy_stream.wait_event(done)
             with torch.cuda.stream(copy_stream):
                 host.copy_(lab, non_blocking=True)
@@ -309,6 +322,7 @@ def main():
         model = make_model(WIDTHS[width], seed).to(dev)
         model.precision = precision
         step_host, step_dev = make_step(model, strips, True), make_step(model, strips, False)
+        step_prof = make_step(model, strips, False, cc_overlap=False)      # per-kernel HIP events: everything on one stream
         res = {}
         with torch.no_grad():
             for _ in range(args.warmup):
@@ -320,7 +334,7 @@ def main():
                 # same K steps again with HIP events around every kernel launch (on the launch stream) for the roofline
                 _lib.lib.cs_prof_reset()
                 _lib.lib.cs_prof_enable(1)
-                dt_prof, _ = time_steps(step_dev, args.steps, barrier)
+                dt_prof, _ = time_steps(step_prof, args.steps, barrier)
                 _lib.lib.cs_prof_enable(0)
                 res["prof"] = _lib.prof_collect()
         dt, dt_dev, dt_prof = max_over_ranks([dt, dt_dev, dt_prof])

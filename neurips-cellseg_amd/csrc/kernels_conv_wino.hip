@@ -298,13 +298,11 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
 // the fp32 VECTOR rate and, unlike the 16-bit MFMAs, does not execute beside another wave's VALU instructions on the same SIMD -
 // so on the fp32 path the only lever is the number of VALU instructions per MFMA and not stalling, and specialising waves buys
 // nothing.  Also measured without effect (+-1.5 %): a channel-tile-major block order (the blocks resident on an XCD stream ONE weight
-// slice), a weight ring that runs a whole chunk ahead - the weight stream is not what this kernel waits for - and a 128-channel form
-// (512 threads, both channel halves contracting the same V so that the staging work per MFMA halves, raw patch and V double-buffered
-// around ONE barrier per chunk, one block per CU): 512->512 in 1469 us against 1438 us - with both waves of a SIMD in the same block
-// the barrier skew ate what the shared staging saved (git history: "128-channel double-buffered kernel").  32-channel blocks at
-// three per CU for every layer (more waves to cover stalls, twice the staging per MFMA): 10 % slower.  Several tiles per block for the
-// short-K layers (the next tile's first patch requested before the epilogue of the current one): no change for 32->32 (683 us),
-// 2 % slower for the deep layers (registers) - the wait for the first patch is already covered by the other blocks of the CU.
+// slice) and a weight ring that runs a whole chunk ahead - the weight stream is not what this kernel waits for; a 128-channel form
+// with 512 threads (both channel halves contracting the same V, two waves per SIMD from the same block, one barrier per chunk):
+// 512->512 in 1469 us against 1438 us (barrier skew); 32-channel blocks at three per CU for every layer: 10 % slower; several
+// tiles per block for the short-K layers (the next tile's first patch requested before the epilogue of the current one): no
+// change for 32->32 (683 us) - the wait for the first patch is already covered by the other blocks of the CU.
 
 // ------------------------------------------------------------------------------------------------
 // 128-channel form for the layers with cout % 128 == 0 (60 % of the Winograd FLOPs of the 32-base net): ONE wave per SIMD.

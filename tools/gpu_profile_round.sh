@@ -9,9 +9,9 @@ EXTRA="${@:2}"          # extra bench.py arguments (e.g. --precision bf16); the 
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --streams 1 --no-cpu-baseline --no-secondary $EXTRA > $O/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-secondary $EXTRA > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-secondary $EXTRA > $O/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --streams 1 --cc-stream 0 --no-cpu-baseline --no-secondary $EXTRA > $O/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 1 --warmup 0 --streams 1 --cc-stream 0 --no-cpu-baseline --no-secondary $EXTRA > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 1 --warmup 0 --streams 1 --cc-stream 0 --no-cpu-baseline --no-secondary $EXTRA > $O/write.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
-    --output-format csv -d $O/sq -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-secondary $EXTRA > $O/sq.log 2>&1
+    --output-format csv -d $O/sq -- python3 bench.py --steps 1 --warmup 0 --streams 1 --cc-stream 0 --no-cpu-baseline --no-secondary $EXTRA > $O/sq.log 2>&1
 find $O -name "*.csv" | sort

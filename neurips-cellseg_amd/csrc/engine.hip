@@ -567,9 +567,9 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         if (!dry) {
             if (u.first) {
                 if (a16 && u.unit0.wb)
-                    CS_TRY(launch_conv_first16(s, src, pc, u.unit0.wb, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n));
+                    CS_TRY(launch_conv_first16(s, src, pc, u.unit0.wb, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, c));
                 else
-                    CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, a16));
+                    CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, a16, c));   // statistics for the unit0 half only
             } else {
                 CS_TRY(conv_fwd(s, net, 3, 2, q8 ? raw8_src(prevq, pc) : raw_src(prev, pc, pc, a16), u.unit0, E, c0, c0, rt_down[d][0].stats, n, ph, pw));
             }

@@ -116,11 +116,11 @@ struct WindowSrc {
     int roi_h = 0, roi_w = 0;                // window size = conv input size
 };
 int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
-                      float* out, int pitch_out, int cout, double* stats, int n, bool out16 = false);
+                      float* out, int pitch_out, int cout, double* stats, int n, bool out16 = false, int stats_c = 0);   // stats_c: statistics for channels [0, stats_c) only (0 = all)
 // bf16 / fp8 datapaths: the image is converted to bf16 while it is staged, one v_mfma_f32_16x16x32_bf16 per 16 x 16 output tile
 // (the fp32 form needs seven 16x16x4 steps = 14x the matrix-pipe cycles), bf16 out
 int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsigned short* wpack16, const float* bias, float* out,
-                        int pitch_out, int cout, double* stats, int n);
+                        int pitch_out, int cout, double* stats, int n, int stats_c = 0);
 
 // transposed 3x3 stride 2 pad 1 output_padding 1 (MFMA), input = concat(a, b); out is [n, 2h, 2w, cout]
 int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* wpack, const float* bias,

@@ -529,6 +529,7 @@ struct FirstParams {
     float* out;
     double* stats;
     int pitch_out, cout, ntile_total, n, hout, wout, tiles_x, tiles_y;
+    int stats_c;       // statistics only for channels [0, stats_c): the residual half of a fused [unit0 || residual] launch feeds no norm
 };
 
 template <int S, int CIN, int NT, int MT, bool OUT16>
@@ -619,6 +620,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
         const int co = nt * 16 + pl;
         const float bias = p.bias ? p.bias[co] : 0.f;
         double s = 0.0, qq = 0.0;
+        const bool want = p.stats && nt * 16 < p.stats_c;        // block-uniform: the fp64 work is skipped for channels nobody normalises
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int oy = oy0 + wave * MT + m;
@@ -627,13 +629,13 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
                 const int ox = ox0 + g * 4 + r;
                 const float v = acc[m][nt][r] + bias;
                 acc[m][nt][r] = v;
-                if (oy < p.hout && ox < p.wout) {
+                if (want && oy < p.hout && ox < p.wout) {
                     s += (double)v;
                     qq += (double)v * (double)v;
                 }
             }
         }
-        if (p.stats) {
+        if (want) {
             s += __shfl_xor(s, 16);
             qq += __shfl_xor(qq, 16);
             s += __shfl_xor(s, 32);
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
     }
     if (p.stats) {
         __syncthreads();
-        if (tid < 32 * NT) {
+        if (tid < 32 * NT && (tid >> 1) < p.stats_c) {
             const int c = tid >> 1, k = tid & 1;
             const double v = st_s[(0 * 16 * NT + c) * 2 + k] + st_s[(1 * 16 * NT + c) * 2 + k] + st_s[(2 * 16 * NT + c) * 2 + k] +
                              st_s[(3 * 16 * NT + c) * 2 + k];
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
 }
 
 int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
-                      float* out, int pitch_out, int cout, double* stats, int n, bool out16) {
+                      float* out, int pitch_out, int cout, double* stats, int n, bool out16, int stats_c) {
     CS_REQUIRE(cin == 3, "first conv: in_channels %d unsupported (the reference always feeds 3)", cin);
     CS_REQUIRE(stride == 2, "first conv: stride %d unsupported", stride);
     CS_REQUIRE(cout == 16 || cout == 32 || cout == 64 || cout == 128, "first conv: fused cout %d unsupported", cout);
@@ -673,6 +675,7 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
     p.img_h = src.img_h; p.img_w = src.img_w; p.roi_h = src.roi_h; p.roi_w = src.roi_w;
     p.wpack = wpack; p.bias = bias; p.out = out; p.stats = stats;
     p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16; p.n = n;
+    p.stats_c = stats_c > 0 ? stats_c : cout;
     p.hout = (src.roi_h + 2 - 3) / 2 + 1;
     p.wout = (src.roi_w + 2 - 3) / 2 + 1;
     constexpr int MT = 2;
@@ -806,6 +809,7 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(FirstParams p) {
         const int co = nt * 16 + pl;
         const float bias = p.bias ? p.bias[co] : 0.f;
         double s = 0.0, qq = 0.0;
+        const bool want = p.stats && nt * 16 < p.stats_c;        // block-uniform: the fp64 work is skipped for channels nobody normalises
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int oy = oy0 + wave * MT + m;
@@ -814,13 +818,13 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(FirstParams p) {
                 const int ox = ox0 + g * 4 + r;
                 const float v = acc[m][nt][r] + bias;
                 acc[m][nt][r] = v;
-                if (oy < p.hout && ox < p.wout) {
+                if (want && oy < p.hout && ox < p.wout) {
                     s += (double)v;
                     qq += (double)v * (double)v;
                 }
             }
         }
-        if (p.stats) {
+        if (want) {
             s += __shfl_xor(s, 16);
             qq += __shfl_xor(qq, 16);
             s += __shfl_xor(s, 32);
@@ -839,7 +843,7 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(FirstParams p) {
     }
     if (p.stats) {
         __syncthreads();
-        if (tid < 32 * NT) {
+        if (tid < 32 * NT && (tid >> 1) < p.stats_c) {
             const int c = tid >> 1, k = tid & 1;
             const double v = st_s[(0 * 16 * NT + c) * 2 + k] + st_s[(1 * 16 * NT + c) * 2 + k] + st_s[(2 * 16 * NT + c) * 2 + k] +
                              st_s[(3 * 16 * NT + c) * 2 + k];
@@ -849,7 +853,7 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(FirstParams p) {
 }
 
 int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsigned short* wpack16, const float* bias, float* out,
-                        int pitch_out, int cout, double* stats, int n) {
+                        int pitch_out, int cout, double* stats, int n, int stats_c) {
     CS_REQUIRE(cin == 3, "first conv: in_channels %d unsupported (the reference always feeds 3)", cin);
     CS_REQUIRE(cout == 16 || cout == 32 || cout == 64 || cout == 128, "first conv: fused cout %d unsupported", cout);
     FirstParams p{};
@@ -859,6 +863,7 @@ int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsi
     p.img_h = src.img_h; p.img_w = src.img_w; p.roi_h = src.roi_h; p.roi_w = src.roi_w;
     p.wpack = reinterpret_cast<const float*>(wpack16); p.bias = bias; p.out = out; p.stats = stats;
     p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16; p.n = n;
+    p.stats_c = stats_c > 0 ? stats_c : cout;
     p.hout = (src.roi_h + 2 - 3) / 2 + 1;
     p.wout = (src.roi_w + 2 - 3) / 2 + 1;
     constexpr int MT = 2;

@@ -598,3 +598,17 @@ def test_winograd_and_direct_kernels_agree_forward_and_backward(tmp_path):
     for k, g0 in outs["0"]["g"].items():
         g1 = outs["1"]["g"][k]
         assert (g0 - g1).abs().max().item() <= 2e-4 * max(g0.abs().max().item(), 1e-3 * scale), k
+
+
+def test_backward_side_stream_is_bitwise_identical(tmp_path):
+    """The weight gradients run on a side stream beside the data-gradient chain (engine.hip: wg_begin); with CS_BWD_SIDE=0 the
+    whole backward stays on the caller's stream.  The kernels are deterministic, so the two schedules must agree bit for bit."""
+    outs = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"side{mode}.pt")
+        env = dict(os.environ, CS_BWD_SIDE=mode)
+        subprocess.run([sys.executable, "-c", _WINO_AB.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
+        outs[mode] = torch.load(path)
+    assert torch.equal(outs["0"]["y"], outs["1"]["y"])
+    for k, g0 in outs["0"]["g"].items():
+        assert torch.equal(g0, outs["1"]["g"][k]), k

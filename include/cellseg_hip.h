@@ -197,6 +197,24 @@ int cs_interior_map(const int32_t* inst, int h, int w, int min_size, uint8_t* ou
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training loss  -  replaces `loss_function = monai.losses.DiceCELoss(softmax=True)` and
+ * `loss = loss_function(outputs, labels_onehot); loss.backward()` (baseline/model_training_3class.py:234, :256-260):
+ *   p = softmax(logits, dim 1); dice_nc = 1 - (2 sum(p t) + nr) / (sum t + sum p + dr), mean over n * classes (include_background);
+ *   ce = mean_pixels -log p[argmax t];  loss = lambda_dice * dice + lambda_ce * ce     (MONAI defaults: nr = dr = 1e-5, lambdas 1).
+ * logits / target: fp32 [n][classes][h][w] addressed by 4 element strides (n, class, h, w) - the engine's NHWC logits are read
+ * in place; classes in 2..4.  cs_dice_ce_forward zeroes and fills `workspace` (cs_dice_ce_workspace_bytes: fp64 sums) and writes
+ * the scalar loss to the device float `loss_out`; cs_dice_ce_backward reads the same workspace and writes
+ * grad_loss * d loss / d logits (grad_loss: device float or NULL = 1) with the logits' strides.
+ * ---------------------------------------------------------------------------------------------- */
+size_t cs_dice_ce_workspace_bytes(int n, int classes);
+int cs_dice_ce_forward(const float* logits, const int64_t* logit_strides, const float* target, const int64_t* target_strides, int n, int classes,
+                       int h, int w, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, float* loss_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int cs_dice_ce_backward(const float* logits, const int64_t* logit_strides, const float* target, const int64_t* target_strides, int n, int classes,
+                        int h, int w, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, const float* grad_loss,
+                        const void* workspace, size_t workspace_bytes, float* grad_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * F1 harness pieces  -  the O(H*W) parts of baseline/compute_metric.py (the metric of record):
  *   cs_label_max               max label of one or two int32 maps (out2[0], out2[1]) - `x.max()`, `y.max()` (:60)
  *   cs_label_overlap           _label_overlap (:39-70): overlap[(n_gt+1) x (n_seg+1)] pixel-pair counts (uint32)

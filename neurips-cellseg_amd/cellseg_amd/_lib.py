@@ -71,6 +71,11 @@ def _load() -> C.CDLL:
         "cs_ccl_postprocess": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
         "cs_ccl_label": (i32, [vp, i32, i32, i32, vp, vp, vp, sz, vp]),
         "cs_interior_map": (i32, [vp, i32, i32, i32, vp, vp, sz, vp]),
+        "cs_dice_ce_workspace_bytes": (sz, [i32, i32]),
+        "cs_dice_ce_forward": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), i32, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     vp, vp, sz, vp]),
+        "cs_dice_ce_backward": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), i32, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      vp, vp, sz, vp, vp]),
         "cs_prof_enable": (i32, [i32]),
         "cs_prof_reset": (i32, []),
         "cs_prof_collect": (i32, [C.c_char_p, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
@@ -88,7 +93,8 @@ EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_des
             "cs_swi_window_start cs_swi_workspace_bytes cs_swi_infer cs_swi_finalize cs_normalize_workspace_bytes "
             "cs_normalize_image cs_label_max cs_label_overlap cs_remove_boundary_workspace_bytes cs_remove_boundary_cells "
             "cs_ccl_workspace_bytes "
-            "cs_ccl_postprocess cs_ccl_label cs_interior_map cs_prof_enable cs_prof_reset cs_prof_collect").split()
+            "cs_ccl_postprocess cs_ccl_label cs_interior_map cs_dice_ce_workspace_bytes cs_dice_ce_forward cs_dice_ce_backward "
+            "cs_prof_enable cs_prof_reset cs_prof_collect").split()
 
 
 def check(rc: int, what: str = "") -> int:

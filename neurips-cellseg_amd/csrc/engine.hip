@@ -33,7 +33,7 @@ static const char* kNames[K_NUM_IDS] = {
     "conv3x3_s1_mfma", "conv3x3_s2_mfma", "conv1x1_mfma", "conv_first_mfma", "convT3x3s2_mfma", "convT_top_mfma",
     "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
     "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset", "norm_bwd",
-    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric", "wgrad_unpack", "conv3x3_s1_wino"};
+    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric", "wgrad_unpack", "conv3x3_s1_wino", "dice_ce_loss"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
 
 struct ProfRecord {
@@ -1217,6 +1217,24 @@ int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspac
     rc = unet_backward_impl(net, grad_logits_nhwc, acc, buf, flat_grad, s, net->bwd_side, use_side ? (n_side_env >= 2 ? 2 : 1) : 0, net->bwd_ev, 48);
     net->tape.valid = false;      // the gradient buffers reused nothing of the tape, but one backward per forward
     return rc;
+}
+
+size_t cs_dice_ce_workspace_bytes(int n, int classes) { return (n > 0 && classes > 0) ? dice_ce_workspace_bytes(n, classes) : 0; }
+
+int cs_dice_ce_forward(const float* logits, const int64_t* logit_strides, const float* target, const int64_t* target_strides, int n, int classes,
+                       int h, int w, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, float* loss_out, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(logit_strides && target_strides, "dice_ce_forward: null strides");
+    return dice_ce_forward((hipStream_t)stream, logits, logit_strides, target, target_strides, n, classes, h, w, smooth_nr, smooth_dr, lambda_dice,
+                           lambda_ce, loss_out, workspace, workspace_bytes);
+}
+
+int cs_dice_ce_backward(const float* logits, const int64_t* logit_strides, const float* target, const int64_t* target_strides, int n, int classes,
+                        int h, int w, float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, const float* grad_loss,
+                        const void* workspace, size_t workspace_bytes, float* grad_logits, void* stream) {
+    CS_REQUIRE(logit_strides && target_strides, "dice_ce_backward: null strides");
+    return dice_ce_backward((hipStream_t)stream, logits, logit_strides, target, target_strides, n, classes, h, w, smooth_nr, smooth_dr, lambda_dice,
+                            lambda_ce, grad_loss, workspace, workspace_bytes, grad_logits);
 }
 
 int cs_swi_window_start(int i, int interval, int padded_size, int roi) {

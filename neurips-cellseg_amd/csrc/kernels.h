@@ -213,6 +213,16 @@ size_t remove_boundary_workspace_bytes(int32_t n_labels);
 int remove_boundary_cells(hipStream_t s, const int32_t* lab, int h, int w, int border, int32_t n_labels, int32_t* out, int32_t* n_out,
                           void* ws, size_t ws_bytes);
 
+// ---- DiceCE loss (kernels_loss.hip) ---------------------------------------------------------------
+// logits / target: [n, c, h, w] fp32 addressed by element strides ls[4] / ts[4] (n, c, h, w); c in 2..4.  ws: dice_ce_workspace_bytes
+// (fp64 sums: zeroed and filled by the forward, read by the backward).  grad_logits is written with the logits' strides.
+size_t dice_ce_workspace_bytes(int n, int c);
+int dice_ce_forward(hipStream_t s, const float* logits, const int64_t* ls, const float* target, const int64_t* ts, int n, int c, int h, int w,
+                    float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, float* loss_out, void* ws, size_t ws_bytes);
+int dice_ce_backward(hipStream_t s, const float* logits, const int64_t* ls, const float* target, const int64_t* ts, int n, int c, int h, int w,
+                     float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, const float* grad_loss, const void* ws,
+                     size_t ws_bytes, float* grad_logits);
+
 // ---- connected components ----------------------------------------------------------------------
 size_t ccl_workspace_bytes(int h, int w);
 int ccl_postprocess(hipStream_t s, const uint8_t* mask, int h, int w, int hole_area, int min_size, int32_t* labels,

@@ -215,6 +215,17 @@ int cs_dice_ce_backward(const float* logits, const int64_t* logit_strides, const
                         const void* workspace, size_t workspace_bytes, float* grad_logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Optimiser  -  replaces `optimizer = torch.optim.AdamW(model.parameters(), args.initial_lr)` ... `optimizer.step()`
+ * (baseline/model_training_3class.py:237, :262) with torch's update rule (amsgrad / maximize off) for ALL tensors in one launch:
+ *   p *= 1 - lr wd;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * table: device int64 [n_tensors][3] = (device pointer of the parameter tensor, float offset of the tensor in the flat buffers,
+ * element count), offsets ascending (cs_unet_grad_offset); grad: the flat gradient bucket cs_unet_backward wrote (`total` =
+ * cs_unet_grad_numel floats); exp_avg / exp_avg_sq: flat moment buffers of the same size (zero before step 1); step = 1, 2, ...
+ * ---------------------------------------------------------------------------------------------- */
+int cs_adamw_step(const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * F1 harness pieces  -  the O(H*W) parts of baseline/compute_metric.py (the metric of record):
  *   cs_label_max               max label of one or two int32 maps (out2[0], out2[1]) - `x.max()`, `y.max()` (:60)
  *   cs_label_overlap           _label_overlap (:39-70): overlap[(n_gt+1) x (n_seg+1)] pixel-pair counts (uint32)

@@ -5,6 +5,7 @@ Host-side mirror of the reference's interfaces (same names, arguments and error 
   sliding_window_inference   <- monai.inferers.sliding_window_inference (baseline/predict.py:109)
   label / mask_to_instances  <- skimage.measure.label / morphology.remove_small_* (baseline/predict.py:113)
   create_interior_map        <- data/pre_process_3class.py:31-56
+  DiceCELoss / AdamW         <- monai.losses.DiceCELoss(softmax=True) / torch.optim.AdamW (baseline/model_training_3class.py:234-237)
 All arithmetic runs in libcellseg_hip.so; importing this package without the built library raises.
 """
 from ._lib import CellSegHipError, LIB_PATH, lib  # noqa: F401
@@ -12,7 +13,8 @@ from .unet import UNet  # noqa: F401
 from .inferers import make_plan, rank_rows, sliding_window_inference, swi_infer_image, window_starts  # noqa: F401
 from .postprocess import create_interior_map, label, mask_to_instances, prob_to_instances  # noqa: F401
 from .losses import DiceCELoss, one_hot  # noqa: F401
+from .optim import AdamW  # noqa: F401
 from . import metrics, parallel  # noqa: F401
 
 __all__ = ["UNet", "sliding_window_inference", "swi_infer_image", "make_plan", "window_starts", "rank_rows",
-           "label", "mask_to_instances", "prob_to_instances", "create_interior_map", "DiceCELoss", "one_hot", "CellSegHipError", "lib", "LIB_PATH"]
+           "label", "mask_to_instances", "prob_to_instances", "create_interior_map", "DiceCELoss", "one_hot", "AdamW", "CellSegHipError", "lib", "LIB_PATH"]

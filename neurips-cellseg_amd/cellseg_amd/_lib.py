@@ -76,6 +76,7 @@ def _load() -> C.CDLL:
                                      vp, vp, sz, vp]),
         "cs_dice_ce_backward": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), i32, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                       vp, vp, sz, vp, vp]),
+        "cs_adamw_step": (i32, [vp, i32, i64, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
         "cs_prof_enable": (i32, [i32]),
         "cs_prof_reset": (i32, []),
         "cs_prof_collect": (i32, [C.c_char_p, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
@@ -93,7 +94,7 @@ EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_des
             "cs_swi_window_start cs_swi_workspace_bytes cs_swi_infer cs_swi_finalize cs_normalize_workspace_bytes "
             "cs_normalize_image cs_label_max cs_label_overlap cs_remove_boundary_workspace_bytes cs_remove_boundary_cells "
             "cs_ccl_workspace_bytes "
-            "cs_ccl_postprocess cs_ccl_label cs_interior_map cs_dice_ce_workspace_bytes cs_dice_ce_forward cs_dice_ce_backward "
+            "cs_ccl_postprocess cs_ccl_label cs_interior_map cs_dice_ce_workspace_bytes cs_dice_ce_forward cs_dice_ce_backward cs_adamw_step "
             "cs_prof_enable cs_prof_reset cs_prof_collect").split()
 
 

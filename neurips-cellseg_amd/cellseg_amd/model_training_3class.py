@@ -94,7 +94,7 @@ def main(argv=None):
     model = ca.UNet(spatial_dims=2, in_channels=3, out_channels=args.num_class, channels=(16, 32, 64, 128, 256),
                     strides=(2, 2, 2, 2), num_res_units=2).to(device)
     loss_function = ca.DiceCELoss(softmax=True)
-    optimizer = torch.optim.AdamW(model.parameters(), args.initial_lr)
+    optimizer = ca.AdamW(model, args.initial_lr)      # torch.optim.AdamW's update rule and state_dict layout, one HIP launch per step
 
     best_metric, best_metric_epoch = -1, -1
     epoch_loss_values, metric_values = [], []

@@ -1237,6 +1237,11 @@ int cs_dice_ce_backward(const float* logits, const int64_t* logit_strides, const
                             lambda_ce, grad_loss, workspace, workspace_bytes, grad_logits);
 }
 
+int cs_adamw_step(const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+    return adamw_step((hipStream_t)stream, table, n_tensors, total, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step);
+}
+
 int cs_swi_window_start(int i, int interval, int padded_size, int roi) {
     const int s = i * interval;
     return s < padded_size - roi ? s : padded_size - roi;

@@ -223,6 +223,10 @@ int dice_ce_backward(hipStream_t s, const float* logits, const int64_t* ls, cons
                      float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, const float* grad_loss, const void* ws,
                      size_t ws_bytes, float* grad_logits);
 
+// AdamW over many tensors in one launch: table [n_tensors][3] = (parameter pointer, flat offset, element count), offsets ascending
+int adamw_step(hipStream_t s, const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq,
+               float lr, float beta1, float beta2, float eps, float weight_decay, int step);
+
 // ---- connected components ----------------------------------------------------------------------
 size_t ccl_workspace_bytes(int h, int w);
 int ccl_postprocess(hipStream_t s, const uint8_t* mask, int h, int w, int hole_area, int min_size, int32_t* labels,

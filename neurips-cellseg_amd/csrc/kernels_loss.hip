@@ -199,3 +199,49 @@ int dice_ce_backward(hipStream_t s, const float* logits, const int64_t* ls, cons
 }
 
 }  // namespace cs
+
+// ------------------------------------------------------------------------------------------------
+// AdamW (row O): `optimizer = torch.optim.AdamW(model.parameters(), lr)` ... `optimizer.step()`
+// (baseline/model_training_3class.py:237 and :262), torch's update rule (amsgrad off, maximize off):
+//   p *= 1 - lr wd;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// for ALL parameter tensors in one launch: the gradients already sit in one flat bucket (cs_unet_backward), the two moment
+// buffers use the same offsets, and a small device table maps flat offsets to the parameter tensors torch owns.  torch's
+// foreach implementation needs a dozen multi-tensor launches for the 63 tensors (0.18 ms of a 6.5 ms training step).
+// ------------------------------------------------------------------------------------------------
+namespace cs {
+namespace {
+__global__ __launch_bounds__(256) void adamw_kernel(const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg,
+                                                    float* exp_avg_sq, float decay, float b1, float b2, float eps, float step_size, float inv_bc2_sqrt) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int lo = 0, hi = n_tensors - 1;                            // last tensor whose flat offset is <= e
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 3 + 1] <= e) lo = mid;
+        else hi = mid - 1;
+    }
+    const int64_t local = e - table[lo * 3 + 1];
+    if (local < 0 || local >= table[lo * 3 + 2]) return;         // alignment gap between two tensors
+    float* p = reinterpret_cast<float*>(table[lo * 3]) + local;
+    const float g = grad[e];
+    float m = exp_avg[e], v = exp_avg_sq[e];
+    m = m + (g - m) * (1.f - b1);
+    v = v * b2 + (1.f - b2) * g * g;
+    exp_avg[e] = m;
+    exp_avg_sq[e] = v;
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    *p = *p * decay - step_size * (m / denom);
+}
+}  // namespace
+
+int adamw_step(hipStream_t s, const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq,
+               float lr, float beta1, float beta2, float eps, float weight_decay, int step) {
+    CS_REQUIRE(table && grad && exp_avg && exp_avg_sq && n_tensors > 0 && total > 0 && step >= 1, "adamw: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    ProfScope prof(K_LOSS, s, 0, 28.0 * (double)total);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, n_tensors, total, grad, exp_avg, exp_avg_sq,
+                       (float)(1.0 - (double)lr * weight_decay), beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+}  // namespace cs

@@ -43,25 +43,54 @@ class AdamW:
     def _bind(self, flat: torch.Tensor) -> None:
         model = self.model
         params = dict(model.named_parameters())
-        ptrs = [params[k].data_ptr() for k in model._param_keys]
+        ptrs = [(params[k].data_ptr(), params[k].requires_grad) for k in model._param_keys]
         if self._table is None or ptrs != self._ptrs:
-            rows = sorted((model._grad_slots[k][0], model._grad_slots[k][1], params[k].data_ptr()) for k in model._param_keys)
+            rows = []
             for k in model._param_keys:
                 p = params[k]
+                if not p.requires_grad:
+                    continue                     # frozen tensors are left alone, as torch.optim does for parameters without a gradient
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.device != flat.device:
                     raise _lib.CellSegHipError(f"AdamW: parameter {k} must be a contiguous fp32 tensor on {flat.device}")
-            self._table = torch.tensor([[ptr, off, numel] for off, numel, ptr in rows], dtype=torch.int64).to(flat.device)
+                off, numel, _ = model._grad_slots[k]
+                rows.append((off, numel, p.data_ptr()))
+            rows.sort()
+            self._table = torch.tensor([[ptr, off, numel] for off, numel, ptr in rows], dtype=torch.int64).reshape(-1, 3).to(flat.device)
             self._ptrs = ptrs
         if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
 
+    def _gradients(self):
+        """The flat fp32 gradient bucket of the step.  Normally that is ``model.flat_grad`` itself (every ``p.grad`` is a view of it);
+        when autograd has accumulated several backward passes into other storage the ``p.grad`` tensors are gathered into a flat copy."""
+        model = self.model
+        flat = model.flat_grad
+        params = dict(model.named_parameters())
+        grads = [(k, params[k].grad) for k in model._param_keys if params[k].requires_grad]
+        if not grads or all(g is None for _, g in grads):
+            return None
+        base = flat.data_ptr() if flat is not None else None
+        if base is not None and all(g is not None and g.data_ptr() == base + 4 * model._grad_slots[k][0] for k, g in grads):
+            return flat
+        model.engine(True)
+        total = int(lib.cs_unet_grad_numel(model._engine.handle))
+        dev = next(model.parameters()).device
+        gathered = torch.zeros(total, dtype=torch.float32, device=dev)
+        for k, g in grads:
+            if g is not None:
+                off, numel, _ = model._grad_slots[k]
+                gathered[off:off + numel] = g.reshape(-1).float()
+        return gathered
+
     @torch.no_grad()
     def step(self) -> None:
-        flat = self.model.flat_grad
+        flat = self._gradients()
         if flat is None:
-            raise _lib.CellSegHipError("AdamW.step(): no gradients - run loss.backward() first")
+            return                               # nothing to do without gradients (torch.optim.AdamW behaves the same)
         self._bind(flat)
+        if self._table.shape[0] == 0:
+            return
         g = self.param_groups[0]
         self._step += 1
         with torch.cuda.device(flat.device):

@@ -651,3 +651,29 @@ def test_native_adamw_matches_torch_adamw_and_its_checkpoints(tmp_path):
     k0 = a._param_keys[0]
     off, numel, shape = a._grad_slots[k0]
     assert torch.allclose(oc._m[off:off + numel].view(shape), ob.state[pb[k0]]["exp_avg"], rtol=0, atol=0)
+
+
+def test_native_adamw_gradient_accumulation_and_frozen_parameters():
+    """Two backward passes before one step (autograd accumulates into p.grad, away from the engine's newest flat bucket) and a frozen
+    tensor: cellseg_amd.AdamW must follow torch.optim.AdamW in both cases."""
+    import cellseg_amd as ca
+    torch.manual_seed(5)
+    a = ca.UNet(channels=(16, 32), strides=(2,), num_res_units=1).to(_dev()).train()
+    b = ca.UNet(channels=(16, 32), strides=(2,), num_res_units=1).to(_dev()).train()
+    b.load_state_dict(a.state_dict())
+    frozen = a._param_keys[2]
+    dict(a.named_parameters())[frozen].requires_grad_(False)
+    dict(b.named_parameters())[frozen].requires_grad_(False)
+    xs = [torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(s)).to(_dev()) for s in (1, 2)]
+    y = ca.one_hot(torch.randint(0, 3, (2, 1, 32, 32), generator=torch.Generator().manual_seed(3)).to(_dev()), 3)
+    loss_fn = ca.DiceCELoss(softmax=True)
+    oa, ob = ca.AdamW(a, 1e-3), torch.optim.AdamW([p for p in b.parameters() if p.requires_grad], 1e-3)
+    for _ in range(3):
+        for model, opt in ((a, oa), (b, ob)):
+            opt.zero_grad()
+            for x in xs:                                          # gradient accumulation over two micro-batches
+                loss_fn(model(x), y).backward()
+            opt.step()
+    pb = dict(b.named_parameters())
+    for k, p in a.named_parameters():
+        assert (p - pb[k]).abs().max().item() <= 2e-6 * max(1.0, pb[k].abs().max().item()), k

@@ -548,6 +548,8 @@ def test_training_with_bf16_forward_tracks_the_fp32_curve():
     ((32, 64, 128), (1, 3, 24, 72)),                     # 12 x 36, 6 x 18, bottom 6 x 18: odd tile counts, 2-row remainders
     ((32, 64, 128, 256, 512), (2, 3, 80, 48)),           # 5 x 3 pixels at the bottom: ODD heights and widths (half Winograd tiles)
     ((64, 128, 256), (3, 3, 56, 40)),
+    ((32, 64, 128), (96, 3, 72, 88)),                    # enough blocks for the 128-channel one-wave-per-SIMD kernel (>= 512), 18 x 22 and 9 x 11 maps
+    ((64, 128, 256), (160, 3, 40, 24)),                  # the same kernel on 10 x 6 maps (256-channel bottom layers)
 ])
 def test_winograd_layers_on_partial_and_odd_tiles_match_oracle(channels, shape):
     """Every 3x3 stride-1 layer of these nets runs in Winograd form (cout % 32 == 0); the shapes leave partial block tiles,

@@ -116,6 +116,9 @@ static inline unsigned xcd_grid(int n_spatial, int n_ct) { return (unsigned)(((n
 
 __device__ __forceinline__ float prelu_h(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
+// The split modes (fp32-grade results) sum every value in fp64.  The bf16 datapath, whose outputs are rounded to 8 mantissa bits
+// anyway, sums one lane's values (<= 32 per channel) in fp32 and only these partial sums in fp64: the fp64 conversions and FMAs
+// of the epilogue were 15 % of the stride-1 kernels' time (1.2 ms per slide), the fp32 partials carry a relative error <= 2e-6.
 __device__ __forceinline__ void stats_commit_b(double s, double q, double* dst, int lane) {
     s += __shfl_xor(s, 16);
     q += __shfl_xor(q, 16);
@@ -124,6 +127,28 @@ __device__ __forceinline__ void stats_commit_b(double s, double q, double* dst, 
     if (lane < 16) {
         atomicAdd(dst, s);
         atomicAdd(dst + 1, q);
+    }
+}
+// Block-level form for kernels whose WM waves hold different pixel rows of the SAME channels: every wave leaves its sums in LDS
+// (red[wm][channel of the block][2]) and, after the block's next barrier, stats_flush_b() issues ONE pair of atomics per channel.
+// The device-scope fp64 atomics themselves were 0.5 ms per slide on the bf16 datapath (4 M per 32-channel layer launch).
+__device__ __forceinline__ void stats_stash_b(double s, double q, double* red_c, int lane) {
+    s += __shfl_xor(s, 16);
+    q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (lane < 16) {
+        red_c[0] = s;
+        red_c[1] = q;
+    }
+}
+template <int WM, int NCH>
+__device__ __forceinline__ void stats_flush_b(const double* red, double* dst, int tid) {
+    if (tid < NCH * 2) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) v += red[w * NCH * 2 + tid];
+        atomicAdd(dst + tid, v);
     }
 }
 
@@ -153,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     constexpr bool DB = 2 * IN_BYTES <= EP_BYTES + 4096;    // double-buffered input where the epilogue slab already pays for the LDS
     constexpr int SM_BYTES = (DB ? 2 : 1) * IN_BYTES > EP_BYTES ? (DB ? 2 : 1) * IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    __shared__ double red[WM > 1 ? WM * NTB * 32 : 1];      // per-wave statistics of the block's channels (stats_stash_b)
 
     // fp16 mode: an out-of-range operand saturates at +-65504 instead of becoming inf (MODE.FP16_OVFL, bit 23 of HW_REG_MODE):
     // an activation beyond the documented domain then costs accuracy in its window, not a NaN from the next InstanceNorm
@@ -324,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
         const int co = (nt_w + t) * 16 + pl;
         const float bias = p.bias ? p.bias[co] : 0.f;
         double s = 0.0, qq = 0.0;
+        float sf = 0.f, qf = 0.f;                            // bf16 datapath: this lane's <= 32 values are summed in fp32 (see stats_commit_b)
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             const int row = wm * MTW + m, oy = oy0 + row;
@@ -334,15 +361,29 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
                 if constexpr (F16) v *= F16_OUT_SCALE;
                 v += bias;
                 ep[(row * 16 + g * 4 + r) * EPS + (wn * NTW + t) * 16 + pl] = v;
-                if (oy < p.hout && ox < p.wout) {
-                    s += (double)v;
-                    qq += (double)v * (double)v;
+                if (p.stats && oy < p.hout && ox < p.wout) {
+                    if constexpr (A16) {
+                        sf += v;
+                        qf = fmaf(v, v, qf);
+                    } else {
+                        s += (double)v;
+                        qq += (double)v * (double)v;
+                    }
                 }
             }
         }
-        if (p.stats) stats_commit_b(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        if constexpr (A16) {
+            s = (double)sf;
+            qq = (double)qf;
+        }
+        if (p.stats) {
+            if constexpr (WM > 1) stats_stash_b(s, qq, red + ((wm * NTB + wn * NTW + t) * 16 + pl) * 2, lane);
+            else stats_commit_b(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        }
     }
     __syncthreads();
+    if constexpr (WM > 1)
+        if (p.stats) stats_flush_b<WM, NTB * 16>(red, p.stats + ((size_t)img * p.cout + wk.ct * NTB * 16) * 2, tid);
     {
         constexpr int F4 = NTB * 4;                          // float4 per pixel record of this block
         const size_t el0 = (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + wk.ct * NTB * 16;
@@ -711,6 +752,7 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     constexpr int EP_BYTES = 2 * TH * 32 * EPS * 4;          // 8 output rows x 32 output pixels
     constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    __shared__ double red[WM > 1 ? WM * NTB * 32 : 1];      // per-wave statistics of the block's channels (stats_stash_b)
     char* const in_s = smem;
 
     // fp16 mode: an out-of-range operand saturates at +-65504 instead of becoming inf (MODE.FP16_OVFL, bit 23 of HW_REG_MODE):
@@ -864,6 +906,7 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
         const int co = (nt_w + t) * 16 + pl;
         const float bias = p.bias ? p.bias[co] : 0.f;
         double s = 0.0, qq = 0.0;
+        float sf = 0.f, qf = 0.f;                            // bf16 datapath: fp32 partial sums per lane (see stats_commit_b)
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             const int row = wm * MTW + m, iy = iy0 + row;
@@ -876,15 +919,29 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
                     if constexpr (F16) v *= F16_OUT_SCALE;
                     v += bias;
                     ep[((2 * row + (ph >> 1)) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + (wn * NTW + t) * 16 + pl] = v;
-                    if (iy < p.hin && ix < p.win) {
-                        s += (double)v;
-                        qq += (double)v * (double)v;
+                    if (p.stats && iy < p.hin && ix < p.win) {
+                        if constexpr (A16) {
+                            sf += v;
+                            qf = fmaf(v, v, qf);
+                        } else {
+                            s += (double)v;
+                            qq += (double)v * (double)v;
+                        }
                     }
                 }
         }
-        if (p.stats) stats_commit_b(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        if constexpr (A16) {
+            s = (double)sf;
+            qq = (double)qf;
+        }
+        if (p.stats) {
+            if constexpr (WM > 1) stats_stash_b(s, qq, red + ((wm * NTB + wn * NTW + t) * 16 + pl) * 2, lane);
+            else stats_commit_b(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        }
     }
     __syncthreads();
+    if constexpr (WM > 1)
+        if (p.stats) stats_flush_b<WM, NTB * 16>(red, p.stats + ((size_t)img * p.cout + wk.ct * NTB * 16) * 2, tid);
     {
         constexpr int F4 = NTB * 4;
         const size_t el0 = (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;

@@ -12,6 +12,7 @@ CPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, Sequence, Tuple
 
@@ -113,6 +114,10 @@ def _host_param_table(in_ch, out_ch, channels, nru, norm, act):
 
     block("model", in_ch, out_ch, tuple(channels), True)
     return tab
+
+
+_POISON = os.environ.get("CS_POISON_WORKSPACE", "0") == "1"
+_GUARD = 1 << 20
 
 
 class _UNetFunction(torch.autograd.Function):
@@ -292,9 +297,25 @@ class UNet(nn.Module):
         ws = self._ws.get(tag)
         if ws is None or ws.numel() < nbytes or ws.device != device:
             self._ws = {k: v for k, v in self._ws.items() if k[0] != tag[0]}    # one buffer per kind
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            if _POISON:                          # diagnostics: guard bands on both sides, checked by check_guards()
+                base = torch.full((nbytes + 2 * _GUARD,), 0x5A, dtype=torch.uint8, device=device)
+                self._ws_base = getattr(self, "_ws_base", {})
+                self._ws_base[tag] = base
+                ws = base[_GUARD:_GUARD + nbytes]
+            else:
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self._ws[tag] = ws
         return ws
+
+    def check_guards(self) -> None:
+        """CS_POISON_WORKSPACE=1 only: raise if a kernel wrote outside one of the engine workspaces."""
+        for tag, base in getattr(self, "_ws_base", {}).items():
+            n = base.numel() - 2 * _GUARD
+            lo, hi = base[:_GUARD], base[_GUARD + n:]
+            if not (bool((lo == 0x5A).all()) and bool((hi == 0x5A).all())):
+                blo = (lo != 0x5A).nonzero().flatten(); bhi = (hi != 0x5A).nonzero().flatten()
+                raise _lib.CellSegHipError(f"workspace {tag}: guard band overwritten ({blo.numel()} bytes below, first at -{_GUARD - int(blo[0]) if blo.numel() else 0}; "
+                                           f"{bhi.numel()} bytes above, first at +{int(bhi[0]) if bhi.numel() else 0})")
 
     def _forward_engine(self, x: torch.Tensor, tag: str = "fwd", train: bool = False):
         n, _, h, w = x.shape
@@ -306,6 +327,9 @@ class UNet(nn.Module):
                 raise _lib.CellSegHipError(f"cs_unet_workspace_bytes: {lib.cs_last_error().decode()}")
             ws = self.workspace((tag, n, h, w), nbytes, x.device)
             out = torch.empty((n, h, w, self.out_channels), dtype=torch.float32, device=x.device)
+            if _POISON:
+                ws.fill_(255)
+                out.fill_(float("nan"))
             sn, sc, sh, sw = x.stride()
             check(lib.cs_unet_forward(eng.handle, C.c_void_p(x.data_ptr()), sn, sc, sh, sw, n, h, w,
                                       C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
@@ -341,6 +365,9 @@ class UNet(nn.Module):
                 raise _lib.CellSegHipError(f"cs_unet_backward_workspace_bytes: {lib.cs_last_error().decode()}")
             ws = self.workspace(("bwd", n, h, w), nbytes, g.device)
             flat = torch.empty(int(lib.cs_unet_grad_numel(eng.handle)), dtype=torch.float32, device=g.device)
+            if _POISON:                          # diagnostics: a kernel that reads scratch memory it has not written turns the result into NaN
+                ws.fill_(255)
+                flat.fill_(float("nan"))
             check(lib.cs_unet_backward(eng.handle, C.c_void_p(g.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
                                        C.c_void_p(flat.data_ptr()), _lib.stream_ptr()), "cs_unet_backward")
         self.flat_grad = flat

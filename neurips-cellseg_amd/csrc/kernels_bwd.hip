@@ -567,10 +567,151 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient against a NARROW operand (<= 3 channels: the image at the first layer, dU at the top transposed conv), 3x3 stride 2.
+// The general kernel gives every tap its own 16-column tile and uses b_c of the 16 columns (3 of 16: 81 % of its MFMAs multiply
+// zeros, 69 us per launch for 0.9 GFLOP).  Here the 9 taps x b_c channels ARE the columns: column j = tap * b_c + c, 27 of the 32
+// columns of two tiles for three channels, 4.5 x fewer MFMAs.  A lane's B value is an LDS read at its own (tap, channel) offset -
+// LDS reads are per-lane addressed anyway.  K tiles of 8 x 16 pixels; the narrow operand is staged as scalars, one (pixel, channel)
+// item per lane and pass, so that every lane carries a load (the general kernel's narrow mode used one lane in four).
+// Same split-K partial layout as wgrad_mfma_kernel: [split_k][tap][co_total][ci_total].
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256, 2) void wgrad_narrow_kernel(WgradParams p) {
+    constexpr int TH = 8, TW = 16, S = 2;
+    constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+    constexpr int IWP = IW + 2;                                // padded row: tap rows land 12 banks apart
+    constexpr int COP = (MT & 1) ? 16 * MT : 16 * MT + 16;     // dy pixel pitch == 16 (mod 32): conflict-free A reads
+    constexpr int A_ITERS = TH * TW * 4 * MT / 256;
+    constexpr int B_ITERS = (IH * IW * 3 + 255) / 256;
+    constexpr int A_FLOATS = TH * TW * COP, B_FLOATS = IH * IWP * 4;
+    constexpr int NT = 2 * MT;                                 // (column tile, co tile) pairs of the block
+    constexpr int NACC = (NT + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
+    float* const a_s = smem;
+    float* const b_s = smem + A_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int ks_id = blockIdx.x;
+    const int co0 = blockIdx.y * 16 * MT;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ncol = 9 * p.b_c;
+
+    f32x4 acc[NACC];
+    int b_off[NACC], col[NACC];
+    const int m_w = (MT == 4) ? wave : (MT == 2) ? (wave & 1) : 0;      // all tiles of a wave share one co tile
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int t = wave + 4 * i;
+        const int ct = (t < NT) ? t / MT : 0;
+        const int j = ct * 16 + li;
+        const int jj = j < ncol ? j : 0;
+        const int tap = jj / p.b_c, c = jj - tap * p.b_c;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        col[i] = (t < NT && j < ncol) ? tap * 4 + c : -1;             // (tap, channel) of this lane's column, -1: no such column
+        b_off[i] = (ky * IWP + kx) * 4 + c;
+    }
+
+    f32x4 ra[A_ITERS];
+    float rb[B_ITERS];
+    unsigned ok_a = 0, ok_b = 0;
+    auto load_tile = [&](int tile) {
+        const int img = tile / tiles_per_img, tl = tile - img * tiles_per_img;
+        const int tile_y = tl / p.tiles_x, tile_x = tl - tile_y * p.tiles_x;
+        const int oy0 = tile_y * TH, ox0 = tile_x * TW;
+        ok_a = 0;
+        ok_b = 0;
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            const int px = i / (4 * MT), c4 = i - px * (4 * MT);
+            const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+            const bool ok = oy < p.ho && ox < p.wo;
+            const size_t off = ok ? (((size_t)img * p.ho + oy) * p.wo + ox) * p.a_pitch + co0 + 4 * c4 : 0;
+            ra[it] = *reinterpret_cast<const f32x4*>(p.a + off);
+            ok_a |= (ok ? 1u : 0u) << it;
+        }
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            const int c = i / (IH * IW), pix = i - c * (IH * IW);       // channel-major items: a wave reads a run of one row
+            const int iy = pix / IW, ix = pix - iy * IW;
+            const int gy = oy0 * S - 1 + iy, gx = ox0 * S - 1 + ix;
+            const bool ok = c < p.b_c && gy >= 0 && gy < p.hi && gx >= 0 && gx < p.wi;
+            rb[it] = p.b_ptr[ok ? img * p.b_sn + c * p.b_sc + gy * p.b_sh + gx * p.b_sw : 0];
+            ok_b |= (ok ? 1u : 0u) << it;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            const int px = i / (4 * MT), c4 = i - px * (4 * MT);
+            *reinterpret_cast<f32x4*>(&a_s[px * COP + 4 * c4]) = ((ok_a >> it) & 1u) ? ra[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it) {
+            const int i = tid + 256 * it;
+            const int c = i / (IH * IW), pix = i - c * (IH * IW);
+            const int iy = pix / IW, ix = pix - iy * IW;
+            if (c < 3) b_s[(iy * IWP + ix) * 4 + c] = ((ok_b >> it) & 1u) ? rb[it] : 0.f;
+        }
+    };
+
+    const int t_begin = (int)((int64_t)ks_id * p.total_tiles / p.split_k);
+    const int t_end = (int)((int64_t)(ks_id + 1) * p.total_tiles / p.split_k);
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile();
+    }
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const bool more = tile + 1 < t_end;
+        if (more) load_tile(tile + 1);
+        float a_op[2], b_op[2][NACC];
+        auto read_ops = [&](int step, float& av, float (&bv)[NACC]) {
+            const int row = step >> 2, ks = step & 3;
+            av = a_s[(row * 16 + 4 * ks + kk) * COP + m_w * 16 + li];
+            const int pb = (row * S * IWP + (4 * ks + kk) * S) * 4;
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) bv[i] = b_s[pb + b_off[i]];
+        };
+        read_ops(0, a_op[0], b_op[0]);
+#pragma unroll
+        for (int step = 0; step < 4 * TH; ++step) {
+            if (step + 1 < 4 * TH) read_ops(step + 1, a_op[(step + 1) & 1], b_op[(step + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+                if (NT % 4 == 0 || wave + 4 * i < NT) acc[i] = mfma4b(a_op[step & 1], b_op[step & 1][i], acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+    float* part = p.part + (size_t)ks_id * 9 * p.co_total * p.ci_total;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+        if (col[i] >= 0) {
+            const int tap = col[i] >> 2, c = col[i] & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                part[((size_t)tap * p.co_total + p.co_off + co0 + m_w * 16 + kk * 4 + r) * p.ci_total + p.ci_off + c] = acc[i][r];
+        }
+}
+
 // how many split-K slices a weight-gradient launch should use: enough blocks to fill the chip, never more than tiles
 // pixel rows per K tile: 8 for the 3x3 stride-1 layers with 64-channel blocks (twice the MFMAs per barrier pair), else 4
 static int g_wgrad_th8 = getenv("CS_WGRAD_TH8") ? atoi(getenv("CS_WGRAD_TH8")) : 1;
+static int g_wgrad_narrow = getenv("CS_WGRAD_NARROW") ? atoi(getenv("CS_WGRAD_NARROW")) : 1;   // 0: narrow operands through the general kernel
+static inline bool wgrad_narrow_cols(int ksize, int stride, int b_c) { return g_wgrad_narrow && ksize == 3 && stride == 2 && b_c <= 3; }
 static inline int wgrad_th(int ksize, int stride, int a_c, int b_c, int ho) {
+    if (wgrad_narrow_cols(ksize, stride, b_c)) return 8;
     return (g_wgrad_th8 && ksize == 3 && stride == 1 && a_c % 64 == 0 && b_c >= 16 && ho >= 8) ? 8 : 4;
 }
 
@@ -626,7 +767,15 @@ int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pit
     }
     if (nb) {
         CS_REQUIRE(ksize == 3 && stride == 2, "wgrad: the narrow operand is only used by stride-2 3x3 layers");
-        CS_WG(2, 3, true)
+        if (wgrad_narrow_cols(ksize, stride, nb->c)) {
+            switch (mt) {
+                case 4: hipLaunchKernelGGL((wgrad_narrow_kernel<4>), grid, dim3(256), 0, s, p); break;
+                case 2: hipLaunchKernelGGL((wgrad_narrow_kernel<2>), grid, dim3(256), 0, s, p); break;
+                default: hipLaunchKernelGGL((wgrad_narrow_kernel<1>), grid, dim3(256), 0, s, p); break;
+            }
+        } else {
+            CS_WG(2, 3, true)
+        }
     } else if (ksize == 1) { CS_WG(1, 1, false) } else if (stride == 1 && th == 8) {
         hipLaunchKernelGGL((wgrad_mfma_kernel<1, 3, 4, false, 8>), grid, dim3(256), 0, s, p);
     } else if (stride == 1) { CS_WG(1, 3, false) } else { CS_WG(2, 3, false) }

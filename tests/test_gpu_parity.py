@@ -263,7 +263,10 @@ def _grad_check(channels, nru, shape, seed=0, kink_free=False):
 @pytest.mark.parametrize("channels,nru,shape", [((16, 32), 1, (2, 3, 32, 32)), ((16, 32, 64), 2, (2, 3, 64, 64)),
                                                 ((16, 32, 64, 128, 256), 2, (2, 3, 64, 64)),
                                                 ((16, 32, 64, 128, 256), 3, (1, 3, 64, 96)),
-                                                ((32, 64, 128, 256, 512), 2, (2, 3, 128, 128))])
+                                                ((32, 64, 128, 256, 512), 2, (2, 3, 128, 128)),
+                                                # partial 8 x 16 K tiles of the narrow-operand weight gradients (first layer, top
+                                                # transposed conv) with 32- and 64-channel blocks
+                                                ((32, 64), 1, (2, 3, 40, 24)), ((64, 128), 1, (1, 3, 40, 56))])
 def test_backward_matches_torch_autograd(channels, nru, shape):
     _grad_check(channels, nru, shape, kink_free=channels[0] >= 32)
 

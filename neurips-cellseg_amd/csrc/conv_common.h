@@ -11,7 +11,11 @@ struct SrcDev {
     const float2* tab;
     const float* slope;
     int c, pitch, tab_c, tab_off;
+    const float* ptr2;             // second tensor of a SUM source (ConvSrc::ptr2), nullptr otherwise
+    const float2* tab2;
+    const float* slope2;
 };
+__device__ __forceinline__ SrcDev second_of(const SrcDev& s) { return SrcDev{s.ptr2, s.tab2, s.slope2, s.c, s.pitch, s.tab_c, s.tab_off, nullptr, nullptr, nullptr}; }
 
 struct ConvParams {
     SrcDev a, b;

@@ -594,6 +594,13 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         ph = oh; pw = ow; pc = c;
         if (tape) { tape->E[d] = E; tape->Y[d] = Y; }
     }
+    // fp32 inference: the residual sum of a decoder level (D[d] = act(norm(V)) + act(norm(U))) has ONE
+    // consumer, the transposed conv of the level above.  When that is the MFMA kernel (every level but the 3-channel top one) it reads
+    // the two tensors itself (a SUM source) and the norm_act_add pass - two reads and one write of the tensor - is not launched.
+    // Training keeps the sums (the tape needs them).  CS_FUSE_SUM=0 materialises them as before.
+    static const int fuse_env = getenv("CS_FUSE_SUM") ? atoi(getenv("CS_FUSE_SUM")) : 1;
+    const bool fuse_sum = fuse_env && !tape && net->planes == 0 && !q8 && !a16;
+    ConvSrc sub;                                                 // "sub" input of the next transposed conv
     // ---- bottom ----
     float* S = nullptr;   // "sub" input of the next up layer
     unsigned char* Sq = nullptr;
@@ -622,8 +629,12 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 CS_TRY(finish_norm(s, net, u.norms[su], rt_bottom[su], n, c, ph * pw, dry));
             }
             const int last = u.subunits - 1;
-            CS_TRY(launch_norm_act_add(s, lazy_src(Y[last], c, c, rt_bottom[last], u.norms[last], c, a16),
-                                       u.res_conv ? raw_src(R, c, c, a16) : raw_src(prev, c, pc, a16), S, c, (int64_t)ph * pw, n, a16, Sq, c));
+            const ConvSrc ly = lazy_src(Y[last], c, c, rt_bottom[last], u.norms[last], c, a16);
+            // (the bottom unit's sum act(norm(Y)) + R is materialised: handed to the level above as a SUM source it saved 0.27 ms of
+            // norm_act_add per slide and cost 0.32 ms in that transposed conv, 32 of whose 48 input chunks then stage two tensors)
+            CS_TRY(launch_norm_act_add(s, ly, u.res_conv ? raw_src(R, c, c, a16) : raw_src(prev, c, pc, a16), S, c, (int64_t)ph * pw, n,
+                                       a16, Sq, c));
+            sub = raw_src(S, c, c, a16);
         }
         if (tape) { tape->Yb = Y; tape->Rb = R; tape->Sb = S; }
     }
@@ -648,7 +659,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         if (!dry) {
             const bool in8 = q8 && !u.top;
             const ConvSrc a = in8 ? raw8_src(Xq[d], u.cin_skip) : raw_src(X[d], u.cin_skip, u.cin_skip, a16);
-            const ConvSrc b = in8 ? raw8_src(Sq, sc) : raw_src(S, sc, sc, a16);
+            const ConvSrc b = in8 ? raw8_src(Sq, sc) : sub;
             if (c % 16 == 0 && net->planes == 5 && u.convt.w8) {
                 CS_TRY(launch_convt_fp8(s, a, b, u.convt.w8, u.convt.wscale, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
             } else if (c % 16 == 0 && net->planes > 0 && net->planes <= 4 && u.convt.wb) {
@@ -667,7 +678,18 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 if (q8) CS_TRY(launch_act_quant(s, lu, Uq, c, (int64_t)oh * ow, n));
                 CS_TRY(conv_fwd(s, net, 3, 1, q8 ? raw8_src(Uq, c) : lu, u.unit0, V, c, c, rt_upu[d].stats, n, oh, ow));
                 CS_TRY(finish_norm(s, net, u.norm_u, rt_upu[d], n, c, oh * ow, dry));
-                CS_TRY(launch_norm_act_add(s, lazy_src(V, c, c, rt_upu[d], u.norm_u, c, a16), lu, D, c, (int64_t)oh * ow, n, a16, Dq, c));
+                const ConvSrc lv = lazy_src(V, c, c, rt_upu[d], u.norm_u, c, a16);
+                // (consumers with 64-channel blocks are left alone: the second tensor costs that kernel variant a third of its occupancy -
+                // measured on the 32-base slide: level 2 fused -0.47 ms, level 3 fused -0.06 ms, CS_FUSE_SUM=2 fuses every level)
+                const int c_up = net->up[d - 1].cout;
+                const bool fused = fuse_sum && d >= 2 && c_up % 16 == 0 && (c_up % 64 != 0 || fuse_env == 2) && rt_upt[d].tab && rt_upu[d].tab;
+                if (fused) {
+                    sub = lv;
+                    sub.ptr2 = U; sub.tab2 = rt_upt[d].tab; sub.slope2 = u.norm_t.slope;
+                } else {
+                    CS_TRY(launch_norm_act_add(s, lv, lu, D, c, (int64_t)oh * ow, n, a16, Dq, c));
+                    sub = raw_src(D, c, c, a16);
+                }
             }
         }
         S = D;

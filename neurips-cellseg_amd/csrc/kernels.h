@@ -16,6 +16,13 @@ struct ConvSrc {
     bool h16 = false;              // `ptr` really points at bf16 elements (the bf16 datapath keeps activations as bf16 in HBM);
                                    // pitch / c still count elements
     bool q8 = false;               // `ptr` points at e4m3 bytes: an ACTIVATED tensor materialised for the fp8 kernels (no table)
+    // SUM source: the value is act(norm(ptr)) + act(norm(ptr2)), two raw tensors of the same shape and pitch with their own lazy
+    // tables (tab_c / tab_off shared; tab2 == nullptr: the second tensor is added as it is) - a residual sum, consumed without
+    // ever being written to HBM.  Only the `b` operand of launch_convt_mfma understands it (fp32 inference); every other
+    // launcher refuses such a source.
+    const float* ptr2 = nullptr;
+    const float2* tab2 = nullptr;
+    const float* slope2 = nullptr;
 };
 
 // ---- weight packing (PyTorch layout -> MFMA fragment order) -----------------------------------

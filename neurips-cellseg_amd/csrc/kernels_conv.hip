@@ -446,7 +446,7 @@ static const int g_conv_variant_init = [] {
     return 0;
 }();
 
-static SrcDev to_dev(const ConvSrc& s) { return SrcDev{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
+static SrcDev to_dev(const ConvSrc& s) { return SrcDev{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off, s.ptr2, s.tab2, s.slope2}; }
 
 static int apply_extra(ConvParams& p, const ConvOutExtra* ex, int cout, int* nt) {
     if (!ex) return CS_OK;
@@ -468,6 +468,7 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
     CS_REQUIRE(stride == 1 || stride == 2, "conv: stride %d unsupported", stride);
     CS_REQUIRE(!(ksize == 1 && stride != 1), "conv: 1x1 stride 2 unsupported");
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0, "conv: input channels (%d,%d) must be multiples of 16", a.c, b.c);
+    CS_REQUIRE(!a.ptr2 && !b.ptr2, "conv: sum sources are only understood by the transposed convolution");
     CS_REQUIRE(cout % 16 == 0, "conv: cout %d must be a multiple of 16", cout);
     CS_REQUIRE((a.pitch % 4) == 0 && (b.c == 0 || (b.pitch % 4) == 0), "conv: pixel pitch must be a multiple of 4 floats");
     ConvParams p{};
@@ -888,8 +889,10 @@ int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsi
 //   out[2i+a][2j+b] += in[i+di][j+dj] * W[ky][kx],  ky: 0->(a=1,di=1) 1->(a=0,di=0) 2->(a=1,di=0); same for kx.
 // M tile = 16 input pixels of one row; each wave owns one input row of the block's 4-row tile.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void convt_mfma_kernel(ConvParams p) {
+// SUM2: the `b` source is a sum of two lazily normalised tensors (ConvSrc::ptr2: the decoder's residual sum, never materialised):
+// its chunks load both tensors and both tables and add the two activated values on the way into LDS.
+template <int NT, bool SUM2 = false>
+__global__ __launch_bounds__(256, SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2)) void convt_mfma_kernel(ConvParams p) {
     constexpr int TH = 4, TW = 16, IH = TH + 1, IW = TW + 1, CS = 24;
     constexpr int IN_ITERS = (IH * IW + 63) / 64;
     constexpr int W_ITERS = (9 * NT * 64 + 255) / 256;
@@ -932,7 +935,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void convt_mfma_kernel(ConvPa
 
     const int chunks_a = p.a.c >> 4, chunks = (p.a.c + p.b.c) >> 4;
     f32x4 rin[IN_ITERS], rw[W_ITERS];
-    Lazy4 lz;
+    f32x4 rin2[SUM2 ? IN_ITERS : 1];
+    Lazy4 lz, lz2;
+    bool two = false;                                          // the chunk in flight comes from the SUM source
     auto load_chunk = [&](int ch) {
         const bool from_a = ch < chunks_a;
         const SrcDev& src = from_a ? p.a : p.b;
@@ -943,6 +948,19 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void convt_mfma_kernel(ConvPa
         for (int it = 0; it < IN_ITERS; ++it) {
             const int o = goff[it] >= 0 ? goff[it] : 0;
             rin[it] = *reinterpret_cast<const f32x4*>(base + (size_t)o * src.pitch);
+        }
+        if constexpr (SUM2) {
+            two = !from_a;
+            if (two) {
+                const SrcDev s2 = second_of(p.b);
+                lz2.load(s2, img, c0 + 4 * q, p.wpack);
+                const float* base2 = s2.ptr + (size_t)img * p.hin * p.win * s2.pitch + c0 + 4 * q;
+#pragma unroll
+                for (int it = 0; it < IN_ITERS; ++it) {
+                    const int o = goff[it] >= 0 ? goff[it] : 0;
+                    rin2[it] = *reinterpret_cast<const f32x4*>(base2 + (size_t)o * s2.pitch);
+                }
+            }
         }
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + ((size_t)ch * 9 * p.ntile_total + nt0) * 64;
 #pragma unroll
@@ -959,7 +977,10 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void convt_mfma_kernel(ConvPa
         for (int it = 0; it < IN_ITERS; ++it) {
             const int pix = (tid >> 2) + 64 * it;
             if (pix < IH * IW) {
-                const f32x4 v = goff[it] >= 0 ? lz.apply(rin[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 v = lz.apply(rin[it]);
+                if constexpr (SUM2)
+                    if (two) v += lz2.apply(rin2[it]);        // (a raw second tensor - no table - is added as it is)
+                if (goff[it] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(&in_s[pix * CS + 4 * q]) = v;
             }
         }
@@ -1081,6 +1102,7 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win, const ConvOutExtra* ex) {
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0, "convT: input channels (%d,%d) must be multiples of 16", a.c, b.c);
     CS_REQUIRE(cout % 16 == 0, "convT: cout %d must be a multiple of 16", cout);
+    CS_REQUIRE(!a.ptr2, "convT: only the second operand may be a sum source");
     ConvParams p{};
     p.a = to_dev(a);
     p.b = to_dev(b);
@@ -1093,8 +1115,18 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
     if (int rc = apply_extra(p, ex, cout, &nt)) return rc;
     dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * n, p.ntile_total / nt));
     const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
-    const double bytes = 4.0 * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
+    const double bytes = 4.0 * n * ((double)hin * win * (a.c + (b.ptr2 ? 2 : 1) * b.c) + 4.0 * hin * win * cout);
     ProfScope prof(K_CONVT, s, flops, bytes);
+    if (b.ptr2) {
+        CS_REQUIRE(b.c > 0, "convT: empty sum source");
+        switch (nt) {
+            case 4: hipLaunchKernelGGL((convt_mfma_kernel<4, true>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((convt_mfma_kernel<2, true>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((convt_mfma_kernel<1, true>), grid, dim3(256), 0, s, p); break;
+        }
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     switch (nt) {
         case 4: hipLaunchKernelGGL((convt_mfma_kernel<4>), grid, dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL((convt_mfma_kernel<2>), grid, dim3(256), 0, s, p); break;

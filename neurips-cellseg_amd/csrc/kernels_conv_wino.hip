@@ -603,7 +603,7 @@ int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, c
                      double* stats, int n, int h, int w, const ConvOutExtra* ex) {
     CS_REQUIRE(a.c % 16 == 0 && a.c > 0 && cout % 32 == 0, "conv(winograd): channels (%d -> %d) unsupported", a.c, cout);
     CS_REQUIRE((a.pitch % 4) == 0 && (pitch_out % 4) == 0, "conv(winograd): pixel pitch must be a multiple of 4 floats");
-    CS_REQUIRE(!a.h16 && !a.q8, "conv(winograd): fp32 activations only");
+    CS_REQUIRE(!a.h16 && !a.q8 && !a.ptr2, "conv(winograd): plain fp32 activations only");
     ConvParams p{};
     p.a = SrcDev{a.ptr, a.tab, a.slope, a.c, a.pitch, a.tab_c ? a.tab_c : a.c, a.tab_off};
     p.wpack = wpack_wino;

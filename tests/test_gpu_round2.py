@@ -635,6 +635,39 @@ def test_poisoned_workspaces_change_nothing(tmp_path):
         assert torch.equal(g0, outs["1"]["g"][k]), k
 
 
+_FUSE_AB = r"""
+import sys, torch
+sys.path[:0] = [{root!r}, {pkg!r}]
+import cellseg_amd as ca
+torch.manual_seed(5)
+outs = {{}}
+for name, ch, shape in (("base32", (32, 64, 128, 256, 512), (2, 3, 96, 128)), ("ref16", (16, 32, 64, 128, 256), (3, 3, 80, 48)),
+                        ("three", (32, 64, 128), (2, 3, 40, 56))):
+    net = ca.UNet(channels=ch, strides=(2,) * (len(ch) - 1), num_res_units=2).to("cuda:0").eval()
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(1)).to("cuda:0")
+    with torch.no_grad():
+        outs[name] = net(x).cpu()
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_decoder_sums_read_by_the_transposed_conv_equal_the_materialised_form(tmp_path):
+    """fp32 inference hands the decoder's residual sum act(norm(V)) + act(norm(U)) to the transposed conv of the level above as a
+    SUM source (two tensors, two lazy tables) instead of writing it with norm_act_add first.  CS_FUSE_SUM=0 (every sum
+    materialised), the default (levels whose consumer uses < 64-channel blocks) and CS_FUSE_SUM=2 (every level) in three
+    processes: the same fp32 operations in the same order, so the logits are bitwise equal."""
+    outs = {}
+    for mode in ("0", "1", "2"):
+        path = str(tmp_path / f"fuse{mode}.pt")
+        env = dict(os.environ, CS_FUSE_SUM=mode)
+        subprocess.run([sys.executable, "-c", _FUSE_AB.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
+        outs[mode] = torch.load(path)
+    for name, y0 in outs["0"].items():
+        assert torch.isfinite(y0).all()
+        for mode in ("1", "2"):
+            assert torch.equal(y0, outs[mode][name]), (name, mode, (y0 - outs[mode][name]).abs().max().item())
+
+
 def test_narrow_operand_weight_gradients_agree_with_the_general_kernel(tmp_path):
     """First-layer and top-transposed-conv weight gradients: the tap-packed kernel (27 columns = 9 taps x 3 channels) against the
     general kernel (CS_WGRAD_NARROW=0: one 16-column tile per tap), two processes.  Different summation order only."""

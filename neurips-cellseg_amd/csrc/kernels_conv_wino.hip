@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
     const int cw = (c4 & 3) * 4;
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, qsum[4] = {0.0, 0.0, 0.0, 0.0};
+    double sq8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // (sum, sum of squares) of this thread's 4 channels
+    float sf[4] = {0.f, 0.f, 0.f, 0.f}, qf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < 128 / PPP; ++it) {
         const int pix = tid / F4 + PPP * it;
@@ -252,29 +253,37 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
             if (p.stats) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    ssum[k] += (double)y[k];
-                    qsum[k] += (double)y[k] * (double)y[k];
+                    sf[k] += y[k];
+                    qf[k] = __builtin_fmaf(y[k], y[k], qf[k]);
                 }
+            }
+        }
+        // at most 4 values per channel are summed in fp32 (relative error <= 2^-22 of a partial sum, below the rounding the
+        // values themselves carry); everything from there on is fp64.  The fp64 conversions and FMAs of every single value were
+        // 10 % of the 32-channel layers' time (the VALU work of a wave is not hidden behind another wave's fp32 MFMAs).
+        if (p.stats && ((it & 3) == 3 || it == 128 / PPP - 1)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sq8[2 * k] += (double)sf[k];
+                sq8[2 * k + 1] += (double)qf[k];
+                sf[k] = 0.f;
+                qf[k] = 0.f;
             }
         }
     }
     if (p.stats) {
-        // lanes with equal c4 (lane % F4) -> the waves of the block (LDS) -> ONE fp64 atomic pair per block and channel
+        // lanes with equal c4 (lane % F4) -> the waves of the block (LDS) -> ONE fp64 atomic pair per block and channel.  (A butterfly
+        // that halves the values a lane carries at every step - 7 exchanges instead of 24 - was measured SLOWER, 767 vs 671 us on the
+        // 32-channel layer: its per-lane selects and permutes cost more than the plain xor shuffles, which compile to DPP moves.)
         double* st_s = reinterpret_cast<double*>(smem + BODY_FLOATS);      // [4 waves][16*NTW][2]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int e = 0; e < 8; ++e) {
 #pragma unroll
-            for (int sh = F4; sh < 64; sh <<= 1) {
-                ssum[k] += __shfl_xor(ssum[k], sh);
-                qsum[k] += __shfl_xor(qsum[k], sh);
-            }
+            for (int sh = F4; sh < 64; sh <<= 1) sq8[e] += __shfl_xor(sq8[e], sh);
         }
         if (lane < F4) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2] = ssum[k];
-                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2 + 1] = qsum[k];
-            }
+            for (int e = 0; e < 8; ++e) st_s[(wave * 16 * NTW + c4 * 4) * 2 + e] = sq8[e];
         }
         __syncthreads();
         if (tid < 32 * NTW) {
@@ -531,7 +540,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long l
     const int cw = (c4 & 3) * 4;
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, qsum[4] = {0.0, 0.0, 0.0, 0.0};
+    double sq8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // (sum, sum of squares) of this thread's 4 channels
+    float sf[4] = {0.f, 0.f, 0.f, 0.f}, qf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < 128 / PPP; ++it) {
         const int pix = tid / F4 + PPP * it;
@@ -551,28 +561,34 @@ __global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long l
             if (p.stats) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    ssum[k] += (double)y[k];
-                    qsum[k] += (double)y[k] * (double)y[k];
+                    sf[k] += y[k];
+                    qf[k] = __builtin_fmaf(y[k], y[k], qf[k]);
                 }
+            }
+        }
+        // at most 4 values per channel are summed in fp32 (relative error <= 2^-22 of a partial sum, below the rounding the
+        // values themselves carry); everything from there on is fp64.  The fp64 conversions and FMAs of every single value were
+        // 10 % of the 32-channel layers' time (the VALU work of a wave is not hidden behind another wave's fp32 MFMAs).
+        if (p.stats && ((it & 3) == 3 || it == 128 / PPP - 1)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sq8[2 * k] += (double)sf[k];
+                sq8[2 * k + 1] += (double)qf[k];
+                sf[k] = 0.f;
+                qf[k] = 0.f;
             }
         }
     }
     if (p.stats) {
         double* st_s = reinterpret_cast<double*>(smem + BODY_FLOATS);      // [4 waves][16*NTW][2]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int e = 0; e < 8; ++e) {
 #pragma unroll
-            for (int sh = F4; sh < 64; sh <<= 1) {
-                ssum[k] += __shfl_xor(ssum[k], sh);
-                qsum[k] += __shfl_xor(qsum[k], sh);
-            }
+            for (int sh = F4; sh < 64; sh <<= 1) sq8[e] += __shfl_xor(sq8[e], sh);
         }
         if (lane < F4) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2] = ssum[k];
-                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2 + 1] = qsum[k];
-            }
+            for (int e = 0; e < 8; ++e) st_s[(wave * 16 * NTW + c4 * 4) * 2 + e] = sq8[e];
         }
         __syncthreads();
         if (tid < 32 * NTW) {

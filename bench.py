@@ -189,8 +189,8 @@ def launch_ranks(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: whole-slide inference is the headline (train step reported as `train_step`); train: the "
                          "data-parallel training step is the headline")
@@ -207,7 +207,7 @@ def main():
                          "strips with an all-gather of the uint8 mask strips before the connected-component pass (strong scaling); "
                          "the other partition is reported as a secondary object")
     ap.add_argument("--train-batch", type=int, default=32, help="tiles per GPU of the training step (BASELINE configs[1]/[3]: 32)")
-    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--cc-stream", type=int, default=1, help="1: the connected-component pass of slide k runs on its own stream beside "
                                                               "the convolutions of slide k + 1 (0: same stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -599,7 +599,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     // the two tensors itself (a SUM source) and the norm_act_add pass - two reads and one write of the tensor - is not launched.
     // Training keeps the sums (the tape needs them).  CS_FUSE_SUM=0 materialises them as before.
     static const int fuse_env = getenv("CS_FUSE_SUM") ? atoi(getenv("CS_FUSE_SUM")) : 1;
-    const bool fuse_sum = fuse_env && !tape && net->planes == 0 && !q8 && !a16;
+    const bool fuse_sum = fuse_env && !tape && !q8 && (a16 ? net->planes == 1 : net->planes == 0);   // fp32 path and bf16 datapath
     ConvSrc sub;                                                 // "sub" input of the next transposed conv
     // ---- bottom ----
     float* S = nullptr;   // "sub" input of the next up layer
@@ -682,7 +682,8 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 // (consumers with 64-channel blocks are left alone: the second tensor costs that kernel variant a third of its occupancy -
                 // measured on the 32-base slide: level 2 fused -0.47 ms, level 3 fused -0.06 ms, CS_FUSE_SUM=2 fuses every level)
                 const int c_up = net->up[d - 1].cout;
-                const bool fused = fuse_sum && d >= 2 && c_up % 16 == 0 && (c_up % 64 != 0 || fuse_env == 2) && rt_upt[d].tab && rt_upu[d].tab;
+                const bool fused = fuse_sum && d >= 2 && c_up % 16 == 0 && rt_upt[d].tab && rt_upu[d].tab &&
+                                   (a16 ? (c % 32 == 0 && net->up[d - 1].convt.wb != nullptr) : (c_up % 64 != 0 || fuse_env == 2));
                 if (fused) {
                     sub = lv;
                     sub.ptr2 = U; sub.tab2 = rt_upt[d].tab; sub.slope2 = u.norm_t.slope;

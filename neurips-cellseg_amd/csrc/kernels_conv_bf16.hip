@@ -85,6 +85,9 @@ struct SrcDevB {
     const float2* tab;
     const float* slope;
     int c, pitch, tab_c, tab_off;
+    const float* ptr2;             // second tensor of a SUM source (ConvSrc::ptr2; the transposed conv's `b` operand only)
+    const float2* tab2;
+    const float* slope2;
 };
 
 struct ConvBParams {
@@ -650,7 +653,7 @@ static int launch_bp(hipStream_t s, ConvBParams p) {
     return CS_OK;
 }
 
-static SrcDevB to_devb(const ConvSrc& s) { return SrcDevB{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off}; }
+static SrcDevB to_devb(const ConvSrc& s) { return SrcDevB{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off, s.ptr2, s.tab2, s.slope2}; }
 
 template <int S, int KS, int WN, int NTW, int NP, int THX = 1, bool A16 = false>
 static int launch_b(hipStream_t s, ConvBParams p) {
@@ -672,6 +675,7 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     CS_REQUIRE((stride == 1 || stride == 2) && !(ksize == 1 && stride != 1), "conv(bf16): stride %d unsupported", stride);
     CS_REQUIRE(planes >= 1 && planes <= 4, "conv(bf16): %d planes", planes);
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "conv(bf16): channels must be multiples of 16");
+    CS_REQUIRE(!a.ptr2 && !b.ptr2, "conv(bf16): sum sources are only understood by the transposed convolution");
     ConvBParams p{};
     p.a = to_devb(a);
     p.b = to_devb(b);
@@ -737,9 +741,12 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
 // transposed conv k3 s2 p1 op1, split-bf16: same operand handling as above, 4 output phases per input pixel
 //   out[2i+a][2j+b] += in[i+di][j+dj] * W[ky][kx],  ky: 0->(a=1,di=1) 1->(a=0,di=0) 2->(a=1,di=0); same for kx.
 // ------------------------------------------------------------------------------------------------
-template <int WN, int NTW, int NP, bool A16>
+// SUM2 (bf16 datapath): the `b` source is the decoder's residual sum act(norm(V)) + act(norm(U)), read as its two bf16 tensors.
+// The loads stay unconditional (chunks of `a` fetch their own item twice, an L1 hit) so that the waits keep their counts.
+template <int WN, int NTW, int NP, bool A16, bool SUM2 = false>
 __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     static_assert(!A16 || NP == 1, "bf16 activations in HBM only make sense for the plain-bf16 mode");
+    static_assert(!SUM2 || A16, "sum sources are implemented for the bf16 datapath");
     typedef typename std::conditional<A16, u32x2, f32x4>::type raw4;
     constexpr bool F16 = SplitCfg<NP>::f16;
     constexpr int NPL = SplitCfg<NP>::planes, NTERM = SplitCfg<NP>::terms, NACC = 1;
@@ -792,9 +799,10 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     }
     const int chunks_a = (p.a.c + 31) >> 5, chunks = chunks_a + ((p.b.c + 31) >> 5);
     raw4 rin[IN_ITERS];
-    f32x4 t0, t1;
-    float slope = 0.f;
-    bool lazy = false, qvalid = false;
+    u32x2 rin2[SUM2 ? IN_ITERS : 1];
+    f32x4 t0, t1, t0b, t1b;
+    float slope = 0.f, slope_b = 0.f;
+    bool lazy = false, qvalid = false, two = false;
     auto load_input = [&](int ch) {
         const bool from_a = ch < chunks_a;
         const SrcDevB& src = from_a ? p.a : p.b;
@@ -816,6 +824,23 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
             if constexpr (A16) rin[it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(src.ptr) + base_el + (size_t)o * src.pitch);
             else rin[it] = *reinterpret_cast<const f32x4*>(src.ptr + base_el + (size_t)o * src.pitch);
         }
+        if constexpr (SUM2) {
+            two = !from_a;
+            const float2* tab2 = two ? p.b.tab2 : src.tab;                  // (not `two`: the same table / item again, never used)
+            const f32x4* tb = tab2 ? reinterpret_cast<const f32x4*>(tab2 + (size_t)img * src.tab_c + src.tab_off + cq)
+                                   : reinterpret_cast<const f32x4*>(p.dummy);
+            t0b = tb[0];
+            t1b = tb[1];
+            const float* sp2 = (two && p.b.slope2) ? p.b.slope2 : p.dummy;
+            slope_b = *sp2;
+            if (!(two && p.b.slope2)) slope_b = 0.f;
+            const float* ptr2 = two ? p.b.ptr2 : src.ptr;
+#pragma unroll
+            for (int it = 0; it < IN_ITERS; ++it) {
+                const int o = goff[it] >= 0 ? goff[it] : 0;
+                rin2[it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(ptr2) + base_el + (size_t)o * src.pitch);
+            }
+        }
     };
     auto store_input = [&]() {
 #pragma unroll
@@ -830,6 +855,15 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
                     v.y = prelu_h(v.y * t0.z + t0.w, slope);
                     v.z = prelu_h(v.z * t1.x + t1.y, slope);
                     v.w = prelu_h(v.w * t1.z + t1.w, slope);
+                }
+                if constexpr (SUM2) {
+                    if (two) {
+                        const f32x4 u = bf16x4_to_f32(rin2[it]);
+                        v.x += prelu_h(u.x * t0b.x + t0b.y, slope_b);
+                        v.y += prelu_h(u.y * t0b.z + t0b.w, slope_b);
+                        v.z += prelu_h(u.z * t1b.x + t1b.y, slope_b);
+                        v.w += prelu_h(u.w * t1b.z + t1b.w, slope_b);
+                    }
                 }
                 if (goff[it] < 0 || !qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -961,6 +995,13 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
 template <int WN, int NTW, int NP, bool A16 = false>
 static int launch_tb(hipStream_t s, ConvBParams p) {
     dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
+    if constexpr (A16) {
+        if (p.b.ptr2) {
+            hipLaunchKernelGGL((convt_bf16s_kernel<WN, NTW, NP, A16, true>), grid, dim3(256), 0, s, p);
+            CS_HIP(hipGetLastError());
+            return CS_OK;
+        }
+    }
     hipLaunchKernelGGL((convt_bf16s_kernel<WN, NTW, NP, A16>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -972,6 +1013,7 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
     CS_REQUIRE(!act16 || planes == 1, "convT(bf16): bf16 activations in HBM go with the plain-bf16 mode only");
     CS_REQUIRE(a.h16 == act16 && (b.c == 0 || b.h16 == act16), "convT(bf16): activation element type does not match the mode");
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "convT(bf16): channels must be multiples of 16");
+    CS_REQUIRE(!a.ptr2 && (!b.ptr2 || (act16 && b.c % 32 == 0)), "convT(bf16): a sum source must be the second operand of the bf16 datapath, in whole 32-channel chunks");
     ConvBParams p{};
     p.a = to_devb(a);
     p.b = to_devb(b);
@@ -982,7 +1024,7 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
     p.tiles_y = ceil_div(hin, 4);
     const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
     const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
-    const double bytes = (act16 ? 2.0 : 4.0) * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout);
+    const double bytes = (act16 ? 2.0 : 4.0) * n * ((double)hin * win * (a.c + (b.ptr2 ? 2 : 1) * b.c) + 4.0 * hin * win * cout);
     ProfScope prof(K_CONVT, s, flops, bytes);
 #define CS_TB(NP_, A16_)                                             \
     switch (wn) {                                                    \

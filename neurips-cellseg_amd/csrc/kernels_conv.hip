@@ -359,6 +359,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
                     for (int t = 0; t < NTW; ++t) wc[((ky + 1) % KS) * KS + kx][t] = wnext[(size_t)kx * wtap + t * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
+            // (hipcc reads each A fragment and waits lgkmcnt(0) directly in front of the 4 * NTW MFMAs it feeds.  Reading it one step
+            // ahead by hand - as the weight-gradient kernel does - was measured neutral here: stride-2 group 7.80 -> 7.73 ms on the
+            // slide, 0.617 -> 0.642 ms in the training step; the three blocks per CU already cover each other's LDS round trips.)
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
                 f32x4 b[NTW];
@@ -563,7 +566,18 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
     } else {
         image += (size_t)img * p.sn;
     }
+    // the block's weight fragments (7 KB from L2) are requested FIRST and parked in registers: as a plain copy loop behind the
+    // patch stores hipcc kept the loop rolled - load, vmcnt(0), LDS store, seven L2 round trips in a row, about half of a block's life
+    constexpr int W4 = KSTEPS * NT * 16, W_ITERS = (W4 + 255) / 256;
+    f32x4 rwt[W_ITERS];
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+        const int i = tid + 256 * it;
+        rwt[it] = reinterpret_cast<const f32x4*>(p.wpack)[(W4 % 256 == 0 || i < W4) ? i : 0];
+    }
     // unconditional (clamped) loads, fully unrolled: a load under a branch makes hipcc wait for it before issuing the next
+    // (a row-per-wave gather with the row arithmetic on the scalar unit - 13 half-empty loads instead of 7 full ones, ~50 fewer VALU
+    // instructions per load - was measured: 1.34 vs 1.30 ms per slide, no gain)
     constexpr int ST_ITERS = (IH * IW * CIN + 255) / 256;
     float rv[ST_ITERS];
 #pragma unroll
@@ -584,7 +598,11 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
         if (i < IH * IW * CIN) in_s[i] = rv[it];
     }
     if (tid < 4) in_s[IH * IW * CIN + tid] = 0.f;
-    for (int i = tid; i < KSTEPS * NT * 64; i += 256) w_s[i] = p.wpack[i];
+#pragma unroll
+    for (int it = 0; it < W_ITERS; ++it) {
+        const int i = tid + 256 * it;
+        if (W4 % 256 == 0 || i < W4) reinterpret_cast<f32x4*>(w_s)[i] = rwt[it];
+    }
     __syncthreads();
 
     f32x4 acc[MT][NT];
@@ -1003,6 +1021,9 @@ __global__ __launch_bounds__(256, SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2)) 
 #pragma unroll
             for (int dj = 0; dj < 2; ++dj)
                 a[di][dj] = *reinterpret_cast<const f32x4*>(&in_s[((wave + di) * IW + pl + dj) * CS + 4 * g]);
+        // (reading every B fragment one step ahead of its 4 MFMAs - as the stride-2 kernel does with its A fragments - was measured:
+        // 10.4 vs 9.2 ms per slide.  The 64-channel variant sits at its register cap (166 of 168 for three blocks per CU): the second
+        // fragment buffer spilled the weight prefetch to scratch and made the allocator rotate accumulators through s_nop hazards.)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;

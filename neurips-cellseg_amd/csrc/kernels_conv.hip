@@ -909,9 +909,11 @@ int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsi
 // ------------------------------------------------------------------------------------------------
 // SUM2: the `b` source is a sum of two lazily normalised tensors (ConvSrc::ptr2: the decoder's residual sum, never materialised):
 // its chunks load both tensors and both tables and add the two activated values on the way into LDS.
-template <int NT, bool SUM2 = false>
-__global__ __launch_bounds__(256, SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2)) void convt_mfma_kernel(ConvParams p) {
-    constexpr int TH = 4, TW = 16, IH = TH + 1, IW = TW + 1, CS = 24;
+// RW: input rows per wave (block tile = 4 RW rows).  RW = 2 doubles the MFMAs behind every barrier pair and every B fragment read
+// (two rows x four phases x NT tiles = 128 accumulator registers at NT = 4: two blocks per CU instead of three).
+template <int NT, bool SUM2 = false, int RW = 1>
+__global__ __launch_bounds__(256, RW == 2 ? 2 : (SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2))) void convt_mfma_kernel(ConvParams p) {
+    constexpr int TH = 4 * RW, TW = 16, IH = TH + 1, IW = TW + 1, CS = 24;
     constexpr int IN_ITERS = (IH * IW + 63) / 64;
     constexpr int W_ITERS = (9 * NT * 64 + 255) / 256;
     constexpr int IN_FLOATS = (IH * IW * CS + 3) / 4 * 4;
@@ -936,11 +938,13 @@ __global__ __launch_bounds__(256, SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2)) 
     const int nt0 = wk.ct * NT;
     const int q = tid & 3;
 
-    f32x4 acc[4][NT];
+    f32x4 acc[RW][4][NT];
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph)
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[ph][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[r][ph][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int goff[IN_ITERS];
 #pragma unroll
@@ -1015,12 +1019,12 @@ __global__ __launch_bounds__(256, SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2)) 
     for (int ch = 0; ch < chunks; ++ch) {
         const bool more = ch + 1 < chunks;
         if (more) load_chunk(ch + 1);
-        f32x4 a[2][2];
+        f32x4 a[RW + 1][2];
 #pragma unroll
-        for (int di = 0; di < 2; ++di)
+        for (int di = 0; di < RW + 1; ++di)
 #pragma unroll
             for (int dj = 0; dj < 2; ++dj)
-                a[di][dj] = *reinterpret_cast<const f32x4*>(&in_s[((wave + di) * IW + pl + dj) * CS + 4 * g]);
+                a[di][dj] = *reinterpret_cast<const f32x4*>(&in_s[((wave * RW + di) * IW + pl + dj) * CS + 4 * g]);
         // (reading every B fragment one step ahead of its 4 MFMAs - as the stride-2 kernel does with its A fragments - was measured:
         // 10.4 vs 9.2 ms per slide.  The 64-channel variant sits at its register cap (166 of 168 for three blocks per CU): the second
         // fragment buffer spilled the weight prefetch to scratch and made the allocator rotate accumulators through s_nop hazards.)
@@ -1033,10 +1037,13 @@ __global__ __launch_bounds__(256, SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2)) 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const f32x4 b = reinterpret_cast<const f32x4*>(w_s)[(tap * NT + nt) * 64 + lane];
-                acc[ph][nt] = mfma4(a[di][dj].x, b.x, acc[ph][nt]);
-                acc[ph][nt] = mfma4(a[di][dj].y, b.y, acc[ph][nt]);
-                acc[ph][nt] = mfma4(a[di][dj].z, b.z, acc[ph][nt]);
-                acc[ph][nt] = mfma4(a[di][dj].w, b.w, acc[ph][nt]);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    acc[r][ph][nt] = mfma4(a[r + di][dj].x, b.x, acc[r][ph][nt]);
+                    acc[r][ph][nt] = mfma4(a[r + di][dj].y, b.y, acc[r][ph][nt]);
+                    acc[r][ph][nt] = mfma4(a[r + di][dj].z, b.z, acc[r][ph][nt]);
+                    acc[r][ph][nt] = mfma4(a[r + di][dj].w, b.w, acc[r][ph][nt]);
+                }
             }
         }
         __syncthreads();
@@ -1046,7 +1053,6 @@ __global__ __launch_bounds__(256, SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2)) 
         }
     }
 
-    const int iy = iy0 + wave;
     float* ep = smem + wave * 32 * EPS;
     double* st_s = reinterpret_cast<double*>(smem + 4 * 32 * EPS);     // [4 waves][16*NT][2]: block-reduced statistics
 #pragma unroll
@@ -1055,15 +1061,19 @@ __global__ __launch_bounds__(256, SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2)) 
         const float bias = p.bias ? p.bias[co] : 0.f;
         double s = 0.0, qq = 0.0;
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
+        for (int rr = 0; rr < RW; ++rr) {
+            const int iy = iy0 + wave * RW + rr;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ix = ix0 + g * 4 + r;
-                const float v = acc[ph][nt][r] + bias;
-                acc[ph][nt][r] = v;
-                if (iy < p.hin && ix < p.win) {
-                    s += (double)v;
-                    qq += (double)v * (double)v;
+            for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ix = ix0 + g * 4 + r;
+                    const float v = acc[rr][ph][nt][r] + bias;
+                    acc[rr][ph][nt][r] = v;
+                    if (iy < p.hin && ix < p.win) {
+                        s += (double)v;
+                        qq += (double)v * (double)v;
+                    }
                 }
             }
         }
@@ -1082,31 +1092,35 @@ __global__ __launch_bounds__(256, SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2)) 
     const OutSel o = select_out(p, nt0);
     const int cols_valid = 2 * (p.win - ix0);
 #pragma unroll
-    for (int pa = 0; pa < 2; ++pa) {                           // output row 2*iy + pa through the wave-private slab
+    for (int rr = 0; rr < RW; ++rr) {
+        const int iy = iy0 + wave * RW + rr;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int pa = 0; pa < 2; ++pa) {                       // output row 2*iy + pa through the wave-private slab
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ep[(2 * (g * 4 + r) + pb) * EPS + nt * 16 + pl] = acc[pa * 2 + pb][nt][r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        if (iy < p.hin) {
-            const size_t pix0 = ((size_t)img * p.hout + 2 * iy + pa) * p.wout + 2 * ix0;
-            float* out0 = o.out + pix0 * o.pitch + o.ch0;
-            const float* add0 = o.add ? o.add + pix0 * o.pitch_add + o.ch0 : nullptr;
+                for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-            for (int i = lane; i < 32 * F4_PER_PIX; i += 64) {
-                const int x = i / F4_PER_PIX, c4 = i - x * F4_PER_PIX;
-                if (x < cols_valid) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(&ep[x * EPS + c4 * 4]);
-                    if (add0) v += *reinterpret_cast<const f32x4*>(add0 + (int64_t)x * o.pitch_add + c4 * 4);
-                    *reinterpret_cast<f32x4*>(out0 + (int64_t)x * o.pitch + c4 * 4) = v;
+                    for (int r = 0; r < 4; ++r) ep[(2 * (g * 4 + r) + pb) * EPS + nt * 16 + pl] = acc[rr][pa * 2 + pb][nt][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (iy < p.hin) {
+                const size_t pix0 = ((size_t)img * p.hout + 2 * iy + pa) * p.wout + 2 * ix0;
+                float* out0 = o.out + pix0 * o.pitch + o.ch0;
+                const float* add0 = o.add ? o.add + pix0 * o.pitch_add + o.ch0 : nullptr;
+#pragma unroll
+                for (int i = lane; i < 32 * F4_PER_PIX; i += 64) {
+                    const int x = i / F4_PER_PIX, c4 = i - x * F4_PER_PIX;
+                    if (x < cols_valid) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(&ep[x * EPS + c4 * 4]);
+                        if (add0) v += *reinterpret_cast<const f32x4*>(add0 + (int64_t)x * o.pitch_add + c4 * 4);
+                        *reinterpret_cast<f32x4*>(out0 + (int64_t)x * o.pitch + c4 * 4) = v;
+                    }
                 }
             }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                // slab reads done before the next pass overwrites it
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                    // slab reads done before the second pass overwrites it
-        __builtin_amdgcn_wave_barrier();
     }
     if (p.stats) {
         __syncthreads();
@@ -1134,6 +1148,17 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
     p.tiles_y = ceil_div(hin, 4);
     int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
     if (int rc = apply_extra(p, ex, cout, &nt)) return rc;
+    // two input rows per wave for the 64-channel blocks when the grid still fills the chip at two blocks per CU (CS_CONVT_RW2=0: never)
+    static const int rw2_env = getenv("CS_CONVT_RW2") ? atoi(getenv("CS_CONVT_RW2")) : 1;
+    if (rw2_env && nt == 4 && !b.ptr2 && hin >= 8 && xcd_grid(p.tiles_x * ceil_div(hin, 8) * n, p.ntile_total / nt) >= 1024) {
+        p.tiles_y = ceil_div(hin, 8);
+        dim3 grid2(xcd_grid(p.tiles_x * p.tiles_y * n, p.ntile_total / nt));
+        const double flops2 = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
+        ProfScope prof2(K_CONVT, s, flops2, 4.0 * n * ((double)hin * win * (a.c + b.c) + 4.0 * hin * win * cout));
+        hipLaunchKernelGGL((convt_mfma_kernel<4, false, 2>), grid2, dim3(256), 0, s, p);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * n, p.ntile_total / nt));
     const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
     const double bytes = 4.0 * n * ((double)hin * win * (a.c + (b.ptr2 ? 2 : 1) * b.c) + 4.0 * hin * win * cout);

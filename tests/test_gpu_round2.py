@@ -550,6 +550,7 @@ def test_training_with_bf16_forward_tracks_the_fp32_curve():
     ((64, 128, 256), (3, 3, 56, 40)),
     ((32, 64, 128), (96, 3, 72, 88)),                    # enough blocks for the 128-channel one-wave-per-SIMD kernel (>= 512), 18 x 22 and 9 x 11 maps
     ((64, 128, 256), (160, 3, 40, 24)),                  # the same kernel on 10 x 6 maps (256-channel bottom layers)
+    ((64, 128, 256), (520, 3, 40, 24)),                  # >= 1024 blocks: the two-rows-per-wave transposed conv on a 10 x 6 map (partial 8 x 16 tiles)
 ])
 def test_winograd_layers_on_partial_and_odd_tiles_match_oracle(channels, shape):
     """Every 3x3 stride-1 layer of these nets runs in Winograd form (cout % 32 == 0); the shapes leave partial block tiles,

@@ -42,8 +42,10 @@ __device__ __forceinline__ void epilogue_store(float* ep, const f32x4 (&vals)[RO
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the slab is wave-private, no barrier needed
     __builtin_amdgcn_wave_barrier();
     constexpr int F4_PER_PIX = NT * 4;
+    static_assert((ROWS * 16 * F4_PER_PIX) % 64 == 0, "whole passes of the wave");
 #pragma unroll
-    for (int i = lane; i < ROWS * 16 * F4_PER_PIX; i += 64) {
+    for (int it = 0; it < ROWS * 16 * F4_PER_PIX / 64; ++it) {   // (trip count visible to the unroller: started at `lane`, hipcc kept
+        const int i = lane + 64 * it;                            // the loop rolled - one LDS round trip per pass - in the first-layer kernels)
         const int pix = i / F4_PER_PIX, c4 = i - pix * F4_PER_PIX;
         const int m = pix >> 4, x = pix & 15;
         if (m < n_rows_valid && x < n_cols_valid) {

@@ -390,7 +390,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     {
         constexpr int F4 = NTB * 4;                          // float4 per pixel record of this block
         const size_t el0 = (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + wk.ct * NTB * 16;
-        for (int i = tid; i < TH * 16 * F4; i += 256) {
+#pragma unroll
+        for (int it_ = 0; it_ < (TH * 16 * F4 + 255) / 256; ++it_) {      // (trip count visible to the unroller: the LDS reads of all passes go out together)
+            const int i = tid + 256 * it_;
+            if ((TH * 16 * F4) % 256 != 0 && i >= TH * 16 * F4) break;
             const int pix = i / F4, c4 = i - pix * F4;
             const int row = pix >> 4, x = pix & 15;
             if (oy0 + row < p.hout && ox0 + x < p.wout) {
@@ -613,7 +616,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16p_kernel(ConvBParams p, int n
         {
             constexpr int F8 = NTB * 2;                      // 16-byte (8-channel) records per pixel
             const size_t el0 = (((size_t)cur.img * p.hout + cur.oy0) * p.wout + cur.ox0) * p.pitch_out + ct * NTB * 16;
-            for (int i = tid; i < TH * 16 * F8; i += 256) {
+#pragma unroll
+            for (int it_ = 0; it_ < (TH * 16 * F8 + 255) / 256; ++it_) {      // (trip count visible to the unroller: the LDS reads of all passes go out together)
+                const int i = tid + 256 * it_;
+                if ((TH * 16 * F8) % 256 != 0 && i >= TH * 16 * F8) break;
                 const int pix = i / F8, c8 = i - pix * F8;
                 const int row = pix >> 4, x = pix & 15;
                 if (cur.oy0 + row < p.hout && cur.ox0 + x < p.wout) {
@@ -979,7 +985,10 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     {
         constexpr int F4 = NTB * 4;
         const size_t el0 = (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;
-        for (int i = tid; i < 2 * TH * 32 * F4; i += 256) {
+#pragma unroll
+        for (int it_ = 0; it_ < (2 * TH * 32 * F4 + 255) / 256; ++it_) {      // (trip count visible to the unroller: the LDS reads of all passes go out together)
+            const int i = tid + 256 * it_;
+            if ((2 * TH * 32 * F4) % 256 != 0 && i >= 2 * TH * 32 * F4) break;
             const int pix = i / F4, c4 = i - pix * F4;
             const int row = pix >> 5, x = pix & 31;
             if (2 * iy0 + row < p.hout && 2 * ix0 + x < p.wout) {

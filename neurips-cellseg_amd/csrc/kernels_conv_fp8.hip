@@ -83,6 +83,28 @@ __device__ __forceinline__ void stats_commit8(double s, double q, double* dst, i
     }
 }
 
+// As on the bf16 datapath (kernels_conv_bf16.hip): a lane's values are summed in fp32 (the outputs are stored as bf16 anyway), the
+// waves of a block that hold the same channels leave their sums in LDS and ONE fp64 atomic pair per block and channel follows.
+__device__ __forceinline__ void stats_stash8(double s, double q, double* red_c, int lane) {
+    s += __shfl_xor(s, 16);
+    q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (lane < 16) {
+        red_c[0] = s;
+        red_c[1] = q;
+    }
+}
+template <int WM, int NCH>
+__device__ __forceinline__ void stats_flush8(const double* red, double* dst, int tid) {
+    if (tid < NCH * 2) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) v += red[w * NCH * 2 + tid];
+        atomicAdd(dst + tid, v);
+    }
+}
+
 // Staging of one 128-channel chunk: item = (pixel, 16 channels) = one 16-byte load and one 16-byte LDS store.
 
 // MODE 0: conv (S in {1,2}, KS in {3,1});  the transposed conv has its own kernel below.
@@ -105,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
     constexpr bool DB = 2 * IN_BYTES <= EP_BYTES + 4096;
     constexpr int SM_BYTES = (DB ? 2 : 1) * IN_BYTES > EP_BYTES ? (DB ? 2 : 1) * IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    __shared__ double red8[WM > 1 ? WM * NTB * 32 : 1];     // per-wave statistics of the block's channels (stats_stash8)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
         const int co = (nt_w + t) * 16 + pl;
         const float bias = p.bias ? p.bias[co] : 0.f;
         const float ws = p.wscale[co];
-        double s = 0.0, qq = 0.0;
+        float sf = 0.f, qf = 0.f;
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             const int row = wm * MTW + m, oy = oy0 + row;
@@ -242,15 +265,20 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
                 const int ox = ox0 + g * 4 + r;
                 const float v = acc[m][t][r] * ws + bias;
                 ep[(row * 16 + g * 4 + r) * EPS + (wn * NTW + t) * 16 + pl] = v;
-                if (oy < p.hout && ox < p.wout) {
-                    s += (double)v;
-                    qq += (double)v * (double)v;
+                if (p.stats && oy < p.hout && ox < p.wout) {
+                    sf += v;
+                    qf = fmaf(v, v, qf);
                 }
             }
         }
-        if (p.stats) stats_commit8(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        if (p.stats) {
+            if constexpr (WM > 1) stats_stash8((double)sf, (double)qf, red8 + ((wm * NTB + wn * NTW + t) * 16 + pl) * 2, lane);
+            else stats_commit8((double)sf, (double)qf, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        }
     }
     __syncthreads();
+    if constexpr (WM > 1)
+        if (p.stats) stats_flush8<WM, NTB * 16>(red8, p.stats + ((size_t)img * p.cout + wk.ct * NTB * 16) * 2, tid);
     {
         constexpr int F4 = NTB * 4;
         const size_t el0 = (((size_t)img * p.hout + oy0) * p.wout + ox0) * p.pitch_out + wk.ct * NTB * 16;
@@ -334,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
     constexpr int EP_BYTES = 2 * TH * 32 * EPS * 4;
     constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
+    __shared__ double red8[WM > 1 ? WM * NTB * 32 : 1];     // per-wave statistics of the block's channels (stats_stash8)
     char* const in_s = smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
         const int co = (nt_w + t) * 16 + pl;
         const float bias = p.bias ? p.bias[co] : 0.f;
         const float ws = p.wscale[co];
-        double s = 0.0, qq = 0.0;
+        float sf = 0.f, qf = 0.f;
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             const int row = wm * MTW + m, iy = iy0 + row;
@@ -465,15 +494,20 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
                     const int ix = ix0 + g * 4 + r;
                     const float v = acc[m][ph][t][r] * ws + bias;
                     ep[((2 * row + (ph >> 1)) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + (wn * NTW + t) * 16 + pl] = v;
-                    if (iy < p.hin && ix < p.win) {
-                        s += (double)v;
-                        qq += (double)v * (double)v;
+                    if (p.stats && iy < p.hin && ix < p.win) {
+                        sf += v;
+                        qf = fmaf(v, v, qf);
                     }
                 }
         }
-        if (p.stats) stats_commit8(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        if (p.stats) {
+            if constexpr (WM > 1) stats_stash8((double)sf, (double)qf, red8 + ((wm * NTB + wn * NTW + t) * 16 + pl) * 2, lane);
+            else stats_commit8((double)sf, (double)qf, p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        }
     }
     __syncthreads();
+    if constexpr (WM > 1)
+        if (p.stats) stats_flush8<WM, NTB * 16>(red8, p.stats + ((size_t)img * p.cout + wk.ct * NTB * 16) * 2, tid);
     {
         constexpr int F4 = NTB * 4;
         const size_t el0 = (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;

@@ -15,7 +15,8 @@ GPU) and forwards rank 0's JSON line.
 
 Multi-GPU legs:
   slides  (headline, weak scaling)   every rank segments its own slide, no data-path collective
-  strips  (`strips` object, strong)  ONE slide cut into row strips, all-gather (RCCL) of the uint8 mask strips, CC on every rank
+  strips  (`strips` object, strong)  ONE slide split by WINDOW rows (no window evaluated twice), seam halves sent to the neighbour
+                                     below (RCCL send/recv), all-gather (RCCL) of the uint8 mask strips, CC on every rank (own stream)
   train   (`train_step` object; `--mode train` makes it the headline) data-parallel training step, batch 32x3x256x256 per
           GPU (BASELINE.json configs[1]/[3]): forward + DiceCE + backward + ONE flat-bucket RCCL all-reduce + AdamW
 Prints ONE JSON line on rank 0 (contract in the task description), including `roofline` (dominant kernel, HIP
@@ -46,7 +47,7 @@ MFMA_PEAK = {"fp32": PEAK_F32_MFMA_TFLOPS, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3, 
              "bf16": PEAK_BF16_MFMA_TFLOPS, "fp8": PEAK_FP8_MFMA_TFLOPS}
 DTYPE = {"fp32": "f32", "fp16x3": "f32 (split-fp16, 2 planes x 3 MFMA terms, fp32 accumulate)", "bf16x6": "f32 (split-bf16, 3 planes x 6 MFMA terms, fp32 accumulate)",
          "bf16x3": "split-bf16 (2 planes x 3 terms)", "bf16": "bf16 (weights, activations in HBM; fp32 accumulate)",
-         "fp8": "fp8 e4m3 (weights with per-channel scales, activations converted from bf16 while staged; fp32 accumulate)"}
+         "fp8": "fp8 e4m3 (weights with per-channel scales; every conv input materialised once as activated e4m3, conv outputs bf16; fp32 accumulate)"}
 PEAK_HBM_GBS = 8000.0
 WIDTHS = {"baseline32": (32, 64, 128, 256, 512), "reference16": (16, 32, 64, 128, 256),
           "deep64": (64, 128, 256, 512, 1024)}          # BASELINE.json configs[4] width (use with --roi 512)
@@ -130,11 +131,16 @@ def cpu_baseline(size, roi, overlap, channels, seed):
     img = torch.from_numpy(synthetic_wsi(size, seed)[:, :crop, :crop])[None]
     n_sample = len(window_grid(crop, crop, (roi, roi), overlap))
     n_full = len(window_grid(size, size, (roi, roi), overlap))
+    t_reps = []
     with torch.no_grad():
         sliding_window_inference_ref(img[:, :, :roi, :roi], (roi, roi), 4, net, overlap)          # warm up
-        t0 = time.perf_counter()
-        logits = sliding_window_inference_ref(img, (roi, roi), 4, net, overlap)
-        t_net = time.perf_counter() - t0
+        while sum(t_reps) < 3.0 or len(t_reps) < 3:                                               # >= 3 s of windows, >= 3 repeats
+            t0 = time.perf_counter()
+            logits = sliding_window_inference_ref(img, (roi, roi), 4, net, overlap)
+            t_reps.append(time.perf_counter() - t0)
+            if len(t_reps) >= 12:
+                break
+    t_net = sorted(t_reps)[len(t_reps) // 2]                                                      # median repeat
     prob = softmax_interior_ref(logits[0].numpy())
     reps = int(np.ceil(size / crop))
     prob_full = np.tile(prob, (reps, reps))[:size, :size]                                       # full-size CC input
@@ -143,9 +149,12 @@ def cpu_baseline(size, roi, overlap, channels, seed):
     t_cc = time.perf_counter() - t0
     t_sk = skimage_chain_seconds((prob_full > 0.5).astype(np.uint8))
     t_full = t_net * n_full / n_sample + t_cc
+    spread = [round(size * size / 1e6 / (t * n_full / n_sample + t_cc), 4) for t in (max(t_reps), min(t_reps))]
     out = {"value": round(size * size / 1e6 / t_full, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-           "sample": f"torch-CPU oracle on {n_sample} of {n_full} windows ({crop}x{crop} crop, {t_net:.2f}s, {threads} threads) "
-                     f"scaled to the slide + plain-C CC oracle on a full {size}x{size} mask ({t_cc:.2f}s, 1 thread)"}
+           "value_spread": spread,
+           "sample": f"torch-CPU oracle on {n_sample} of {n_full} windows ({crop}x{crop} crop), {len(t_reps)} repeats = {sum(t_reps):.2f}s, median "
+                     f"{t_net:.2f}s (value_spread = slowest / fastest repeat), {threads} threads, scaled to the slide + plain-C CC oracle on a "
+                     f"full {size}x{size} mask ({t_cc:.2f}s, 1 thread)"}
     if t_sk is not None:
         out["value_skimage_chain"] = round(size * size / 1e6 / (t_net * n_full / n_sample + t_sk), 4)
         out["skimage_chain_s"] = round(t_sk, 3)
@@ -156,9 +165,12 @@ def cpu_baseline(size, roi, overlap, channels, seed):
 # ----------------------------------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` without a torchrun environment starts the N ranks itself
 # ----------------------------------------------------------------------------------------------------------------------
-def launch_ranks(n: int) -> int:
+def launch_ranks(n: int, script: str = None, argv=None) -> int:
     """Start n children (one per GPU) running this same script; the parent never initialises the GPU
-    (torch.cuda.device_count() does not, on this image) and never re-execs itself."""
+    (torch.cuda.device_count() does not, on this image) and never re-execs itself.  All children are polled: when any of them
+    exits non-zero the others are terminated within seconds (a rank that died at start-up would otherwise leave the rest in
+    dist.barrier() until the collective timeout) and every rank's stderr tail is forwarded."""
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -167,21 +179,51 @@ def launch_ranks(n: int) -> int:
         print(f"bench.py: --gpus {n} but only {n_dev} HIP device(s) visible "
               "(BENCH_DEVICE=0 BENCH_BACKEND=gloo shares one GPU between the ranks for a functional check)", file=sys.stderr)
         return 2
-    procs = []
+    procs, logs = [], []
+    out0 = tempfile.TemporaryFile("w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out0:
-        sys.stdout.write(out0)
+        logs.append(tempfile.TemporaryFile("w+"))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv), env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=logs[r], text=True))
+    codes = [None] * n
+    failed_first = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed_first is None:
+                    failed_first = r
+        if failed_first is not None:
+            deadline = time.time() + 5.0
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()                      # exact children of this process, by handle
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    text0 = out0.read()
+    if text0:
+        sys.stdout.write(text0)
         sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    for r, log in enumerate(logs):
+        log.seek(0)
+        tail = log.read()[-(4000 if bad else 1500):]
+        if tail.strip():
+            print(f"---- rank {r} stderr (tail) ----\n{tail}", file=sys.stderr)
     if bad:
-        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+        print(f"bench.py: ranks failed (rank, exit code): {bad}; first failure: rank {failed_first}; the other ranks were terminated",
+              file=sys.stderr)
         return 1
     return 0
 
@@ -206,6 +248,8 @@ def main():
                     help="headline multi-GPU partition: one slide per rank (weak scaling, no collective) or ONE slide cut into row "
                          "strips with an all-gather of the uint8 mask strips before the connected-component pass (strong scaling); "
                          "the other partition is reported as a secondary object")
+    ap.add_argument("--strip-batch", type=int, default=64, help="engine batch of the strips leg (a rank holds ~1/N of the windows; smaller "
+                                                                "chunks keep both internal streams busy)")
     ap.add_argument("--train-batch", type=int, default=32, help="tiles per GPU of the training step (BASELINE configs[1]/[3]: 32)")
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--cc-stream", type=int, default=1, help="1: the connected-component pass of slide k runs on its own stream beside "
@@ -229,9 +273,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: initialise the process group at world size 1 too, so that the RCCL calls of the data path (flat-bucket
+    # all-reduce, mask all-gather) really execute on a one-GPU box
+    force_dist = os.environ.get("BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # the line contract is ONE JSON line on stdout: whatever the collective library prints while it connects (gloo announces its
         # peers on stdout) goes to stderr
         sys.stdout.flush()
@@ -273,24 +326,30 @@ def main():
     # ------------------------------------------------------------------------------------------------------------------
     images = {}
 
-    def slide(strips):
-        """strips: every rank holds the SAME slide; slides: every rank its own."""
-        key = seed if strips else seed + rank
-        if key not in images:
-            images[key] = torch.from_numpy(synthetic_wsi(args.size, key)).to(dev)      # resident in HBM before timing
-        return images[key]
+    def slide_pair(strips):
+        """Two DIFFERENT slides per leg, alternating step by step (strips: every rank holds the SAME pair; slides: every rank its own)."""
+        keys = (seed, seed + 1000) if strips else (seed + rank, seed + 1000 + rank)
+        for key in keys:
+            if key not in images:
+                images[key] = torch.from_numpy(synthetic_wsi(args.size, key)).to(dev)      # resident in HBM before timing
+        return [images[k] for k in keys]
 
-    def make_step(model, strips, d2h, cc_overlap=True):
-        image = slide(strips)
-        row_lo, row_hi = ca.rank_rows(args.size, rank, world) if strips else (0, args.size)
+    strip_parts = [ca.strip_partition(plan, r, world) for r in range(world)]
+    strip_rows_all = [(st.row_begin, st.row_end) for st in strip_parts]
 
-        def step_slide():
+    def seam_exchange(win, pl, r, w):
+        return parallel.exchange_seam(win, pl, r, w)
+
+    def make_step(model, strips, d2h, cc_overlap=True, sim=None):
+        imgs = slide_pair(strips)
+        it = [0]
+        pipelined = bool(args.cc_stream) and cc_overlap
+
+        def labelled(mask):
             """The connected-component pass of slide k runs on its own stream (ordered after the slide's mask by an event), so its
             latency-bound kernels execute beside the convolutions of slide k + 1 - the same software pipeline the label copy
             already is part of.  Every timed slide is complete when the timed region ends (torch.cuda.synchronize())."""
-            _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch, want_logits=False,
-                                            want_mask=True, streams=args.streams)
-            if args.cc_stream == 0 or not cc_overlap:
+            if not pipelined:
                 return ca.mask_to_instances(mask, return_num=True)
             mask_ready.record()
             cc_stream.wait_event(mask_ready)
@@ -299,19 +358,44 @@ def main():
             mask.record_stream(cc_stream)
             return lab, num
 
-        def step_strips():
-            """One slide across ranks: every rank runs the windows that touch its row strip, finalises its rows, the uint8 mask
-            strips are all-gathered (RCCL), and every rank labels the full mask (2.1 MB per rank at 4096^2)."""
-            _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch, rows=(row_lo, row_hi),
-                                            want_logits=False, want_mask=True, streams=args.streams)
-            strip = mask[row_lo:row_hi]
-            if backend != "nccl":
-                full = parallel.gather_row_strips(strip.cpu(), args.size).to(dev)
-            else:
-                full = parallel.gather_row_strips(strip, args.size)
-            return ca.mask_to_instances(full, return_num=True)
+        def step_slide():
+            image = imgs[it[0] % 2]
+            it[0] += 1
+            _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch, want_logits=False,
+                                            want_mask=True, streams=args.streams)
+            return labelled(mask)
 
-        inner = step_strips if (strips and world > 1) else step_slide
+        def step_strips():
+            """One slide across ranks, split by WINDOW rows (31 rows over 8 ranks = 4,4,4,4,4,4,4,3; no window evaluated twice): every
+            rank runs its windows, the seam halves go to the neighbour below (RCCL send/recv), every rank finalises its rows, the uint8
+            mask strips are all-gathered (RCCL) and every rank labels the full mask on the CC stream beside its next slide."""
+            image = imgs[it[0] % 2]
+            it[0] += 1
+            st, _, _, mask = ca.swi_infer_strip(model, image, roi, args.overlap, rank, world, engine_batch=args.strip_batch,
+                                                streams=args.streams, exchange=seam_exchange)
+            full = parallel.gather_row_strips(mask[st.row_begin:st.row_end], args.size, rows=strip_rows_all)
+            return labelled(full)
+
+        def step_sim():
+            """ONE GPU doing the work of rank sim[0] of sim[1] of the strips leg: its windows, the local pack / unpack copies of the
+            seam exchange (the link transfer itself, 12 MB over one xGMI link, is not simulated), the finalize of its rows, and the
+            connected-component pass over a FULL mask (sim[2], from the single-GPU leg) on the CC stream."""
+            image = imgs[it[0] % 2]
+            it[0] += 1
+            r, w, full_mask = sim
+
+            def fake_exchange(win, pl, rr, ww):
+                me = ca.strip_partition(pl, rr, ww)
+                for src, dst, j, r0 in parallel.seam_transfers(pl, ww):
+                    if dst == rr:
+                        win[j - me.halo_begin, :, r0:].copy_(win[me.win_row_end - 1 - me.halo_begin, :, r0:].contiguous())
+                    elif src == rr:
+                        win[j - me.halo_begin, :, r0:].contiguous()
+            ca.swi_infer_strip(model, image, roi, args.overlap, r, w, engine_batch=args.strip_batch, streams=args.streams,
+                               exchange=fake_exchange)
+            return labelled(full_mask)
+
+        inner = step_sim if sim else (step_strips if (strips and dist is not None) else step_slide)
         if not d2h:
             return inner
 
@@ -320,7 +404,7 @@ def main():
             overlaps the inference of slide k + 1 - what the predict CLI does with its writer thread.  Every timed step's labels
             are on the host when the timed region ends (torch.cuda.synchronize() drains both streams)."""
             lab, num = inner()
-            done.record(cc_stream if (inner is step_slide and args.cc_stream and cc_overlap) else None)
+            done.record(cc_stream if pipelined else None)
             copy_stream.wait_event(done)
             with torch.cuda.stream(copy_stream):
                 host.copy_(lab, non_blocking=True)
@@ -328,8 +412,9 @@ def main():
             return lab, num
         return step_d2h
 
-    def measure_infer(width, precision, strips, with_prof):
-        """-> dict(dt (labels on host), dt_dev (labels in HBM), prof, ...): K timed steps each, max over ranks."""
+    def measure_infer(width, precision, strips, with_prof, extras=False):
+        """-> dict(dt (labels on host), dt_dev (labels in HBM), prof, ...): K timed steps each, max over ranks.
+        extras (rank 0's primary leg): per-image latency, the reference's timer scope, the strips-leg simulation."""
         model = make_model(WIDTHS[width], seed).to(dev)
         model.precision = precision
         step_host, step_dev = make_step(model, strips, True), make_step(model, strips, False)
@@ -348,10 +433,79 @@ def main():
                 dt_prof, _ = time_steps(step_prof, args.steps, barrier)
                 _lib.lib.cs_prof_enable(0)
                 res["prof"] = _lib.prof_collect()
+            if extras:
+                res["latency"] = measure_latency(model)
+                res["incl_tiff"] = measure_reference_scope(model)
+                if world == 1 and dist is None:
+                    res["strips_sim"] = measure_strips_sim(model, dt_dev / args.steps)
         dt, dt_dev, dt_prof = max_over_ranks([dt, dt_dev, dt_prof])
         res.update(dt=dt, dt_dev=dt_dev, dt_prof=dt_prof, n_instances=int(num.item()),
                    fg_frac=float((labels > 0).float().mean().item()), labels=labels)
         return res
+
+    def measure_latency(model, reps=6):
+        """per-image latency = image tensor resident in HBM -> int32 label map on the host, ONE slide at a time,
+        synchronised on both sides, no overlap with a neighbour slide (the two slides alternate)."""
+        imgs = slide_pair(False)
+        ms = []
+        for i in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, _, mask = ca.swi_infer_image(model, imgs[i % 2], roi, args.overlap, engine_batch=args.engine_batch, want_logits=False,
+                                            want_mask=True, streams=args.streams)
+            lab = ca.mask_to_instances(mask)
+            host.copy_(lab, non_blocking=True)
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        ms = sorted(ms[1:])
+        return {"latency_ms": round(ms[len(ms) // 2], 3), "min_ms": round(ms[0], 3), "max_ms": round(ms[-1], 3), "reps": reps}
+
+    def measure_reference_scope(model, reps=3):
+        """The reference's own timer scope (baseline/predict.py:106-116), one image at a time as its loop does: the uint8 HWC image on
+        the host -> `/ max`, float tensor on the device -> sliding-window inference -> softmax / threshold / post-process -> labels
+        on the host -> `<name>_label.tiff` (int32, deflate) written to disk."""
+        import tempfile
+        from cellseg_amd.preprocess import write_label_tiff
+        imgs = slide_pair(False)
+        pre = [(im.permute(1, 2, 0) * 255).round().to(torch.uint8).cpu().pin_memory() for im in imgs]      # pre_img_data, uint8 HWC
+        ms = []
+        with tempfile.TemporaryDirectory() as td:
+            for i in range(reps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                u8 = pre[i % 2].to(dev, non_blocking=True)
+                x = (u8.float() / u8.max()).permute(2, 0, 1)                   # [3,H,W] view of the HWC tensor, read in place
+                _, _, mask = ca.swi_infer_image(model, x, roi, args.overlap, engine_batch=args.engine_batch, want_logits=False,
+                                                want_mask=True, streams=args.streams)
+                lab = ca.mask_to_instances(mask)
+                host.copy_(lab, non_blocking=True)
+                torch.cuda.synchronize()
+                write_label_tiff(os.path.join(td, f"slide{i}_label.tiff"), host.numpy())
+                ms.append((time.perf_counter() - t0) * 1e3)
+        ms = sorted(ms[1:])
+        med = ms[len(ms) // 2]
+        return {"value_incl_tiff": round(mpix / med * 1e3, 3), "ms_per_image": round(med, 3), "min_ms": round(ms[0], 3), "max_ms": round(ms[-1], 3),
+                "scope": "baseline/predict.py:106-116: uint8 HWC image on the host -> /max -> device -> sliding-window inference -> softmax, "
+                         "threshold, post-process -> labels on the host -> int32 deflate TIFF on disk (strip-parallel writer), one image at a time"}
+
+    def measure_strips_sim(model, full_s, sim_rank=3, sim_world=8):
+        """How long ONE rank of the 8-GPU strips leg works per slide, measured on this GPU (see step_sim)."""
+        _, _, full_mask = ca.swi_infer_image(model, slide_pair(True)[0], roi, args.overlap, engine_batch=args.engine_batch,
+                                             want_logits=False, want_mask=True, streams=args.streams)
+        step = make_step(model, True, False, sim=(sim_rank, sim_world, full_mask))
+        for _ in range(2):
+            step()
+        dt_sim, _ = time_steps(step, args.steps, barrier)
+        st = ca.strip_partition(plan, sim_rank, sim_world)
+        most = max(p.win_row_end - p.win_row_begin for p in (ca.strip_partition(plan, r, sim_world) for r in range(sim_world)))
+        return {"rank": sim_rank, "of": sim_world, "windows": (st.win_row_end - st.win_row_begin) * plan.n_w,
+                "max_windows_per_rank": most * plan.n_w, "window_rows_per_rank": [p.win_row_end - p.win_row_begin for p in
+                                                                               (ca.strip_partition(plan, r, sim_world) for r in range(sim_world))],
+                "ms_per_slide": round(dt_sim / args.steps * 1e3, 3), "full_slide_ms": round(full_s * 1e3, 3),
+                "ratio": round(full_s / (dt_sim / args.steps), 3),
+                "note": "one GPU doing rank 3's share of the 8-rank strips leg (its windows, the seam pack / unpack copies, its finalize, the "
+                        "CC pass over a full mask on the CC stream); the seam transfer (12 MB over one xGMI link) and the 2 MB-per-rank mask "
+                        "all-gather are not included"}
 
     def infer_summary(res, strips):
         slides = 1 if strips else world
@@ -378,7 +532,7 @@ def main():
             opt.zero_grad(set_to_none=True)
             loss = loss_fn(model(x), onehot)
             loss.backward()
-            if world > 1:
+            if dist is not None:                              # also at world size 1 under BENCH_FORCE_DIST: the RCCL all-reduce really runs
                 ev[0].record()
                 parallel.sync_gradients(model)
                 ev[1].record()
@@ -390,7 +544,7 @@ def main():
         k = args.train_steps
         dt, loss = time_steps(step, k, barrier)
         allreduce_ms = None
-        if world > 1:
+        if dist is not None:
             torch.cuda.synchronize()
             allreduce_ms = round(ev[0].elapsed_time(ev[1]), 4)   # the last step's exchange (events on the launch stream)
         prof = {}
@@ -418,25 +572,28 @@ def main():
         return out
 
     # ------------------------------------------------------------------------------------------------------------------
-    head_strips = args.shard == "strips" and world > 1
+    head_strips = args.shard == "strips" and dist is not None
     main_res = sec_res = None
     modes, other_part, train_res = {}, None, None
+    strips_equal = None
     if args.mode == "infer":
-        main_res = measure_infer(args.width, args.precision, head_strips, True)
+        main_res = measure_infer(args.width, args.precision, head_strips, True, extras=not args.no_secondary and rank == 0)
         if not args.no_secondary:
-            if world > 1:
+            if dist is not None:
                 other = measure_infer(args.width, args.precision, not head_strips, False)
                 other_part = infer_summary(other, not head_strips)
-            if world == 1 and args.width != "reference16":
+                # rank 0's slides-leg slide pair is the strips leg's pair: the two partitions must produce the same label map
+                strips_equal = bool(torch.equal(other["labels"], main_res["labels"])) if rank == 0 else None
+            if world == 1 and dist is None and args.width != "reference16":
                 sec_res = measure_infer("reference16", args.precision, False, True)
-            if world == 1 and args.precision == "fp32":
+            if world == 1 and dist is None and args.precision == "fp32":
                 for prec in ("fp16x3", "bf16x6", "bf16", "fp8"):
                     r = measure_infer(args.width, prec, False, False)
                     modes[prec] = dict(infer_summary(r, False), foreground_agreement_vs_primary=round(
                         float(((r["labels"] > 0) == (main_res["labels"] > 0)).float().mean().item()), 6))
             tw = args.width if args.width in WINDOW_GFLOP and args.roi == 256 else "baseline32"
             train_res = measure_train(tw)
-            if world == 1:                                        # configs[1]: the same step with the forward convolutions on the bf16 pipe
+            if world == 1 and dist is None:                      # configs[1]: the same step with the forward convolutions on the bf16 pipe
                 t16 = measure_train(tw, with_prof=False, precision="bf16")
                 train_res["bf16_forward"] = {k: t16[k] for k in ("images_per_s", "ms_per_step", "loss", "dtype")}
     else:
@@ -495,7 +652,7 @@ def main():
         out = {
             "metric": "images/s data-parallel training step (3x256x256 tiles, batch 32 per GPU)",
             "value": train_res["images_per_s"], "unit": "images/s",
-            "n_gpus": world, "rccl_ranks": rccl_ranks, "collective_backend": backend if world > 1 else None,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "collective_backend": backend if dist else None,
             "steps": args.train_steps, "warmup": max(args.warmup, 2), "ms_per_step": train_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"training step on {args.train_batch}x3x256x256 synthetic tiles per GPU, 3-class residual U-Net channels="
@@ -515,7 +672,7 @@ def main():
         "metric": "Mpixels/s sliding-window inference (4096^2 WSI) incl. GPU connected components, label map on host",
         "value": round(slides * mpix * args.steps / main_res["dt"], 3),
         "unit": "Mpixels/s",
-        "n_gpus": world, "rccl_ranks": rccl_ranks, "collective_backend": backend if world > 1 else None,
+        "n_gpus": world, "rccl_ranks": rccl_ranks, "collective_backend": backend if dist else None,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "strong" if head_strips else "weak", "vs_baseline": None,
@@ -526,7 +683,8 @@ def main():
                                f"remove_small_objects(16) + 8-conn label on GPU, int32 labels copied to pinned host memory; "
                                + ("one slide cut into row strips" if head_strips else "one slide per GPU"),
                    "windows": n_windows, "engine_batch": args.engine_batch, "streams": args.streams, "precision": args.precision,
-                   "parallelism": (f"1 slide in {world} row strips + mask all-gather" if head_strips else f"slides x{world}"),
+                   "parallelism": (f"1 slide split by window rows over {world} ranks + seam send/recv + mask all-gather" if head_strips
+                                   else f"slides x{world}"),
                    "instances_found": main_res["n_instances"], "foreground_fraction": round(main_res["fg_frac"], 4)},
         "value_device": round(slides * mpix * args.steps / main_res["dt_dev"], 3),
         "value_device_note": "same loop ending when the int32 label map is complete in HBM (no copy to the host)",
@@ -534,11 +692,29 @@ def main():
         "roofline": roofline(main_res),
         "kernels": kernel_table(main_res),
     }
+    strips_info = {"window_rows_per_rank": [st.win_row_end - st.win_row_begin for st in strip_parts],
+                   "windows_per_rank": [(st.win_row_end - st.win_row_begin) * plan.n_w for st in strip_parts],
+                   "output_rows_per_rank": [st.row_end - st.row_begin for st in strip_parts], "strip_batch": args.strip_batch,
+                   "equal_to_single_gpu_labels": strips_equal}
     if other_part:
         out["strips" if not head_strips else "slides"] = dict(
             other_part, scaling="strong" if not head_strips else "weak",
-            note=("ONE slide cut into row strips across the ranks, uint8 mask strips all-gathered before CC: value = one slide's pixels / time"
+            note=("ONE slide split by window rows across the ranks (no window evaluated twice), seam halves sent to the neighbour below, "
+                  "uint8 mask strips all-gathered, CC on every rank on its CC stream: value = one slide's pixels / time"
                   if not head_strips else "one slide per rank, no collective: value = N slides' pixels / time"))
+        out["strips" if not head_strips else "slides"].update(strips_info if not head_strips else {})
+        out["value_slides"] = out["value"] if not head_strips else other_part["value"]
+        out["value_strips"] = other_part["value"] if not head_strips else out["value"]
+        if head_strips:
+            out["config"].update(strips_info)
+    if main_res.get("latency"):
+        out.update(latency_ms=main_res["latency"]["latency_ms"], latency=dict(
+            main_res["latency"], note="one slide at a time: image tensor resident in HBM -> int32 labels in pinned host memory, synchronised "
+                                      "on both sides, no overlap with a neighbour slide (SURVEY 8(d) per-image latency)"))
+    if main_res.get("incl_tiff"):
+        out.update(value_incl_tiff=main_res["incl_tiff"]["value_incl_tiff"], reference_timer_scope=main_res["incl_tiff"])
+    if main_res.get("strips_sim"):
+        out["strips_sim"] = main_res["strips_sim"]
     if sec_res:
         out["reference_width"] = dict(infer_summary(sec_res, False), channels=list(WIDTHS["reference16"]), roofline=roofline(sec_res))
     if modes:

@@ -157,6 +157,31 @@ int cs_swi_infer(cs_unet* net, const cs_swi_plan* plan_host, const float* image,
                  float* logits_nchw, float* prob1, uint8_t* mask,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Window pass alone (the first half of cs_swi_infer): runs every window of window rows [win_row_begin, win_row_end) through the
+ * network and writes their logits to win_logits[(ih - win_row_begin) * n_w + iw][roi_h][roi_w][out_channels] fp32 - the layout
+ * cs_swi_finalize reads with ih_base = win_row_begin.  workspace: cs_swi_windows_workspace_bytes (activations + window origins,
+ * no window-logit buffer).  Together with cs_swi_partition and cs_swi_finalize this is the multi-GPU split of ONE image by WINDOW
+ * rows ("split the window list evenly and exchange seam partial sums with one neighbour send/recv"): a rank runs its
+ * own window rows, receives from the rank above the lower part of that rank's last window row(s) into the slots in front of
+ * its own, and finalises its output rows - no window is evaluated twice.  The reference is single-device
+ * (baseline/predict.py:109 calls sliding_window_inference on the whole image). */
+size_t cs_swi_windows_workspace_bytes(const cs_unet* net, const cs_swi_plan* plan_host, int engine_batch);
+int cs_swi_windows(cs_unet* net, const cs_swi_plan* plan_host, const float* image, int64_t sc, int64_t sh, int64_t sw,
+                   int engine_batch, int win_row_begin, int win_row_end, float* win_logits,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* Window-row partition of one image over `world` ranks (shares differ by at most one window row):
+ *   [win_row_begin, win_row_end)  window rows rank `rank` evaluates
+ *   [row_begin, row_end)          output rows it finalises: from the first image row of its first window row to the first image row
+ *                                 of the next rank's first window row (rank 0 starts at 0, the last rank ends at img_h)
+ *   [halo_begin, win_row_begin)   window rows of EARLIER ranks that still cover row_begin (one row for overlap <= 0.5, two next to a
+ *                                 clamped last window): their window-local rows >= row_begin + pad_top - start(ih) are needed */
+typedef struct cs_swi_strip {
+    int win_row_begin, win_row_end;
+    int halo_begin;
+    int row_begin, row_end;
+} cs_swi_strip;
+int cs_swi_partition(const cs_swi_plan* plan_host, int rank, int world, cs_swi_strip* out_host);
+
 /* Finalize step alone (average overlapping windows in window-index order, softmax, threshold) for window
  * predictions produced by any predictor: win_logits [(#window rows from ih_base) * n_w][roi_h][roi_w][classes]. */
 int cs_swi_finalize(const cs_swi_plan* plan_host, const float* win_logits, int classes, int ih_base,

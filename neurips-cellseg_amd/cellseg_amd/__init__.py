@@ -10,11 +10,12 @@ All arithmetic runs in libcellseg_hip.so; importing this package without the bui
 """
 from ._lib import CellSegHipError, LIB_PATH, lib  # noqa: F401
 from .unet import UNet  # noqa: F401
-from .inferers import make_plan, rank_rows, sliding_window_inference, swi_infer_image, window_starts  # noqa: F401
+from .inferers import (make_plan, rank_rows, sliding_window_inference, strip_partition, swi_infer_image, swi_infer_strip,  # noqa: F401
+                       window_starts)
 from .postprocess import create_interior_map, label, mask_to_instances, prob_to_instances  # noqa: F401
 from .losses import DiceCELoss, one_hot  # noqa: F401
 from .optim import AdamW  # noqa: F401
 from . import metrics, parallel  # noqa: F401
 
-__all__ = ["UNet", "sliding_window_inference", "swi_infer_image", "make_plan", "window_starts", "rank_rows",
+__all__ = ["UNet", "sliding_window_inference", "swi_infer_image", "make_plan", "window_starts", "rank_rows", "strip_partition", "swi_infer_strip",
            "label", "mask_to_instances", "prob_to_instances", "create_interior_map", "DiceCELoss", "one_hot", "AdamW", "CellSegHipError", "lib", "LIB_PATH"]

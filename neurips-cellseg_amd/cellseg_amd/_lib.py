@@ -21,6 +21,11 @@ class CellSegHipError(RuntimeError):
     pass
 
 
+class SwiStrip(C.Structure):
+    """Mirror of ``cs_swi_strip`` (window-row partition of one image over ranks)."""
+    _fields_ = [(n, C.c_int) for n in ("win_row_begin", "win_row_end", "halo_begin", "row_begin", "row_end")]
+
+
 class SwiPlan(C.Structure):
     """Mirror of ``cs_swi_plan``."""
     _fields_ = [(n, C.c_int) for n in ("img_h", "img_w", "roi_h", "roi_w", "pad_top", "pad_left", "pad_h", "pad_w",
@@ -59,6 +64,9 @@ def _load() -> C.CDLL:
         "cs_swi_make_plan": (i32, [i32, i32, i32, i32, f64, C.POINTER(SwiPlan)]),
         "cs_swi_window_start": (i32, [i32, i32, i32, i32]),
         "cs_swi_workspace_bytes": (sz, [vp, C.POINTER(SwiPlan), i32]),
+        "cs_swi_windows_workspace_bytes": (sz, [vp, C.POINTER(SwiPlan), i32]),
+        "cs_swi_windows": (i32, [vp, C.POINTER(SwiPlan), vp, i64, i64, i64, i32, i32, i32, vp, vp, sz, vp]),
+        "cs_swi_partition": (i32, [C.POINTER(SwiPlan), i32, i32, C.POINTER(SwiStrip)]),
         "cs_swi_infer": (i32, [vp, C.POINTER(SwiPlan), vp, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
         "cs_swi_finalize": (i32, [C.POINTER(SwiPlan), vp, i32, i32, i32, i32, vp, vp, vp, vp]),
         "cs_normalize_workspace_bytes": (sz, [i32, i32]),
@@ -91,7 +99,7 @@ lib = _load()
 EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_destroy cs_unet_set_precision cs_unet_set_training cs_unet_set_batch_stats cs_unet_read_param cs_unet_set_streams cs_unet_num_params "
             "cs_unet_param_info cs_unet_load_param cs_unet_load_begin cs_unet_load_end cs_unet_workspace_bytes cs_unet_forward cs_unet_grad_numel "
             "cs_unet_grad_offset cs_unet_backward_workspace_bytes cs_unet_backward cs_swi_make_plan "
-            "cs_swi_window_start cs_swi_workspace_bytes cs_swi_infer cs_swi_finalize cs_normalize_workspace_bytes "
+            "cs_swi_window_start cs_swi_workspace_bytes cs_swi_windows_workspace_bytes cs_swi_windows cs_swi_partition cs_swi_infer cs_swi_finalize cs_normalize_workspace_bytes "
             "cs_normalize_image cs_label_max cs_label_overlap cs_remove_boundary_workspace_bytes cs_remove_boundary_cells "
             "cs_ccl_workspace_bytes "
             "cs_ccl_postprocess cs_ccl_label cs_interior_map cs_dice_ce_workspace_bytes cs_dice_ce_forward cs_dice_ce_backward cs_adamw_step "

@@ -18,7 +18,7 @@ from typing import Callable, Optional, Sequence, Tuple, Union
 import torch
 
 from . import _lib
-from ._lib import SwiPlan, check, lib
+from ._lib import SwiPlan, SwiStrip, check, lib
 from .unet import UNet
 
 DEFAULT_ENGINE_BATCH = 256
@@ -45,12 +45,21 @@ def rank_rows(img_h: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def strip_partition(plan: SwiPlan, rank: int, world: int) -> SwiStrip:
+    """Window-row partition of one image (``cs_swi_partition``): the window rows `rank` evaluates, the output rows it finalises
+    and the earlier ranks' window rows (the halo) whose lower part still covers them.  Shares differ by at most one window row:
+    31 rows over 8 ranks = 4,4,4,4,4,4,4,3 - no window is evaluated twice (``rank_rows`` strips duplicate one per seam)."""
+    st = SwiStrip()
+    check(lib.cs_swi_partition(C.byref(plan), int(rank), int(world), C.byref(st)), "cs_swi_partition")
+    return st
+
+
 WORKSPACE_BUDGET = 64 << 30     # bytes of HBM the tiler may take for window activations (of 288 GB)
 
 
 def _held_bytes(model: UNet) -> int:
     """Workspace bytes the model already holds for the tiler (they are free for re-use by the next call)."""
-    return sum(v.numel() for k, v in getattr(model, "_ws", {}).items() if k and k[0] == "swi")
+    return sum(v.numel() for k, v in getattr(model, "_ws", {}).items() if k and k[0] in ("swi", "swistrip", "swiwin"))
 
 
 def swi_infer_image(model: UNet, image: torch.Tensor, roi_size, overlap: float = 0.25, *, engine_batch: int = DEFAULT_ENGINE_BATCH,
@@ -68,15 +77,9 @@ def swi_infer_image(model: UNet, image: torch.Tensor, roi_size, overlap: float =
     dev = image.device
     with torch.cuda.device(dev):
         check(lib.cs_unet_set_streams(eng.handle, int(streams)), "cs_unet_set_streams")
-        nbytes = lib.cs_swi_workspace_bytes(eng.handle, C.byref(plan), int(engine_batch))
         # the activation workspace scales with engine_batch x streams x window area x width: stay inside a memory budget
         # (wide nets on 512^2 windows would otherwise ask for > 100 GB at the default batch of 256 windows)
-        budget = min(WORKSPACE_BUDGET, int(0.6 * torch.cuda.mem_get_info(dev)[0]) + _held_bytes(model))
-        while nbytes > budget and engine_batch > 4:
-            engine_batch = max(4, int(engine_batch) // 2)
-            nbytes = lib.cs_swi_workspace_bytes(eng.handle, C.byref(plan), int(engine_batch))
-        if nbytes == 0:
-            raise _lib.CellSegHipError(f"cs_swi_workspace_bytes: {lib.cs_last_error().decode()}")
+        engine_batch, nbytes = _capped_batch(model, eng, plan, engine_batch, dev, lib.cs_swi_workspace_bytes)
         ws = model.workspace(("swi", h, w, plan.roi_h, plan.roi_w, plan.n_h, plan.n_w, int(engine_batch), int(streams)), nbytes, dev)
         logits = torch.empty((model.out_channels, h, w), dtype=torch.float32, device=dev) if want_logits else None
         prob = torch.empty((h, w), dtype=torch.float32, device=dev) if want_prob else None
@@ -87,6 +90,69 @@ def swi_infer_image(model: UNet, image: torch.Tensor, roi_size, overlap: float =
         check(lib.cs_swi_infer(eng.handle, C.byref(plan), ptr(image), sc, sh, sw, int(engine_batch), int(r0), int(r1),
                                ptr(logits), ptr(prob), ptr(mask), ptr(ws), ws.numel(), _lib.stream_ptr()), "cs_swi_infer")
     return logits, prob, mask
+
+
+def _capped_batch(model: UNet, eng, plan: SwiPlan, engine_batch: int, dev, size_fn) -> Tuple[int, int]:
+    """Largest engine batch (halving from the request) whose workspace stays inside the memory budget -> (batch, bytes)."""
+    nbytes = size_fn(eng.handle, C.byref(plan), int(engine_batch))
+    budget = min(WORKSPACE_BUDGET, int(0.6 * torch.cuda.mem_get_info(dev)[0]) + _held_bytes(model))
+    while nbytes > budget and engine_batch > 4:
+        engine_batch = max(4, int(engine_batch) // 2)
+        nbytes = size_fn(eng.handle, C.byref(plan), int(engine_batch))
+    if nbytes == 0:
+        raise _lib.CellSegHipError(f"swi workspace: {lib.cs_last_error().decode()}")
+    return int(engine_batch), int(nbytes)
+
+
+def swi_infer_strip(model: UNet, image: torch.Tensor, roi_size, overlap: float, rank: int, world: int, *,
+                    engine_batch: int = DEFAULT_ENGINE_BATCH, streams: int = DEFAULT_STREAMS, exchange=None,
+                    want_logits: bool = False, want_prob: bool = False, want_mask: bool = True):
+    """ONE image split over `world` ranks by WINDOW rows (multi-GPU tiled inference; the reference is single-device,
+    baseline/predict.py:109).  This rank evaluates its own window rows (``cs_swi_windows``), obtains the lower part of the earlier
+    ranks' window rows that still cover its first output rows (the halo) through ``exchange(win, plan, rank, world)`` -
+    ``parallel.exchange_seam`` under torch.distributed; ``None`` evaluates the halo rows locally (single process) - and finalises
+    its output rows (``cs_swi_finalize``).  Because the reference adds window predictions in window-index order, the halo rows are
+    exactly the prefix of every seam pixel's sum: the result is bit-identical to the single-GPU one.
+    -> (strip, logits | None, prob1 | None, mask | None); only rows [strip.row_begin, strip.row_end) of the outputs are written."""
+    _lib.require_gpu(image)
+    if image.dim() != 3:
+        raise ValueError("image must be [C,H,W]")
+    if image.dtype != torch.float32:
+        image = image.float()
+    _, h, w = image.shape
+    plan = make_plan(h, w, roi_size, overlap)
+    st = strip_partition(plan, rank, world)
+    eng = model.engine()
+    dev = image.device
+    logits = torch.empty((model.out_channels, h, w), dtype=torch.float32, device=dev) if want_logits else None
+    prob = torch.empty((h, w), dtype=torch.float32, device=dev) if want_prob else None
+    mask = torch.empty((h, w), dtype=torch.uint8, device=dev) if want_mask else None
+    if st.win_row_end == st.win_row_begin:
+        return st, logits, prob, mask
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()   # noqa: E731
+    with torch.cuda.device(dev):
+        check(lib.cs_unet_set_streams(eng.handle, int(streams)), "cs_unet_set_streams")
+        engine_batch, nbytes = _capped_batch(model, eng, plan, engine_batch, dev, lib.cs_swi_windows_workspace_bytes)
+        ws = model.workspace(("swistrip", h, w, plan.roi_h, plan.roi_w, plan.n_h, plan.n_w, engine_batch, int(streams)), nbytes, dev)
+        n_rows = st.win_row_end - st.halo_begin
+        win_bytes = n_rows * plan.n_w * plan.roi_h * plan.roi_w * model.out_channels * 4
+        win = model.workspace(("swiwin", n_rows, plan.n_w, plan.roi_h, plan.roi_w), win_bytes, dev)[:win_bytes]
+        win = win.view(torch.float32).view(n_rows, plan.n_w, plan.roi_h, plan.roi_w, model.out_channels)
+        sc, sh, sw = image.stride()
+        halo = st.win_row_begin - st.halo_begin
+
+        def run(row_lo, row_hi):
+            check(lib.cs_swi_windows(eng.handle, C.byref(plan), ptr(image), sc, sh, sw, engine_batch, int(row_lo), int(row_hi),
+                                     ptr(win[row_lo - st.halo_begin]), ptr(ws), ws.numel(), _lib.stream_ptr()), "cs_swi_windows")
+
+        run(st.win_row_begin, st.win_row_end)
+        if exchange is not None:
+            exchange(win, plan, rank, world)
+        elif halo:
+            run(st.halo_begin, st.win_row_begin)
+        check(lib.cs_swi_finalize(C.byref(plan), ptr(win), model.out_channels, st.halo_begin, st.row_begin, st.row_end,
+                                  ptr(logits), ptr(prob), ptr(mask), _lib.stream_ptr()), "cs_swi_finalize")
+    return st, logits, prob, mask
 
 
 def sliding_window_inference(inputs: torch.Tensor, roi_size: Union[Sequence[int], int], sw_batch_size: int,

@@ -31,6 +31,7 @@ class AdamW:
         self._step = 0
         self._m = self._v = self._table = None
         self._ptrs = None
+        self._touched = set()            # keys that have taken part in at least one step (the ones state_dict() reports, like torch)
 
     # -- torch.optim.Optimizer surface the training loop uses --------------------------------------------
     def zero_grad(self, set_to_none: bool = True) -> None:
@@ -40,16 +41,18 @@ class AdamW:
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def _bind(self, flat: torch.Tensor) -> None:
+    def _bind(self, flat: torch.Tensor, active) -> None:
+        """Kernel table of the tensors this step updates: parameters that require a gradient AND have one (torch.optim.AdamW skips
+        a parameter whose .grad is None entirely - no weight decay, no moment update)."""
         model = self.model
         params = dict(model.named_parameters())
-        ptrs = [(params[k].data_ptr(), params[k].requires_grad) for k in model._param_keys]
+        ptrs = [(params[k].data_ptr(), k in active) for k in model._param_keys]
         if self._table is None or ptrs != self._ptrs:
             rows = []
             for k in model._param_keys:
                 p = params[k]
-                if not p.requires_grad:
-                    continue                     # frozen tensors are left alone, as torch.optim does for parameters without a gradient
+                if k not in active:
+                    continue                     # frozen tensors / tensors without a gradient are left alone
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.device != flat.device:
                     raise _lib.CellSegHipError(f"AdamW: parameter {k} must be a contiguous fp32 tensor on {flat.device}")
                 off, numel, _ = model._grad_slots[k]
@@ -57,38 +60,40 @@ class AdamW:
             rows.sort()
             self._table = torch.tensor([[ptr, off, numel] for off, numel, ptr in rows], dtype=torch.int64).reshape(-1, 3).to(flat.device)
             self._ptrs = ptrs
+        self._touched.update(active)
         if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
 
     def _gradients(self):
-        """The flat fp32 gradient bucket of the step.  Normally that is ``model.flat_grad`` itself (every ``p.grad`` is a view of it);
-        when autograd has accumulated several backward passes into other storage the ``p.grad`` tensors are gathered into a flat copy."""
+        """-> (flat fp32 gradient bucket of the step, keys of the parameters that have a gradient) or (None, ()).  Normally the
+        bucket is ``model.flat_grad`` itself (every ``p.grad`` is a view of it); when autograd has accumulated several backward
+        passes into other storage the ``p.grad`` tensors are gathered into a flat copy."""
         model = self.model
         flat = model.flat_grad
         params = dict(model.named_parameters())
-        grads = [(k, params[k].grad) for k in model._param_keys if params[k].requires_grad]
-        if not grads or all(g is None for _, g in grads):
-            return None
+        grads = [(k, params[k].grad) for k in model._param_keys if params[k].requires_grad and params[k].grad is not None]
+        if not grads:
+            return None, ()
+        active = frozenset(k for k, _ in grads)
         base = flat.data_ptr() if flat is not None else None
-        if base is not None and all(g is not None and g.data_ptr() == base + 4 * model._grad_slots[k][0] for k, g in grads):
-            return flat
+        if base is not None and all(g.data_ptr() == base + 4 * model._grad_slots[k][0] for k, g in grads):
+            return flat, active
         model.engine(True)
         total = int(lib.cs_unet_grad_numel(model._engine.handle))
         dev = next(model.parameters()).device
         gathered = torch.zeros(total, dtype=torch.float32, device=dev)
         for k, g in grads:
-            if g is not None:
-                off, numel, _ = model._grad_slots[k]
-                gathered[off:off + numel] = g.reshape(-1).float()
-        return gathered
+            off, numel, _ = model._grad_slots[k]
+            gathered[off:off + numel] = g.reshape(-1).float()
+        return gathered, active
 
     @torch.no_grad()
     def step(self) -> None:
-        flat = self._gradients()
+        flat, active = self._gradients()
         if flat is None:
             return                               # nothing to do without gradients (torch.optim.AdamW behaves the same)
-        self._bind(flat)
+        self._bind(flat, active)
         if self._table.shape[0] == 0:
             return
         g = self.param_groups[0]
@@ -104,6 +109,8 @@ class AdamW:
         state = {}
         if self._m is not None:
             for i, k in enumerate(self.model._param_keys):
+                if k not in self._touched:
+                    continue                     # torch.optim keeps no state for a parameter it has never updated (frozen / no gradient)
                 off, numel, shape = self.model._grad_slots[k]
                 state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": self._m[off:off + numel].view(shape).clone(),
                             "exp_avg_sq": self._v[off:off + numel].view(shape).clone()}
@@ -114,6 +121,7 @@ class AdamW:
         for key in ("lr", "betas", "eps", "weight_decay"):
             self.param_groups[0][key] = tuple(g[key]) if key == "betas" else float(g[key])
         state = sd.get("state", {})
+        self._touched = set()
         if not state:
             self._step, self._m, self._v = 0, None, None
             return
@@ -124,9 +132,12 @@ class AdamW:
         self._m = torch.zeros(total, dtype=torch.float32, device=dev)
         self._v = torch.zeros(total, dtype=torch.float32, device=dev)
         for i, k in enumerate(model._param_keys):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue                         # a torch checkpoint holds no entry for a parameter that never had a gradient: moments stay zero
             off, numel, _ = model._grad_slots[k]
-            st = state[i] if i in state else state[str(i)]
             self._m[off:off + numel] = st["exp_avg"].reshape(-1).to(dev, torch.float32)
             self._v[off:off + numel] = st["exp_avg_sq"].reshape(-1).to(dev, torch.float32)
-            self._step = int(float(st["step"]))
+            self._step = max(self._step if self._touched else 0, int(float(st["step"])))
+            self._touched.add(k)
         self._table = None

@@ -9,7 +9,7 @@ world_size-2 gloo tests on CPU.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -23,19 +23,95 @@ def shard_items(n_items: int, rank: int, world: int) -> range:
     return range(lo, lo + base + (1 if rank < rem else 0))
 
 
-def gather_row_strips(strip: torch.Tensor, img_h: int, group=None) -> torch.Tensor:
-    """all-gather row strips [rows_r, W] (rows_r per ``rank_rows``) into the full [img_h, W] tensor on every rank."""
+def _collectives_on(group=None) -> bool:
+    """True when a process group exists: every collective below then really runs, also at world size 1 (so the RCCL call path
+    can be executed and tested on a one-GPU box); without a process group the functions are local no-ops."""
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    if world == 1:
+    return dist.is_available() and dist.is_initialized()
+
+
+def _host_bounce(t: torch.Tensor, group=None) -> bool:
+    """gloo cannot reduce / gather device tensors: functional checks on a shared GPU go through the host."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def gather_row_strips(strip: torch.Tensor, img_h: int, group=None, rows: Optional[Sequence[Tuple[int, int]]] = None) -> torch.Tensor:
+    """all-gather row strips [rows_r, W] into the full [img_h, W] tensor on every rank (ONE collective; RCCL on device tensors).
+    `rows`: the (begin, end) rows of every rank - default ``rank_rows`` strips; ``strip_rows`` for the window-row partition."""
+    import torch.distributed as dist
+    if not _collectives_on(group):
         return strip
-    max_rows = -(-img_h // world)
-    padded = strip.new_zeros((max_rows,) + tuple(strip.shape[1:]))
-    padded[: strip.shape[0]] = strip
-    parts: List[torch.Tensor] = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    rows = [rank_rows(img_h, r, world) for r in range(world)]
-    return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(rows)], 0)
+    world = dist.get_world_size(group)
+    if rows is None:
+        rows = [rank_rows(img_h, r, world) for r in range(world)]
+    max_rows = max(hi - lo for lo, hi in rows)
+    bounce = _host_bounce(strip, group)
+    src = strip.cpu() if bounce else strip
+    padded = src.new_zeros((max_rows,) + tuple(src.shape[1:]))
+    padded[: src.shape[0]] = src
+    out = padded.new_empty((world * max_rows,) + tuple(src.shape[1:]))
+    dist.all_gather_into_tensor(out, padded, group=group)
+    if all(hi - lo == max_rows for lo, hi in rows):
+        full = out
+    else:
+        full = torch.cat([out[r * max_rows: r * max_rows + hi - lo] for r, (lo, hi) in enumerate(rows)], 0)
+    return full.to(strip.device) if bounce else full
+
+
+def strip_rows(plan, world: int) -> List[Tuple[int, int]]:
+    """Output rows of every rank under the window-row partition (``inferers.strip_partition``)."""
+    from .inferers import strip_partition
+    return [(st.row_begin, st.row_end) for st in (strip_partition(plan, r, world) for r in range(world))]
+
+
+def seam_transfers(plan, world: int) -> List[Tuple[int, int, int, int]]:
+    """Every (src_rank, dst_rank, window_row, first_local_row) the window-row partition needs: window row `window_row`, owned by
+    src_rank, still covers dst_rank's first output rows - its window-local rows [first_local_row, roi_h) are what dst_rank reads.
+    Deterministic and identical on every rank (both ends of a transfer derive it from the plan alone)."""
+    from .inferers import strip_partition
+    from ._lib import lib
+    strips = [strip_partition(plan, r, world) for r in range(world)]
+    owner = {}
+    for r, st in enumerate(strips):
+        for j in range(st.win_row_begin, st.win_row_end):
+            owner[j] = r
+    out = []
+    for dst, st in enumerate(strips):
+        for j in range(st.halo_begin, st.win_row_begin):
+            hs = lib.cs_swi_window_start(j, plan.interval_h, plan.pad_h, plan.roi_h)
+            out.append((owner[j], dst, j, max(0, st.row_begin + plan.pad_top - hs)))
+    return out
+
+
+def exchange_seam(win: torch.Tensor, plan, rank: int, world: int, group=None) -> int:
+    """Seam exchange of the window-row partition ("exchange seam partial sums with one neighbour send/recv").
+    win: this rank's window logits [(win_row_end - halo_begin), n_w, roi_h, roi_w, C] with its own rows behind the halo slots
+    (``inferers.swi_infer_strip``).  Sends the lower part of its last window row(s) to the rank(s) below and receives its halo
+    from the rank above: batched point-to-point (RCCL send/recv over the direct xGMI link of the pair; 12 MB per seam at 4096^2 /
+    stride 128).  Returns the number of transfers this rank took part in."""
+    import torch.distributed as dist
+    from .inferers import strip_partition
+    me = strip_partition(plan, rank, world)
+    ops, landing = [], []
+    for src, dst, j, r0 in seam_transfers(plan, world):
+        if rank not in (src, dst) or src == dst:
+            continue
+        view = win[j - me.halo_begin, :, r0:]                       # [n_w, roi_h - r0, roi_w, C]: contiguous per window
+        if rank == src:
+            buf = view.contiguous()
+            buf = buf.cpu() if _host_bounce(buf, group) else buf
+            ops.append(dist.P2POp(dist.isend, buf, dst, group))
+        else:
+            buf = torch.empty(view.shape, dtype=view.dtype, device="cpu" if _host_bounce(view, group) else view.device)
+            ops.append(dist.P2POp(dist.irecv, buf, src, group))
+            landing.append((view, buf))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for view, buf in landing:
+        view.copy_(buf, non_blocking=True)
+    return len(ops)
 
 
 def sync_gradients(model, group=None, reduce: bool = True) -> None:
@@ -48,15 +124,16 @@ def sync_gradients(model, group=None, reduce: bool = True) -> None:
     flat = model.flat_grad
     if flat is None:
         raise RuntimeError("sync_gradients: run backward first")
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world > 1 and reduce:
-        if flat.is_cuda and dist.get_backend(group) == "gloo":     # functional checks on a shared GPU: gloo reduces on the host
+    if _collectives_on(group) and reduce:                          # also at world size 1: the collective really runs
+        world = dist.get_world_size(group)
+        if _host_bounce(flat, group):                               # functional checks on a shared GPU: gloo reduces on the host
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
             flat.copy_(host)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.mul_(1.0 / world)
+        if world > 1:
+            flat.mul_(1.0 / world)
     for key, p in model.named_parameters():
         off, numel, shape = model._grad_slots[key]
         p.grad = flat[off:off + numel].view(shape)

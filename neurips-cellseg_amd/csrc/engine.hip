@@ -49,12 +49,12 @@ struct ProfState {
     double flops[K_NUM_IDS] = {}, bytes[K_NUM_IDS] = {}, ms[K_NUM_IDS] = {};
     int64_t launches[K_NUM_IDS] = {};
 };
-static ProfState g_prof[16];
+static ProfState g_prof[64];       // one slot per HIP device index (a node has 8; 64 leaves room for partitioned modes)
 static bool g_prof_any = false;                 // fast path: nobody has ever enabled profiling in this process
 static ProfState& prof_state() {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    return g_prof[dev >= 0 && dev < 16 ? dev : 0];
+    return g_prof[dev >= 0 && dev < 64 ? dev : 0];
 }
 bool prof_enabled() { return g_prof_any && prof_state().on; }
 
@@ -1237,8 +1237,14 @@ int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspac
         for (auto& ev : net->bwd_ev) CS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     const bool use_side = side_env && !prof_enabled() && net->bwd_side[0];
+    net->tape.valid = false;      // the gradient buffers reuse nothing of the tape, but one backward per forward (also when it fails)
     rc = unet_backward_impl(net, grad_logits_nhwc, acc, buf, flat_grad, s, net->bwd_side, use_side ? (n_side_env >= 2 ? 2 : 1) : 0, net->bwd_ev, 48);
-    net->tape.valid = false;      // the gradient buffers reused nothing of the tape, but one backward per forward
+    if (rc != CS_OK && use_side) {
+        // an early return skipped the join at the end of the pass: side-stream weight gradients may still be reading / writing the
+        // caller's buffers, which the caller is about to free - drain them before reporting the error
+        for (auto& st : net->bwd_side)
+            if (st) (void)hipStreamSynchronize(st);
+    }
     return rc;
 }
 
@@ -1309,13 +1315,113 @@ static void swi_row_windows(const cs_swi_plan* pl, int row_begin, int row_end, i
     *ih_hi = hi;
 }
 
-size_t cs_swi_workspace_bytes(const cs_unet* net, const cs_swi_plan* pl, int engine_batch) {
+size_t cs_swi_windows_workspace_bytes(const cs_unet* net, const cs_swi_plan* pl, int engine_batch) {
     if (!net || !pl || engine_batch <= 0) return 0;
     const size_t nwin = (size_t)pl->n_h * pl->n_w;
     const size_t eb = (size_t)engine_batch < nwin ? (size_t)engine_batch : nwin;
     const size_t unet = cs_unet_workspace_bytes(net, (int)eb, pl->roi_h, pl->roi_w) * (size_t)net->n_streams;
     if (unet == 0) return 0;
-    return unet + (nwin * 8 + 255) / 256 * 256 + (nwin * pl->roi_h * pl->roi_w * net->out_ch * 4 + 255) / 256 * 256 + 512;
+    return unet + (nwin * 8 + 255) / 256 * 256 + 512;
+}
+
+size_t cs_swi_workspace_bytes(const cs_unet* net, const cs_swi_plan* pl, int engine_batch) {
+    const size_t win = cs_swi_windows_workspace_bytes(net, pl, engine_batch);
+    if (win == 0) return 0;
+    const size_t nwin = (size_t)pl->n_h * pl->n_w;
+    return win + (nwin * pl->roi_h * pl->roi_w * net->out_ch * 4 + 255) / 256 * 256;
+}
+
+// Window pass over window rows [ih_lo, ih_hi): logits of window (ih, iw) go to win_logits[(ih - ih_lo) * n_w + iw].
+static int swi_run_windows(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_t sc, int64_t sh, int64_t sw, int engine_batch,
+                           int ih_lo, int ih_hi, float* win_logits, cs::Bump& b, hipStream_t s) {
+    const int nwin = (ih_hi - ih_lo) * pl->n_w;
+    const size_t win_floats = (size_t)pl->roi_h * pl->roi_w * net->out_ch;
+    int2* origins = b.take<int2>((size_t)nwin);
+    if (!b.ok()) { cs::set_error("swi: workspace too small"); return CS_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(cs::swi_origins_kernel, dim3((unsigned)cs::ceil_div(nwin, 256)), dim3(256), 0, s, *pl, ih_lo, nwin, origins);
+    CS_HIP(hipGetLastError());
+    WindowSrc src;
+    src.image = image; src.sn = 0; src.sc = sc; src.sh = sh; src.sw = sw;
+    src.img_h = pl->img_h; src.img_w = pl->img_w; src.roi_h = pl->roi_h; src.roi_w = pl->roi_w;
+    // sliding-window inference is an inference call: BatchNorm layers use their running statistics whatever mode the handle was
+    // left in (a train-mode handle would otherwise normalise every window chunk with that chunk's own statistics and update the
+    // running ones once per chunk, from several streams)
+    struct BatchStatsOff {
+        cs_unet* n; bool saved;
+        explicit BatchStatsOff(cs_unet* m) : n(m), saved(m->batch_stats) { m->batch_stats = false; }
+        ~BatchStatsOff() { n->batch_stats = saved; }
+    } stats_guard(net);
+    // chunks of `engine_batch` windows; with side streams the chunks are dealt round-robin to them, each stream owning
+    // its own slice of the activation workspace (stream order serialises the chunks that share a slice).  Per-kernel
+    // profiling (cs_prof_enable) forces one stream so that event-timed durations are not inflated by overlap.
+    const int ns = (net->n_streams > 1 && !cs::prof_enabled() && nwin > engine_batch) ? net->n_streams : 1;
+    const size_t mark = b.off;
+    const size_t slice = ns > 1 ? ((b.cap - mark) / ns) / 256 * 256 : 0;
+    if (ns > 1) {
+        CS_HIP(hipEventRecord(net->ev_fork, s));
+        for (int i = 0; i < ns; ++i) CS_HIP(hipStreamWaitEvent(net->side[i], net->ev_fork, 0));
+    }
+    int chunk = 0, rc = CS_OK;
+    for (int k0 = 0; k0 < nwin && rc == CS_OK; k0 += engine_batch, ++chunk) {
+        const int nb = nwin - k0 < engine_batch ? nwin - k0 : engine_batch;
+        src.origins = origins + k0;
+        if (ns > 1) {
+            cs::Bump bs(b.base + mark + (size_t)(chunk % ns) * slice, slice);
+            rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, bs, net->side[chunk % ns]);
+        } else {
+            b.off = mark;   // every chunk reuses the same activation workspace (stream order serialises them)
+            rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, b, s);
+        }
+    }
+    if (ns > 1) {                                  // joined on every path: the caller may free the workspace after an error
+        for (int i = 0; i < ns; ++i) {
+            CS_HIP(hipEventRecord(net->ev_join[i], net->side[i]));
+            CS_HIP(hipStreamWaitEvent(s, net->ev_join[i], 0));
+        }
+    }
+    return rc;
+}
+
+int cs_swi_windows(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_t sc, int64_t sh, int64_t sw, int engine_batch,
+                   int win_row_begin, int win_row_end, float* win_logits, void* workspace, size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(net && pl && image && workspace && win_logits, "swi_windows: null argument");
+    CS_REQUIRE(engine_batch > 0, "swi_windows: engine_batch %d", engine_batch);
+    CS_REQUIRE(win_row_begin >= 0 && win_row_end <= pl->n_h && win_row_begin <= win_row_end, "swi_windows: bad window-row range [%d, %d) of %d",
+               win_row_begin, win_row_end, pl->n_h);
+    if (int rcd = check_device(net)) return rcd;
+    if (int rc = check_loaded(net)) return rc;
+    if (win_row_begin == win_row_end) return CS_OK;
+    cs::Bump b(workspace, workspace_bytes);
+    return swi_run_windows(net, pl, image, sc, sh, sw, engine_batch, win_row_begin, win_row_end, win_logits, b, (hipStream_t)stream);
+}
+
+int cs_swi_partition(const cs_swi_plan* pl, int rank, int world, cs_swi_strip* out) {
+    CS_REQUIRE(pl && out && world >= 1 && rank >= 0 && rank < world, "swi_partition: bad argument (rank %d of %d)", rank, world);
+    auto first_row = [&](int r) {                     // first window row of rank r (sizes differ by at most one, larger shares first)
+        const int base = pl->n_h / world, rem = pl->n_h % world;
+        return r * base + (r < rem ? r : rem);
+    };
+    auto first_out = [&](int r) {                     // first output row (image coordinates) rank r finalises
+        if (r <= 0) return 0;
+        const int a = first_row(r);
+        if (r >= world || a >= pl->n_h) return pl->img_h;
+        int y = cs_swi_window_start(a, pl->interval_h, pl->pad_h, pl->roi_h) - pl->pad_top;
+        y = y < 0 ? 0 : y;
+        return y > pl->img_h ? pl->img_h : y;
+    };
+    out->win_row_begin = first_row(rank);
+    out->win_row_end = first_row(rank + 1);
+    out->row_begin = first_out(rank);
+    out->row_end = first_out(rank + 1);
+    if (out->win_row_begin == out->win_row_end) out->row_end = out->row_begin;      // a rank without windows finalises nothing
+    // earlier ranks' window rows that still cover this rank's first output row
+    int halo = out->win_row_begin;
+    if (out->row_end > out->row_begin) {
+        const int p0 = out->row_begin + pl->pad_top;
+        while (halo > 0 && cs_swi_window_start(halo - 1, pl->interval_h, pl->pad_h, pl->roi_h) + pl->roi_h > p0) --halo;
+    }
+    out->halo_begin = halo;
+    return CS_OK;
 }
 
 int cs_swi_infer(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_t sc, int64_t sh, int64_t sw, int engine_batch,
@@ -1333,44 +1439,11 @@ int cs_swi_infer(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_
     CS_REQUIRE(ih_hi >= ih_lo, "swi_infer: no window intersects rows [%d, %d)", row_begin, row_end);
     const int nwin = (ih_hi - ih_lo + 1) * pl->n_w;
     Bump b(workspace, workspace_bytes);
-    int2* origins = b.take<int2>((size_t)nwin);
     const size_t win_floats = (size_t)pl->roi_h * pl->roi_w * net->out_ch;
     float* win_logits = b.take<float>((size_t)nwin * win_floats);
     if (!b.ok()) { cs::set_error("swi_infer: workspace too small"); return CS_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(cs::swi_origins_kernel, dim3((unsigned)cs::ceil_div(nwin, 256)), dim3(256), 0, s, *pl, ih_lo, nwin, origins);
-    CS_HIP(hipGetLastError());
-    WindowSrc src;
-    src.image = image; src.sn = 0; src.sc = sc; src.sh = sh; src.sw = sw;
-    src.img_h = pl->img_h; src.img_w = pl->img_w; src.roi_h = pl->roi_h; src.roi_w = pl->roi_w;
-    // chunks of `engine_batch` windows; with side streams the chunks are dealt round-robin to them, each stream owning
-    // its own slice of the activation workspace (stream order serialises the chunks that share a slice).  Per-kernel
-    // profiling (cs_prof_enable) forces one stream so that event-timed durations are not inflated by overlap.
-    const int ns = (net->n_streams > 1 && !cs::prof_enabled() && nwin > engine_batch) ? net->n_streams : 1;
-    const size_t mark = b.off;
-    const size_t slice = ns > 1 ? ((workspace_bytes - mark) / ns) / 256 * 256 : 0;
-    if (ns > 1) {
-        CS_HIP(hipEventRecord(net->ev_fork, s));
-        for (int i = 0; i < ns; ++i) CS_HIP(hipStreamWaitEvent(net->side[i], net->ev_fork, 0));
-    }
-    int chunk = 0;
-    for (int k0 = 0; k0 < nwin; k0 += engine_batch, ++chunk) {
-        const int nb = nwin - k0 < engine_batch ? nwin - k0 : engine_batch;
-        src.origins = origins + k0;
-        if (ns > 1) {
-            Bump bs((char*)workspace + mark + (size_t)(chunk % ns) * slice, slice);
-            rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, bs, net->side[chunk % ns]);
-        } else {
-            b.off = mark;   // every chunk reuses the same activation workspace (stream order serialises them)
-            rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, b, s);
-        }
-        if (rc) return rc;
-    }
-    if (ns > 1) {
-        for (int i = 0; i < ns; ++i) {
-            CS_HIP(hipEventRecord(net->ev_join[i], net->side[i]));
-            CS_HIP(hipStreamWaitEvent(s, net->ev_join[i], 0));
-        }
-    }
+    rc = swi_run_windows(net, pl, image, sc, sh, sw, engine_batch, ih_lo, ih_hi + 1, win_logits, b, s);
+    if (rc) return rc;
     SwiFinalizeArgs fa{};
     fa.win_logits = win_logits;
     fa.plan = *pl;

@@ -707,12 +707,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_narrow_kernel(WgradParams p) {
 
 // how many split-K slices a weight-gradient launch should use: enough blocks to fill the chip, never more than tiles
 // pixel rows per K tile: 8 for the 3x3 stride-1 layers with 64-channel blocks (twice the MFMAs per barrier pair), else 4
-static int g_wgrad_th8 = getenv("CS_WGRAD_TH8") ? atoi(getenv("CS_WGRAD_TH8")) : 1;
 static int g_wgrad_narrow = getenv("CS_WGRAD_NARROW") ? atoi(getenv("CS_WGRAD_NARROW")) : 1;   // 0: narrow operands through the general kernel
 static inline bool wgrad_narrow_cols(int ksize, int stride, int b_c) { return g_wgrad_narrow && ksize == 3 && stride == 2 && b_c <= 3; }
 static inline int wgrad_th(int ksize, int stride, int a_c, int b_c, int ho) {
     if (wgrad_narrow_cols(ksize, stride, b_c)) return 8;
-    return (g_wgrad_th8 && ksize == 3 && stride == 1 && a_c % 64 == 0 && b_c >= 16 && ho >= 8) ? 8 : 4;
+    return (ksize == 3 && stride == 1 && a_c % 64 == 0 && b_c >= 16 && ho >= 8) ? 8 : 4;
 }
 
 int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo, int ksize, int stride) {
@@ -721,7 +720,7 @@ int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo, int ksize, int stride
     const int total_tiles = n * ceil_div(wo, 16) * ceil_div(ho, wgrad_th(ksize, stride, a_c, b_c, ho));
     // blocks per launch: measured on the 32-base step (wgrad + unpack ms): 1024 -> 2.46 + 0.50, 768 -> 2.67 + 0.40, 512 -> 2.53 + 0.30,
     // 384 -> 3.17 + 0.25: fewer slices halve the partial slabs the unpack pass has to sum
-    static const int target_blocks = getenv("CS_WGRAD_BLOCKS") ? atoi(getenv("CS_WGRAD_BLOCKS")) : 512;
+    const int target_blocks = 512;
     // (four times the blocks for the narrow launches - 3-channel operand, 70 us each, four per step - was measured: the launches got
     // 5 us shorter and the unpack pass 15 us longer each)
     int k = ceil_div(target_blocks, combos);

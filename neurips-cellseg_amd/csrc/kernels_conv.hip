@@ -445,12 +445,6 @@ static int launch_conv_wreg(hipStream_t s, const ConvParams& p0) {
     return CS_OK;
 }
 
-int g_conv_variant = 7;   // bit mask: 1 = stride-1, 2 = stride-2 3x3 layers take the register-weights kernel (A/B switch CS_CONV_VARIANT)
-static const int g_conv_variant_init = [] {
-    if (const char* e = getenv("CS_CONV_VARIANT")) g_conv_variant = atoi(e);
-    return 0;
-}();
-
 static SrcDev to_dev(const ConvSrc& s) { return SrcDev{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off, s.ptr2, s.tab2, s.slope2}; }
 
 static int apply_extra(ConvParams& p, const ConvOutExtra* ex, int cout, int* nt) {
@@ -505,16 +499,15 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
     }
     // 64-channel blocks of the 3x3 layers take the register-weights kernel (measured: s1 31.9 -> 30.3 ms, s2 9.8 -> 8.3 ms per
     // 4096^2 slide; the 32-channel and 1x1 layers were not faster with it and keep the LDS-weights kernel)
-    if ((g_conv_variant & 1) && nt == 4 && ksize == 3 && stride == 1) return launch_conv_wreg<1, 3, 4, 8, 3, 1>(s, p);
-    if ((g_conv_variant & 2) && nt == 4 && ksize == 3 && stride == 2) {
+    if (nt == 4 && ksize == 3 && stride == 1) return launch_conv_wreg<1, 3, 4, 8, 3, 1>(s, p);
+    if (nt == 4 && ksize == 3 && stride == 2) {
         // 128-channel blocks (two channel tiles per wave: every A fragment feeds 8 MFMAs, 288 MFMAs per barrier) when the
         // channel count and the (out, out2) split allow it
-        const bool wide = (g_conv_variant & 4) && cout % 128 == 0;
+        const bool wide = cout % 128 == 0;
         return wide ? launch_conv_wreg<2, 3, 4, 4, 3, 2>(s, p) : launch_conv_wreg<2, 3, 4, 4, 3, 1>(s, p);
     }
-    // 32-channel stride-1 layers (bit 8): register weights with a 16-row tile - every wave owns one channel tile and 8 rows, so a
-    // B fragment feeds 32 MFMAs (the LDS-weights kernel re-reads its weights from LDS for every 2 rows)
-    if ((g_conv_variant & 8) && nt == 2 && ksize == 3 && stride == 1 && p.hout >= 16) return launch_conv_wreg<1, 3, 2, 16, 2, 1>(s, p);
+    // (a register-weights form of the 32-channel stride-1 layers with a 16-row tile was measured in round 2: 30.9 vs 30.6 ms per
+    // slide for the stride-1 group - not kept)
     if (ksize == 1) { CS_DISPATCH_NT(1, 1, 2) }
     if (stride == 1) { CS_DISPATCH_NT(1, 3, 2) }
     CS_DISPATCH_NT(2, 3, 1)
@@ -1150,9 +1143,8 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
     p.tiles_y = ceil_div(hin, 4);
     int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
     if (int rc = apply_extra(p, ex, cout, &nt)) return rc;
-    // two input rows per wave for the 64-channel blocks when the grid still fills the chip at two blocks per CU (CS_CONVT_RW2=0: never)
-    static const int rw2_env = getenv("CS_CONVT_RW2") ? atoi(getenv("CS_CONVT_RW2")) : 1;
-    if (rw2_env && nt == 4 && !b.ptr2 && hin >= 8 && xcd_grid(p.tiles_x * ceil_div(hin, 8) * n, p.ntile_total / nt) >= 1024) {
+    // two input rows per wave for the 64-channel blocks when the grid still fills the chip at two blocks per CU
+    if (nt == 4 && !b.ptr2 && hin >= 8 && xcd_grid(p.tiles_x * ceil_div(hin, 8) * n, p.ntile_total / nt) >= 1024) {
         p.tiles_y = ceil_div(hin, 8);
         dim3 grid2(xcd_grid(p.tiles_x * p.tiles_y * n, p.ntile_total / nt));
         const double flops2 = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
@@ -1349,12 +1341,16 @@ int pack_batch_flush(PackCtx* pc, hipStream_t s) {
         }
     }
     const size_t n = jobs.size();
-    // the pinned staging table is rewritten here: the previous copy out of it must have completed
-    if (pc->copied_pending) CS_HIP(hipEventSynchronize(pc->copied));
+    // The pinned staging table is rewritten here and its device twin is overwritten by the copy below: the previous flush - its
+    // copy out of the pinned table AND its pack kernels, which read the device table - must be complete.  `copied` is recorded
+    // behind those kernels; the host waits for it (pinned table) and `s` is ordered behind it (device table: consecutive flushes
+    // may arrive on different streams).
+    if (pc->copied_pending) {
+        CS_HIP(hipEventSynchronize(pc->copied));
+        CS_HIP(hipStreamWaitEvent(s, pc->copied, 0));
+    }
     memcpy(pc->host, jobs.data(), n * sizeof(PackJob));
     CS_HIP(hipMemcpyAsync(pc->dev, pc->host, n * sizeof(PackJob), hipMemcpyHostToDevice, s));
-    CS_HIP(hipEventRecord(pc->copied, s));
-    pc->copied_pending = true;
     double bytes = 8.0 * (double)total_elems;
     for (size_t i = n_elem; i < n; ++i)
         bytes += 4.0 * 256 * pack_job_elems(jobs[i]) * (jobs[i].taps * (jobs[i].dst2 ? 3 : 2) + 16 * ((jobs[i].dstw ? 1 : 0) + (jobs[i].dstw2 ? 1 : 0)));
@@ -1364,6 +1360,8 @@ int pack_batch_flush(PackCtx* pc, hipStream_t s) {
     if (total_blocks > 0)
         hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)total_blocks), dim3(256), 0, s, pc->dev + n_elem, (int)(n - n_elem));
     CS_HIP(hipGetLastError());
+    CS_HIP(hipEventRecord(pc->copied, s));
+    pc->copied_pending = true;
     jobs.clear();
     return CS_OK;
 }

@@ -406,259 +406,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// PERSISTENT form of the kernel above for the bf16 datapath (NP = 1, bf16 in / out).  A block keeps its output-channel tile and
-// walks spatial tiles with a stride of gridDim.x; while the last chunk of tile T is multiplied and its epilogue runs, the FIRST
-// chunk of tile T + 1 is already in flight (registers), and the weight ring simply wraps to the first tap row (same channel
-// tile, same weights).  Why: the low-channel layers of the 16-bit modes are HBM-bound (a 32-channel 3x3 layer: 144 FLOP/B),
-// and a non-persistent block has bytes in flight only during its prologue - 16 k blocks of 12.8 us each moved 2 TB/s.
-// Items are (pixel, 8 channels) = 16-byte loads and LDS stores (the kernel above moves 8 bytes per item).
-// ------------------------------------------------------------------------------------------------
-typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
-template <int S, int KS, int WN, int NTW, int THX>
-__global__ __launch_bounds__(256, 2) void conv_bf16p_kernel(ConvBParams p, int n_spatial, int n_ct) {
-    constexpr int WM = 4 / WN;
-    constexpr int TH = THX * ((S == 1) ? 8 : 4), TW = 16;
-    constexpr int MTW = TH / WM;
-    constexpr int NTB = WN * NTW;
-    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
-    constexpr int PITCH = (S == 1) ? 96 : 80;
-    constexpr int PAD = KS / 2, TAPS = KS * KS;
-    constexpr int IN_ITEMS = IH * IW * 4;                   // (pixel, 8-channel octet) items per 32-channel chunk
-    constexpr int IN_ITERS = (IN_ITEMS + 255) / 256;
-    constexpr int IN_BYTES = (IH * IW * PITCH + 15) / 16 * 16;
-    constexpr int EPS = 16 * NTB + 4;
-    constexpr int EP_BYTES = TH * 16 * EPS * 4;
-    constexpr bool DB = 2 * IN_BYTES <= EP_BYTES + 4096;
-    constexpr int SM_BYTES = (DB ? 2 : 1) * IN_BYTES > EP_BYTES ? (DB ? 2 : 1) * IN_BYTES : EP_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pl = lane & 15, g = lane >> 4;
-    const int wn = wave % WN, wm = wave / WN;
-    const int q = tid & 3;                                   // channel octet inside the 32-channel chunk
-    // work ids: [spatial group of 8][channel tile][8] (XCD-aware, see decode_work); gridDim.x is a multiple of 8 * n_ct, so a
-    // block keeps its channel tile and its XCD lane while it strides over the spatial groups
-    const int id0 = blockIdx.x, lane8 = id0 & 7, rest0 = id0 >> 3;
-    const int ct = rest0 % n_ct;
-    int sg = rest0 / n_ct;
-    const int sg_step = (int)gridDim.x / (8 * n_ct);
-    if (sg * 8 + lane8 >= n_spatial) return;
-    const int nt_w = ct * NTB + wn * NTW;
-
-    struct Tile {
-        int img, oy0, ox0;
-    };
-    auto tile_of = [&](int sgi) {
-        int bid = sgi * 8 + lane8;
-        const int tx = bid % p.tiles_x;
-        bid /= p.tiles_x;
-        const int ty = bid % p.tiles_y;
-        return Tile{bid / p.tiles_y, ty * TH, tx * TW};
-    };
-    auto offsets_of = [&](const Tile& t, int (&go)[IN_ITERS]) {
-#pragma unroll
-        for (int it = 0; it < IN_ITERS; ++it) {
-            const int pix = (tid >> 2) + 64 * it;
-            const int iy = pix / IW, ix = pix - iy * IW;
-            const int gy = t.oy0 * S - PAD + iy, gx = t.ox0 * S - PAD + ix;
-            go[it] = (pix < IH * IW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win) ? gy * p.win + gx : -1;
-        }
-    };
-
-    const int chunks_a = (p.a.c + 31) >> 5, chunks = chunks_a + ((p.b.c + 31) >> 5);
-    u32x4b rin[IN_ITERS];
-    f32x4 tb[4];                   // lazy table of the staged chunk's 8 channels: (scale, shift) pairs
-    float slope = 0.f;
-    bool lazy = false, qvalid = false;
-
-    auto load_input = [&](const Tile& t, const int (&go)[IN_ITERS], int ch) {
-        const bool from_a = ch < chunks_a;
-        const SrcDevB& src = from_a ? p.a : p.b;
-        const int c0 = (from_a ? ch : ch - chunks_a) << 5;
-        qvalid = c0 + 8 * q < src.c;
-        const int cq = qvalid ? c0 + 8 * q : 0;
-        lazy = src.tab != nullptr;
-        const f32x4* tp = lazy ? reinterpret_cast<const f32x4*>(src.tab + (size_t)t.img * src.tab_c + src.tab_off + cq)
-                               : reinterpret_cast<const f32x4*>(p.dummy);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) tb[k] = tp[k];
-        const float* sp = (lazy && src.slope) ? src.slope : p.dummy;
-        slope = *sp;
-        if (!(lazy && src.slope)) slope = 0.f;
-        const unsigned short* base = reinterpret_cast<const unsigned short*>(src.ptr) + (size_t)t.img * p.hin * p.win * src.pitch + cq;
-#pragma unroll
-        for (int it = 0; it < IN_ITERS; ++it) {
-            const int o = go[it] >= 0 ? go[it] : 0;
-            rin[it] = *reinterpret_cast<const u32x4b*>(base + (size_t)o * src.pitch);
-        }
-    };
-    auto store_input = [&](char* in_s, const int (&go)[IN_ITERS]) {
-#pragma unroll
-        for (int it = 0; it < IN_ITERS; ++it) {
-            const int pix = (tid >> 2) + 64 * it;
-            if (IN_ITEMS % 256 == 0 || pix < IH * IW) {
-                u32x4b o = rin[it];
-                if (lazy) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float lo = prelu_h(__builtin_bit_cast(float, o[k] << 16) * tb[k].x + tb[k].y, slope);
-                        const float hi = prelu_h(__builtin_bit_cast(float, o[k] & 0xffff0000u) * tb[k].z + tb[k].w, slope);
-                        o[k] = f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
-                    }
-                }
-                if (go[it] < 0 || !qvalid) o = u32x4b{0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4b*>(in_s + pix * PITCH + q * 16) = o;
-            }
-        }
-    };
-    bf16x8 bq[KS][NTW];
-    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)nt_w * 3 * 64 + lane;
-    auto load_b = [&](int ch, int ky, int kx) {
-        const bf16x8* w = wbase + ((size_t)ch * TAPS + ky * KS + kx) * p.ntile_total * 3 * 64;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) bq[kx][t] = w[t * 3 * 64];
-    };
-
-    Tile cur = tile_of(sg);
-    int go_cur[IN_ITERS], go_nxt[IN_ITERS];
-    offsets_of(cur, go_cur);
-    load_input(cur, go_cur, 0);
-#pragma unroll
-    for (int kx = 0; kx < KS; ++kx) load_b(0, 0, kx);
-    store_input(smem, go_cur);
-    __syncthreads();
-
-    const int rows_total = chunks * KS;
-    int buf = 0;                                             // LDS buffer that holds the chunk being multiplied (DB only)
-    while (true) {
-        const int sg_next = sg + sg_step;
-        const bool has_next = sg_next * 8 + lane8 < n_spatial;
-        const Tile nxt = tile_of(has_next ? sg_next : sg);
-        offsets_of(nxt, go_nxt);
-
-        f32x4 acc[MTW][NTW];
-#pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int ch = 0; ch < chunks; ++ch) {
-            const bool more = ch + 1 < chunks;
-            // UNCONDITIONAL loads: the next chunk of this tile, or chunk 0 of the next tile (of this one again at the very end)
-            if (more) load_input(cur, go_cur, ch + 1);
-            else load_input(nxt, go_nxt, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            const char* in_s = smem + (DB ? buf * IN_BYTES : 0);
-#pragma unroll
-            for (int ky = 0; ky < KS; ++ky) {
-                int row_next = ch * KS + ky + 1;
-                row_next = row_next < rows_total ? row_next : 0;      // wraps: the next tile starts with the same weights
-                const int ch_n = row_next / KS, ky_n = row_next - ch_n * KS;
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    bf16x8 b[NTW];
-#pragma unroll
-                    for (int t = 0; t < NTW; ++t) b[t] = bq[kx][t];
-                    load_b(ch_n, ky_n, kx);
-                    __builtin_amdgcn_sched_barrier(0);
-                    constexpr int MG = (MTW % 2 == 0) ? 2 : 1;
-#pragma unroll
-                    for (int m0 = 0; m0 < MTW; m0 += MG) {
-                        bf16x8 a[MG];
-#pragma unroll
-                        for (int mm = 0; mm < MG; ++mm)
-                            a[mm] = *reinterpret_cast<const bf16x8*>(in_s + (((wm * MTW + m0 + mm) * S + ky) * IW + pl * S + kx) * PITCH + g * 16);
-#pragma unroll
-                        for (int mm = 0; mm < MG; ++mm)
-#pragma unroll
-                            for (int t = 0; t < NTW; ++t) {
-                                acc[m0 + mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mm], b[t], acc[m0 + mm][t], 0, 0, 0);
-                                asm volatile("" : "+v"(acc[m0 + mm][t]));      // pinned (see kernels_conv_fp8.hip)
-                            }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (more) {
-                if (!DB) __syncthreads();
-                store_input(smem + (DB ? (buf ^ 1) * IN_BYTES : 0), go_cur);
-                __syncthreads();
-                buf ^= 1;
-            }
-        }
-        __syncthreads();                                     // every wave is done with the input buffers: the slab may overwrite them
-
-        // ---- epilogue of `cur`: bias, fp64 statistics, bf16 stores through the block-wide LDS slab ----
-        float* ep = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int co = (nt_w + t) * 16 + pl;
-            const float bias = p.bias ? p.bias[co] : 0.f;
-            double s = 0.0, qq = 0.0;
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const int row = wm * MTW + m, oy = cur.oy0 + row;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ox = cur.ox0 + g * 4 + r;
-                    const float v = acc[m][t][r] + bias;
-                    ep[(row * 16 + g * 4 + r) * EPS + (wn * NTW + t) * 16 + pl] = v;
-                    if (oy < p.hout && ox < p.wout) {
-                        s += (double)v;
-                        qq += (double)v * (double)v;
-                    }
-                }
-            }
-            if (p.stats) stats_commit_b(s, qq, p.stats + ((size_t)cur.img * p.cout + co) * 2, lane);
-        }
-        __syncthreads();
-        {
-            constexpr int F8 = NTB * 2;                      // 16-byte (8-channel) records per pixel
-            const size_t el0 = (((size_t)cur.img * p.hout + cur.oy0) * p.wout + cur.ox0) * p.pitch_out + ct * NTB * 16;
-#pragma unroll
-            for (int it_ = 0; it_ < (TH * 16 * F8 + 255) / 256; ++it_) {      // (trip count visible to the unroller: the LDS reads of all passes go out together)
-                const int i = tid + 256 * it_;
-                if ((TH * 16 * F8) % 256 != 0 && i >= TH * 16 * F8) break;
-                const int pix = i / F8, c8 = i - pix * F8;
-                const int row = pix >> 4, x = pix & 15;
-                if (cur.oy0 + row < p.hout && cur.ox0 + x < p.wout) {
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c8 * 8]);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c8 * 8 + 4]);
-                    const uint2 lo = cs::f32x4_to_bf16(v0), hi = cs::f32x4_to_bf16(v1);
-                    *reinterpret_cast<u32x4b*>(reinterpret_cast<unsigned short*>(p.out) + el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c8 * 8) =
-                        u32x4b{lo.x, lo.y, hi.x, hi.y};
-                }
-            }
-        }
-        if (!has_next) break;
-        __syncthreads();                                     // slab reads are done: the next tile's first chunk may land in LDS
-        store_input(smem, go_nxt);
-        __syncthreads();
-        buf = 0;
-        cur = nxt;
-#pragma unroll
-        for (int it = 0; it < IN_ITERS; ++it) go_cur[it] = go_nxt[it];
-        sg = sg_next;
-    }
-}
-
-template <int S, int KS, int WN, int NTW, int THX = 1>
-static int launch_bp(hipStream_t s, ConvBParams p) {
-    constexpr int TH = THX * ((S == 1) ? 8 : 4);
-    p.tiles_x = ceil_div(p.wout, 16);
-    p.tiles_y = ceil_div(p.hout, TH);
-    const int n_spatial = p.tiles_x * p.tiles_y * p.n, n_ct = p.ntile_total / (WN * NTW);
-    const int unit = 8 * n_ct;                               // blocks that share one spatial group of 8
-    const int groups = (n_spatial + 7) / 8;
-    int resident = (256 * 4) / unit;                         // ~4 blocks per CU worth of spatial groups in flight
-    resident = resident < 1 ? 1 : resident;
-    const int g_launch = groups < resident ? groups : resident;
-    hipLaunchKernelGGL((conv_bf16p_kernel<S, KS, WN, NTW, THX>), dim3((unsigned)(g_launch * unit)), dim3(256), 0, s, p, n_spatial, n_ct);
-    CS_HIP(hipGetLastError());
-    return CS_OK;
-}
-
 static SrcDevB to_devb(const ConvSrc& s) { return SrcDevB{s.ptr, s.tab, s.slope, s.c, s.pitch, s.tab_c ? s.tab_c : s.c, s.tab_off, s.ptr2, s.tab2, s.slope2}; }
 
 template <int S, int KS, int WN, int NTW, int NP, int THX = 1, bool A16 = false>
@@ -692,23 +439,20 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     p.hout = (hin + 2 * pad - ksize) / stride + 1;
     p.wout = (win + 2 * pad - ksize) / stride + 1;
     const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
-    // Tile-shape choices that cut the per-wave weight streaming from L2 (the limiter of these kernels); bit mask for A/B runs
-    // (CS_BF16_TALL): 1 double-height tiles for stride 1 (two-plane modes), 2 stride-2 layers as 128-channel blocks in which
-    // every wave owns all 4 rows, 4 stride-1 layers with >= 128 channels as 128-channel blocks in which every wave owns all 8 rows.
-    static const int tall_env = getenv("CS_BF16_TALL") ? atoi(getenv("CS_BF16_TALL")) : 7;
-    // persistent blocks with cross-tile prefetch (conv_bf16p_kernel): built and measured - 6.73 vs 6.05 ms per slide for the
-    // stride-1 group.  Holding the next tile's patch in registers across the epilogue costs 40-70 VGPRs (144 -> 215 on the
-    // 32-channel kernel), the occupancy drops from 3 to 2 blocks per CU and that loses more than the prefetch hides.  Off by default.
-    static const int persist_env = getenv("CS_BF16_PERSIST") ? atoi(getenv("CS_BF16_PERSIST")) : 0;
-    const bool tall = (tall_env & 1) && stride == 1 && p.hout >= 16;
-    const bool wide128 = (tall_env & 2) && cout % 128 == 0;
+    // Tile shapes that cut the per-wave weight streaming from L2 (the limiter of these kernels): double-height tiles for stride 1
+    // (two-plane modes), stride-2 layers as 128-channel blocks in which every wave owns all 4 rows, stride-1 layers with >= 128
+    // channels as 128-channel blocks in which every wave owns all 8 rows.  (A persistent form with cross-tile prefetch was built
+    // in round 2 and measured slower - 6.73 vs 6.05 ms per slide for the stride-1 group: the next tile's patch held in registers
+    // across the epilogue costs 40-70 VGPRs and a block per CU - it lives in the history only.)
+    const bool tall = stride == 1 && p.hout >= 16;
+    const bool wide128 = cout % 128 == 0;
     const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
     const double esz = act16 ? 2.0 : 4.0;
     const double bytes = esz * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
 #define CS_B3(S_, KS_, NP_, A16_)                                                   \
     switch (wn) {                                                                   \
-        case 4: if ((tall_env & 4) && S_ == 1 && KS_ == 3 && NP_ != 3 && cout % 128 == 0) return launch_b<S_, KS_, 4, 2, (NP_ == 3 ? 4 : NP_), 1, A16_>(s, p); \
+        case 4: if (S_ == 1 && KS_ == 3 && NP_ != 3 && cout % 128 == 0) return launch_b<S_, KS_, 4, 2, (NP_ == 3 ? 4 : NP_), 1, A16_>(s, p); \
                 if (tall && (NP_ == 4 || NP_ <= 2) && KS_ == 3) return launch_b<S_, KS_, 2, 2, (NP_ == 3 ? 4 : NP_), 2, A16_>(s, p); \
                 if (wide128 && S_ == 2) return launch_b<S_, KS_, 4, 2, NP_, 1, A16_>(s, p);    \
                 return launch_b<S_, KS_, 2, 2, NP_, 1, A16_>(s, p);                 \
@@ -716,18 +460,7 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
                 return launch_b<S_, KS_, 2, 1, NP_, 1, A16_>(s, p);                 \
         default: return launch_b<S_, KS_, 1, 1, NP_, 1, A16_>(s, p);                \
     }
-#define CS_BP(S_, KS_)                                                              \
-    switch (wn) {                                                                   \
-        case 4: if (S_ == 1 && KS_ == 3 && cout % 128 == 0) return launch_bp<S_, KS_, 4, 2>(s, p);  \
-                if (tall && KS_ == 3) return launch_bp<S_, KS_, 2, 2, 2>(s, p);     \
-                if (wide128 && S_ == 2) return launch_bp<S_, KS_, 4, 2>(s, p);      \
-                return launch_bp<S_, KS_, 2, 2>(s, p);                              \
-        case 2: if (tall && KS_ == 3) return launch_bp<S_, KS_, 1, 2, 2>(s, p);     \
-                return launch_bp<S_, KS_, 2, 1>(s, p);                              \
-        default: return launch_bp<S_, KS_, 1, 1>(s, p);                             \
-    }
 #define CS_B2(S_, KS_)                                                              \
-    if (act16 && persist_env) { CS_BP(S_, KS_) }                                    \
     if (act16) { CS_B3(S_, KS_, 1, true) }                                          \
     switch (planes) {                                                               \
         case 4: CS_B3(S_, KS_, 4, false)                                            \
@@ -740,7 +473,6 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     CS_B2(2, 3)
 #undef CS_B2
 #undef CS_B3
-#undef CS_BP
 }
 
 // ------------------------------------------------------------------------------------------------

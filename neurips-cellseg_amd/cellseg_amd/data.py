@@ -5,8 +5,10 @@ with ``<stem>_label.png`` labels, seeded 90/10 split, whole-image min-max intens
 ``input_size``, random axis flip, random 90-degree rotation, Gaussian noise (p 0.25, std 0.1), gamma contrast
 (p 0.25, gamma in (1,2)), Gaussian smoothing (p 0.25, sigma_x in (1,2)), histogram shift (p 0.25, 3 control points)
 and zoom (p 0.15, 0.8-1.5, area / nearest, size kept).  They are CPU-side augmentations in DataLoader workers, outside
-the accelerated path, written from MONAI's published behaviour (MONAI itself is absent: parity unpinned, and the random
-streams differ from MONAI's by construction).
+the accelerated path, written from MONAI's published behaviour (MONAI itself is absent).  Their deterministic kernels - zoom, histogram
+shift, Gaussian smoothing - are pinned to the third-party primitives MONAI calls for them (``torch.nn.functional.interpolate``
+area / nearest, ``np.interp``, a separable torch convolution with MONAI's erf taps): fixtures ``tests/golden/augment_golden.npz``,
+generator ``tests/golden/make_augment_golden.py``.  The random streams differ from MONAI's by construction.
 """
 from __future__ import annotations
 
@@ -67,9 +69,9 @@ def gaussian_smooth(img: np.ndarray, sigma_y: float, sigma_x: float) -> np.ndarr
 def histogram_shift(img: np.ndarray, floating: np.ndarray) -> np.ndarray:
     """Piecewise-linear intensity remap through control points (RandHistogramShiftd's deterministic part): reference
     points are evenly spaced over [min, max]; `floating` holds their images as fractions of that range."""
-    lo, hi = float(img.min()), float(img.max())
-    ref = np.linspace(lo, hi, len(floating))
-    return np.interp(img, ref, np.asarray(floating, np.float64) * (hi - lo) + lo).astype(np.float32)
+    lo, hi = img.min(), img.max()
+    ref = np.linspace(0, 1, len(floating))                     # MONAI scales both point sets the same way: p * (max - min) + min
+    return np.interp(img, ref * (hi - lo) + lo, np.asarray(floating, np.float64) * (hi - lo) + lo).astype(np.float32)
 
 
 def random_control_points(rng, n: int) -> np.ndarray:

@@ -253,3 +253,24 @@ def test_worker_seeding_gives_distinct_streams():
             torch.utils.data.get_worker_info = real
         draws.append(ds.rng.random(4).tolist())
     assert draws[0] != draws[1] and draws[0] != draws[2] and draws[1] != draws[2]
+
+
+def test_augmentation_kernels_match_the_primitives_monai_calls():
+    """zoom / histogram shift / Gaussian smoothing against fixtures produced by the primitives MONAI's transforms call
+    (torch.nn.functional.interpolate area + nearest with MONAI's crop / edge-pad rule, np.interp, a separable torch conv with
+    MONAI's erf taps): tests/golden/make_augment_golden.py.  Reference: baseline/model_training_3class.py:119-162."""
+    from cellseg_amd import data
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment_golden.npz"))
+    img, lab = g["zoom_img"], g["zoom_lab"]
+    for i, z in enumerate(g["zoom_factors"]):
+        zi, zl = data.zoom_keep_size(img, lab, float(z))
+        assert zi.shape == img.shape and zl.shape == lab.shape and zl.dtype == lab.dtype
+        assert np.array_equal(zi, g[f"zoom_area_{i}"]), ("area", z)
+        assert np.array_equal(zl, g[f"zoom_nearest_{i}"]), ("nearest", z)
+    for i, fl in enumerate(g["hist_floating"]):
+        assert np.array_equal(data.histogram_shift(g["hist_img"], fl), g[f"hist_out_{i}"]), fl
+    for i, (s0, s1) in enumerate(g["gauss_sigmas"]):
+        taps = data.gaussian_kernel_1d(float(s0))
+        assert taps.shape == g[f"gauss_taps_{i}"].shape and np.abs(taps - g[f"gauss_taps_{i}"]).max() <= 1e-7
+        got = data.gaussian_smooth(g["gauss_img"], float(s0), float(s1))
+        assert np.abs(got - g[f"gauss_out_{i}"]).max() <= 2e-6, (s0, s1)

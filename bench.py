@@ -16,7 +16,7 @@ GPU) and forwards rank 0's JSON line.
 Multi-GPU legs:
   slides  (headline, weak scaling)   every rank segments its own slide, no data-path collective
   strips  (`strips` object, strong)  ONE slide split by WINDOW rows (no window evaluated twice), seam halves sent to the neighbour
-                                     below (RCCL send/recv), all-gather (RCCL) of the uint8 mask strips, CC on every rank (own stream)
+                                     below (RCCL send/recv), all-gather (RCCL) of the uint8 mask strips, CC on rank 0 (own stream)
   train   (`train_step` object; `--mode train` makes it the headline) data-parallel training step, batch 32x3x256x256 per
           GPU (BASELINE.json configs[1]/[3]): forward + DiceCE + backward + ONE flat-bucket RCCL all-reduce + AdamW
 Prints ONE JSON line on rank 0 (contract in the task description), including `roofline` (dominant kernel, HIP
@@ -337,6 +337,8 @@ def main():
     strip_parts = [ca.strip_partition(plan, r, world) for r in range(world)]
     strip_rows_all = [(st.row_begin, st.row_end) for st in strip_parts]
 
+    no_labels, no_num = torch.zeros((1, 1), dtype=torch.int32, device=dev), torch.zeros((), dtype=torch.int32, device=dev)
+
     def seam_exchange(win, pl, r, w):
         return parallel.exchange_seam(win, pl, r, w)
 
@@ -366,20 +368,21 @@ def main():
             return labelled(mask)
 
         def step_strips():
-            """One slide across ranks, split by WINDOW rows (31 rows over 8 ranks = 4,4,4,4,4,4,4,3; no window evaluated twice): every
+            """One slide across ranks, split by WINDOW rows (31 rows over 8 ranks = 3,4,4,4,4,4,4,4; no window evaluated twice): every
             rank runs its windows, the seam halves go to the neighbour below (RCCL send/recv), every rank finalises its rows, the uint8
-            mask strips are all-gathered (RCCL) and every rank labels the full mask on the CC stream beside its next slide."""
+            mask strips are all-gathered (RCCL) and RANK 0 - which holds the smaller share of windows - labels the full mask on its CC
+            stream beside its next slide ("gather the mask to rank 0 and label there"); its label map is the job's output."""
             image = imgs[it[0] % 2]
             it[0] += 1
             st, _, _, mask = ca.swi_infer_strip(model, image, roi, args.overlap, rank, world, engine_batch=args.strip_batch,
                                                 streams=args.streams, exchange=seam_exchange)
             full = parallel.gather_row_strips(mask[st.row_begin:st.row_end], args.size, rows=strip_rows_all)
-            return labelled(full)
+            return labelled(full) if rank == 0 else (no_labels, no_num)
 
         def step_sim():
             """ONE GPU doing the work of rank sim[0] of sim[1] of the strips leg: its windows, the local pack / unpack copies of the
-            seam exchange (the link transfer itself, 12 MB over one xGMI link, is not simulated), the finalize of its rows, and the
-            connected-component pass over a FULL mask (sim[2], from the single-GPU leg) on the CC stream."""
+            seam exchange (the link transfer itself, 12 MB over one xGMI link, is not simulated), the finalize of its rows, and - for
+            rank 0 - the connected-component pass over a FULL mask (sim[2], from the single-GPU leg) on the CC stream."""
             image = imgs[it[0] % 2]
             it[0] += 1
             r, w, full_mask = sim
@@ -393,7 +396,7 @@ def main():
                         win[j - me.halo_begin, :, r0:].contiguous()
             ca.swi_infer_strip(model, image, roi, args.overlap, r, w, engine_batch=args.strip_batch, streams=args.streams,
                                exchange=fake_exchange)
-            return labelled(full_mask)
+            return labelled(full_mask) if r == 0 else (no_labels, no_num)
 
         inner = step_sim if sim else (step_strips if (strips and dist is not None) else step_slide)
         if not d2h:
@@ -404,6 +407,8 @@ def main():
             overlaps the inference of slide k + 1 - what the predict CLI does with its writer thread.  Every timed step's labels
             are on the host when the timed region ends (torch.cuda.synchronize() drains both streams)."""
             lab, num = inner()
+            if lab is no_labels:
+                return lab, num                              # strips leg: only rank 0 labels (and copies) the gathered mask
             done.record(cc_stream if pipelined else None)
             copy_stream.wait_event(done)
             with torch.cuda.stream(copy_stream):
@@ -488,24 +493,28 @@ def main():
                 "scope": "baseline/predict.py:106-116: uint8 HWC image on the host -> /max -> device -> sliding-window inference -> softmax, "
                          "threshold, post-process -> labels on the host -> int32 deflate TIFF on disk (strip-parallel writer), one image at a time"}
 
-    def measure_strips_sim(model, full_s, sim_rank=3, sim_world=8):
-        """How long ONE rank of the 8-GPU strips leg works per slide, measured on this GPU (see step_sim)."""
+    def measure_strips_sim(model, full_s, sim_world=8):
+        """How long ONE rank of the 8-GPU strips leg works per slide, measured on this GPU (see step_sim): rank 0 (smaller share of the
+        windows + the connected-component pass) and an interior rank (larger share, no labelling); the job runs at the slower of them."""
         _, _, full_mask = ca.swi_infer_image(model, slide_pair(True)[0], roi, args.overlap, engine_batch=args.engine_batch,
                                              want_logits=False, want_mask=True, streams=args.streams)
-        step = make_step(model, True, False, sim=(sim_rank, sim_world, full_mask))
-        for _ in range(2):
-            step()
-        dt_sim, _ = time_steps(step, args.steps, barrier)
-        st = ca.strip_partition(plan, sim_rank, sim_world)
-        most = max(p.win_row_end - p.win_row_begin for p in (ca.strip_partition(plan, r, sim_world) for r in range(sim_world)))
-        return {"rank": sim_rank, "of": sim_world, "windows": (st.win_row_end - st.win_row_begin) * plan.n_w,
-                "max_windows_per_rank": most * plan.n_w, "window_rows_per_rank": [p.win_row_end - p.win_row_begin for p in
-                                                                               (ca.strip_partition(plan, r, sim_world) for r in range(sim_world))],
-                "ms_per_slide": round(dt_sim / args.steps * 1e3, 3), "full_slide_ms": round(full_s * 1e3, 3),
-                "ratio": round(full_s / (dt_sim / args.steps), 3),
-                "note": "one GPU doing rank 3's share of the 8-rank strips leg (its windows, the seam pack / unpack copies, its finalize, the "
-                        "CC pass over a full mask on the CC stream); the seam transfer (12 MB over one xGMI link) and the 2 MB-per-rank mask "
-                        "all-gather are not included"}
+        parts = [ca.strip_partition(plan, r, sim_world) for r in range(sim_world)]
+        ranks = {}
+        for sim_rank in sorted({0, min(3, sim_world - 1)}):
+            step = make_step(model, True, False, sim=(sim_rank, sim_world, full_mask))
+            for _ in range(2):
+                step()
+            dt_sim, _ = time_steps(step, args.steps, barrier)
+            st = parts[sim_rank]
+            ranks[str(sim_rank)] = {"windows": (st.win_row_end - st.win_row_begin) * plan.n_w, "labels_the_mask": sim_rank == 0,
+                                    "ms_per_slide": round(dt_sim / args.steps * 1e3, 3)}
+        worst = max(v["ms_per_slide"] for v in ranks.values())
+        return {"of": sim_world, "ranks": ranks, "window_rows_per_rank": [p.win_row_end - p.win_row_begin for p in parts],
+                "max_windows_per_rank": max(p.win_row_end - p.win_row_begin for p in parts) * plan.n_w,
+                "ms_per_slide": worst, "full_slide_ms": round(full_s * 1e3, 3), "ratio": round(full_s * 1e3 / worst, 3),
+                "note": "one GPU doing one rank's share of the 8-rank strips leg (its windows, the seam pack / unpack copies, its finalize; "
+                        "rank 0 also the CC pass over a full mask on the CC stream); ms_per_slide = the slower of the simulated ranks; the seam "
+                        "transfer (12 MB over one xGMI link) and the 2 MB-per-rank mask all-gather are not included"}
 
     def infer_summary(res, strips):
         slides = 1 if strips else world
@@ -515,20 +524,22 @@ def main():
     # ------------------------------------------------------------------------------------------------------------------
     # training leg (BASELINE.json configs[1] at N=1, configs[3] at N=8): the reference loop, model_training_3class.py:247-267
     # ------------------------------------------------------------------------------------------------------------------
-    def measure_train(width, with_prof=True, precision="fp32"):
+    def measure_train(width, with_prof=True, precision="fp32", batch=None, eager_too=True):
         torch.manual_seed(seed)                                   # identical replicas on every rank
         model = ca.UNet(channels=WIDTHS[width], strides=(2, 2, 2, 2), num_res_units=2).to(dev)
         model.precision = precision                               # forward arithmetic; activations stay fp32 and the backward runs in fp32
         g = torch.Generator(device="cpu").manual_seed(seed + 1 + rank)      # every rank its own shard of the global batch
-        b = args.train_batch
+        b = batch or args.train_batch
         x = torch.rand(b, 3, 256, 256, generator=g).to(dev)
         y = torch.randint(0, 3, (b, 1, 256, 256), generator=g).to(dev)
         onehot = ca.one_hot(y, 3)
         loss_fn, opt = ca.DiceCELoss(softmax=True), ca.AdamW(model, 6e-4)      # torch.optim.AdamW's rule, one launch for the 63 tensors
         model.train()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        k = args.train_steps
 
-        def step():
+        def eager_step():
+            """The loop body as the reference writes it (model_training_3class.py:250-262), through autograd, launch by launch."""
             opt.zero_grad(set_to_none=True)
             loss = loss_fn(model(x), onehot)
             loss.backward()
@@ -539,16 +550,28 @@ def main():
             opt.step()
             return loss
 
-        for _ in range(max(args.warmup, 2)):
-            step()
-        k = args.train_steps
-        dt, loss = time_steps(step, k, barrier)
+        eager_ms = None
+        if eager_too:
+            for _ in range(max(args.warmup, 2)):
+                eager_step()
+            dt_e, _ = time_steps(eager_step, k, barrier)
+            (dt_e,) = max_over_ranks([dt_e])
+            eager_ms = dt_e / k * 1e3
         allreduce_ms = None
-        if dist is not None:
+        if dist is not None and eager_too:
             torch.cuda.synchronize()
-            allreduce_ms = round(ev[0].elapsed_time(ev[1]), 4)   # the last step's exchange (events on the launch stream)
+            allreduce_ms = round(ev[0].elapsed_time(ev[1]), 4)   # the last eager step's exchange (events on the launch stream)
+        # the same body as ONE captured launch sequence (two graphs around the all-reduce under data parallel): ca.TrainStep
+        captured = ca.TrainStep(model, loss_fn, opt)
+
+        def step():
+            return captured(x, onehot)
+
+        for _ in range(max(args.warmup, 3)):
+            step()
+        dt, loss = time_steps(step, k, barrier)
         prof = {}
-        if with_prof:
+        if with_prof:                                          # per-kernel HIP events: eager launches on one stream (a capture holds no events)
             _lib.lib.cs_prof_reset()
             _lib.lib.cs_prof_enable(1)
             time_steps(step, k, barrier)
@@ -558,6 +581,7 @@ def main():
         ms = dt / k * 1e3
         tot = sum(v["ms"] for v in prof.values()) or 1.0
         out = {"images_per_s": round(world * b * k / dt, 1), "ms_per_step": round(ms, 3),
+               "eager_ms_per_step": round(eager_ms, 3) if eager_ms else None, "graph_nodes": captured.graph_nodes(),
                "tflops": round(world * 3 * b * WINDOW_GFLOP[width] / ms, 2),
                "frac_of_fp32_mfma_peak": round(3 * b * WINDOW_GFLOP[width] / ms / PEAK_F32_MFMA_TFLOPS, 4),
                "global_batch": world * b, "per_gpu_batch": b, "width": list(WIDTHS[width]),
@@ -568,7 +592,9 @@ def main():
                "kernels": {n: {"ms_per_step": round(v["ms"] / k, 4), "share": round(v["ms"] / tot, 4),
                                "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] else None}
                            for n, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:10]},
-               "note": "forward + DiceCE(softmax) + backward + flat-bucket all-reduce (N>1) + AdamW, all through the C-ABI (network, loss and optimiser kernels); FLOPs = 3 x forward conv FLOPs (SURVEY 8(d))"}
+               "note": "forward + DiceCE(softmax) + backward + flat-bucket all-reduce (when a process group exists) + AdamW + weight re-pack, all "
+                       "through the C-ABI; ms_per_step = the step replayed as a captured hipGraph (cellseg_amd.TrainStep), eager_ms_per_step = "
+                       "the same body through autograd, launch by launch; FLOPs = 3 x forward conv FLOPs (SURVEY 8(d))"}
         return out
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -576,6 +602,7 @@ def main():
     main_res = sec_res = None
     modes, other_part, train_res = {}, None, None
     strips_equal = None
+    train_ref = None
     if args.mode == "infer":
         main_res = measure_infer(args.width, args.precision, head_strips, True, extras=not args.no_secondary and rank == 0)
         if not args.no_secondary:
@@ -594,8 +621,12 @@ def main():
             tw = args.width if args.width in WINDOW_GFLOP and args.roi == 256 else "baseline32"
             train_res = measure_train(tw)
             if world == 1 and dist is None:                      # configs[1]: the same step with the forward convolutions on the bf16 pipe
-                t16 = measure_train(tw, with_prof=False, precision="bf16")
+                t16 = measure_train(tw, with_prof=False, precision="bf16", eager_too=False)
                 train_res["bf16_forward"] = {k: t16[k] for k in ("images_per_s", "ms_per_step", "loss", "dtype")}
+                # the reference's own training configuration (model_training_3class.py:201-208, --batch_size 8): 16...256 channels, batch 8
+                tref = measure_train("reference16", with_prof=False, batch=8)
+                train_ref = {k: tref[k] for k in ("images_per_s", "ms_per_step", "eager_ms_per_step", "graph_nodes", "tflops", "loss",
+                                                  "per_gpu_batch", "width")}
     else:
         train_res = measure_train(args.width, precision=args.precision if args.precision in ("fp32", "bf16", "fp16x3", "bf16x6") else "fp32")
 
@@ -700,7 +731,7 @@ def main():
         out["strips" if not head_strips else "slides"] = dict(
             other_part, scaling="strong" if not head_strips else "weak",
             note=("ONE slide split by window rows across the ranks (no window evaluated twice), seam halves sent to the neighbour below, "
-                  "uint8 mask strips all-gathered, CC on every rank on its CC stream: value = one slide's pixels / time"
+                  "uint8 mask strips all-gathered, CC on rank 0 (smaller window share) on its CC stream: value = one slide's pixels / time"
                   if not head_strips else "one slide per rank, no collective: value = N slides' pixels / time"))
         out["strips" if not head_strips else "slides"].update(strips_info if not head_strips else {})
         out["value_slides"] = out["value"] if not head_strips else other_part["value"]
@@ -726,6 +757,9 @@ def main():
                                            "width most layers fill a fraction of its K = 128)", **modes}
     if train_res:
         out["train_step"] = train_res
+    if train_ref:
+        out["train_step_reference"] = dict(train_ref, note="the reference's own training setting: channels 16...256, batch 8 x 3 x 256 x 256 "
+                                                            "(baseline/model_training_3class.py:201-208, 247-267), captured step vs eager loop")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.overlap, WIDTHS[args.width], seed)
     print(json.dumps(out))

@@ -105,6 +105,16 @@ int cs_unet_load_param(cs_unet* net, const char* key_host, const float* data, in
 int cs_unet_load_begin(cs_unet* net);
 int cs_unet_load_end(cs_unet* net, void* stream);
 
+/* Training loops whose parameter tensors stay where they are (model_training_3class.py:247-267: the optimiser updates them in
+ * place, step after step): cs_unet_bind_params records the (re)pack of ALL parameters from `param_ptrs_host[i]` (device pointer of
+ * parameter i in cs_unet_param_info order, PyTorch layout) ONCE - under the precision / training mode set at that moment - runs
+ * it, and keeps the job table on the device; cs_unet_repack then re-runs it with two kernel launches and no host bookkeeping (what
+ * follows every optimiser step), and cs_unet_readback copies the BatchNorm running statistics the last train-mode forward updated
+ * back into the bound running_mean / running_var tensors.  Both are plain launches: they can be stream-captured. */
+int cs_unet_bind_params(cs_unet* net, const float* const* param_ptrs_host, int n_params, void* stream);
+int cs_unet_repack(cs_unet* net, void* stream);
+int cs_unet_readback(cs_unet* net, void* stream);
+
 /* Bytes of caller workspace needed for a forward over `n` windows of h x w (multiples of 2^(levels)). */
 size_t cs_unet_workspace_bytes(const cs_unet* net, int n, int h, int w);
 
@@ -169,7 +179,8 @@ size_t cs_swi_windows_workspace_bytes(const cs_unet* net, const cs_swi_plan* pla
 int cs_swi_windows(cs_unet* net, const cs_swi_plan* plan_host, const float* image, int64_t sc, int64_t sh, int64_t sw,
                    int engine_batch, int win_row_begin, int win_row_end, float* win_logits,
                    void* workspace, size_t workspace_bytes, void* stream);
-/* Window-row partition of one image over `world` ranks (shares differ by at most one window row):
+/* Window-row partition of one image over `world` ranks (shares differ by at most one window row, the larger shares last: rank 0,
+ * which also labels the gathered mask, takes a smaller one - 31 rows over 8 ranks = 3,4,4,4,4,4,4,4):
  *   [win_row_begin, win_row_end)  window rows rank `rank` evaluates
  *   [row_begin, row_end)          output rows it finalises: from the first image row of its first window row to the first image row
  *                                 of the next rank's first window row (rank 0 starts at 0, the last rank ends at img_h)
@@ -250,6 +261,29 @@ int cs_dice_ce_backward(const float* logits, const int64_t* logit_strides, const
 int cs_adamw_step(const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* The same update with every per-step quantity in device memory, so that the launch can be stream-captured and replayed:
+ * hyper: device float[16] - [0..4] = lr, beta1, beta2, eps, weight_decay (the host rewrites them when a scheduler changes them),
+ * [8..10] scratch (decay, step size, 1 / sqrt(bias correction 2) of the step being applied); step: device int32, the number of steps
+ * applied so far (zero before the first): the call increments it and applies that step. */
+int cs_adamw_step_dev(const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq,
+                      float* hyper, int32_t* step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Captured launch sequences (hipGraph).  The loop body of baseline/model_training_3class.py:250-262 - forward, DiceCE, backward,
+ * AdamW, weight re-pack - is ~230 launches of a few microseconds each at the reference's width and batch 8: issued one by one the
+ * host, not the GPU, sets the pace.  Every entry point of this library that only enqueues work (cs_unet_forward, cs_unet_backward
+ * with its side-stream weight gradients, cs_dice_ce_*, cs_adamw_step_dev, cs_unet_repack, cs_unet_readback) may be called between
+ * cs_graph_begin and cs_graph_end on buffers that stay allocated; cs_graph_launch then replays the whole sequence as ONE submission.
+ * Not capturable: anything that uploads host tables (cs_unet_load_*), per-kernel profiling (cs_prof_enable).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cs_graph cs_graph;
+int cs_graph_begin(void* stream);                 /* hipStreamBeginCapture on `stream` */
+int cs_graph_end(void* stream, cs_graph** out);   /* end the capture and instantiate the executable graph */
+int cs_graph_abort(void* stream);                 /* end a capture whose recording failed, discarding it */
+int cs_graph_launch(cs_graph* g, void* stream);
+int cs_graph_num_nodes(const cs_graph* g);
+int cs_graph_destroy(cs_graph* g);
+
 /* ------------------------------------------------------------------------------------------------
  * F1 harness pieces  -  the O(H*W) parts of baseline/compute_metric.py (the metric of record):
  *   cs_label_max               max label of one or two int32 maps (out2[0], out2[1]) - `x.max()`, `y.max()` (:60)
@@ -272,6 +306,7 @@ int cs_remove_boundary_cells(const int32_t* labels, int h, int w, int border, in
  * ---------------------------------------------------------------------------------------------- */
 enum { CS_PROF_MAX_KERNELS = 32 };
 int cs_prof_enable(int on);
+int cs_prof_is_enabled(void);
 int cs_prof_reset(void);
 /* names_out: CS_PROF_MAX_KERNELS x 48 chars; ms_out / launches_out / flops_out / bytes_out: CS_PROF_MAX_KERNELS.
  * flops/bytes are ALGORITHMIC figures accumulated per launch (DESIGN.md "Roofline accounting"). Returns #ids. */

@@ -6,6 +6,7 @@ Host-side mirror of the reference's interfaces (same names, arguments and error 
   label / mask_to_instances  <- skimage.measure.label / morphology.remove_small_* (baseline/predict.py:113)
   create_interior_map        <- data/pre_process_3class.py:31-56
   DiceCELoss / AdamW         <- monai.losses.DiceCELoss(softmax=True) / torch.optim.AdamW (baseline/model_training_3class.py:234-237)
+  TrainStep                  <- the loop body baseline/model_training_3class.py:250-262 as one captured launch sequence (hipGraph)
 All arithmetic runs in libcellseg_hip.so; importing this package without the built library raises.
 """
 from ._lib import CellSegHipError, LIB_PATH, lib  # noqa: F401
@@ -15,7 +16,8 @@ from .inferers import (make_plan, rank_rows, sliding_window_inference, strip_par
 from .postprocess import create_interior_map, label, mask_to_instances, prob_to_instances  # noqa: F401
 from .losses import DiceCELoss, one_hot  # noqa: F401
 from .optim import AdamW  # noqa: F401
+from .trainer import TrainStep  # noqa: F401
 from . import metrics, parallel  # noqa: F401
 
 __all__ = ["UNet", "sliding_window_inference", "swi_infer_image", "make_plan", "window_starts", "rank_rows", "strip_partition", "swi_infer_strip",
-           "label", "mask_to_instances", "prob_to_instances", "create_interior_map", "DiceCELoss", "one_hot", "AdamW", "CellSegHipError", "lib", "LIB_PATH"]
+           "label", "mask_to_instances", "prob_to_instances", "create_interior_map", "DiceCELoss", "one_hot", "AdamW", "TrainStep", "CellSegHipError", "lib", "LIB_PATH"]

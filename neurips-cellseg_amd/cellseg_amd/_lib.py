@@ -85,6 +85,17 @@ def _load() -> C.CDLL:
         "cs_dice_ce_backward": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), i32, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                       vp, vp, sz, vp, vp]),
         "cs_adamw_step": (i32, [vp, i32, i64, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
+        "cs_unet_bind_params": (i32, [vp, C.POINTER(vp), i32, vp]),
+        "cs_unet_repack": (i32, [vp, vp]),
+        "cs_unet_readback": (i32, [vp, vp]),
+        "cs_adamw_step_dev": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, vp]),
+        "cs_graph_begin": (i32, [vp]),
+        "cs_graph_end": (i32, [vp, C.POINTER(vp)]),
+        "cs_graph_abort": (i32, [vp]),
+        "cs_graph_launch": (i32, [vp, vp]),
+        "cs_graph_num_nodes": (i32, [vp]),
+        "cs_graph_destroy": (i32, [vp]),
+        "cs_prof_is_enabled": (i32, []),
         "cs_prof_enable": (i32, [i32]),
         "cs_prof_reset": (i32, []),
         "cs_prof_collect": (i32, [C.c_char_p, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
@@ -103,7 +114,8 @@ EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_des
             "cs_normalize_image cs_label_max cs_label_overlap cs_remove_boundary_workspace_bytes cs_remove_boundary_cells "
             "cs_ccl_workspace_bytes "
             "cs_ccl_postprocess cs_ccl_label cs_interior_map cs_dice_ce_workspace_bytes cs_dice_ce_forward cs_dice_ce_backward cs_adamw_step "
-            "cs_prof_enable cs_prof_reset cs_prof_collect").split()
+            "cs_unet_bind_params cs_unet_repack cs_unet_readback cs_adamw_step_dev cs_graph_begin cs_graph_end cs_graph_abort cs_graph_launch "
+            "cs_graph_num_nodes cs_graph_destroy cs_prof_is_enabled cs_prof_enable cs_prof_reset cs_prof_collect").split()
 
 
 def check(rc: int, what: str = "") -> int:

@@ -48,7 +48,7 @@ def rank_rows(img_h: int, rank: int, world: int) -> Tuple[int, int]:
 def strip_partition(plan: SwiPlan, rank: int, world: int) -> SwiStrip:
     """Window-row partition of one image (``cs_swi_partition``): the window rows `rank` evaluates, the output rows it finalises
     and the earlier ranks' window rows (the halo) whose lower part still covers them.  Shares differ by at most one window row:
-    31 rows over 8 ranks = 4,4,4,4,4,4,4,3 - no window is evaluated twice (``rank_rows`` strips duplicate one per seam)."""
+    31 rows over 8 ranks = 3,4,4,4,4,4,4,4 (larger shares last) - no window is evaluated twice (``rank_rows`` strips duplicate one per seam)."""
     st = SwiStrip()
     check(lib.cs_swi_partition(C.byref(plan), int(rank), int(world), C.byref(st)), "cs_swi_partition")
     return st

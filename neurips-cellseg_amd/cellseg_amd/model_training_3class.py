@@ -46,6 +46,8 @@ def main(argv=None):
     parser.add_argument("--initial_lr", type=float, default=6e-4, help="learning rate")
     parser.add_argument("--synthetic", type=int, default=0, help="train on N seeded synthetic images instead of --data_path")
     parser.add_argument("--val_start_epoch", type=int, default=20, help="validate only after this epoch (reference: 20)")
+    parser.add_argument("--eager", action="store_true", help="issue the training step launch by launch through autograd instead of "
+                                                              "replaying it as a captured hipGraph (cellseg_amd.TrainStep)")
     args = parser.parse_args(argv)
     if args.model_name.lower() != "unet" or args.num_class != 3:
         raise SystemExit("only --model_name unet --num_class 3 is implemented by the MI355X engine")
@@ -95,6 +97,7 @@ def main(argv=None):
                     strides=(2, 2, 2, 2), num_res_units=2).to(device)
     loss_function = ca.DiceCELoss(softmax=True)
     optimizer = ca.AdamW(model, args.initial_lr)      # torch.optim.AdamW's update rule and state_dict layout, one HIP launch per step
+    train_step = None if args.eager else ca.TrainStep(model, loss_function, optimizer)
 
     best_metric, best_metric_epoch = -1, -1
     epoch_loss_values, metric_values = [], []
@@ -107,13 +110,17 @@ def main(argv=None):
         epoch_loss, step, t0 = 0.0, 0, time.time()
         for step, batch in enumerate(train_loader, 1):
             inputs, labels = batch["img"].to(device, non_blocking=True), batch["label"].to(device, non_blocking=True)
-            optimizer.zero_grad()
-            outputs = model(inputs)
-            loss = loss_function(outputs, ca.one_hot(labels, args.num_class))
-            loss.backward()
-            if world > 1:
-                parallel.sync_gradients(model)
-            optimizer.step()
+            if train_step is not None:
+                # the loop body below as one replayed launch sequence (forward, DiceCE, backward, all-reduce, AdamW, re-pack)
+                loss = train_step(inputs, ca.one_hot(labels, args.num_class))
+            else:
+                optimizer.zero_grad()
+                outputs = model(inputs)
+                loss = loss_function(outputs, ca.one_hot(labels, args.num_class))
+                loss.backward()
+                if world > 1:
+                    parallel.sync_gradients(model)
+                optimizer.step()
             epoch_loss += loss.item()
         epoch_loss /= max(step, 1)
         epoch_loss_values.append(epoch_loss)

@@ -114,12 +114,13 @@ def exchange_seam(win: torch.Tensor, plan, rank: int, world: int, group=None) ->
     return len(ops)
 
 
-def sync_gradients(model, group=None, reduce: bool = True) -> None:
+def sync_gradients(model, group=None, reduce: bool = True, rebind: bool = True) -> None:
     """Data-parallel gradient exchange: ONE RCCL all-reduce over the engine's flat fp32
     gradient bucket (6.5 MB at the reference width), then the mean.  `loss.backward()` leaves every parameter
     gradient as a view of ``model.flat_grad``; this re-binds the views after the in-place reduction so the optimiser
     reads the averaged values whatever autograd did with the originals.  ``reduce=False`` only re-binds (the caller has
-    already averaged ``model.flat_grad`` in place, e.g. through a host-side backend)."""
+    already averaged ``model.flat_grad`` in place, e.g. through a host-side backend); ``rebind=False`` skips the re-binding
+    (``TrainStep``: the gradients live in one static bucket)."""
     import torch.distributed as dist
     flat = model.flat_grad
     if flat is None:
@@ -134,6 +135,8 @@ def sync_gradients(model, group=None, reduce: bool = True) -> None:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if world > 1:
             flat.mul_(1.0 / world)
+    if not rebind:
+        return
     for key, p in model.named_parameters():
         off, numel, shape = model._grad_slots[key]
         p.grad = flat[off:off + numel].view(shape)

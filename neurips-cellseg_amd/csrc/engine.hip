@@ -232,6 +232,17 @@ struct cs_unet {
     hipEvent_t bwd_ev[48] = {};
     int device = -1;                 // the device the weight arena and the packing tables live on
     cs::PackCtx* pack = nullptr;     // per-handle weight-packing state (job tables allocated once, at creation)
+    // cs_unet_bind_params: the re-pack of ALL parameters from fixed source tensors as a frozen job table (cs_unet_repack re-runs it),
+    // and the copy of the BatchNorm running statistics back to the host's buffers (cs_unet_readback)
+    cs::PackCtx* pack_bound = nullptr;
+    cs::PackCtx* pack_readback = nullptr;
+    int bound_planes = -1;
+    bool bound_training = false;
+};
+
+struct cs_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 namespace cs {
@@ -1121,6 +1132,8 @@ int cs_unet_destroy(cs_unet* net) {
         if (ev) (void)hipEventDestroy(ev);
     if (net->arena) (void)hipFree(net->arena);
     cs::pack_ctx_destroy(net->pack);
+    cs::pack_ctx_destroy(net->pack_bound);
+    cs::pack_ctx_destroy(net->pack_readback);
     delete net;
     return CS_OK;
 }
@@ -1157,6 +1170,109 @@ int cs_unet_load_param(cs_unet* net, const char* key_host, const float* data, in
     }
     cs::set_error("load_param: unknown key '%s'", key_host);
     return CS_ERR_UNKNOWN_KEY;
+}
+
+int cs_unet_bind_params(cs_unet* net, const float* const* param_ptrs_host, int n_params, void* stream) {
+    CS_REQUIRE(net && param_ptrs_host, "bind_params: null argument");
+    CS_REQUIRE(n_params == (int)net->params.size(), "bind_params: %d pointers for %d parameters", n_params, (int)net->params.size());
+    if (int rcd = check_device(net)) return rcd;
+    hipStream_t s = (hipStream_t)stream;
+    cs::pack_ctx_destroy(net->pack_bound);
+    cs::pack_ctx_destroy(net->pack_readback);
+    net->pack_bound = cs::pack_ctx_create(4 * (int)net->params.size() + 16);
+    net->pack_readback = cs::pack_ctx_create((int)net->params.size() + 16);
+    CS_REQUIRE(net->pack_bound && net->pack_readback, "bind_params: allocating the job tables failed");
+    // the parameters' own load functions record into whatever context the handle points at: point it at the bound table
+    cs::PackCtx* const own = net->pack;
+    net->pack = net->pack_bound;
+    cs::pack_batch_begin(net->pack);
+    int rc = CS_OK;
+    for (size_t i = 0; i < net->params.size() && rc == CS_OK; ++i) {
+        ParamEntry& p = net->params[i];
+        if (!param_ptrs_host[i]) { cs::set_error("bind_params: null pointer for '%s'", p.key.c_str()); rc = CS_ERR_INVALID; break; }
+        rc = p.load(param_ptrs_host[i], s);
+        if (rc == CS_OK) {
+            p.loaded = true;
+            p.dgrad_packed = net->training;
+            p.wb_format = net->planes == 5 ? 3 : net->planes == 4 ? 2 : net->planes > 0 ? 1 : 0;
+        }
+    }
+    if (rc == CS_OK) rc = cs::pack_batch_freeze(net->pack, s);
+    net->pack = own;
+    if (rc != CS_OK) return rc;
+    cs::pack_batch_begin(net->pack_readback);
+    for (size_t i = 0; i < net->params.size() && rc == CS_OK; ++i) {
+        const ParamEntry& p = net->params[i];
+        const size_t kl = p.key.size();
+        const bool running = p.raw && ((kl > 13 && p.key.compare(kl - 13, 13, ".running_mean") == 0) || (kl > 12 && p.key.compare(kl - 12, 12, ".running_var") == 0));
+        if (running) rc = cs::pack_copy(net->pack_readback, s, p.raw, const_cast<float*>(param_ptrs_host[i]), (size_t)p.numel());
+    }
+    if (rc == CS_OK) rc = cs::pack_batch_freeze(net->pack_readback, s);
+    net->bound_planes = net->planes;
+    net->bound_training = net->training;
+    return rc;
+}
+
+int cs_unet_repack(cs_unet* net, void* stream) {
+    CS_REQUIRE(net && net->pack_bound, "repack: call cs_unet_bind_params first");
+    CS_REQUIRE(net->bound_planes == net->planes && net->bound_training == net->training,
+               "repack: the parameters were bound under another precision / training mode: bind them again");
+    return cs::pack_replay(net->pack_bound, (hipStream_t)stream);
+}
+
+int cs_unet_readback(cs_unet* net, void* stream) {
+    CS_REQUIRE(net && net->pack_readback, "readback: call cs_unet_bind_params first");
+    return cs::pack_replay(net->pack_readback, (hipStream_t)stream);
+}
+
+int cs_graph_begin(void* stream) {
+    CS_REQUIRE(!cs::prof_enabled(), "graph_begin: per-kernel profiling (cs_prof_enable) records events around every launch and cannot be captured");
+    CS_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
+    return CS_OK;
+}
+
+int cs_graph_end(void* stream, cs_graph** out) {
+    CS_REQUIRE(out, "graph_end: null argument");
+    cs_graph* g = new cs_graph();
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g->graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        cs::set_error("graph_end: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        cs_graph_destroy(g);
+        return CS_ERR_HIP;
+    }
+    *out = g;
+    return CS_OK;
+}
+
+int cs_graph_abort(void* stream) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture((hipStream_t)stream, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return CS_OK;
+}
+
+int cs_graph_launch(cs_graph* g, void* stream) {
+    CS_REQUIRE(g && g->exec, "graph_launch: null graph");
+    CS_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return CS_OK;
+}
+
+int cs_graph_num_nodes(const cs_graph* g) {
+    if (!g || !g->graph) return CS_ERR_INVALID;
+    size_t n = 0;
+    if (hipGraphGetNodes(g->graph, nullptr, &n) != hipSuccess) return CS_ERR_HIP;
+    return (int)n;
+}
+
+int cs_graph_destroy(cs_graph* g) {
+    if (!g) return CS_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return CS_OK;
 }
 
 size_t cs_unet_workspace_bytes(const cs_unet* net, int n, int h, int w) {
@@ -1269,6 +1385,11 @@ int cs_dice_ce_backward(const float* logits, const int64_t* logit_strides, const
 int cs_adamw_step(const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
     return adamw_step((hipStream_t)stream, table, n_tensors, total, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step);
+}
+
+int cs_adamw_step_dev(const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq, float* hyper,
+                      int32_t* step, void* stream) {
+    return adamw_step_dev((hipStream_t)stream, table, n_tensors, total, grad, exp_avg, exp_avg_sq, hyper, step);
 }
 
 int cs_swi_window_start(int i, int interval, int padded_size, int roi) {
@@ -1397,20 +1518,21 @@ int cs_swi_windows(cs_unet* net, const cs_swi_plan* pl, const float* image, int6
 
 int cs_swi_partition(const cs_swi_plan* pl, int rank, int world, cs_swi_strip* out) {
     CS_REQUIRE(pl && out && world >= 1 && rank >= 0 && rank < world, "swi_partition: bad argument (rank %d of %d)", rank, world);
-    auto first_row = [&](int r) {                     // first window row of rank r (sizes differ by at most one, larger shares first)
-        const int base = pl->n_h / world, rem = pl->n_h % world;
-        return r * base + (r < rem ? r : rem);
+    auto first_row = [&](int r) {                     // first window row of rank r: shares differ by at most one, the LARGER ones last -
+        const int base = pl->n_h / world, rem = pl->n_h % world;   // rank 0, which also labels the gathered mask, gets a smaller one
+        const int extra = r - (world - rem);
+        return r * base + (extra > 0 ? extra : 0);
     };
     auto first_out = [&](int r) {                     // first output row (image coordinates) rank r finalises
-        if (r <= 0) return 0;
-        const int a = first_row(r);
-        if (r >= world || a >= pl->n_h) return pl->img_h;
+        const int a = r >= world ? pl->n_h : first_row(r);
+        if (a <= 0) return 0;
+        if (a >= pl->n_h) return pl->img_h;
         int y = cs_swi_window_start(a, pl->interval_h, pl->pad_h, pl->roi_h) - pl->pad_top;
         y = y < 0 ? 0 : y;
         return y > pl->img_h ? pl->img_h : y;
     };
     out->win_row_begin = first_row(rank);
-    out->win_row_end = first_row(rank + 1);
+    out->win_row_end = rank + 1 >= world ? pl->n_h : first_row(rank + 1);
     out->row_begin = first_out(rank);
     out->row_end = first_out(rank + 1);
     if (out->win_row_begin == out->win_row_end) out->row_end = out->row_begin;      // a rank without windows finalises nothing
@@ -1526,6 +1648,8 @@ int cs_prof_enable(int on) {
     if (on) cs::g_prof_any = true;
     return CS_OK;
 }
+
+int cs_prof_is_enabled(void) { return cs::prof_enabled() ? 1 : 0; }
 
 int cs_prof_reset(void) {
     cs::ProfState& ps = cs::prof_state();

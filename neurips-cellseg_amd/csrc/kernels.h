@@ -48,6 +48,8 @@ int pack_first_weights16(PackCtx* pc, hipStream_t s, const float* w, int cout, i
 // batched packing: between begin and flush the pack_* entry points only record jobs; flush runs them in (at most) two kernels
 void pack_batch_begin(PackCtx* pc);
 int pack_batch_flush(PackCtx* pc, hipStream_t s);
+int pack_batch_freeze(PackCtx* pc, hipStream_t s);         // flush + keep the device job table: pack_replay re-runs it (kernel launches only)
+int pack_replay(PackCtx* pc, hipStream_t s);
 int pack_copy(PackCtx* pc, hipStream_t s, const float* src, float* dst, size_t n);
 int pack_bf16_submit(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int taps, unsigned short* packed,
                      int cout_off, int ntile_total, int cin_split, int chunks_total, bool f16);
@@ -231,6 +233,8 @@ int dice_ce_backward(hipStream_t s, const float* logits, const int64_t* ls, cons
                      size_t ws_bytes, float* grad_logits);
 
 // AdamW over many tensors in one launch: table [n_tensors][3] = (parameter pointer, flat offset, element count), offsets ascending
+int adamw_step_dev(hipStream_t s, const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   float* hyper, int* step);
 int adamw_step(hipStream_t s, const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq,
                float lr, float beta1, float beta2, float eps, float weight_decay, int step);
 

@@ -1322,9 +1322,21 @@ static int pack_submit(PackCtx* pc, hipStream_t s, const PackJob& jb) {
     return pack_batch_flush(pc, s);
 }
 
+static int pack_launch(PackCtx* pc, hipStream_t s) {
+    ProfScope prof(K_PACK, s, 0, pc->bytes);
+    if (pc->total_elems > 0)
+        hipLaunchKernelGGL(pack_jobs_kernel, dim3((unsigned)((pc->total_elems + 255) / 256)), dim3(256), 0, s, pc->dev, (int)pc->n_elem,
+                           pc->total_elems);
+    if (pc->total_blocks > 0)
+        hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)pc->total_blocks), dim3(256), 0, s, pc->dev + pc->n_elem, (int)(pc->n_jobs - pc->n_elem));
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 int pack_batch_flush(PackCtx* pc, hipStream_t s) {
     pc->recording = false;
     if (pc->jobs.empty()) return CS_OK;
+    CS_REQUIRE(!pc->frozen, "pack: this job table is frozen (pack_replay re-runs it)");
     // element-wise jobs first, tile jobs behind them; `begin` = first element / first block inside its own group
     std::vector<PackJob>& jobs = pc->jobs;
     std::stable_partition(jobs.begin(), jobs.end(), [](const PackJob& j) { return j.kind != PK_CONV; });
@@ -1354,16 +1366,28 @@ int pack_batch_flush(PackCtx* pc, hipStream_t s) {
     double bytes = 8.0 * (double)total_elems;
     for (size_t i = n_elem; i < n; ++i)
         bytes += 4.0 * 256 * pack_job_elems(jobs[i]) * (jobs[i].taps * (jobs[i].dst2 ? 3 : 2) + 16 * ((jobs[i].dstw ? 1 : 0) + (jobs[i].dstw2 ? 1 : 0)));
-    ProfScope prof(K_PACK, s, 0, bytes);
-    if (total_elems > 0)
-        hipLaunchKernelGGL(pack_jobs_kernel, dim3((unsigned)((total_elems + 255) / 256)), dim3(256), 0, s, pc->dev, (int)n_elem, total_elems);
-    if (total_blocks > 0)
-        hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)total_blocks), dim3(256), 0, s, pc->dev + n_elem, (int)(n - n_elem));
-    CS_HIP(hipGetLastError());
+    pc->n_elem = n_elem; pc->n_jobs = n; pc->total_elems = total_elems; pc->total_blocks = total_blocks; pc->bytes = bytes;
+    if (int rc = pack_launch(pc, s)) return rc;
     CS_HIP(hipEventRecord(pc->copied, s));
     pc->copied_pending = true;
     jobs.clear();
     return CS_OK;
+}
+
+// Flush once and keep the device job table for good: pack_replay() then re-runs exactly these jobs (same sources, same
+// destinations) with two kernel launches and nothing else - no job recording, no table upload, nothing a stream capture cannot
+// hold.  Used for the per-step re-pack of a training loop whose parameter tensors stay where they are.
+int pack_batch_freeze(PackCtx* pc, hipStream_t s) {
+    if (int rc = pack_batch_flush(pc, s)) return rc;
+    CS_HIP(hipStreamSynchronize(s));                          // the pinned table has been read: nothing refers to it any more
+    pc->frozen = true;
+    return CS_OK;
+}
+
+int pack_replay(PackCtx* pc, hipStream_t s) {
+    CS_REQUIRE(pc && pc->frozen, "pack: no frozen job table to replay");
+    if (pc->n_jobs == 0) return CS_OK;
+    return pack_launch(pc, s);
 }
 
 int pack_conv_weights(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize, float* packed,

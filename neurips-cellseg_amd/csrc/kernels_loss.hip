@@ -232,7 +232,53 @@ __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* table, int n_
     const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
     *p = *p * decay - step_size * (m / denom);
 }
+// device-resident hyperparameters (captured training step: nothing of the update may live in kernel arguments that change per step)
+//   hyper[0..4] = lr, beta1, beta2, eps, weight_decay (written by the host when they change); hyper[8..10] = decay, step size, 1 / sqrt(bc2)
+//   of the step being applied (written by the tick kernel); *step = number of steps applied so far
+__global__ void adamw_tick_kernel(float* hyper, int* step) {
+    const int t = *step + 1;
+    *step = t;
+    const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2], wd = hyper[4];
+    const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+    hyper[8] = (float)(1.0 - lr * wd);
+    hyper[9] = (float)(lr / bc1);
+    hyper[10] = (float)(1.0 / sqrt(bc2));
+}
+__global__ __launch_bounds__(256) void adamw_dev_kernel(const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg,
+                                                        float* exp_avg_sq, const float* hyper) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int lo = 0, hi = n_tensors - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 3 + 1] <= e) lo = mid;
+        else hi = mid - 1;
+    }
+    const int64_t local = e - table[lo * 3 + 1];
+    if (local < 0 || local >= table[lo * 3 + 2]) return;
+    const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], decay = hyper[8], step_size = hyper[9], inv_bc2_sqrt = hyper[10];
+    float* p = reinterpret_cast<float*>(table[lo * 3]) + local;
+    const float g = grad[e];
+    float m = exp_avg[e], v = exp_avg_sq[e];
+    m = m + (g - m) * (1.f - b1);
+    v = v * b2 + (1.f - b2) * g * g;
+    exp_avg[e] = m;
+    exp_avg_sq[e] = v;
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    *p = *p * decay - step_size * (m / denom);
+}
 }  // namespace
+
+int adamw_step_dev(hipStream_t s, const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   float* hyper, int* step) {
+    CS_REQUIRE(table && grad && exp_avg && exp_avg_sq && hyper && step && n_tensors > 0 && total > 0, "adamw(dev): bad argument");
+    ProfScope prof(K_LOSS, s, 0, 28.0 * (double)total);
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, s, hyper, step);
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, n_tensors, total, grad, exp_avg, exp_avg_sq,
+                       hyper);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
 
 int adamw_step(hipStream_t s, const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq,
                float lr, float beta1, float beta2, float eps, float weight_decay, int step) {

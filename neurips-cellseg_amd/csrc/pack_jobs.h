@@ -30,6 +30,11 @@ struct PackCtx {
     hipEvent_t copied = nullptr;   // the last H2D copy out of `host` (the next flush rewrites it)
     bool copied_pending = false;
     int device = -1;
+    // layout of the job table that was uploaded last (element-wise jobs first, tile jobs behind them): what pack_replay re-runs
+    size_t n_elem = 0, n_jobs = 0;
+    long long total_elems = 0, total_blocks = 0;
+    double bytes = 0.0;
+    bool frozen = false;           // pack_batch_freeze: the device table is final, pack_replay launches the kernels only
 };
 
 __device__ __forceinline__ void pack_first_elem(const PackJob& jb, int64_t e) {

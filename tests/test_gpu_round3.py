@@ -71,7 +71,7 @@ def test_seam_exchange_between_two_ranks_sharing_the_gpu():
     line = _bench("--gpus", "2", "--shard", "strips", "--size", "1024", "--steps", "2", "--warmup", "1", "--train-batch", "2",
                   "--train-steps", "2", "--strip-batch", "8", BENCH_DEVICE=0, BENCH_BACKEND="gloo")
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
-    assert line["config"]["window_rows_per_rank"] == [4, 3] and line["config"]["equal_to_single_gpu_labels"] is True
+    assert line["config"]["window_rows_per_rank"] == [3, 4] and line["config"]["equal_to_single_gpu_labels"] is True
     assert line["value_strips"] == line["value"] and line["value_slides"] == line["slides"]["value"]
 
 
@@ -115,7 +115,7 @@ def test_rccl_allreduce_and_allgather_execute_at_world_size_one(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["backend"] == "nccl" and res["world"] == 1
-    assert res["grad_same"] and res["mask_same"] and res["gathered_is_new_tensor"] and res["bucket"] > 100000
+    assert res["grad_same"] and res["mask_same"] and res["gathered_is_new_tensor"] and res["bucket"] > 50000
 
 
 def test_bench_force_dist_runs_rccl_on_one_gpu():
@@ -131,7 +131,7 @@ def test_bench_line_has_latency_reference_scope_and_strips_simulation():
     assert line["latency_ms"] > 0 and line["latency"]["min_ms"] <= line["latency_ms"] <= line["latency"]["max_ms"]
     assert 0 < line["value_incl_tiff"] < line["value"] * 1.5
     sim = line["strips_sim"]
-    assert sim["of"] == 8 and sim["windows"] <= sim["max_windows_per_rank"] == -(-7 // 8) * 7 and sim["ratio"] > 1
+    assert sim["of"] == 8 and sim["max_windows_per_rank"] == -(-7 // 8) * 7 and sim["ratio"] > 1 and sim["ranks"]["0"]["labels_the_mask"]
 
 
 # ------------------------------------------------------------------------------------------- BatchNorm under the tiler
@@ -206,3 +206,79 @@ def test_native_adamw_leaves_parameters_without_gradient_alone_and_checkpoints_s
     oc.load_state_dict(sb)                                          # torch's checkpoint: no entry for `skip`
     assert oc._step == 2 and idx not in oc.state_dict()["state"]
     ob.load_state_dict(sa)                                          # and the other way round
+
+
+# ------------------------------------------------------------------------------------------- the captured training step
+def _lockstep_models(norm="instance", act="prelu", channels=(16, 32, 64), n=3):
+    import cellseg_amd as ca
+    torch.manual_seed(21)
+    ms = [ca.UNet(channels=channels, strides=(2,) * (len(channels) - 1), num_res_units=2, norm=norm, act=act) for _ in range(n)]
+    for m in ms[1:]:
+        m.load_state_dict(ms[0].state_dict())
+    return [m.to(_dev()).train() for m in ms]
+
+
+@pytest.mark.parametrize("norm,act", [("instance", "prelu"), ("batch", "relu")])
+def test_captured_training_step_is_the_eager_step_bit_for_bit(norm, act):
+    """ca.TrainStep replays forward + DiceCE + backward (side-stream weight gradients) + AdamW + re-pack as ONE hipGraph: gradients
+    and parameters must be the bits of the same launch sequence issued eagerly, step after step, and both must track the
+    autograd loop of the reference (model_training_3class.py:250-262) that uses the host-scalar AdamW."""
+    import cellseg_amd as ca
+    a, b, c = _lockstep_models(norm, act)
+    loss_fn = ca.DiceCELoss(softmax=True)
+    oa, ob, oc = ca.AdamW(a, 6e-4), ca.AdamW(b, 6e-4), ca.AdamW(c, 6e-4)
+    step_a, step_b = ca.TrainStep(a, loss_fn, oa, capture=True), ca.TrainStep(b, loss_fn, ob, capture=False)
+    g = torch.Generator().manual_seed(8)
+    losses = []
+    for it in range(6):
+        x = torch.rand(4, 3, 64, 64, generator=g).to(_dev())
+        y = ca.one_hot(torch.randint(0, 3, (4, 1, 64, 64), generator=g).to(_dev()), 3)
+        la, lb = step_a(x, y), step_b(x, y)
+        oc.zero_grad()
+        lc = loss_fn(c(x), y)
+        lc.backward()
+        oc.step()
+        assert torch.equal(step_a.flat, step_b.flat), f"step {it}: captured and eager gradients differ"
+        for (k, pa), (_, pb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert torch.equal(pa, pb), (it, k)
+        losses.append((la.item(), lb.item(), lc.item()))
+        assert abs(la.item() - lc.item()) <= 2e-5, losses
+    assert step_a.graph_nodes() > 60 and step_b.graph_nodes() == 0
+    sc = c.state_dict()
+    for k, pa in a.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(pa) == 6 == int(sc[k])
+        else:
+            assert (pa - sc[k]).abs().max().item() <= 2e-5 * max(1.0, sc[k].abs().max().item()), k
+    assert oa._step == 6 and sorted(oa.state_dict()["state"]) == sorted(oc.state_dict()["state"])
+    # the model keeps working through the ordinary interfaces: inference sees the updated weights
+    with torch.no_grad():
+        xa = torch.rand(2, 3, 64, 64, generator=g).to(_dev())
+        assert torch.equal(a.eval()(xa), b.eval()(xa))
+
+
+def test_captured_training_step_notices_outside_changes_and_new_shapes():
+    """load_state_dict / a changed learning rate / another batch shape between steps: the captured step must follow."""
+    import cellseg_amd as ca
+    a, b = _lockstep_models(n=2)
+    loss_fn = ca.DiceCELoss(softmax=True)
+    oa, ob = ca.AdamW(a, 1e-3), ca.AdamW(b, 1e-3)
+    step_a, step_b = ca.TrainStep(a, loss_fn, oa), ca.TrainStep(b, loss_fn, ob, capture=False)
+    g = torch.Generator().manual_seed(9)
+
+    def batch(n, hw):
+        return (torch.rand(n, 3, hw, hw, generator=g).to(_dev()), ca.one_hot(torch.randint(0, 3, (n, 1, hw, hw), generator=g).to(_dev()), 3))
+    for _ in range(3):
+        x, y = batch(2, 64)
+        step_a(x, y), step_b(x, y)
+    torch.manual_seed(77)
+    fresh = ca.UNet(channels=(16, 32, 64), strides=(2, 2), num_res_units=2).state_dict()
+    a.load_state_dict(fresh), b.load_state_dict(fresh)               # e.g. resuming from a checkpoint
+    for opt in (oa, ob):
+        opt.param_groups[0]["lr"] = 2e-4                              # a scheduler
+    for n, hw in ((2, 64), (2, 64), (3, 32), (3, 32), (2, 64)):
+        x, y = batch(n, hw)
+        la, lb = step_a(x, y), step_b(x, y)
+        assert la.item() == lb.item()
+    for (k, pa), (_, pb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(pa, pb), k

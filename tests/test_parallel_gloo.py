@@ -144,7 +144,7 @@ def test_window_row_partition_covers_every_pixel_once(world, h, overlap):
     for src, dst, j, r0 in transfers:
         assert src < dst and parts[src].win_row_begin <= j < parts[src].win_row_end and 0 <= r0 < roi
     if (h, overlap, world) == (4096, 0.5, 8):
-        assert sizes == [4, 4, 4, 4, 4, 4, 4, 3] and plan.n_h == 31
+        assert sizes == [3, 4, 4, 4, 4, 4, 4, 4] and plan.n_h == 31
         assert [(s, d) for s, d, _, _ in transfers] == [(r, r + 1) for r in range(7)] and all(r0 == 128 for *_, r0 in transfers)
 
 

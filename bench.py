@@ -561,11 +561,20 @@ def main():
         if dist is not None and eager_too:
             torch.cuda.synchronize()
             allreduce_ms = round(ev[0].elapsed_time(ev[1]), 4)   # the last eager step's exchange (events on the launch stream)
-        # the same body as ONE captured launch sequence (two graphs around the all-reduce under data parallel): ca.TrainStep
-        captured = ca.TrainStep(model, loss_fn, opt)
+        # the same body as one lean launch sequence on static buffers (ca.TrainStep), and replayed as a captured hipGraph
+        graph_ms = None
+        if eager_too:
+            captured = ca.TrainStep(model, loss_fn, opt, capture=True)
+            for _ in range(max(args.warmup, 3)):
+                captured(x, onehot)
+            dt_g, _ = time_steps(lambda: captured(x, onehot), k, barrier)
+            (dt_g,) = max_over_ranks([dt_g])
+            graph_ms, graph_nodes = dt_g / k * 1e3, captured.graph_nodes()
+            del captured
+        lean = ca.TrainStep(model, loss_fn, opt)
 
         def step():
-            return captured(x, onehot)
+            return lean(x, onehot)
 
         for _ in range(max(args.warmup, 3)):
             step()
@@ -581,7 +590,8 @@ def main():
         ms = dt / k * 1e3
         tot = sum(v["ms"] for v in prof.values()) or 1.0
         out = {"images_per_s": round(world * b * k / dt, 1), "ms_per_step": round(ms, 3),
-               "eager_ms_per_step": round(eager_ms, 3) if eager_ms else None, "graph_nodes": captured.graph_nodes(),
+               "eager_ms_per_step": round(eager_ms, 3) if eager_ms else None,
+               "graph_ms_per_step": round(graph_ms, 3) if graph_ms else None, "graph_nodes": graph_nodes if graph_ms else None,
                "tflops": round(world * 3 * b * WINDOW_GFLOP[width] / ms, 2),
                "frac_of_fp32_mfma_peak": round(3 * b * WINDOW_GFLOP[width] / ms / PEAK_F32_MFMA_TFLOPS, 4),
                "global_batch": world * b, "per_gpu_batch": b, "width": list(WIDTHS[width]),
@@ -593,8 +603,9 @@ def main():
                                "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] else None}
                            for n, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:10]},
                "note": "forward + DiceCE(softmax) + backward + flat-bucket all-reduce (when a process group exists) + AdamW + weight re-pack, all "
-                       "through the C-ABI; ms_per_step = the step replayed as a captured hipGraph (cellseg_amd.TrainStep), eager_ms_per_step = "
-                       "the same body through autograd, launch by launch; FLOPs = 3 x forward conv FLOPs (SURVEY 8(d))"}
+                       "through the C-ABI; ms_per_step = cellseg_amd.TrainStep (the launches on static buffers, frozen re-pack table), "
+                       "graph_ms_per_step = the same sequence replayed as a captured hipGraph (TrainStep(capture=True)), eager_ms_per_step = "
+                       "the body through autograd as the reference writes it; FLOPs = 3 x forward conv FLOPs (SURVEY 8(d))"}
         return out
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -625,7 +636,7 @@ def main():
                 train_res["bf16_forward"] = {k: t16[k] for k in ("images_per_s", "ms_per_step", "loss", "dtype")}
                 # the reference's own training configuration (model_training_3class.py:201-208, --batch_size 8): 16...256 channels, batch 8
                 tref = measure_train("reference16", with_prof=False, batch=8)
-                train_ref = {k: tref[k] for k in ("images_per_s", "ms_per_step", "eager_ms_per_step", "graph_nodes", "tflops", "loss",
+                train_ref = {k: tref[k] for k in ("images_per_s", "ms_per_step", "eager_ms_per_step", "graph_ms_per_step", "graph_nodes", "tflops", "loss",
                                                   "per_gpu_batch", "width")}
     else:
         train_res = measure_train(args.width, precision=args.precision if args.precision in ("fp32", "bf16", "fp16x3", "bf16x6") else "fp32")
@@ -759,7 +770,7 @@ def main():
         out["train_step"] = train_res
     if train_ref:
         out["train_step_reference"] = dict(train_ref, note="the reference's own training setting: channels 16...256, batch 8 x 3 x 256 x 256 "
-                                                            "(baseline/model_training_3class.py:201-208, 247-267), captured step vs eager loop")
+                                                            "(baseline/model_training_3class.py:201-208, 247-267)")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.overlap, WIDTHS[args.width], seed)
     print(json.dumps(out))

@@ -46,8 +46,9 @@ def main(argv=None):
     parser.add_argument("--initial_lr", type=float, default=6e-4, help="learning rate")
     parser.add_argument("--synthetic", type=int, default=0, help="train on N seeded synthetic images instead of --data_path")
     parser.add_argument("--val_start_epoch", type=int, default=20, help="validate only after this epoch (reference: 20)")
-    parser.add_argument("--eager", action="store_true", help="issue the training step launch by launch through autograd instead of "
-                                                              "replaying it as a captured hipGraph (cellseg_amd.TrainStep)")
+    parser.add_argument("--eager", action="store_true", help="run the training step through autograd as the reference writes it instead of "
+                                                              "cellseg_amd.TrainStep (the same launches on static buffers)")
+    parser.add_argument("--graph", action="store_true", help="replay the training step as a captured hipGraph (cellseg_amd.TrainStep(capture=True))")
     args = parser.parse_args(argv)
     if args.model_name.lower() != "unet" or args.num_class != 3:
         raise SystemExit("only --model_name unet --num_class 3 is implemented by the MI355X engine")
@@ -97,7 +98,7 @@ def main(argv=None):
                     strides=(2, 2, 2, 2), num_res_units=2).to(device)
     loss_function = ca.DiceCELoss(softmax=True)
     optimizer = ca.AdamW(model, args.initial_lr)      # torch.optim.AdamW's update rule and state_dict layout, one HIP launch per step
-    train_step = None if args.eager else ca.TrainStep(model, loss_function, optimizer)
+    train_step = None if args.eager else ca.TrainStep(model, loss_function, optimizer, capture=args.graph)
 
     best_metric, best_metric_epoch = -1, -1
     epoch_loss_values, metric_values = [], []
@@ -111,7 +112,7 @@ def main(argv=None):
         for step, batch in enumerate(train_loader, 1):
             inputs, labels = batch["img"].to(device, non_blocking=True), batch["label"].to(device, non_blocking=True)
             if train_step is not None:
-                # the loop body below as one replayed launch sequence (forward, DiceCE, backward, all-reduce, AdamW, re-pack)
+                # the loop body below as one lean launch sequence on static buffers (forward, DiceCE, backward, all-reduce, AdamW, re-pack)
                 loss = train_step(inputs, ca.one_hot(labels, args.num_class))
             else:
                 optimizer.zero_grad()

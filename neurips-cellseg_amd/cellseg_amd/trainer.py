@@ -1,15 +1,23 @@
-"""``TrainStep`` - the loop body of the reference's training script as ONE replayed launch sequence.
+"""``TrainStep`` - the loop body of the reference's training script as one lean launch sequence, optionally a captured hipGraph.
 
 Reference: /root/reference/baseline/model_training_3class.py:250-262
 
     optimizer.zero_grad(); outputs = model(inputs); loss = loss_function(outputs, labels_onehot); loss.backward(); optimizer.step()
 
-At the reference's own setting (16...256 channels, batch 8) that body is ~230 kernel launches of a few microseconds each, and issued
-one by one through autograd the HOST sets the pace (3.4 ms of launch and bookkeeping per step against < 2 ms of GPU work).  This
-class issues the same C-ABI calls - ``cs_unet_forward``, ``cs_dice_ce_forward / _backward``, ``cs_unet_backward`` (side-stream
-weight gradients included), ``cs_adamw_step_dev``, ``cs_unet_repack`` - on buffers that stay allocated, records them once into a
-hipGraph (``cs_graph_begin / _end``) and replays the graph every step.  Under data parallel the step is two graphs with the
-flat-bucket all-reduce between them.  Same kernels in the same order as the eager path: the gradients are the eager path's bits.
+At the reference's own setting (16...256 channels, batch 8) that body is ~175 kernel launches of a few microseconds each; issued
+through autograd, with a 63-tensor upload check and the optimiser's bookkeeping around them, the HOST sets the pace (2.25 ms of
+enqueue per step for 1.8 ms of GPU work).  This class issues the same C-ABI calls - ``cs_unet_forward``,
+``cs_dice_ce_forward / _backward``, ``cs_unet_backward`` (side-stream weight gradients included), ``cs_adamw_step_dev``,
+``cs_unet_repack`` (a frozen re-pack table: two launches, no host table) - on buffers that stay allocated: 0.8 ms of enqueue,
+the step is GPU-bound again (measured on one MI355X, tests/diagnostics/gpu_train_step_modes.py: autograd loop 2.25 ms,
+this class 1.83 ms at 16...256 x 8; 6.18 vs 6.22 ms at 32...512 x 32, which was GPU-bound already).
+
+``capture=True`` records that sequence once into a hipGraph (``cs_graph_begin / _end``) and replays it every step (two graphs
+around the flat-bucket all-reduce under data parallel): the host enqueue drops to 0.55 ms and no longer depends on Python, but on
+ROCm 7.2 the replayed graph runs its 186 nodes SLOWER on the GPU than the same launches from streams (2.13 vs 1.83 ms, 6.67 vs
+6.22 ms: the graph's branch streams and per-node barriers cost more than they hide), so it is off by default - a choice for
+hosts whose cores are busy elsewhere.  Same kernels in the same order either way: the gradients are bit for bit those of the
+launch-by-launch sequence (``tests/test_gpu_round3.py``).
 
     step = ca.TrainStep(model, loss_function, optimizer)
     for batch in loader:
@@ -41,7 +49,7 @@ class _Shape:
 
 
 class TrainStep:
-    def __init__(self, model: UNet, loss_function: DiceCELoss, optimizer: AdamW, *, capture: bool = True, group=None,
+    def __init__(self, model: UNet, loss_function: DiceCELoss, optimizer: AdamW, *, capture: bool = False, group=None,
                  sync_gradients: Optional[bool] = None):
         if not isinstance(model, UNet) or not isinstance(loss_function, DiceCELoss) or not isinstance(optimizer, AdamW):
             raise TypeError("TrainStep drives cellseg_amd.UNet + cellseg_amd.DiceCELoss + cellseg_amd.AdamW")

@@ -751,6 +751,14 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         return CS_OK;
     };
 
+    // fp64 accumulators that end up as fp32 gradients (slope gradients, the last conv's weight / bias sums) are handed over by ONE
+    // launch at the end of the pass
+    F64Jobs f64_jobs;
+    auto f64_job = [&](const double* src, float* dst, int count, int slots) -> int {
+        CS_REQUIRE(f64_jobs.n < (int)(sizeof(f64_jobs.j) / sizeof(f64_jobs.j[0])), "backward: more than %d fp64 hand-overs", f64_jobs.n);
+        f64_jobs.j[f64_jobs.n++] = F64Job{src, dst, count, slots};
+        return CS_OK;
+    };
     // helpers -------------------------------------------------------------------------------------------
     // `before_norm`: the conv feeds an InstanceNorm, which removes any per-(image, channel) constant - the bias gradient is
     // analytically zero (autograd returns rounding noise there), so it is written as exact zeros instead of summing dy
@@ -764,11 +772,11 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     auto norm_bwd = [&](const NormSite& ns, const NormRt& rt, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch,
                         int64_t npix) -> int {
         double* red = acc.take<double>((size_t)n * y.c * 2);
-        double* dsl = acc.take<double>(1);
+        double* dsl = acc.take<double>(NORM_DSLOPE_SLOTS);
         if (dry) return CS_OK;
         CS_TRY(launch_norm_bwd(s, y, da, da_pitch, dy, dy_pitch, red, dsl, npix, n, bn ? rt.xtab : nullptr, bn,
                                bn && ns.p_bn_w >= 0 ? gptr(ns.p_bn_w) : nullptr, bn && ns.p_bn_b >= 0 ? gptr(ns.p_bn_b) : nullptr));
-        if (ns.p_slope >= 0) return launch_f64_to_f32(s, dsl, gptr(ns.p_slope), 1);
+        if (ns.p_slope >= 0) return f64_job(dsl, gptr(ns.p_slope), 1, NORM_DSLOPE_SLOTS);
         return CS_OK;
     };
     auto rsrc = [&](const float* p, int c, int pitch) { return raw_src(p, c, pitch); };
@@ -804,8 +812,8 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             if (!buf.ok()) return oom();
             if (!dry) {
                 CS_TRY(launch_conv_last_bwd(s, dlogits, lu, u.unit0.w, d_au, dw_last, last_part, n, oh, ow));
-                CS_TRY(launch_f64_to_f32(s, dw_last, gptr(u.unit0.p_w[0]), c * c * 9));
-                CS_TRY(launch_f64_to_f32(s, dw_last + 81, gptr(u.unit0.p_b[0]), c));
+                CS_TRY(f64_job(dw_last, gptr(u.unit0.p_w[0]), c * c * 9, 1));
+                CS_TRY(f64_job(dw_last + 81, gptr(u.unit0.p_b[0]), c, 1));
             }
         } else {
             float* dV = buf.take<float>((size_t)n * oh * ow * c);
@@ -950,6 +958,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         CS_TRY(launch_unpack_wgrad(sw, gf.part, gf.k, c0, cin, 0, 0, c, cin, 9, gptr(u.unit0.p_w[0])));
         CS_TRY(launch_unpack_wgrad(sw, gf.part, gf.k, c0, cin, c, 0, c, cin, 9, gptr(u.unit0.p_w[1])));
     }
+    if (!dry) CS_TRY(launch_f64_jobs(s, f64_jobs));
     if (side_on) {                             // join: the caller's stream continues behind the last weight gradients
         for (int i = 0; i < n_side; ++i) {
             const hipEvent_t ev = side_ev[side_used++ % n_side_ev];

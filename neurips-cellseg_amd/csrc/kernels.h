@@ -189,7 +189,10 @@ int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pit
 // sums the split_k partials and converts to the PyTorch layout dst[row][col][tap]
 int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_total, int cols_total, int row_off, int col_off,
                         int rows, int cols, int taps, float* dst);
-int launch_f64_to_f32(hipStream_t s, const double* src, float* dst, int n);
+constexpr int NORM_DSLOPE_SLOTS = 64;          // partial accumulators of one PReLU slope gradient (launch_norm_bwd's `dslope`)
+struct F64Job { const double* src; float* dst; int count, slots; };
+struct F64Jobs { F64Job j[96]; int n = 0; };   // passed by value as a kernel argument (2.3 KB)
+int launch_f64_jobs(hipStream_t s, const F64Jobs& jobs);   // dst[i] = (float) sum over slots of src[slot * count + i], one block per job
 // dw_db: 84 doubles = [81 weight gradients | 3 bias gradients]; partial: conv_last_bwd_partial_floats(n) floats of scratch
 size_t conv_last_bwd_partial_floats(int n);
 int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw_db,

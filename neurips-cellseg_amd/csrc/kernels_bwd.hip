@@ -33,7 +33,8 @@ struct NormBwdParams {
     const float2* tab; int tab_c, tab_off;
     const float* slope;
     double* red;       // [n][c][2]
-    double* dslope;    // scalar accumulator (or null for ReLU)
+    double* dslope;    // NORM_DSLOPE_SLOTS partial accumulators (or null for ReLU): blocks spread their atomics over the slots -
+                       // thousands of fp64 atomics on ONE address serialised at ~35 ns each (70 us of an 80 us pass at 8 x 128^2 x 16)
     float* dy;         int dy_pitch;
     int c, npix;       // channels, pixels per image
     int pix_per_block;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
         if (threadIdx.x < 64) {
             for (int l = threadIdx.x; l < 256; l += 64) tot += sh[l * 9 + 8];
             for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
-            if (threadIdx.x == 0) atomicAdd(p.dslope, (double)tot);
+            if (threadIdx.x == 0) atomicAdd(p.dslope + ((blockIdx.x + 13 * blockIdx.y) & (NORM_DSLOPE_SLOTS - 1)), (double)tot);
         }
     }
 }
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_small_kernel(NormBwdParam
         atomicAdd(p.red + (size_t)img * C * 2 + threadIdx.x,
                   (double)blk[0][threadIdx.x] + (double)blk[1][threadIdx.x] + (double)blk[2][threadIdx.x] + (double)blk[3][threadIdx.x]);
     if (p.dslope && threadIdx.x == 2 * C)
-        atomicAdd(p.dslope, (double)blk[0][2 * C] + (double)blk[1][2 * C] + (double)blk[2][2 * C] + (double)blk[3][2 * C]);
+        atomicAdd(p.dslope + ((blockIdx.x + 13 * blockIdx.y) & (NORM_DSLOPE_SLOTS - 1)),
+                  (double)blk[0][2 * C] + (double)blk[1][2 * C] + (double)blk[2][2 * C] + (double)blk[3][2 * C]);
 }
 
 template <int C>
@@ -287,18 +289,23 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
         CS_REQUIRE(y.c % 4 == 0 && c4n <= 256 && 256 % c4n == 0, "norm_bwd: %d channels unsupported (need a power of two in 16..1024)", y.c);
         // enough blocks to keep ~30 KB of loads in flight per CU: ~4096 blocks over the batch (the round-1 choice of 1024 pixels
         // per block left 2 blocks per CU on the large tensors and ran the pass at 1 TB/s)
-        auto chunk = [&](int64_t target_blocks) {
+        // ... but never so many that a block's share shrinks to a handful of elements per thread: at 8 x 128^2 x 16 channels 2048 blocks
+        // held 4 elements per thread and the pass was nothing but 65 k fp64 atomics on 256 addresses (70 us for 17 MB; 16 of the 172
+        // launches of the reference-width training step were a fifth of its time) - at least `min_elems` elements per thread
+        auto chunk = [&](int64_t target_blocks, int min_elems) {
             int64_t ppb = (npix * n + target_blocks - 1) / target_blocks;
+            const int64_t ppb_min = (int64_t)min_elems * 256 / y.c;
+            ppb = ppb < ppb_min ? ppb_min : ppb;
             ppb = ppb < 64 ? 64 : ppb;
             ppb = (ppb + 63) / 64 * 64;
             return (int)(ppb < npix ? ppb : npix);
         };
-        p.pix_per_block = chunk(2048);
+        p.pix_per_block = chunk(2048, 64);
         dim3 grid((unsigned)ceil_div((int)npix, p.pix_per_block), (unsigned)n);
         hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(256), 0, s, p);
         bn_finalize();
         NormBwdParams pa = p;                                // finer pixel chunks: the apply pass has no per-block reduction to amortise
-        pa.pix_per_block = chunk(4096);
+        pa.pix_per_block = chunk(4096, 16);
         hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)ceil_div((int)npix, pa.pix_per_block), (unsigned)n), dim3(256), 0, s, pa);
     }
     CS_HIP(hipGetLastError());
@@ -830,7 +837,10 @@ int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_
 #define CS_UNPACK(EL_, T_)                                                                                                       \
     hipLaunchKernelGGL((unpack_wgrad_kernel<EL_, T_>), dim3((unsigned)ceil_div(rows * cols, EL_)), dim3(256), 0, s, part, split_k, \
                        rows_total, cols_total, row_off, col_off, rows, cols, dst)
-    if (split_k > 16) {
+    if (split_k > 64 && rows * cols <= 1024 && taps == 9) {
+        CS_UNPACK(2, 9);            // small tensor, hundreds of slices (16- and 32-channel layers at 128^2): 8 elements per block left 32
+                                    // blocks summing 512 slabs (65 us); 2 elements x 128 split-K lanes put the same loads on 4x the CUs
+    } else if (split_k > 16) {
         if (taps == 9) CS_UNPACK(8, 9); else CS_UNPACK(8, 1);
     } else {
         if (taps == 9) CS_UNPACK(64, 9); else CS_UNPACK(64, 1);
@@ -840,12 +850,20 @@ int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_
     return CS_OK;
 }
 
-__global__ void f64_to_f32_kernel(const double* src, float* dst, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = (float)src[i];
+// All fp64 -> fp32 hand-overs of one backward pass (PReLU slope gradients: NORM_DSLOPE_SLOTS partial sums each; the last conv's
+// 84 weight / bias sums) in ONE launch at the end of the pass: block b does job b, dst[i] = sum over slots of src[slot * count + i].
+// (One small launch behind every norm backward was 19 launches of ~5 us on the critical chain of a 2 ms step.)
+__global__ void f64_jobs_kernel(F64Jobs jobs) {
+    const F64Job jb = jobs.j[blockIdx.x];
+    for (int i = threadIdx.x; i < jb.count; i += blockDim.x) {
+        double t = 0.0;
+        for (int sl = 0; sl < jb.slots; ++sl) t += jb.src[(size_t)sl * jb.count + i];
+        jb.dst[i] = (float)t;
+    }
 }
-int launch_f64_to_f32(hipStream_t s, const double* src, float* dst, int n) {
-    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, src, dst, n);
+int launch_f64_jobs(hipStream_t s, const F64Jobs& jobs) {
+    if (jobs.n == 0) return CS_OK;
+    hipLaunchKernelGGL(f64_jobs_kernel, dim3((unsigned)jobs.n), dim3(64), 0, s, jobs);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -263,7 +263,7 @@ def test_captured_training_step_notices_outside_changes_and_new_shapes():
     a, b = _lockstep_models(n=2)
     loss_fn = ca.DiceCELoss(softmax=True)
     oa, ob = ca.AdamW(a, 1e-3), ca.AdamW(b, 1e-3)
-    step_a, step_b = ca.TrainStep(a, loss_fn, oa), ca.TrainStep(b, loss_fn, ob, capture=False)
+    step_a, step_b = ca.TrainStep(a, loss_fn, oa, capture=True), ca.TrainStep(b, loss_fn, ob, capture=False)
     g = torch.Generator().manual_seed(9)
 
     def batch(n, hw):

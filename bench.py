@@ -162,6 +162,56 @@ def cpu_baseline(size, roi, overlap, channels, seed):
     return out
 
 
+def lowprec_accuracy(dev, steps=150, n_images=2, size=1024, precisions=("fp16x3", "bf16x6", "bf16", "fp8"), seed=7):
+    """Accuracy of the low-precision datapaths where it means something: on a TRAINED net (random-init logits sit at the 0.5
+    threshold).  A 32-base U-Net is trained for `steps` AdamW steps on seeded synthetic cells (fp32 engine, ca.TrainStep), then
+    `n_images` held-out synthetic images of size^2 are segmented in fp32 and in every mode: instance F1@0.5 against the fp32
+    instances (compute_metric.py semantics), pixel agreement of the interior masks, and F1 against the synthetic ground truth
+    (the reference's accuracy target is "F1 within 1e-3 of the reference path")."""
+    import cellseg_amd as ca
+    from cellseg_amd import data, metrics
+    torch.manual_seed(seed)
+    model = ca.UNet(channels=WIDTHS["baseline32"], strides=(2, 2, 2, 2), num_res_units=2).to(dev).train()
+    ds = data.SyntheticCells(64, 256, 2022)
+    batches = [(torch.stack([ds[i]["img"] for i in range(b, b + 8)]).to(dev),
+                ca.one_hot(torch.stack([ds[i]["label"] for i in range(b, b + 8)]).to(dev), 3)) for b in range(0, 64, 8)]
+    step = ca.TrainStep(model, ca.DiceCELoss(softmax=True), ca.AdamW(model, 6e-4))
+    first = last = None
+    for it in range(steps):
+        loss = step(*batches[it % len(batches)])
+        if it == 0:
+            first = loss.item()
+    last = loss.item()
+    model.eval()
+    held = data.SyntheticCells(n_images, size, 9900)
+    sums = {p: dict(f1_vs_fp32=0.0, pixel_agreement=0.0, f1_vs_truth=0.0) for p in precisions}
+    f1_truth_fp32, cells = 0.0, 0
+    with torch.no_grad():
+        for i in range(n_images):
+            item = held[i]
+            img = item["img"].to(dev)
+            truth = ca.label((item["label"][0] == 1).to(dev).to(torch.uint8), connectivity=1)      # ground-truth interiors as instances
+            res = {}
+            for prec in ("fp32",) + tuple(precisions):
+                model.precision = prec
+                _, _, mask = ca.swi_infer_image(model, img, (256, 256), 0.5, want_logits=False, want_mask=True)
+                res[prec] = (mask.clone(), ca.mask_to_instances(mask))
+            cells += int(res["fp32"][1].max())
+            f1_truth_fp32 += metrics.f1_score(truth, res["fp32"][1])[5]
+            for prec in precisions:
+                sums[prec]["f1_vs_fp32"] += metrics.f1_score(res["fp32"][1], res[prec][1])[5]
+                sums[prec]["pixel_agreement"] += float((res["fp32"][0] == res[prec][0]).float().mean())
+                sums[prec]["f1_vs_truth"] += metrics.f1_score(truth, res[prec][1])[5]
+    model.precision = "fp32"
+    out = {"trained_net": {"channels": list(WIDTHS["baseline32"]), "steps": steps, "loss_first": round(first, 4), "loss_last": round(last, 4),
+                           "held_out_images": n_images, "image_size": size, "cells_found_fp32": cells,
+                           "f1_vs_truth_fp32": round(f1_truth_fp32 / n_images, 5)}}
+    for prec in precisions:
+        out[prec] = {k: round(v / n_images, 5) for k, v in sums[prec].items()}
+        out[prec]["delta_f1_vs_truth"] = round(out[prec]["f1_vs_truth"] - out["trained_net"]["f1_vs_truth_fp32"], 5)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` without a torchrun environment starts the N ranks itself
 # ----------------------------------------------------------------------------------------------------------------------
@@ -627,8 +677,13 @@ def main():
             if world == 1 and dist is None and args.precision == "fp32":
                 for prec in ("fp16x3", "bf16x6", "bf16", "fp8"):
                     r = measure_infer(args.width, prec, False, False)
-                    modes[prec] = dict(infer_summary(r, False), foreground_agreement_vs_primary=round(
+                    modes[prec] = dict(infer_summary(r, False), foreground_agreement_vs_primary_random_init=round(
                         float(((r["labels"] > 0) == (main_res["labels"] > 0)).float().mean().item()), 6))
+                # ... and what the modes do to the RESULT, on a net whose logits are decisive (trained on synthetic cells, ~1 s)
+                acc = lowprec_accuracy(dev)
+                modes["accuracy_on_trained_net"] = acc.pop("trained_net")
+                for prec, a in acc.items():
+                    modes[prec].update(a)
             tw = args.width if args.width in WINDOW_GFLOP and args.roi == 256 else "baseline32"
             train_res = measure_train(tw)
             if world == 1 and dist is None:                      # configs[1]: the same step with the forward convolutions on the bf16 pipe
@@ -765,7 +820,10 @@ def main():
                                            "6 terms are fp32-grade (logits within 1e-4 of the oracle in the GPU tests); bf16 = the bf16 datapath "
                                            "(bf16 weights, bf16 activations in HBM); fp8 = e4m3 weights with per-channel scales, e4m3-staged "
                                            "activations, v_mfma_scale_f32_16x16x128_f8f6f4 (built for the 64...1024 net of configs[4]: at this "
-                                           "width most layers fill a fraction of its K = 128)", **modes}
+                                           "width most layers fill a fraction of its K = 128).  f1_vs_fp32 / pixel_agreement / delta_f1_vs_truth: "
+                                           "instance F1@0.5 and interior-mask agreement against the fp32 path, and the change of the F1 against "
+                                           "the synthetic ground truth, on the synthetic-trained net described under accuracy_on_trained_net",
+                                   **modes}
     if train_res:
         out["train_step"] = train_res
     if train_ref:

@@ -45,7 +45,7 @@ def main(argv=None):
     parser.add_argument("--input_size", default=256, type=int, help="sliding-window size")
     parser.add_argument("--overlap", default=0.25, type=float, help="window overlap (MONAI default 0.25)")
     parser.add_argument("--random_init", action="store_true", help="no checkpoint: random weights (smoke runs)")
-    parser.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3", "bf16x6", "bf16x3", "bf16"],
+    parser.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3", "bf16x6", "bf16x3", "bf16", "fp8"],
                         help="matrix-core arithmetic of the convolutions (engine option; fp16x3 / bf16x6 are fp32-grade)")
     args = parser.parse_args(argv)
 

@@ -445,11 +445,12 @@ def trained_pair():
     return model.eval()
 
 
-@pytest.mark.parametrize("precision,f1_min,agree_min", [("bf16", 0.97, 0.995), ("fp8", 0.90, 0.98)])
+@pytest.mark.parametrize("precision,f1_min,agree_min", [("bf16", 0.99, 0.998), ("fp8", 0.98, 0.995)])
 def test_low_precision_datapaths_keep_instances_of_a_trained_net(trained_pair, precision, f1_min, agree_min):
     """BASELINE configs[1] / configs[4] datapaths (bf16 activations in HBM; fp8 weights + fp8-staged activations) on the trained
     net: the instance masks of a 1024^2 synthetic image against the fp32 path's - F1@0.5 (compute_metric semantics) and pixel
-    agreement of the interior mask."""
+    agreement of the interior mask.  Measured in round 3 over four held-out images (profiles/lowprec_accuracy_r03.json): bf16 F1
+    0.9986 / agreement 0.99955, fp8 0.9959 / 0.9981; F1 against the synthetic ground truth moves by -6.5e-4 / -1.7e-4."""
     import cellseg_amd as ca
     from cellseg_amd import data, metrics
     model = trained_pair

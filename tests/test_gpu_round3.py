@@ -282,3 +282,34 @@ def test_captured_training_step_notices_outside_changes_and_new_shapes():
         assert la.item() == lb.item()
     for (k, pa), (_, pb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert torch.equal(pa, pb), k
+
+
+# ------------------------------------------------------------------------------------------- low precision: the accuracy target itself
+def test_low_precision_modes_stay_within_1e3_of_the_fp32_f1_against_ground_truth():
+    """north_star: "F1 within 1e-3 of reference on held-out tuning set".  On the synthetic-trained 32-base net (bench.lowprec_accuracy:
+    150 AdamW steps, 4 held-out 1024^2 synthetic images with known ground truth) the F1 of every mode against the ground truth must
+    stay within 1e-3 of the fp32 path's, the fp32-grade modes must reproduce the fp32 instances exactly, and the throughput modes
+    keep F1 >= 0.99 (bf16) / 0.98 (fp8) against the fp32 instances (measured 0.9986 / 0.9959, profiles/lowprec_accuracy_r03.json)."""
+    sys.path[:0] = [ROOT, PKG]
+    from bench import lowprec_accuracy
+    res = lowprec_accuracy(_dev())
+    assert res["trained_net"]["cells_found_fp32"] > 500 and res["trained_net"]["f1_vs_truth_fp32"] > 0.6
+    for prec in ("fp16x3", "bf16x6"):
+        assert res[prec]["f1_vs_fp32"] >= 1.0 - 1e-3 and abs(res[prec]["delta_f1_vs_truth"]) <= 1e-3, (prec, res[prec])
+    assert res["bf16"]["f1_vs_fp32"] >= 0.99 and res["bf16"]["pixel_agreement"] >= 0.998, res["bf16"]
+    assert res["fp8"]["f1_vs_fp32"] >= 0.98 and res["fp8"]["pixel_agreement"] >= 0.995, res["fp8"]
+    for prec in ("bf16", "fp8"):
+        assert abs(res[prec]["delta_f1_vs_truth"]) <= 1e-3, (prec, res[prec])
+
+
+def test_predict_cli_accepts_fp8(tmp_path):
+    """`python -m cellseg_amd.predict --precision fp8` (configs[4]'s datapath behind the reference's CLI contract, predict.py:24-35)."""
+    from PIL import Image
+    inp, outp = tmp_path / "in", tmp_path / "out"
+    inp.mkdir()
+    rng = np.random.default_rng(0)
+    Image.fromarray((rng.random((300, 280, 3)) * 255).astype(np.uint8)).save(inp / "a.png")
+    out = subprocess.run([sys.executable, "-m", "cellseg_amd.predict", "-i", str(inp), "-o", str(outp), "--random_init", "--precision", "fp8"],
+                         capture_output=True, text=True, timeout=600, env=_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert (outp / "a_label.tiff").exists()

@@ -769,25 +769,53 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         if (!buf.ok()) return oom();
         return launch_colsum(s, dy, pitch, c, npix_total, partial, gptr(pidx));
     };
+    // Weight gradients of the 3x3 layers on the 16-bit matrix pipe (kernels_bwd16.hip) when the handle's precision asks for it:
+    // 0 = split fp16, 3 terms (cs_unet_set_precision 4, fp32-grade), 1 = plain bf16 (precision 1: bf16 forward AND backward
+    // arithmetic, fp32 master weights - BASELINE configs[1]), -1 = the fp32 kernels.  Gradient operands of the fp16 mode carry a
+    // dynamic power-of-two scale taken from max|dy|, which the producer of dy maintains in a device float (`amax` slots below).
+    const int bwd16 = net->planes == 4 ? 0 : net->planes == 1 ? 1 : -1;
     auto norm_bwd = [&](const NormSite& ns, const NormRt& rt, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch,
-                        int64_t npix) -> int {
+                        int64_t npix, float** amax_out = nullptr) -> int {
         double* red = acc.take<double>((size_t)n * y.c * 2);
         double* dsl = acc.take<double>(NORM_DSLOPE_SLOTS);
+        float* amax = (bwd16 == 0 && amax_out) ? acc.take<float>(AMAX_SLOTS) : nullptr;
+        if (amax_out) *amax_out = amax;
         if (dry) return CS_OK;
         CS_TRY(launch_norm_bwd(s, y, da, da_pitch, dy, dy_pitch, red, dsl, npix, n, bn ? rt.xtab : nullptr, bn,
-                               bn && ns.p_bn_w >= 0 ? gptr(ns.p_bn_w) : nullptr, bn && ns.p_bn_b >= 0 ? gptr(ns.p_bn_b) : nullptr));
+                               bn && ns.p_bn_w >= 0 ? gptr(ns.p_bn_w) : nullptr, bn && ns.p_bn_b >= 0 ? gptr(ns.p_bn_b) : nullptr, amax));
         if (ns.p_slope >= 0) return f64_job(dsl, gptr(ns.p_slope), 1, NORM_DSLOPE_SLOTS);
         return CS_OK;
     };
     auto rsrc = [&](const float* p, int c, int pitch) { return raw_src(p, c, pitch); };
+    // max |t| of a gradient tensor that no norm backward produced (the residual-branch gradients), on the weight-gradient stream
+    auto amax_of = [&](hipStream_t st, const float* t, size_t numel, float** out) -> int {
+        *out = bwd16 == 0 ? acc.take<float>(AMAX_SLOTS) : nullptr;
+        if (dry || !*out) return CS_OK;
+        return launch_amax(st, t, (int64_t)numel, *out);
+    };
     // weight-gradient partial sums: [split_k][taps][rows][cols] in the (un-zeroed) buffer arena
-    struct WG { float* part; int k; };
+    struct WG { float* part; int k; bool h16; };
     auto wg_alloc = [&](int a_c1, int a_c2, int b_c, int taps, int rows, int cols, int ho, int wo, int ks = 3, int st = 2) {
         WG g;
-        g.k = wgrad_split_k(a_c1, b_c, n, ho, wo, ks, st);
-        if (a_c2 > 0) { const int k2 = wgrad_split_k(a_c2, b_c, n, ho, wo, ks, st); g.k = k2 < g.k ? k2 : g.k; }
+        g.h16 = bwd16 >= 0 && ks == 3 && b_c % 16 == 0 && a_c1 % 16 == 0 && (a_c2 <= 0 || a_c2 % 16 == 0);
+        auto kof = [&](int a_c) { return g.h16 ? wgrad16_split_k(a_c, b_c, n, ho, wo) : wgrad_split_k(a_c, b_c, n, ho, wo, ks, st); };
+        g.k = kof(a_c1);
+        if (a_c2 > 0) { const int k2 = kof(a_c2); g.k = k2 < g.k ? k2 : g.k; }
         g.part = buf.take<float>((size_t)g.k * taps * rows * cols);
         return g;
+    };
+    // one 3x3 weight-gradient launch on whichever pipe `g` was sized for; a_amax / b_amax: the dynamic-scale slots of gradient operands
+    auto wgrad3 = [&](hipStream_t st, const WG& g, int stride, const float* a, int a_c, const float* a_amax, const ConvSrc& b, const float* b_amax,
+                      int co_total, int ci_total, int co_off, int ho, int wo, int hi, int wi) -> int {
+        if (g.h16)
+            return launch_wgrad16(st, bwd16, stride, a, a_c, a_c, a_amax, b, b_amax, g.part, g.k, co_total, ci_total, co_off, 0, n, ho, wo, hi, wi);
+        return launch_wgrad(st, 3, stride, a, a_c, a_c, b, nullptr, g.part, g.k, co_total, ci_total, co_off, 0, n, ho, wo, hi, wi);
+    };
+    auto unpack3 = [&](hipStream_t st, const WG& g, int rows_total, int cols_total, int row_off, int rows, int cols, float* dst, const float* a_amax,
+                       const float* b_amax) -> int {
+        WgradUnscale us;
+        us.a_amax = a_amax; us.b_amax = b_amax;
+        return launch_unpack_wgrad(st, g.part, g.k, rows_total, cols_total, row_off, 0, rows, cols, 9, dst, (g.h16 && bwd16 == 0) ? &us : nullptr);
     };
 
     std::vector<float*> dX(nl, nullptr);
@@ -819,18 +847,20 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             float* dV = buf.take<float>((size_t)n * oh * ow * c);
             const WG gu = wg_alloc(c, 0, c, 9, c, c, oh, ow, 3, 1);
             if (!buf.ok()) return oom();
-            CS_TRY(norm_bwd(u.norm_u, T.rt_upu[d], lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow));
+            float* ax_dV = nullptr;
+            CS_TRY(norm_bwd(u.norm_u, T.rt_upu[d], lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow, &ax_dV));
             CS_TRY(bias_grad(dV, c, c, (int64_t)n * oh * ow, u.unit0.p_b[0], true));
             if (!dry) {
                 CS_TRY(wg_begin());
-                CS_TRY(launch_wgrad(sw, 3, 1, dV, c, c, lu, nullptr, gu.part, gu.k, c, c, 0, 0, n, oh, ow, oh, ow));
-                CS_TRY(launch_unpack_wgrad(sw, gu.part, gu.k, c, c, 0, 0, c, c, 9, gptr(u.unit0.p_w[0])));
+                CS_TRY(wgrad3(sw, gu, 1, dV, c, ax_dV, lu, nullptr, c, c, 0, oh, ow, oh, ow));
+                CS_TRY(unpack3(sw, gu, c, c, 0, c, c, gptr(u.unit0.p_w[0]), ax_dV, nullptr));
                 ConvOutExtra ex;
                 ex.addend = dS; ex.pitch_add = c;          // identity residual of the up ResidualUnit
                 CS_TRY(dgrad_s1(s, u.unit0, dV, c, d_au, c, n, oh, ow, &ex));
             }
         }
-        CS_TRY(norm_bwd(u.norm_t, T.rt_upt[d], lu, d_au, c, dU, c, (int64_t)oh * ow));
+        float* ax_dU = nullptr;
+        CS_TRY(norm_bwd(u.norm_t, T.rt_upt[d], lu, d_au, c, dU, c, (int64_t)oh * ow, u.top ? nullptr : &ax_dU));
         CS_TRY(bias_grad(dU, c, c, (int64_t)n * oh * ow, u.convt.p_b[0], true));
         if (!dry) {
             if (u.top) {
@@ -846,10 +876,11 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 ex.out2 = dSn; ex.pitch_out2 = cb; ex.split = cs;
                 CS_TRY(launch_conv_mfma(s, 3, 2, rsrc(dU, c, c), ConvSrc(), u.convt.wd, nullptr, dX[d], cs, cin_t, nullptr, n, oh, ow, &ex));
                 CS_TRY(wg_begin());
-                CS_TRY(launch_wgrad(sw, 3, 2, T.X[d], cs, cs, rsrc(dU, c, c), nullptr, gt.part, gt.k, cin_t, c, 0, 0, n, ph, pw, oh, ow));
-                CS_TRY(launch_wgrad(sw, 3, 2, Ssub, cb, cb, rsrc(dU, c, c), nullptr, gt.part, gt.k, cin_t, c, cs, 0, n, ph, pw, oh, ow));
+                // (transposed conv: the ACTIVATIONS are the A operand, the gradient dU the shifted B operand)
+                CS_TRY(wgrad3(sw, gt, 2, T.X[d], cs, nullptr, rsrc(dU, c, c), ax_dU, cin_t, c, 0, ph, pw, oh, ow));
+                CS_TRY(wgrad3(sw, gt, 2, Ssub, cb, nullptr, rsrc(dU, c, c), ax_dU, cin_t, c, cs, ph, pw, oh, ow));
             }
-            CS_TRY(launch_unpack_wgrad(sw, gt.part, gt.k, cin_t, c, 0, 0, cin_t, c, 9, gptr(u.convt.p_w[0])));
+            CS_TRY(unpack3(sw, gt, cin_t, c, 0, cin_t, c, gptr(u.convt.p_w[0]), nullptr, u.top ? nullptr : ax_dU));
         }
         dS = dSn;
     }
@@ -877,20 +908,21 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const WG ga = wg_alloc(c, 0, su == 0 ? cin : c, 9, c, su == 0 ? cin : c, ph, pw, 3, 1);
             float* da_new = su > 0 ? buf.take<float>((size_t)n * npix * c) : nullptr;
             if (!buf.ok()) return oom();
-            CS_TRY(norm_bwd(u.norms[su], T.rt_bottom[su], lazy_src(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c), da, c, dY, c, npix));
+            float* ax_dY = nullptr;
+            CS_TRY(norm_bwd(u.norms[su], T.rt_bottom[su], lazy_src(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c), da, c, dY, c, npix, &ax_dY));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (dry) { da = da_new; continue; }
             if (su > 0) {
                 const ConvSrc prev = lazy_src(T.Yb[su - 1], c, c, T.rt_bottom[su - 1], u.norms[su - 1], c);
                 CS_TRY(wg_begin());
-                CS_TRY(launch_wgrad(sw, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, ph, pw, ph, pw));
-                CS_TRY(launch_unpack_wgrad(sw, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
+                CS_TRY(wgrad3(sw, ga, 1, dY, c, ax_dY, prev, nullptr, c, c, 0, ph, pw, ph, pw));
+                CS_TRY(unpack3(sw, ga, c, c, 0, c, c, gptr(cw.p_w[0]), ax_dY, nullptr));
                 CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, ph, pw));
                 da = da_new;
             } else {
                 CS_TRY(wg_begin());
-                CS_TRY(launch_wgrad(sw, 3, 1, dY, c, c, rsrc(Xin, cin, cin), nullptr, ga.part, ga.k, c, cin, 0, 0, n, ph, pw, ph, pw));
-                CS_TRY(launch_unpack_wgrad(sw, ga.part, ga.k, c, cin, 0, 0, c, cin, 9, gptr(cw.p_w[0])));
+                CS_TRY(wgrad3(sw, ga, 1, dY, c, ax_dY, rsrc(Xin, cin, cin), nullptr, c, cin, 0, ph, pw, ph, pw));
+                CS_TRY(unpack3(sw, ga, c, cin, 0, c, cin, gptr(cw.p_w[0]), ax_dY, nullptr));
                 ConvOutExtra ex;
                 ex.addend = dXin; ex.pitch_add = cin;
                 CS_TRY(dgrad_s1(s, cw, dY, c, dXin, cin, n, ph, pw, &ex));
@@ -922,14 +954,15 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             float* da_new = buf.take<float>((size_t)n * npix * c);
             const WG ga = wg_alloc(c, 0, c, 9, c, c, oh, ow, 3, 1);
             if (!buf.ok()) return oom();
-            CS_TRY(norm_bwd(u.norms[su], T.rt_down[d][su], lazy_src(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c), da, c, dY, c, npix));
+            float* ax_dY = nullptr;
+            CS_TRY(norm_bwd(u.norms[su], T.rt_down[d][su], lazy_src(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c), da, c, dY, c, npix, &ax_dY));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (!dry) {
                 const ConvSrc prev = su - 1 == 0 ? lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0)
                                                  : lazy_src(T.Y[d][su - 1], c, c, T.rt_down[d][su - 1], u.norms[su - 1], c);
                 CS_TRY(wg_begin());
-                CS_TRY(launch_wgrad(sw, 3, 1, dY, c, c, prev, nullptr, ga.part, ga.k, c, c, 0, 0, n, oh, ow, oh, ow));
-                CS_TRY(launch_unpack_wgrad(sw, ga.part, ga.k, c, c, 0, 0, c, c, 9, gptr(cw.p_w[0])));
+                CS_TRY(wgrad3(sw, ga, 1, dY, c, ax_dY, prev, nullptr, c, c, 0, oh, ow, oh, ow));
+                CS_TRY(unpack3(sw, ga, c, c, 0, c, c, gptr(cw.p_w[0]), ax_dY, nullptr));
                 CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, oh, ow));
             }
             da = da_new;
@@ -937,14 +970,20 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         float* dY0 = buf.take<float>((size_t)n * npix * c);
         const WG gf = wg_alloc(c, 0, cin, 9, c0, cin, oh, ow);
         if (!buf.ok()) return oom();
-        CS_TRY(norm_bwd(u.norms[0], T.rt_down[d][0], lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0), da, c, dY0, c, npix));
+        float *ax_dY0 = nullptr, *ax_dXd = nullptr;
+        CS_TRY(norm_bwd(u.norms[0], T.rt_down[d][0], lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0), da, c, dY0, c, npix,
+                        u.first ? nullptr : &ax_dY0));
         CS_TRY(bias_grad(dY0, c, c, n * npix, u.unit0.p_b[0], true));
+        if (!u.first && gf.h16) {                                  // the residual conv's gradient is the raw dX[d]: no norm backward measured it
+            if (!dry) CS_TRY(wg_begin());
+            CS_TRY(amax_of(sw, dXd, (size_t)n * npix * c, &ax_dXd));
+        }
         if (dry) continue;
         if (!u.first) {
             const ConvSrc xin = rsrc(T.X[d - 1], cin, cin);
-            CS_TRY(wg_begin());
-            CS_TRY(launch_wgrad(sw, 3, 2, dY0, c, c, xin, nullptr, gf.part, gf.k, c0, cin, 0, 0, n, oh, ow, ph, pw));
-            CS_TRY(launch_wgrad(sw, 3, 2, dXd, c, c, xin, nullptr, gf.part, gf.k, c0, cin, c, 0, n, oh, ow, ph, pw));
+            if (!gf.h16) CS_TRY(wg_begin());
+            CS_TRY(wgrad3(sw, gf, 2, dY0, c, ax_dY0, xin, nullptr, c0, cin, 0, oh, ow, ph, pw));
+            CS_TRY(wgrad3(sw, gf, 2, dXd, c, ax_dXd, xin, nullptr, c0, cin, c, oh, ow, ph, pw));
             ConvOutExtra ex;
             ex.addend = dX[d - 1]; ex.pitch_add = cin;
             CS_TRY(launch_convt_mfma(s, rsrc(dY0, c, c), rsrc(dXd, c, c), u.unit0.wd, nullptr, dX[d - 1], cin, cin, nullptr, n, oh, ow, &ex));
@@ -955,8 +994,8 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             CS_TRY(launch_wgrad(sw, 3, 2, dY0, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, 0, 0, n, oh, ow, ph, pw));
             CS_TRY(launch_wgrad(sw, 3, 2, dXd, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, c, 0, n, oh, ow, ph, pw));
         }
-        CS_TRY(launch_unpack_wgrad(sw, gf.part, gf.k, c0, cin, 0, 0, c, cin, 9, gptr(u.unit0.p_w[0])));
-        CS_TRY(launch_unpack_wgrad(sw, gf.part, gf.k, c0, cin, c, 0, c, cin, 9, gptr(u.unit0.p_w[1])));
+        CS_TRY(unpack3(sw, gf, c0, cin, 0, c, cin, gptr(u.unit0.p_w[0]), ax_dY0, nullptr));
+        CS_TRY(unpack3(sw, gf, c0, cin, c, c, cin, gptr(u.unit0.p_w[1]), ax_dXd, nullptr));
     }
     if (!dry) CS_TRY(launch_f64_jobs(s, f64_jobs));
     if (side_on) {                             // join: the caller's stream continues behind the last weight gradients

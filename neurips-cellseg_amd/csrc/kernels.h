@@ -169,9 +169,11 @@ int launch_act_quant(hipStream_t s, const ConvSrc& src, unsigned char* dst8, int
 // are fp64 accumulators that must be zero on entry.
 // BatchNorm (batch statistics): pass the forward's `xtab` (x_hat table) and batch = true - the two sums are then reduced over
 // the whole batch, and d(gamma) = sum dz*x_hat / d(beta) = sum dz are written to dgamma / dbeta (fp32, may be null).
+// amax (may be null): AMAX_SLOTS device floats that receive partial maxima of |dy| over the whole tensor (zero before the launch): the dynamic fp16 scale of
+// the weight-gradient / data-gradient kernels on the 16-bit matrix pipe (kernels_bwd16.hip)
 int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch, double* red,
                     double* dslope, int64_t npix, int n, const float2* xtab = nullptr, bool batch = false, float* dgamma = nullptr,
-                    float* dbeta = nullptr);
+                    float* dbeta = nullptr, float* amax = nullptr);
 // dst[c] = sum over pixels (fp32 out, fp64 final accumulation); partial: colsum_blocks(npix_total) * c floats of scratch
 int colsum_blocks(int64_t npix_total);
 int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npix_total, float* partial, float* dst);
@@ -187,8 +189,54 @@ int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo, int ksize = 3, int st
 int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pitch, int a_c, const ConvSrc& b, const WgradNarrow* nb,
                  float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi);
 // sums the split_k partials and converts to the PyTorch layout dst[row][col][tap]
+// unscale (may be null): the partials come from launch_wgrad16 in fp16x3 mode and carry the operands' power-of-two scales
+struct WgradUnscale {
+    const float* a_amax = nullptr;   // AMAX_SLOTS device floats behind each dynamic scale (null: the static activation scale)
+    const float* b_amax = nullptr;
+};
 int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_total, int cols_total, int row_off, int col_off,
-                        int rows, int cols, int taps, float* dst);
+                        int rows, int cols, int taps, float* dst, const WgradUnscale* unscale = nullptr);
+// ---- weight gradients on the 16-bit matrix pipe (kernels_bwd16.hip) ----
+constexpr float F16_ACT_SCALE = 16.f;          // static pre-scale of activation operands in the split-fp16 modes (== F16_X_SCALE of the forward)
+constexpr int AMAX_SLOTS = 32;                 // a gradient tensor's max |dy| is kept as AMAX_SLOTS partial maxima (see amax_commit)
+#ifdef __HIPCC__
+// power-of-two scale of a gradient operand: its largest element lands in [2^13, 2^14); null pointer = an activation (static scale)
+__device__ __forceinline__ float f16_dyn_scale(const float* amax_slots) {
+    if (!amax_slots) return F16_ACT_SCALE;
+    unsigned bits = 0;
+#pragma unroll
+    for (int i = 0; i < AMAX_SLOTS; ++i) {
+        const unsigned b = reinterpret_cast<const unsigned*>(amax_slots)[i];
+        bits = b > bits ? b : bits;
+    }
+    const int ex = (int)((bits >> 23) & 0xffu) - 127;               // floor(log2 max|v|)
+    if (ex < -100 || ex > 100) return 1.f;                          // an all-zero (or broken) tensor: any scale will do
+    return __builtin_bit_cast(float, (unsigned)(127 + 13 - ex) << 23);
+}
+// Running maximum of non-negative floats (their bits order like unsigned integers), called by EVERY thread of a 256-thread block with
+// its own maximum: wave shuffle -> LDS -> ONE fire-and-forget atomicMax per block, spread over AMAX_SLOTS words by block index
+// (readers take the maximum of all).  Measured on the training step's norm backward (16 launches of ~4096 blocks): an atomic per
+// wave on one word +0.9 ms, a look-before-you-leap load in front of it (the wave then waits for an L2 round trip before it can
+// retire) +0.35...0.55 ms, this form: see DESIGN.md.
+__device__ __forceinline__ void amax_commit(unsigned* slots, float thread_max) {
+    __shared__ float amax_sh[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) thread_max = fmaxf(thread_max, __shfl_xor(thread_max, off));
+    if ((threadIdx.x & 63) == 0) amax_sh[threadIdx.x >> 6] = thread_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(amax_sh[0], amax_sh[1]), fmaxf(amax_sh[2], amax_sh[3]));
+        if (m > 0.f) atomicMax(slots + ((blockIdx.x + 7u * blockIdx.y) & (AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, m));
+    }
+}
+#endif
+int wgrad16_split_k(int a_c, int b_c, int n, int ho, int wo);
+// mode 0: split fp16, 3 terms (fp32-grade); mode 1: plain bf16.  3x3 only, stride 1 / 2, both operands >= 16 channels; a_amax / b_amax:
+// device scalars max|operand| for gradient operands (dynamic scale, mode 0), null for activations.  Partial layout as launch_wgrad.
+int launch_wgrad16(hipStream_t s, int mode, int stride, const float* a, int a_pitch, int a_c, const float* a_amax, const ConvSrc& b,
+                   const float* b_amax, float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo,
+                   int hi, int wi);
+int launch_amax(hipStream_t s, const float* src, int64_t numel, float* out);   // out[AMAX_SLOTS]: partial maxima of |src|; zero before the first use
 constexpr int NORM_DSLOPE_SLOTS = 64;          // partial accumulators of one PReLU slope gradient (launch_norm_bwd's `dslope`)
 struct F64Job { const double* src; float* dst; int count, slots; };
 struct F64Jobs { F64Job j[96]; int n = 0; };   // passed by value as a kernel argument (2.3 KB)

@@ -40,6 +40,7 @@ struct NormBwdParams {
     int pix_per_block;
     const float2* xtab;   // BatchNorm: (rstd, -mean*rstd) so that x_hat = y*rstd - mean*rstd; null: x_hat == z (InstanceNorm, no affine)
     double inv_m;         // 1 / (elements behind each pair of sums): npix (InstanceNorm) or n*npix (BatchNorm, sums reduced over n)
+    unsigned* amax;       // bits of max |dy| (atomicMax; non-negative floats order like unsigned integers) or null
 };
 
 // wide: c % 4 == 0 and 256 % (c/4) == 0
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p) {
         m2[j] = (float)(red[2 * j + 1] * p.inv_m);
     }
     const float slope = p.slope ? *p.slope : 0.f;
-    if (pl >= lanes) return;
-    for (int64_t px = pix0 + pl; px < pix1; px += 4 * lanes) {
+    float amax = 0.f;
+    for (int64_t px = pix0 + pl; pl < lanes && px < pix1; px += 4 * lanes) {
         f32x4 da[4], y[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -172,8 +173,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p) {
                 o[j] = sc[j] * (dz - m1[j] - xh * m2[j]);
             }
             *reinterpret_cast<f32x4*>(p.dy + g * p.dy_pitch + 4 * quad) = o;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
+    if (p.amax) amax_commit(p.amax, amax);           // (block-uniform branch: every thread of the block gets here)
 }
 
 // narrow (c <= 4, any pitch): one thread per pixel
@@ -266,7 +269,7 @@ __global__ void bn_bwd_finalize_kernel(double* red, int n, int c, float* dgamma,
 }
 
 int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch, double* red,
-                    double* dslope, int64_t npix, int n, const float2* xtab, bool batch, float* dgamma, float* dbeta) {
+                    double* dslope, int64_t npix, int n, const float2* xtab, bool batch, float* dgamma, float* dbeta, float* amax) {
     CS_REQUIRE(y.tab != nullptr, "norm_bwd: the forward table is required");
     CS_REQUIRE(!batch || xtab, "norm_bwd: BatchNorm needs the forward's x_hat table");
     NormBwdParams p{};
@@ -274,6 +277,7 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
     p.tab = y.tab; p.tab_c = y.tab_c ? y.tab_c : y.c; p.tab_off = y.tab_off; p.slope = y.slope;
     p.red = red; p.dslope = y.slope ? dslope : nullptr; p.dy = dy; p.dy_pitch = dy_pitch; p.c = y.c; p.npix = (int)npix;
     p.xtab = xtab;
+    p.amax = reinterpret_cast<unsigned*>(amax);
     p.inv_m = 1.0 / ((double)npix * (batch ? (double)n : 1.0));
     ProfScope prof(K_NORM_BWD, s, 0, 4.0 * n * npix * y.c * 5);
     auto bn_finalize = [&]() {
@@ -797,7 +801,7 @@ int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pit
 // split-K is in the hundreds (round 1: 32 elements x 8 lanes, one tap per block, 22 us per launch on average).
 template <int EL, int TAPS>
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* part, int split_k, int rows_total, int cols_total, int row_off,
-                                                           int col_off, int rows, int cols, float* dst) {
+                                                           int col_off, int rows, int cols, float* dst, WgradUnscale us, int unscale) {
     constexpr int KL = 256 / EL;
     __shared__ float sh[KL][EL * TAPS + 1];
     const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
@@ -821,22 +825,26 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* part, in
     __syncthreads();
     const int e0 = blockIdx.x * EL;
     const int n_out = (per_tap - e0 < EL ? per_tap - e0 : EL) * TAPS;
+    // partials of the split-fp16 kernels carry both operands' power-of-two scales (exact to divide out)
+    const float inv = unscale ? 1.f / (f16_dyn_scale(us.a_amax) * f16_dyn_scale(us.b_amax)) : 1.f;
     for (int i = threadIdx.x; i < n_out; i += 256) {
         float t = 0.f;
 #pragma unroll
         for (int l = 0; l < KL; ++l) t += sh[l][i];
-        dst[(size_t)e0 * TAPS + i] = t;
+        dst[(size_t)e0 * TAPS + i] = t * inv;
     }
 }
 
 int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_total, int cols_total, int row_off, int col_off,
-                        int rows, int cols, int taps, float* dst) {
+                        int rows, int cols, int taps, float* dst, const WgradUnscale* unscale) {
     const int total = rows * cols * taps;
+    const WgradUnscale us = unscale ? *unscale : WgradUnscale();
+    const int do_unscale = unscale ? 1 : 0;
     CS_REQUIRE(taps == 9 || taps == 1, "unpack_wgrad: %d taps", taps);
     ProfScope prof(K_UNPACK, s, 0, 4.0 * total * (split_k + 1));
 #define CS_UNPACK(EL_, T_)                                                                                                       \
     hipLaunchKernelGGL((unpack_wgrad_kernel<EL_, T_>), dim3((unsigned)ceil_div(rows * cols, EL_)), dim3(256), 0, s, part, split_k, \
-                       rows_total, cols_total, row_off, col_off, rows, cols, dst)
+                       rows_total, cols_total, row_off, col_off, rows, cols, dst, us, do_unscale)
     if (split_k > 64 && rows * cols <= 1024 && taps == 9) {
         CS_UNPACK(2, 9);            // small tensor, hundreds of slices (16- and 32-channel layers at 128^2): 8 elements per block left 32
                                     // blocks summing 512 slabs (65 us); 2 elements x 128 split-K lanes put the same loads on 4x the CUs

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: the training step three ways - autograd loop (the reference's body, launch by launch), ca.TrainStep eager (same C-ABI
 calls, no autograd), ca.TrainStep captured (hipGraph replay) - at the reference's setting (16...256, batch 8) and at 32-base x 32.
-    python tests/diagnostics/gpu_train_step_modes.py [only=<captured|lean|autograd>] [cfg=<ref|base>] [steps=N]"""
+    python tests/diagnostics/gpu_train_step_modes.py [only=<captured|lean|autograd>] [cfg=<ref|base>] [steps=N] [precision=fp32|fp16x3|bf16]"""
 import os
 import sys
 import time
@@ -21,6 +21,7 @@ steps = int(opts.get("steps", 30))
 def run(channels, b, mode):
     torch.manual_seed(0)
     model = ca.UNet(channels=channels, strides=(2, 2, 2, 2), num_res_units=2).to(dev).train()
+    model.precision = opts.get("precision", "fp32")
     x = torch.rand(b, 3, 256, 256, device=dev)
     y = ca.one_hot(torch.randint(0, 3, (b, 1, 256, 256), device=dev), 3)
     loss_fn, opt = ca.DiceCELoss(softmax=True), ca.AdamW(model, 6e-4)

@@ -69,7 +69,7 @@ def test_c3_slide_4096_band_of_logits_and_mask_match_oracle():
 
 
 # ------------------------------------------------------------------------------------------- configs[0] at its real shape
-def _grads_fp64_yardstick(channels, shape, seed=0, slope=None, **kw):
+def _grads_fp64_yardstick(channels, shape, seed=0, slope=None, precision="fp32", **kw):
     """-> per-parameter (hip error, torch-fp32 error, fp64 gradient magnitude), all against an fp64 autograd oracle."""
     from oracle.unet_ref import UNetRef
     import cellseg_amd as ca
@@ -85,6 +85,7 @@ def _grads_fp64_yardstick(channels, shape, seed=0, slope=None, **kw):
     hip = ca.UNet(**cfg)
     hip.load_state_dict(ref.state_dict())
     hip = hip.to(_dev()).train()
+    hip.precision = precision
     g = torch.Generator().manual_seed(seed + 1)
     x, wgt = torch.rand(*shape, generator=g), torch.randn(*shape, generator=g)
     (ref64(x.double()) * wgt.double()).sum().backward()

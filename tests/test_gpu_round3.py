@@ -313,3 +313,38 @@ def test_predict_cli_accepts_fp8(tmp_path):
                          capture_output=True, text=True, timeout=600, env=_env())
     assert out.returncode == 0, out.stderr[-2000:]
     assert (outp / "a_label.tiff").exists()
+
+
+# ------------------------------------------------------------------------------------------- backward on the 16-bit matrix pipe
+@pytest.mark.parametrize("channels,shape", [((16, 32, 64, 128, 256), (8, 3, 256, 256)), ((32, 64, 128, 256, 512), (2, 3, 128, 128)),
+                                            ((16, 32, 64), (3, 3, 72, 40))])
+def test_fp16x3_training_gradients_are_fp32_grade(channels, shape):
+    """precision = "fp16x3" in training: forward convolutions AND the 3x3 weight gradients run on v_mfma_f32_16x16x32_f16 with every
+    operand split into two fp16 planes (gradient operands under a dynamic power-of-two scale).  Gate: the fp64-autograd yardstick of
+    the fp32 path - every tensor as close to fp64 as torch's own fp32 autograd (<= 3x its error + 2e-6 of the largest gradient) on the
+    kink-free network (PReLU slopes 1.0: the comparison measures arithmetic, not sign flips at the kink)."""
+    from test_gpu_round2 import _grads_fp64_yardstick
+    res = _grads_fp64_yardstick(channels, shape, slope=1.0, precision="fp16x3", seed=3)
+    scale = max(m for _, _, m in res.values())
+    for k, (eh, et, m) in res.items():
+        assert eh <= 3 * et + 2e-6 * scale, (k, eh, et, m, scale)
+
+
+def test_bf16_training_tracks_the_fp32_loss_curve_with_bf16_weight_gradients():
+    """precision = "bf16" in training (BASELINE configs[1]: bf16 arithmetic, fp32 master weights): bf16 forward convolutions and bf16
+    weight gradients; the loss curve must stay within 0.03 of the fp32 one over 30 steps and end lower than it started."""
+    import cellseg_amd as ca
+    curves = {}
+    for prec in ("fp32", "bf16", "fp16x3"):
+        torch.manual_seed(5)
+        model = ca.UNet(channels=(32, 64, 128), strides=(2, 2), num_res_units=2).to(_dev()).train()
+        model.precision = prec
+        step = ca.TrainStep(model, ca.DiceCELoss(softmax=True), ca.AdamW(model, 1e-3))
+        g = torch.Generator().manual_seed(6)
+        x = torch.rand(8, 3, 64, 64, generator=g).to(_dev())
+        y = ca.one_hot((x.mean(1, keepdim=True) > 0.5).long() + (x[:, :1] > 0.8).long(), 3)
+        curves[prec] = [step(x, y).item() for _ in range(30)]
+    for prec in ("bf16", "fp16x3"):
+        worst = max(abs(a - b) for a, b in zip(curves[prec], curves["fp32"]))
+        assert worst <= (0.03 if prec == "bf16" else 2e-3), (prec, worst, curves[prec][-1], curves["fp32"][-1])
+        assert curves[prec][-1] < 0.8 * curves[prec][0]

@@ -645,7 +645,10 @@ def main():
                "tflops": round(world * 3 * b * WINDOW_GFLOP[width] / ms, 2),
                "frac_of_fp32_mfma_peak": round(3 * b * WINDOW_GFLOP[width] / ms / PEAK_F32_MFMA_TFLOPS, 4),
                "global_batch": world * b, "per_gpu_batch": b, "width": list(WIDTHS[width]),
-               "dtype": "f32" if precision == "fp32" else f"{precision} forward convolutions (fp32 activations), f32 backward",
+               "dtype": {"fp32": "f32", "fp16x3": "f32-grade split fp16 (2 planes x 3 terms): forward convolutions and 3x3 weight gradients on "
+                                                   "v_mfma_f32_16x16x32_f16, data gradients f32",
+                         "bf16": "bf16 forward convolutions and 3x3 weight gradients (fp32 activations, data gradients and master weights)"
+                         }.get(precision, f"{precision} forward convolutions (fp32 activations), f32 backward"),
                "loss": round(float(loss.item()), 5), "grad_bucket_bytes": int(model.flat_grad.numel() * 4),
                "allreduce_ms": allreduce_ms,
                "engine_gpu_ms_per_step": round(tot / k, 3) if prof else None,
@@ -687,8 +690,9 @@ def main():
             tw = args.width if args.width in WINDOW_GFLOP and args.roi == 256 else "baseline32"
             train_res = measure_train(tw)
             if world == 1 and dist is None:                      # configs[1]: the same step with the forward convolutions on the bf16 pipe
-                t16 = measure_train(tw, with_prof=False, precision="bf16", eager_too=False)
-                train_res["bf16_forward"] = {k: t16[k] for k in ("images_per_s", "ms_per_step", "loss", "dtype")}
+                for prec in ("fp16x3", "bf16"):                  # the same step with forward convolutions + weight gradients on the 16-bit pipe
+                    t16 = measure_train(tw, with_prof=False, precision=prec, eager_too=False)
+                    train_res[prec] = {k: t16[k] for k in ("images_per_s", "ms_per_step", "tflops", "loss", "dtype")}
                 # the reference's own training configuration (model_training_3class.py:201-208, --batch_size 8): 16...256 channels, batch 8
                 tref = measure_train("reference16", with_prof=False, batch=8)
                 train_ref = {k: tref[k] for k in ("images_per_s", "ms_per_step", "eager_ms_per_step", "graph_ms_per_step", "graph_nodes", "tflops", "loss",

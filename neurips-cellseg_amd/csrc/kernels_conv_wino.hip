@@ -232,24 +232,34 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
     const int cw = (c4 & 3) * 4;
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-    double sq8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // (sum, sum of squares) of this thread's 4 channels
+    // Output addressing without 64-bit vector arithmetic: the image's base is a scalar, a thread's first pixel one 32-bit element
+    // offset (the launcher keeps an image's tensor below 4 GB), and every pass of the loop moves a whole number of rows down, i.e.
+    // adds a loop-invariant stride.  (Written as ((size_t)img * hout + oy) * wout + ox the loop carried 25 quarter-rate v_mul_lo_u32
+    // and 12 v_mad_u64_u32 per wave - on the fp32 path every VALU cycle is taken from the MFMA stream's.)
+    constexpr int ROWS_PER_IT = PPP / 16;
+    const int pix0 = tid / F4, oyl0 = pix0 >> 4, oxl = pix0 & 15;
+    const int ox = ox0 + oxl;
+    float* const out_img = o.out + (size_t)img * p.hout * p.wout * o.pitch;
+    const float* const add_img = o.add ? o.add + (size_t)img * p.hout * p.wout * o.pitch_add : nullptr;
+    unsigned off_out = (unsigned)((oy0 + oyl0) * p.wout + ox) * (unsigned)o.pitch + (unsigned)(o.ch0 + cw);
+    unsigned off_add = (unsigned)((oy0 + oyl0) * p.wout + ox) * (unsigned)o.pitch_add + (unsigned)(o.ch0 + cw);
+    const unsigned step_out = (unsigned)(ROWS_PER_IT * p.wout) * (unsigned)o.pitch, step_add = (unsigned)(ROWS_PER_IT * p.wout) * (unsigned)o.pitch_add;
+    const int jj = oxl & 1;
+    const float* const rb0 = rs + (jj * 32 + (oxl >> 1)) * RS + c4 * 4;      // + (oyl >> 1) * 8 * RS per row pair
     float sf[4] = {0.f, 0.f, 0.f, 0.f}, qf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < 128 / PPP; ++it) {
-        const int pix = tid / F4 + PPP * it;
-        const int oyl = pix >> 4, oxl = pix & 15;
-        const int tile = (oyl >> 1) * 8 + (oxl >> 1), ii = oyl & 1, jj = oxl & 1;
-        const float* rb = rs + (jj * 32 + tile) * RS + c4 * 4;
+        const int oyl = oyl0 + ROWS_PER_IT * it;
+        const int ii = oyl & 1;
+        const float* rb = rb0 + (oyl >> 1) * 8 * RS;
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(rb + (ii ? 3 * XS : 0));
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(rb + XS);
         const f32x4 x2 = *reinterpret_cast<const f32x4*>(rb + 2 * XS);
         f32x4 y = ii ? (x1 - x2) - x0 : (x0 + x1) + x2;
         y += bias4;
-        const int oy = oy0 + oyl, ox = ox0 + oxl;
-        if (oy < p.hout && ox < p.wout) {
-            const size_t gp = ((size_t)img * p.hout + oy) * p.wout + ox;
-            if (o.add) y += *reinterpret_cast<const f32x4*>(o.add + gp * o.pitch_add + o.ch0 + cw);
-            *reinterpret_cast<f32x4*>(o.out + gp * o.pitch + o.ch0 + cw) = y;
+        if (oy0 + oyl < p.hout && ox < p.wout) {
+            if (add_img) y += *reinterpret_cast<const f32x4*>(add_img + off_add);
+            *reinterpret_cast<f32x4*>(out_img + off_out) = y;
             if (p.stats) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -258,32 +268,30 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
                 }
             }
         }
-        // at most 4 values per channel are summed in fp32 (relative error <= 2^-22 of a partial sum, below the rounding the
-        // values themselves carry); everything from there on is fp64.  The fp64 conversions and FMAs of every single value were
-        // 10 % of the 32-channel layers' time (the VALU work of a wave is not hidden behind another wave's fp32 MFMAs).
-        if (p.stats && ((it & 3) == 3 || it == 128 / PPP - 1)) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                sq8[2 * k] += (double)sf[k];
-                sq8[2 * k + 1] += (double)qf[k];
-                sf[k] = 0.f;
-                qf[k] = 0.f;
-            }
-        }
+        off_out += step_out;
+        off_add += step_add;
     }
     if (p.stats) {
-        // lanes with equal c4 (lane % F4) -> the waves of the block (LDS) -> ONE fp64 atomic pair per block and channel.  (A butterfly
-        // that halves the values a lane carries at every step - 7 exchanges instead of 24 - was measured SLOWER, 767 vs 671 us on the
-        // 32-channel layer: its per-lane selects and permutes cost more than the plain xor shuffles, which compile to DPP moves.)
+        // A thread's (at most 8) values per channel and then the 64 / F4 lanes that hold the same channels are summed in fp32 - at most
+        // 32 values per partial sum, a relative error of a few 2^-24, below the rounding the values themselves carry - and everything
+        // from there on (the block's 4 waves through LDS, the per-(image, channel) atomics, mean and variance) is fp64.  (Shuffling
+        // the sums as doubles cost 48 ds_bpermute + 24 v_add_f64 per wave in this epilogue; a butterfly that halves the values a lane
+        // carries at every step was measured slower still.)
         double* st_s = reinterpret_cast<double*>(smem + BODY_FLOATS);      // [4 waves][16*NTW][2]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int k = 0; k < 4; ++k) {
 #pragma unroll
-            for (int sh = F4; sh < 64; sh <<= 1) sq8[e] += __shfl_xor(sq8[e], sh);
+            for (int sh = F4; sh < 64; sh <<= 1) {
+                sf[k] += __shfl_xor(sf[k], sh);
+                qf[k] += __shfl_xor(qf[k], sh);
+            }
         }
         if (lane < F4) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) st_s[(wave * 16 * NTW + c4 * 4) * 2 + e] = sq8[e];
+            for (int k = 0; k < 4; ++k) {
+                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2] = (double)sf[k];
+                st_s[(wave * 16 * NTW + c4 * 4 + k) * 2 + 1] = (double)qf[k];
+            }
         }
         __syncthreads();
         if (tid < 32 * NTW) {

@@ -131,6 +131,7 @@ struct ConvW {             // packed weights + bias of one (possibly fused) conv
     float* ww = nullptr;   // 3x3 stride-1 layers: Winograd F(2x2,3x3) weights G g G^T in fragment order (kernels_conv_wino.hip)
     float* wwd = nullptr;  // ... and those of the layer's DATA-GRADIENT convolution (channel roles swapped, taps reversed)
     unsigned short* wb = nullptr;   // 3 bf16 planes in 16x16x32 fragment order (split-bf16 forward kernels)
+    unsigned short* wbd = nullptr;  // 3x3 stride-1 layers: the same planes for the layer's DATA-GRADIENT convolution (training on the 16-bit pipe)
     unsigned char* w8 = nullptr;    // e4m3 weights in 16x16x128 fragment order (fp8 forward kernels)
     float* wscale = nullptr;        // their per-output-channel scales [cout]
     float* bias = nullptr;
@@ -300,6 +301,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     float* ww = cw.ww;
     float* wwd = cw.wwd;
     unsigned short* wb = cw.wb;
+    unsigned short* wbd = cw.wbd;
     unsigned char* w8 = cw.w8;
     float* wsc = cw.wscale;
     float* bdst = cw.bias + cout_off;
@@ -329,6 +331,10 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             }
             if (wb && net->planes > 0 && net->planes <= 4)
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0, net->planes == 4)) return rc;
+            // training on the 16-bit pipe (fp16x3 / bf16): the data-gradient convolution of a 3x3 stride-1 layer is a 3x3 stride-1
+            // convolution with the channel roles swapped and the taps reversed - the same kernel family, its own weight planes
+            if (wbd && net->training && dg == DG_S1 && net->planes == 1)
+                if (int rc = pack_conv_weights_bf16(net->pack, s, d, true, cin, cout, ksize, wbd, 0, cin, 0, net->planes == 4, true)) return rc;
             if (w8 && net->planes == 5)
                 if (int rc = pack_conv_weights_fp8(s, d, false, cout, cin, ksize, w8, wsc, cout_off, cout_total, 0)) return rc;
             // 3x3 stride-1 layers: the tile kernel also writes the Winograd weights (forward; data gradient in training mode)
@@ -362,6 +368,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     if (stride == 1 && !u.first && cin % 16 == 0 && c % 32 == 0) u.unit0.ww = ar.take(packed_wino_floats(c, cin));
     if (stride == 1 && !u.first && c % 16 == 0 && cin % 32 == 0) u.unit0.wwd = ar.take(packed_wino_floats(cin, c));
     if (!u.first) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(u.unit0.cout, cin, 0, 3) + 1) / 2);
+    if (stride == 1 && !u.first) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cin, c, 0, 3) + 1) / 2);
     if (u.first) u.unit0.wb = (unsigned short*)ar.take((size_t)(u.unit0.cout / 16) * 512 / 2);      // one bf16 K-step (bf16 / fp8 datapaths)
     if (!u.first) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(u.unit0.cout, cin, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(u.unit0.cout); }
     add_conv_params(net, pfx + ".conv.unit0.conv", u.unit0, c, cin, 3, 0, false, u.first ? 1 : 0, dg0, 0);
@@ -375,6 +382,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         if (c % 32 == 0) cw.ww = ar.take(packed_wino_floats(c, c));
         if (c % 32 == 0) cw.wwd = ar.take(packed_wino_floats(c, c));
         cw.wb = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
+        cw.wbd = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
         cw.w8 = (unsigned char*)ar.take((packed_fp8_bytes(c, c, 0, 3) + 3) / 4);
         cw.wscale = ar.take(c);
         const std::string un = pfx + ".conv.unit" + std::to_string(su);
@@ -414,6 +422,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     if (!small && cout % 32 == 0) u.unit0.ww = ar.take(packed_wino_floats(cout, cout));
     if (!small && cout % 32 == 0) u.unit0.wwd = ar.take(packed_wino_floats(cout, cout));
     if (!small) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
+    if (!small) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
     if (!small) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(cout, cout, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(cout); }
     add_conv_params(net, pfx + ".1.conv.unit0.conv", u.unit0, cout, cout, 3, 0, false, small ? 2 : 0, small ? DG_NONE : DG_S1, 0);
     if (!top) add_norm_params(net, ar, pfx + ".1.conv.unit0.adn", u.norm_u, cout);
@@ -480,9 +489,13 @@ static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, co
 // data gradient of a 3x3 stride-1 conv = a 3x3 stride-1 conv of dy with the channel-swapped, tap-reversed weights: Winograd form
 // when the layer has one (same kernel as the forward), else the direct kernel on cw.wd
 static int dgrad_s1(hipStream_t s, const ConvW& cw, const float* dy, int c_dy, float* out, int c_out, int n, int h, int w,
-                    const ConvOutExtra* ex = nullptr) {
+                    const ConvOutExtra* ex = nullptr, int planes16 = 0, const float* dy_amax = nullptr) {
     ConvSrc src;
     src.ptr = dy; src.c = c_dy; src.pitch = c_dy;
+    // training on the 16-bit pipe: split-fp16 (planes16 == 4; dy under its dynamic power-of-two scale) or plain bf16 (1)
+    if (planes16 && cw.wbd && !(ex && (ex->out2 || ex->addend2)))
+        return launch_conv_bf16s(s, 3, 1, planes16, src, ConvSrc(), cw.wbd, nullptr, out, c_out, c_out, nullptr, n, h, w, false,
+                                 planes16 == 4 ? dy_amax : nullptr, ex);
     if (cw.wwd && wino_enabled() && !(ex && ex->out2) && wino_fits(h, w, c_dy))
         return launch_conv_wino(s, src, cw.wwd, nullptr, out, c_out, c_out, nullptr, n, h, w, ex);
     return launch_conv_mfma(s, 3, 1, src, ConvSrc(), cw.wd, nullptr, out, c_out, c_out, nullptr, n, h, w, ex);
@@ -774,6 +787,12 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     // arithmetic, fp32 master weights - BASELINE configs[1]), -1 = the fp32 kernels.  Gradient operands of the fp16 mode carry a
     // dynamic power-of-two scale taken from max|dy|, which the producer of dy maintains in a device float (`amax` slots below).
     const int bwd16 = net->planes == 4 ? 0 : net->planes == 1 ? 1 : -1;
+    // Data gradients of the 3x3 stride-1 layers: plain bf16 in the bf16 mode (conv_bf16s on the layer's data-gradient planes: 0.72 ->
+    // 0.35 ms per step); the fp16x3 mode keeps the fp32 Winograd form - measured: the split-fp16 kernels (3 terms) need 0.64 ms for
+    // the same launches, no faster than Winograd's 16/36 of the fp32 multiplies, and their slope gradients came out 1.4e-4 off the
+    // fp64 yardstick (20x torch-fp32's error: gradient tensors span many decades, elements far below the tensor maximum lose
+    // relative precision in the second fp16 plane) - so fp32-grade training keeps fp32 data gradients.
+    const int dg16 = bwd16 == 1 ? 1 : 0;
     auto norm_bwd = [&](const NormSite& ns, const NormRt& rt, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch,
                         int64_t npix, float** amax_out = nullptr) -> int {
         double* red = acc.take<double>((size_t)n * y.c * 2);
@@ -856,7 +875,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 CS_TRY(unpack3(sw, gu, c, c, 0, c, c, gptr(u.unit0.p_w[0]), ax_dV, nullptr));
                 ConvOutExtra ex;
                 ex.addend = dS; ex.pitch_add = c;          // identity residual of the up ResidualUnit
-                CS_TRY(dgrad_s1(s, u.unit0, dV, c, d_au, c, n, oh, ow, &ex));
+                CS_TRY(dgrad_s1(s, u.unit0, dV, c, d_au, c, n, oh, ow, &ex, dg16, ax_dV));
             }
         }
         float* ax_dU = nullptr;
@@ -917,7 +936,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 CS_TRY(wg_begin());
                 CS_TRY(wgrad3(sw, ga, 1, dY, c, ax_dY, prev, nullptr, c, c, 0, ph, pw, ph, pw));
                 CS_TRY(unpack3(sw, ga, c, c, 0, c, c, gptr(cw.p_w[0]), ax_dY, nullptr));
-                CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, ph, pw));
+                CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, ph, pw, nullptr, dg16, ax_dY));
                 da = da_new;
             } else {
                 CS_TRY(wg_begin());
@@ -925,7 +944,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 CS_TRY(unpack3(sw, ga, c, cin, 0, c, cin, gptr(cw.p_w[0]), ax_dY, nullptr));
                 ConvOutExtra ex;
                 ex.addend = dXin; ex.pitch_add = cin;
-                CS_TRY(dgrad_s1(s, cw, dY, c, dXin, cin, n, ph, pw, &ex));
+                CS_TRY(dgrad_s1(s, cw, dY, c, dXin, cin, n, ph, pw, &ex, dg16, ax_dY));
             }
         }
         if (!dry) {
@@ -963,7 +982,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 CS_TRY(wg_begin());
                 CS_TRY(wgrad3(sw, ga, 1, dY, c, ax_dY, prev, nullptr, c, c, 0, oh, ow, oh, ow));
                 CS_TRY(unpack3(sw, ga, c, c, 0, c, c, gptr(cw.p_w[0]), ax_dY, nullptr));
-                CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, oh, ow));
+                CS_TRY(dgrad_s1(s, cw, dY, c, da_new, c, n, oh, ow, nullptr, dg16, ax_dY));
             }
             da = da_new;
         }

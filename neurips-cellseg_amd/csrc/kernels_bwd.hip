@@ -977,16 +977,23 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* partial, int
     }
 }
 
-constexpr int LAST_BWD_BLOCKS = 64;      // blocks per image of the last-layer backward
-size_t conv_last_bwd_partial_floats(int n) { return (size_t)n * LAST_BWD_BLOCKS * 84; }
+// blocks per image of the last-layer backward: ~1024 blocks over the batch, 8...64 per image.  (64 per image at batch 32 left every
+// thread 4 pixels and the block an 84-value shuffle-and-LDS reduction behind them: 161 us for 75 MB of traffic.)
+static inline int last_bwd_blocks(int n) {
+    int b = 1024 / (n > 0 ? n : 1);
+    b = b < 8 ? 8 : (b > 64 ? 64 : b);
+    return b;
+}
+size_t conv_last_bwd_partial_floats(int n) { return (size_t)n * last_bwd_blocks(n) * 84; }
 
 int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw_db,
                          float* partial, int n, int h, int w) {
     CS_REQUIRE(u.c == 3 && u.pitch == 3 && u.tab, "conv_last_bwd: 3-class contract");
     ProfScope prof(K_TOP_BWD, s, 4.0 * n * h * w * 81.0, 4.0 * n * (double)h * w * 9);
-    dim3 grid(LAST_BWD_BLOCKS, (unsigned)n);
+    const int blocks = last_bwd_blocks(n);
+    dim3 grid((unsigned)blocks, (unsigned)n);
     hipLaunchKernelGGL((conv_last_bwd_kernel<3>), grid, dim3(256), 0, s, dlogits, u.ptr, u.tab, u.slope, w_torch, d_au, partial, h, w);
-    hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(84, 8)), dim3(256), 0, s, partial, n * LAST_BWD_BLOCKS, 84, dw_db);   // [81 weights | 3 biases]
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(84, 8)), dim3(256), 0, s, partial, n * blocks, 84, dw_db);   // [81 weights | 3 biases]
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

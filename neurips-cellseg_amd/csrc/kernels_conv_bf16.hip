@@ -51,12 +51,12 @@ __device__ __forceinline__ f32x4 mfma_split(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 // split 4 fp32 values into the next 16-bit plane (bits returned in a bf16x4 container) and leave the remainder in v
 template <bool F16>
-__device__ __forceinline__ bf16x4 split_plane(f32x4& v, int pn) {
+__device__ __forceinline__ bf16x4 split_plane(f32x4& v, int pn, float xscale = F16_X_SCALE) {
     if constexpr (F16) {
         f16x4 h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (pn == 0) v[j] *= F16_X_SCALE;
+            if (pn == 0) v[j] *= xscale;
             h[j] = (_Float16)v[j];                           // saturates at +-65504 (MODE.FP16_OVFL is set by the fp16 kernels)
             v[j] -= (float)h[j];
         }
@@ -99,6 +99,12 @@ struct ConvBParams {
     const float* dummy;
     int pitch_out, cout, ntile_total;
     int n, hin, win, hout, wout, tiles_x, tiles_y;
+    // data-gradient use of the stride-1 kernel (training on the 16-bit pipe): the input is a raw GRADIENT tensor whose power-of-two
+    // scale is dynamic (AMAX_SLOTS device floats, see f16_dyn_scale; null: the static activation scale), and the epilogue can add a
+    // tensor to the result (the other branch's gradient)
+    const float* in_amax;
+    const float* addend;
+    int pitch_add;
 };
 
 
@@ -199,6 +205,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int nt_w = wk.ct * NTB + wn * NTW;                 // this wave's first output-channel tile
     const int q = tid & 7;                                   // this thread's channel quad inside the 32-channel chunk
+    const float xscale = (F16 && p.in_amax) ? f16_dyn_scale(p.in_amax) : F16_X_SCALE;
+    const float out_scale = 1.f / (F16_W_SCALE * xscale);
 
     constexpr int NACC = 1;
     f32x4 acc[NACC][MTW][NTW];
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
                 if (goff[it] < 0 || !qvalid) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int pn = 0; pn < NPL; ++pn)
-                    *reinterpret_cast<bf16x4*>(in_s + pn * PLANE_BYTES + pix * PITCH + q * 8) = split_plane<F16>(v, pn);
+                    *reinterpret_cast<bf16x4*>(in_s + pn * PLANE_BYTES + pix * PITCH + q * 8) = split_plane<F16>(v, pn, xscale);
             }
         }
     };
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int ox = ox0 + g * 4 + r;
                 float v = acc[0][m][t][r];
-                if constexpr (F16) v *= F16_OUT_SCALE;
+                if constexpr (F16) v *= out_scale;
                 v += bias;
                 ep[(row * 16 + g * 4 + r) * EPS + (wn * NTW + t) * 16 + pl] = v;
                 if (p.stats && oy < p.hout && ox < p.wout) {
@@ -397,10 +405,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
             const int pix = i / F4, c4 = i - pix * F4;
             const int row = pix >> 4, x = pix & 15;
             if (oy0 + row < p.hout && ox0 + x < p.wout) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
                 const size_t el = el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4;
                 if constexpr (A16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el) = f32x4_to_bf16v(v);
-                else *reinterpret_cast<f32x4*>(p.out + el) = v;
+                else {
+                    if (p.addend)
+                        v += *reinterpret_cast<const f32x4*>(p.addend + (((size_t)img * p.hout + oy0 + row) * p.wout + ox0 + x) * p.pitch_add +
+                                                             wk.ct * NTB * 16 + c4 * 4);
+                    *reinterpret_cast<f32x4*>(p.out + el) = v;
+                }
             }
         }
     }
@@ -421,8 +434,9 @@ static int launch_b(hipStream_t s, ConvBParams p) {
 
 int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
                       const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
-                      int hin, int win, bool act16) {
+                      int hin, int win, bool act16, const float* in_amax, const ConvOutExtra* ex) {
     CS_REQUIRE(ksize == 3 || ksize == 1, "conv(bf16): ksize %d unsupported", ksize);
+    CS_REQUIRE(!ex || (!ex->out2 && !ex->addend2 && !act16), "conv(bf16): only a plain fp32 addend is understood");
     CS_REQUIRE(!act16 || planes == 1, "conv(bf16): bf16 activations in HBM go with the plain-bf16 mode only");
     CS_REQUIRE(a.h16 == act16 && (b.c == 0 || b.h16 == act16), "conv(bf16): activation element type does not match the mode");
     CS_REQUIRE((stride == 1 || stride == 2) && !(ksize == 1 && stride != 1), "conv(bf16): stride %d unsupported", stride);
@@ -435,6 +449,9 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     p.wpack = wpack; p.bias = bias; p.out = out; p.stats = stats; p.dummy = reinterpret_cast<const float*>(wpack);
     p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16;
     p.n = n; p.hin = hin; p.win = win;
+    p.in_amax = in_amax;
+    p.addend = ex ? ex->addend : nullptr;
+    p.pitch_add = ex ? ex->pitch_add : 0;
     const int pad = ksize / 2;
     p.hout = (hin + 2 * pad - ksize) / stride + 1;
     p.wout = (win + 2 * pad - ksize) / stride + 1;
@@ -790,11 +807,11 @@ size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize) {
 }
 
 int pack_conv_weights_bf16(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
-                           unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16) {
+                           unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16, bool flip) {
     CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack(bf16): bad channel counts");
     const int taps = ksize * ksize;
     const int chunks_total = cin_split > 0 ? (cin_split + 31) / 32 + (cin - cin_split + 31) / 32 : (cin + 31) / 32;
-    return pack_bf16_submit(pc, s, w, transposed, cout, cin, taps, packed, cout_off, cout_total / 16, cin_split, chunks_total, f16);
+    return pack_bf16_submit(pc, s, w, transposed, cout, cin, taps, packed, cout_off, cout_total / 16, cin_split, chunks_total, f16, flip);
 }
 
 }  // namespace cs

@@ -86,7 +86,8 @@ __device__ __forceinline__ void pack_bf16_elem(const PackJob& jb, int64_t e) {
     const bool valid = chunk < chunks_a ? k < (cin_split > 0 ? cin_split : cin) : ci < cin;
     const int co = ntl * 16 + (lane & 15);
     float v = 0.f;
-    if (valid) v = jb.transposed ? jb.src[((size_t)ci * cout + co) * taps + tap] : jb.src[((size_t)co * cin + ci) * taps + tap];
+    const int ts = jb.flip ? taps - 1 - tap : tap;            // data-gradient packing of a stride-1 conv: taps reversed
+    if (valid) v = jb.transposed ? jb.src[((size_t)ci * cout + co) * taps + ts] : jb.src[((size_t)co * cin + ci) * taps + ts];
     unsigned short* packed = reinterpret_cast<unsigned short*>(jb.dst);
     const size_t base = (((size_t)chunk * taps + tap) * jb.ntile_total + jb.cout_off / 16 + ntl) * 3;
     if (jb.f16) {                                             // fp16x3: planes of w * 2^8: h0, remainder, unused

@@ -131,7 +131,8 @@ struct ConvW {             // packed weights + bias of one (possibly fused) conv
     float* ww = nullptr;   // 3x3 stride-1 layers: Winograd F(2x2,3x3) weights G g G^T in fragment order (kernels_conv_wino.hip)
     float* wwd = nullptr;  // ... and those of the layer's DATA-GRADIENT convolution (channel roles swapped, taps reversed)
     unsigned short* wb = nullptr;   // 3 bf16 planes in 16x16x32 fragment order (split-bf16 forward kernels)
-    unsigned short* wbd = nullptr;  // 3x3 stride-1 layers: the same planes for the layer's DATA-GRADIENT convolution (training on the 16-bit pipe)
+    unsigned short* wbd = nullptr;  // the same planes for the layer's DATA-GRADIENT launch (bf16 training): stride-1 conv (roles swapped, taps reversed),
+                                    // fused stride-2 pair (as a transposed conv over [dy0 || dr]), transposed conv (as a stride-2 conv)
     unsigned char* w8 = nullptr;    // e4m3 weights in 16x16x128 fragment order (fp8 forward kernels)
     float* wscale = nullptr;        // their per-output-channel scales [cout]
     float* bias = nullptr;
@@ -317,6 +318,10 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             if (mode == 2) return copy_param(net, wdst, d, (size_t)cin * cout * ksize * ksize, s);
             if (wb && net->planes > 0 && net->planes <= 4)
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, true, cout, cin, ksize, wb, cout_off, cout_total, cin_split, net->planes == 4)) return rc;
+            // bf16 training: the data gradient of a transposed conv is a stride-2 conv of dy with the SAME tensor read as conv weights
+            // W[cin_t][cout_t] (no flip)
+            if (wbd && net->training && dg == DG_CONVT_AS_S2 && net->planes == 1)
+                if (int rc = pack_conv_weights_bf16(net->pack, s, d, false, cin, cout, ksize, wbd, 0, cin, 0, false)) return rc;
             if (w8 && net->planes == 5)
                 if (int rc = pack_conv_weights_fp8(s, d, true, cout, cin, ksize, w8, wsc, cout_off, cout_total, cin_split)) return rc;
             return pack_conv_weights(net->pack, s, d, true, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off);
@@ -335,6 +340,11 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             // convolution with the channel roles swapped and the taps reversed - the same kernel family, its own weight planes
             if (wbd && net->training && dg == DG_S1 && net->planes == 1)
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, true, cin, cout, ksize, wbd, 0, cin, 0, net->planes == 4, true)) return rc;
+            // ... and of a (fused) stride-2 conv a transposed conv of [dy0 || dr] with the tensors read as transposed-conv weights
+            // W[cin_t = cout][cout_t = cin] (no flip); the residual conv's tensor is the second input-channel source
+            if (wbd && net->training && dg == DG_S2_AS_CONVT && net->planes == 1)
+                if (int rc = pack_conv_weights_bf16(net->pack, s, d, true, cin, cout, ksize, wbd, 0, cin, 0, false, false, cout_off ? (cout + 31) / 32 : 0))
+                    return rc;
             if (w8 && net->planes == 5)
                 if (int rc = pack_conv_weights_fp8(s, d, false, cout, cin, ksize, w8, wsc, cout_off, cout_total, 0)) return rc;
             // 3x3 stride-1 layers: the tile kernel also writes the Winograd weights (forward; data gradient in training mode)
@@ -369,6 +379,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     if (stride == 1 && !u.first && c % 16 == 0 && cin % 32 == 0) u.unit0.wwd = ar.take(packed_wino_floats(cin, c));
     if (!u.first) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(u.unit0.cout, cin, 0, 3) + 1) / 2);
     if (stride == 1 && !u.first) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cin, c, 0, 3) + 1) / 2);
+    if (stride == 2 && !u.first && u.fused_res) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cin, c, c, 3) + 1) / 2);
     if (u.first) u.unit0.wb = (unsigned short*)ar.take((size_t)(u.unit0.cout / 16) * 512 / 2);      // one bf16 K-step (bf16 / fp8 datapaths)
     if (!u.first) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(u.unit0.cout, cin, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(u.unit0.cout); }
     add_conv_params(net, pfx + ".conv.unit0.conv", u.unit0, c, cin, 3, 0, false, u.first ? 1 : 0, dg0, 0);
@@ -412,6 +423,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     u.convt.bias = ar.take(cout);
     if (!small) u.convt.wd = ar.take(packed_conv_floats(cin, cout, 3));
     if (!small) u.convt.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cin_skip, cin_sub, 3) + 1) / 2);
+    if (!small) u.convt.wbd = (unsigned short*)ar.take((packed_bf16_elems(cin, cout, 0, 3) + 1) / 2);
     if (!small) { u.convt.w8 = (unsigned char*)ar.take((packed_fp8_bytes(cout, cin_skip, cin_sub, 3) + 3) / 4); u.convt.wscale = ar.take(cout); }
     add_conv_params(net, pfx + ".0.conv", u.convt, cout, cin, 3, 0, true, small ? 2 : 0, small ? DG_NONE : DG_CONVT_AS_S2, 0, cin_skip);
     add_norm_params(net, ar, pfx + ".0.adn", u.norm_t, cout);
@@ -893,7 +905,11 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             } else {
                 ConvOutExtra ex;
                 ex.out2 = dSn; ex.pitch_out2 = cb; ex.split = cs;
-                CS_TRY(launch_conv_mfma(s, 3, 2, rsrc(dU, c, c), ConvSrc(), u.convt.wd, nullptr, dX[d], cs, cin_t, nullptr, n, oh, ow, &ex));
+                if (dg16 && u.convt.wbd)
+                    CS_TRY(launch_conv_bf16s(s, 3, 2, dg16, rsrc(dU, c, c), ConvSrc(), u.convt.wbd, nullptr, dX[d], cs, cin_t, nullptr, n, oh, ow, false,
+                                             nullptr, &ex));
+                else
+                    CS_TRY(launch_conv_mfma(s, 3, 2, rsrc(dU, c, c), ConvSrc(), u.convt.wd, nullptr, dX[d], cs, cin_t, nullptr, n, oh, ow, &ex));
                 CS_TRY(wg_begin());
                 // (transposed conv: the ACTIVATIONS are the A operand, the gradient dU the shifted B operand)
                 CS_TRY(wgrad3(sw, gt, 2, T.X[d], cs, nullptr, rsrc(dU, c, c), ax_dU, cin_t, c, 0, ph, pw, oh, ow));
@@ -1005,7 +1021,10 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             CS_TRY(wgrad3(sw, gf, 2, dXd, c, ax_dXd, xin, nullptr, c0, cin, c, oh, ow, ph, pw));
             ConvOutExtra ex;
             ex.addend = dX[d - 1]; ex.pitch_add = cin;
-            CS_TRY(launch_convt_mfma(s, rsrc(dY0, c, c), rsrc(dXd, c, c), u.unit0.wd, nullptr, dX[d - 1], cin, cin, nullptr, n, oh, ow, &ex));
+            if (dg16 && u.unit0.wbd)
+                CS_TRY(launch_convt_bf16s(s, dg16, rsrc(dY0, c, c), rsrc(dXd, c, c), u.unit0.wbd, nullptr, dX[d - 1], cin, cin, nullptr, n, oh, ow, false, &ex));
+            else
+                CS_TRY(launch_convt_mfma(s, rsrc(dY0, c, c), rsrc(dXd, c, c), u.unit0.wd, nullptr, dX[d - 1], cin, cin, nullptr, n, oh, ow, &ex));
         } else {
             WgradNarrow nb;
             nb.ptr = T.src.image; nb.c = cin; nb.sn = T.src.sn; nb.sc = T.src.sc; nb.sh = T.src.sh; nb.sw = T.src.sw;

@@ -52,7 +52,7 @@ int pack_batch_freeze(PackCtx* pc, hipStream_t s);         // flush + keep the d
 int pack_replay(PackCtx* pc, hipStream_t s);
 int pack_copy(PackCtx* pc, hipStream_t s, const float* src, float* dst, size_t n);
 int pack_bf16_submit(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int taps, unsigned short* packed,
-                     int cout_off, int ntile_total, int cin_split, int chunks_total, bool f16, bool flip = false);
+                     int cout_off, int ntile_total, int cin_split, int chunks_total, bool f16, bool flip = false, int chunk_off = 0);
 size_t packed_conv_floats(int cout_total, int cin_total, int ksize);
 // Winograd F(2x2, 3x3) weights of a 3x3 stride-1 conv W[cout][cin][3][3] (kernels_conv_wino.hip): U = G g G^T in fragment order
 // packed[cin/16][16 positions][cout/16][64 lanes][4].  dgrad: the weights of the data-gradient convolution of the same tensor
@@ -98,10 +98,11 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
                       const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
                       int hin, int win, bool act16 = false, const float* in_amax = nullptr, const ConvOutExtra* ex = nullptr);
 int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSrc& b, const unsigned short* wpack, const float* bias,
-                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win, bool act16 = false);
+                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win, bool act16 = false,
+                       const ConvOutExtra* ex = nullptr);
 size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize);
 int pack_conv_weights_bf16(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
-                           unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16 = false, bool flip = false);
+                           unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16 = false, bool flip = false, int chunk_off = 0);
 
 // fp8 variant (kernels_conv_fp8.hip): e4m3 weights with one fp32 scale per output channel, inputs = ACTIVATED e4m3 tensors
 // (ConvSrc::q8; launch_act_quant / launch_norm_act_add produce them) staged as plain 16-byte copies,

@@ -1424,9 +1424,10 @@ int pack_copy(PackCtx* pc, hipStream_t s, const float* src, float* dst, size_t n
 }
 
 int pack_bf16_submit(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int taps, unsigned short* packed,
-                     int cout_off, int ntile_total, int cin_split, int chunks_total, bool f16, bool flip) {
+                     int cout_off, int ntile_total, int cin_split, int chunks_total, bool f16, bool flip, int chunk_off) {
     PackJob jb{};
     jb.flip = flip ? 1 : 0;
+    jb.chunk_off = chunk_off;
     jb.src = w; jb.dst = packed; jb.kind = PK_BF16; jb.transposed = transposed ? 1 : 0; jb.cout = cout; jb.cin = cin; jb.taps = taps;
     jb.cout_off = cout_off; jb.ntile_total = ntile_total; jb.cin_split = cin_split; jb.chunks_total = chunks_total; jb.f16 = f16 ? 1 : 0;
     return pack_submit(pc, s, jb);

@@ -105,6 +105,8 @@ struct ConvBParams {
     const float* in_amax;
     const float* addend;
     int pitch_add;
+    float* out2;                   // channel tiles >= split_nt go to out2 (pitch_out2), the data gradient of a transposed conv splits
+    int pitch_out2, split_nt;      // into its skip and its deeper input this way (stride-2 kernel, fp32 outputs only)
 };
 
 
@@ -409,10 +411,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
                 const size_t el = el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4;
                 if constexpr (A16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el) = f32x4_to_bf16v(v);
                 else {
-                    if (p.addend)
-                        v += *reinterpret_cast<const f32x4*>(p.addend + (((size_t)img * p.hout + oy0 + row) * p.wout + ox0 + x) * p.pitch_add +
-                                                             wk.ct * NTB * 16 + c4 * 4);
-                    *reinterpret_cast<f32x4*>(p.out + el) = v;
+                    const size_t gp = ((size_t)img * p.hout + oy0 + row) * p.wout + ox0 + x;
+                    const int ch = wk.ct * NTB * 16 + c4 * 4;
+                    if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + gp * p.pitch_add + ch);
+                    if (p.out2 && ch >= p.split_nt * 16) *reinterpret_cast<f32x4*>(p.out2 + gp * p.pitch_out2 + ch - p.split_nt * 16) = v;
+                    else *reinterpret_cast<f32x4*>(p.out + el) = v;
                 }
             }
         }
@@ -436,7 +439,8 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
                       const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
                       int hin, int win, bool act16, const float* in_amax, const ConvOutExtra* ex) {
     CS_REQUIRE(ksize == 3 || ksize == 1, "conv(bf16): ksize %d unsupported", ksize);
-    CS_REQUIRE(!ex || (!ex->out2 && !ex->addend2 && !act16), "conv(bf16): only a plain fp32 addend is understood");
+    CS_REQUIRE(!ex || (!ex->addend2 && !act16 && !(ex->out2 && ex->addend)), "conv(bf16): a plain fp32 addend or an (out, out2) channel split");
+    CS_REQUIRE(!ex || !ex->out2 || (ex->split % 16 == 0 && ex->split > 0 && ex->split < cout), "conv(bf16): bad output split %d", ex ? ex->split : 0);
     CS_REQUIRE(!act16 || planes == 1, "conv(bf16): bf16 activations in HBM go with the plain-bf16 mode only");
     CS_REQUIRE(a.h16 == act16 && (b.c == 0 || b.h16 == act16), "conv(bf16): activation element type does not match the mode");
     CS_REQUIRE((stride == 1 || stride == 2) && !(ksize == 1 && stride != 1), "conv(bf16): stride %d unsupported", stride);
@@ -452,6 +456,9 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     p.in_amax = in_amax;
     p.addend = ex ? ex->addend : nullptr;
     p.pitch_add = ex ? ex->pitch_add : 0;
+    p.out2 = ex ? ex->out2 : nullptr;
+    p.pitch_out2 = ex ? ex->pitch_out2 : 0;
+    p.split_nt = ex && ex->out2 ? ex->split / 16 : 0;
     const int pad = ksize / 2;
     p.hout = (hin + 2 * pad - ksize) / stride + 1;
     p.wout = (win + 2 * pad - ksize) / stride + 1;
@@ -741,10 +748,15 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
             const int pix = i / F4, c4 = i - pix * F4;
             const int row = pix >> 5, x = pix & 31;
             if (2 * iy0 + row < p.hout && 2 * ix0 + x < p.wout) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
                 const size_t el = el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4;
                 if constexpr (A16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el) = f32x4_to_bf16v(v);
-                else *reinterpret_cast<f32x4*>(p.out + el) = v;
+                else {
+                    if (p.addend)
+                        v += *reinterpret_cast<const f32x4*>(p.addend + (((size_t)img * p.hout + 2 * iy0 + row) * p.wout + 2 * ix0 + x) * p.pitch_add +
+                                                             wk.ct * NTB * 16 + c4 * 4);
+                    *reinterpret_cast<f32x4*>(p.out + el) = v;
+                }
             }
         }
     }
@@ -766,8 +778,9 @@ static int launch_tb(hipStream_t s, ConvBParams p) {
 }
 
 int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSrc& b, const unsigned short* wpack, const float* bias,
-                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win, bool act16) {
+                       float* out, int pitch_out, int cout, double* stats, int n, int hin, int win, bool act16, const ConvOutExtra* ex) {
     CS_REQUIRE(planes >= 1 && planes <= 4, "convT(bf16): %d planes", planes);
+    CS_REQUIRE(!ex || (!ex->out2 && !ex->addend2 && !act16), "convT(bf16): only a plain fp32 addend is understood");
     CS_REQUIRE(!act16 || planes == 1, "convT(bf16): bf16 activations in HBM go with the plain-bf16 mode only");
     CS_REQUIRE(a.h16 == act16 && (b.c == 0 || b.h16 == act16), "convT(bf16): activation element type does not match the mode");
     CS_REQUIRE(a.c % 16 == 0 && b.c % 16 == 0 && a.c > 0 && cout % 16 == 0, "convT(bf16): channels must be multiples of 16");
@@ -778,6 +791,8 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
     p.wpack = wpack; p.bias = bias; p.out = out; p.stats = stats; p.dummy = reinterpret_cast<const float*>(wpack);
     p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16;
     p.n = n; p.hin = hin; p.win = win; p.hout = 2 * hin; p.wout = 2 * win;
+    p.addend = ex ? ex->addend : nullptr;
+    p.pitch_add = ex ? ex->pitch_add : 0;
     p.tiles_x = ceil_div(win, 16);
     p.tiles_y = ceil_div(hin, 4);
     const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
@@ -807,11 +822,11 @@ size_t packed_bf16_elems(int cout_total, int cin_a, int cin_b, int ksize) {
 }
 
 int pack_conv_weights_bf16(PackCtx* pc, hipStream_t s, const float* w, bool transposed, int cout, int cin, int ksize,
-                           unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16, bool flip) {
+                           unsigned short* packed, int cout_off, int cout_total, int cin_split, bool f16, bool flip, int chunk_off) {
     CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0 && cout_off % 16 == 0 && cout_total % 16 == 0, "pack(bf16): bad channel counts");
     const int taps = ksize * ksize;
     const int chunks_total = cin_split > 0 ? (cin_split + 31) / 32 + (cin - cin_split + 31) / 32 : (cin + 31) / 32;
-    return pack_bf16_submit(pc, s, w, transposed, cout, cin, taps, packed, cout_off, cout_total / 16, cin_split, chunks_total, f16, flip);
+    return pack_bf16_submit(pc, s, w, transposed, cout, cin, taps, packed, cout_off, cout_total / 16, cin_split, chunks_total, f16, flip, chunk_off);
 }
 
 }  // namespace cs

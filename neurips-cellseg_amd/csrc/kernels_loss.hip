@@ -23,7 +23,8 @@ struct LossArgs {
     int64_t tn, tc, th, tw;
     int n, c, h, w;
     float smooth_nr, smooth_dr, lambda_dice, lambda_ce;
-    double* sums;          // [n][c][3] = (sum p t, sum p, sum t), then [1] = sum of -log p[argmax t]
+    double* sums;          // [n][c][3] = (sum p t, sum p, sum t), then [n] = per-image sums of -log p[argmax t] (ONE word for the whole
+                           // batch took 2048 serialised fp64 atomics per launch: 70 us of a 160 us loss)
 };
 
 // softmax over c <= 4 classes of one pixel; returns the index of the largest target (first maximum, as torch.argmax) and
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void dice_ce_sums_kernel(LossArgs a) {
     if (tid < 3 * C + 1) {
         const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
         if (tid < 3 * C) atomicAdd(a.sums + ((size_t)img * C) * 3 + tid, v);
-        else atomicAdd(a.sums + (size_t)a.n * C * 3, v);
+        else atomicAdd(a.sums + (size_t)a.n * C * 3 + img, v);
     }
 }
 
@@ -107,7 +108,9 @@ __global__ void dice_ce_finalize_kernel(LossArgs a, float* loss_out) {
         double dice = 0.0;
         for (int i = 0; i < 256; ++i) dice += part[i];
         dice /= (double)items;
-        const double ce = a.sums[(size_t)items * 3] / ((double)a.n * a.h * a.w);
+        double ce = 0.0;
+        for (int i = 0; i < a.n; ++i) ce += a.sums[(size_t)items * 3 + i];
+        ce /= (double)a.n * a.h * a.w;
         *loss_out = (float)((double)a.lambda_dice * dice + (double)a.lambda_ce * ce);
     }
 }
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void dice_ce_backward_kernel(LossArgs a, const
 }
 }  // namespace
 
-size_t dice_ce_workspace_bytes(int n, int c) { return ((size_t)n * c * 3 + 1) * sizeof(double); }
+size_t dice_ce_workspace_bytes(int n, int c) { return ((size_t)n * c * 3 + n) * sizeof(double); }
 
 static int fill_args(LossArgs& a, const float* logits, const int64_t* ls, const float* target, const int64_t* ts, int n, int c, int h, int w,
                      float smooth_nr, float smooth_dr, float lambda_dice, float lambda_ce, void* ws, size_t ws_bytes) {

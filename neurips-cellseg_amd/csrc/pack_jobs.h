@@ -89,7 +89,8 @@ __device__ __forceinline__ void pack_bf16_elem(const PackJob& jb, int64_t e) {
     const int ts = jb.flip ? taps - 1 - tap : tap;            // data-gradient packing of a stride-1 conv: taps reversed
     if (valid) v = jb.transposed ? jb.src[((size_t)ci * cout + co) * taps + ts] : jb.src[((size_t)co * cin + ci) * taps + ts];
     unsigned short* packed = reinterpret_cast<unsigned short*>(jb.dst);
-    const size_t base = (((size_t)chunk * taps + tap) * jb.ntile_total + jb.cout_off / 16 + ntl) * 3;
+    const size_t base = (((size_t)(chunk + jb.chunk_off) * taps + tap) * jb.ntile_total + jb.cout_off / 16 + ntl) * 3;   // chunk_off: this tensor
+                                                            // is the second input-channel source of a fused launch (data-gradient packings)
     if (jb.f16) {                                             // fp16x3: planes of w * 2^8: h0, remainder, unused
         v = __builtin_amdgcn_fmed3f(v * PACK_F16_W_SCALE, -65504.f, 65504.f);   // saturate (|w| >= 255.9 is outside the mode's domain)
         const _Float16 h0 = (_Float16)v;

@@ -732,11 +732,16 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         if "wino" in name:
-            # Winograd F(2x2,3x3): `achieved` counts the multiplies the algorithm really issues on the matrix pipe (16 per 2x2 output
-            # tile and channel pair); the same launches expressed in direct-convolution FLOPs (36 per tile: SURVEY 8(d)'s figure)
-            rl["algorithm"] = "Winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per output tile and channel pair"
-            rl["direct_conv_equivalent"] = round(rl["achieved"] * 36 / 16, 3)
-            rl["frac_direct_conv_equivalent"] = round(rl["achieved"] * 36 / 16 / rl["peak"], 4)
+            # Winograd: `achieved` counts the multiplies the algorithm really issues on the matrix pipe (F(2x2,3x3): 16 per 2x2 output
+            # tile and channel pair; F(4x4,3x3): 36 per 4x4 tile); the same launches expressed in direct-convolution FLOPs (9 per
+            # output pixel: SURVEY 8(d)'s figure)
+            f4 = name.endswith("wino4")
+            factor = 144 / 36 if f4 else 36 / 16
+            rl["algorithm"] = ("Winograd F(4x4,3x3), fp32: 36 instead of 144 multiplies per 4x4 output tile and channel pair (the layers with "
+                               ">= 128 input channels)" if f4 else
+                               "Winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per output tile and channel pair")
+            rl["direct_conv_equivalent"] = round(rl["achieved"] * factor, 3)
+            rl["frac_direct_conv_equivalent"] = round(rl["achieved"] * factor / rl["peak"], 4)
         rl.update({"kernel": name, "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 5),
                    "algorithmic_per_launch": (k["flops"] if mfma else k["bytes"]) / k["launches"],
                    "share_of_gpu_time": round(k["ms"] / sum(v["ms"] for v in prof.values()), 4)})

@@ -33,7 +33,7 @@ static const char* kNames[K_NUM_IDS] = {
     "conv3x3_s1_mfma", "conv3x3_s2_mfma", "conv1x1_mfma", "conv_first_mfma", "convT3x3s2_mfma", "convT_top_mfma",
     "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
     "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset", "norm_bwd",
-    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric", "wgrad_unpack", "conv3x3_s1_wino", "dice_ce_loss"};
+    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric", "wgrad_unpack", "conv3x3_s1_wino", "dice_ce_loss", "conv3x3_s1_wino4"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
 
 struct ProfRecord {
@@ -130,6 +130,7 @@ struct ConvW {             // packed weights + bias of one (possibly fused) conv
     float* wd = nullptr;   // the same weights packed for the DATA-GRADIENT launch (see kernels_bwd.hip header)
     float* ww = nullptr;   // 3x3 stride-1 layers: Winograd F(2x2,3x3) weights G g G^T in fragment order (kernels_conv_wino.hip)
     float* wwd = nullptr;  // ... and those of the layer's DATA-GRADIENT convolution (channel roles swapped, taps reversed)
+    float* ww4 = nullptr;  // wide 3x3 stride-1 layers (>= 128 input channels): Winograd F(4x4,3x3) weights (kernels_conv_wino4.hip), forward
     unsigned short* wb = nullptr;   // 3 bf16 planes in 16x16x32 fragment order (split-bf16 forward kernels)
     unsigned short* wbd = nullptr;  // the same planes for the layer's DATA-GRADIENT launch (bf16 training): stride-1 conv (roles swapped, taps reversed),
                                     // fused stride-2 pair (as a transposed conv over [dy0 || dr]), transposed conv (as a stride-2 conv)
@@ -301,6 +302,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     float* wd = cw.wd;
     float* ww = cw.ww;
     float* wwd = cw.wwd;
+    float* ww4 = cw.ww4;
     unsigned short* wb = cw.wb;
     unsigned short* wbd = cw.wbd;
     unsigned char* w8 = cw.w8;
@@ -348,6 +350,8 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             if (w8 && net->planes == 5)
                 if (int rc = pack_conv_weights_fp8(s, d, false, cout, cin, ksize, w8, wsc, cout_off, cout_total, 0)) return rc;
             // 3x3 stride-1 layers: the tile kernel also writes the Winograd weights (forward; data gradient in training mode)
+            if (ww4 && wino_level() >= 2 && net->planes == 0)
+                if (int rc = pack_wino4_weights(net->pack, s, d, cout, cin, ww4)) return rc;
             float* const wino_f = (ww && wino_enabled()) ? ww : nullptr;
             float* const wino_d = (wwd && wino_enabled() && net->training && dg == DG_S1) ? wwd : nullptr;
             return pack_conv_weights(net->pack, s, d, false, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off,
@@ -376,6 +380,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     const int dg0 = u.first ? DG_NONE : (stride == 2 ? DG_S2_AS_CONVT : DG_S1);
     if (dg0 != DG_NONE) u.unit0.wd = ar.take(packed_conv_floats(cin, u.unit0.cout, 3));
     if (stride == 1 && !u.first && cin % 16 == 0 && c % 32 == 0) u.unit0.ww = ar.take(packed_wino_floats(c, cin));
+    if (stride == 1 && !u.first && cin >= 128 && cin % 16 == 0 && c % 64 == 0) u.unit0.ww4 = ar.take(packed_wino4_floats(c, cin));
     if (stride == 1 && !u.first && c % 16 == 0 && cin % 32 == 0) u.unit0.wwd = ar.take(packed_wino_floats(cin, c));
     if (!u.first) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(u.unit0.cout, cin, 0, 3) + 1) / 2);
     if (stride == 1 && !u.first) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cin, c, 0, 3) + 1) / 2);
@@ -391,6 +396,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         cw.bias = ar.take(c);
         cw.wd = ar.take(packed_conv_floats(c, c, 3));
         if (c % 32 == 0) cw.ww = ar.take(packed_wino_floats(c, c));
+        if (c >= 128 && c % 64 == 0) cw.ww4 = ar.take(packed_wino4_floats(c, c));
         if (c % 32 == 0) cw.wwd = ar.take(packed_wino_floats(c, c));
         cw.wb = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
         cw.wbd = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
@@ -432,6 +438,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     u.unit0.bias = ar.take(cout);
     if (!small) u.unit0.wd = ar.take(packed_conv_floats(cout, cout, 3));
     if (!small && cout % 32 == 0) u.unit0.ww = ar.take(packed_wino_floats(cout, cout));
+    if (!small && cout >= 128 && cout % 64 == 0) u.unit0.ww4 = ar.take(packed_wino4_floats(cout, cout));
     if (!small && cout % 32 == 0) u.unit0.wwd = ar.take(packed_wino_floats(cout, cout));
     if (!small) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
     if (!small) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
@@ -493,6 +500,9 @@ static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, co
     if (net->planes > 0 && net->planes <= 4 && cw.wb)
         return launch_conv_bf16s(s, ksize, stride, net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin, win, a.h16);
     CS_REQUIRE(!a.h16 && !a.q8, "conv: a layer without low-precision weights met bf16 / e4m3 activations");
+    // fp32, wide layers: Winograd F(4x4,3x3) - 2.25 multiplies per output pixel and channel pair instead of F(2x2)'s 4 (CS_WINO=1: F(2x2) everywhere)
+    if (net->planes == 0 && cw.ww4 && ksize == 3 && stride == 1 && wino_level() >= 2 && wino4_fits(a.c, cout, hin, win) && wino_fits(hin, win, a.pitch))
+        return launch_conv_wino4(s, a, cw.ww4, cw.bias, out, pitch_out, cout, stats, n, hin, win);
     if (net->planes == 0 && cw.ww && ksize == 3 && stride == 1 && wino_enabled() && wino_fits(hin, win, a.pitch))   // fp32: Winograd F(2x2,3x3), 2.25x fewer multiplies
         return launch_conv_wino(s, a, cw.ww, cw.bias, out, pitch_out, cout, stats, n, hin, win);
     return launch_conv_mfma(s, ksize, stride, a, ConvSrc(), cw.w, cw.bias, out, pitch_out, cout, stats, n, hin, win);

@@ -6,7 +6,7 @@
 
 namespace cs {
 
-enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3, PK_FIRST16 = 4, PK_WINO = 5 };
+enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3, PK_FIRST16 = 4, PK_WINO = 5, PK_WINO4 = 6 };
 struct PackJob {
     const float* src;
     void* dst;
@@ -153,6 +153,41 @@ __device__ __forceinline__ void pack_wino_elem(const PackJob& jb, int64_t e) {
         col[b] = xi == 0 ? gk[0][b] : xi == 3 ? gk[2][b] : 0.5 * (xi == 1 ? gk[0][b] + gk[1][b] + gk[2][b] : gk[0][b] - gk[1][b] + gk[2][b]);
     const double u = nu == 0 ? col[0] : nu == 3 ? col[2] : 0.5 * (nu == 1 ? col[0] + col[1] + col[2] : col[0] - col[1] + col[2]);
     reinterpret_cast<float*>(jb.dst)[(((size_t)chunk * 16 + pos) * jb.ntile_total + ntl) * 256 + lane * 4 + j] = (float)u;
+}
+
+// Winograd F(4x4, 3x3) weights U = G g G^T (6 x 6 positions, fp64, rounded once) in fp32 MFMA fragment order (kernels_conv_wino4.hip):
+// packed[chunk][position xi*6+nu][ntile_total][lane][j]: cout = ntile*16 + (lane & 15), cin = chunk*16 + 4*(lane>>4) + j.
+__device__ __forceinline__ void pack_wino4_elem(const PackJob& jb, int64_t e) {
+    const int cout = jb.cout, cin = jb.cin;
+    const int j = e & 3, lane = (e >> 2) & 63;
+    int64_t r = e >> 8;
+    const int ntl = r % (cout / 16);
+    r /= (cout / 16);
+    const int pos = (int)(r % 36);
+    const int chunk = (int)(r / 36);
+    const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
+    const float* src = jb.src + ((size_t)co * cin + ci) * 9;
+    const int xi = pos / 6, nu = pos - xi * 6;
+    // row xi of G: {1/4, 0, 0}, {-1/6, -1/6, -1/6}, {-1/6, 1/6, -1/6}, {1/24, 1/12, 1/6}, {1/24, -1/12, 1/6}, {0, 0, 1}
+    auto grow = [](int k, double (&o)[3]) {
+        switch (k) {
+            case 0: o[0] = 0.25; o[1] = 0.0; o[2] = 0.0; break;
+            case 1: o[0] = -1.0 / 6; o[1] = -1.0 / 6; o[2] = -1.0 / 6; break;
+            case 2: o[0] = -1.0 / 6; o[1] = 1.0 / 6; o[2] = -1.0 / 6; break;
+            case 3: o[0] = 1.0 / 24; o[1] = 1.0 / 12; o[2] = 1.0 / 6; break;
+            case 4: o[0] = 1.0 / 24; o[1] = -1.0 / 12; o[2] = 1.0 / 6; break;
+            default: o[0] = 0.0; o[1] = 0.0; o[2] = 1.0; break;
+        }
+    };
+    double ga[3], gb[3];
+    grow(xi, ga);
+    grow(nu, gb);
+    double u = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) u += ga[a] * (double)src[a * 3 + b] * gb[b];
+    reinterpret_cast<float*>(jb.dst)[(((size_t)chunk * 36 + pos) * jb.ntile_total + ntl) * 256 + lane * 4 + j] = (float)u;
 }
 
 }  // namespace cs

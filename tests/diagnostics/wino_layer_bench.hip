@@ -120,6 +120,40 @@ int main(int argc, char** argv) {
                "max|dy| %.2e of %.1f, stats rel %.1e\n",
                L.hw, L.cin, L.cout, us_w, wino_gf / us_w * 1e3, wino_gf / us_w * 1e3 / 157.3 * 100, direct_gf / us_w * 1e3, us_d,
                direct_gf / us_d * 1e3, err, amax, serr);
+        if (cs::wino4_fits(L.cin, L.cout, L.hw, L.hw)) {        // the same layer as Winograd F(4x4,3x3)
+            float* w4;
+            CK(hipMalloc(&w4, cs::packed_wino4_floats(L.cout, L.cin) * 4));
+            if (cs::pack_wino4_weights(pc, s, w, L.cout, L.cin, w4)) { printf("pack4 failed: %s\n", cs_last_error()); return 1; }
+            CK(hipMemset(st1, 0, (size_t)n * L.cout * 16));
+            CK(hipMemset(y1, 0, npix * L.cout * 4));
+            auto run_4 = [&]() { return cs::launch_conv_wino4(s, a, w4, b, y1, L.cout, L.cout, st1_arg, n, L.hw, L.hw); };
+            if (run_4()) { printf("launch4 failed: %s\n", cs_last_error()); return 1; }
+            CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(o1.data(), y1, o1.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(s1.data(), st1, s1.size() * 8, hipMemcpyDeviceToHost));
+            double err4 = 0, serr4 = 0;
+            size_t worst = 0;
+            for (size_t i = 0; i < o1.size(); ++i) {
+                const double d = fabs((double)o1[i] - o2[i]);
+                if (!(d <= err4)) { err4 = d; worst = i; }
+            }
+            for (size_t i = 0; i < s1.size(); ++i) {
+                const double d = fabs(s1[i] - s2[i]) / (fabs(s2[i]) + 1.0);
+                if (!(d <= serr4)) serr4 = d;
+            }
+            float ms_4 = 0;
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < reps; ++i) run_4();
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms_4, e0, e1));
+            const double us_4 = ms_4 / reps * 1e3, f4_gf = direct_gf * 36 / 144;
+            const size_t wpix = worst / L.cout;
+            printf("      F(4x4): %7.1f us (%5.1f TF issued = %4.1f%% of 157.3; %5.1f TF direct-equivalent)   max|dy| %.2e (at img %zu y %zu x %zu ch %zu), stats rel %.1e\n",
+                   us_4, f4_gf / us_4 * 1e3, f4_gf / us_4 * 1e3 / 157.3 * 100, direct_gf / us_4 * 1e3, err4, wpix / ((size_t)L.hw * L.hw),
+                   (wpix / L.hw) % L.hw, wpix % L.hw, worst % L.cout, serr4);
+            hipFree(w4);
+        }
         if (getenv("WINO_STAMPS")) {       // one more launch with in-kernel stamps: cycles per phase, block 0, per wave
             long long* sb;
             CK(hipMalloc(&sb, 64 * 8));

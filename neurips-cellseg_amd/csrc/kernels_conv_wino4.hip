@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
     constexpr int IN_ITERS = (W4_IH * W4_IW * 4 + 255) / 256;                 // 6: (pixel, channel quad) items per thread
     constexpr int MAIN_FLOATS = RAW4_FLOATS + V4_FLOATS;
     constexpr int BODY_FLOATS = MAIN_FLOATS > M4_FLOATS ? MAIN_FLOATS : M4_FLOATS;
-    constexpr int ST_FLOATS = 2 * 64 * 2 * 2;                                 // fp64 statistics of the two epilogue waves
+    constexpr int ST_FLOATS = 4 * 32 * 2 * 2;                                 // fp64 statistics of the four waves, 32 channels of a half
     __shared__ __attribute__((aligned(16))) float smem[BODY_FLOATS + ST_FLOATS];
     float* const raw = smem;
     float* const vs = smem + RAW4_FLOATS;
@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
     // input transform of one (tile, channel): thread = (tile = tid >> 4, channel = tid & 15)
     const int t_tile = tid >> 4, t_c = tid & 15;
     const float* const t_src = raw + (((t_tile >> 2) * 4) * W4_IW + (t_tile & 3) * 4) * W4_PS + t_c;
-    float* const t_dst = vs + (((t_c >> 2) * 16 + t_tile) * 4) + (t_c & 3);          // + position * 256
+    // V[position][k-group g][tile ^ 2 g][4]: the XOR spreads the four k-groups a 32-lane store group holds over all 32 banks (without it
+    // the 36 stores of a thread were 4-way conflicted); the A-fragment read permutes its tiles the same way and stays conflict-free
+    float* const t_dst = vs + (((t_c >> 2) * 16 + (t_tile ^ (2 * (t_c >> 2)))) * 4) + (t_c & 3);          // + position * 256
     auto transform = [&]() {
         float t[6][6];
 #pragma unroll
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
     __syncthreads();
     transform();
     __syncthreads();
-    const float* const a_src = vs + ((wave * 9 * 4 + g) * 16 + pl) * 4;       // + ps * 256
+    const float* const a_src = vs + ((wave * 9 * 4 + g) * 16 + (pl ^ (2 * g))) * 4;       // + ps * 256
     // one chunk: 9 positions x 16 MFMAs.  A chunk has an ODD number of weight-ring steps, so the ring slot of a position alternates
     // from chunk to chunk: the K loop is unrolled by two (PAR = parity of the chunk) to keep the slot a compile-time constant
     auto do_chunk = [&](int ch, auto par) {
@@ -197,8 +199,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
 
     // ---- epilogue: two 32-channel halves through LDS ----
     float* const ms = smem;                                     // [36 positions][16 tiles][32 channels], channel index XOR 16 for tiles 4..7, 12..15
-    double* const st_s = reinterpret_cast<double*>(smem + BODY_FLOATS);      // [2 waves][32 channels][2]
-    const int e_tile = tid >> 3, e_q = tid & 7;                 // output thread (tid < 128): tile, channel quad of the half
+    double* const st_s = reinterpret_cast<double*>(smem + BODY_FLOATS);      // [4 waves][32 channels][2]
+    const int e_grp = tid >> 7;                                 // output rows 2 e_grp, 2 e_grp + 1 of the tile
+    const int e_tile = (tid & 127) >> 3, e_q = tid & 7;         // output thread: tile, channel quad of the half
     const int e_ty = e_tile >> 2, e_tx = e_tile & 3;
     const int e_sw = ((e_tile >> 2) & 1) << 4;
 #pragma unroll
@@ -214,54 +217,51 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
                     ms[((wave * 9 + ps) * 16 + tile) * 32 + ((tt * 16 + pl) ^ ((g & 1) << 4))] = acc[ps][2 * hf + tt][r];
                 }
         __syncthreads();
-        if (tid < 128) {
+        {
             const int co = nt0 * 16 + hf * 32 + 4 * e_q;
             f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
             const float* src = ms + e_tile * 32 + ((4 * e_q) ^ e_sw);
             float sf[4] = {0.f, 0.f, 0.f, 0.f}, qf[4] = {0.f, 0.f, 0.f, 0.f};
             const int ox = ox0 + 4 * e_tx;
-            // two output rows per pass (the products are read twice): with all four rows of A^T M in registers next to the second half's
-            // 72 accumulators the kernel spilled 48 registers
+            // a thread takes two of the tile's four output rows (both halves of the block read all 36 products: holding all four rows
+            // of A^T M next to the second half's 72 accumulators spilled 48 registers, and 128 idle threads doubled the epilogue)
+            f32x4 tm[2][6];                                     // rows 2 e_grp, 2 e_grp + 1 of A^T M: 6 position columns each
 #pragma unroll
-            for (int ip = 0; ip < 2; ++ip) {
-                f32x4 tm[2][6];                                 // rows 2 ip, 2 ip + 1 of A^T M: 6 position columns each
+            for (int nu = 0; nu < 6; ++nu) {
+                f32x4 m[6];
 #pragma unroll
-                for (int nu = 0; nu < 6; ++nu) {
-                    f32x4 m[6];
+                for (int xi = 0; xi < 6; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(src + (xi * 6 + nu) * 512);
+                f32x4 o[4];
+                at6(m, o);
+                tm[0][nu] = e_grp ? o[2] : o[0];
+                tm[1][nu] = e_grp ? o[3] : o[1];
+            }
 #pragma unroll
-                    for (int xi = 0; xi < 6; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(src + (xi * 6 + nu) * 512);
-                    f32x4 o[4];
-                    at6(m, o);
-                    tm[0][nu] = o[2 * ip];
-                    tm[1][nu] = o[2 * ip + 1];
-                }
+            for (int ii = 0; ii < 2; ++ii) {
+                f32x4 y[4];
+                at6(tm[ii], y);
+                const int oy = oy0 + 4 * e_ty + 2 * e_grp + ii;
 #pragma unroll
-                for (int ii = 0; ii < 2; ++ii) {
-                    f32x4 y[4];
-                    at6(tm[ii], y);
-                    const int oy = oy0 + 4 * e_ty + 2 * ip + ii;
+                for (int jx = 0; jx < 4; ++jx) {
+                    f32x4 v = y[jx] + bias4;
+                    if (oy < p.hout && ox + jx < p.wout) {
+                        const size_t gp = ((size_t)img * p.hout + oy) * p.wout + ox + jx;
+                        if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + gp * p.pitch_add + co);
+                        *reinterpret_cast<f32x4*>(p.out + gp * p.pitch_out + co) = v;
+                        if (p.stats) {
 #pragma unroll
-                    for (int jx = 0; jx < 4; ++jx) {
-                        f32x4 v = y[jx] + bias4;
-                        if (oy < p.hout && ox + jx < p.wout) {
-                            const size_t gp = ((size_t)img * p.hout + oy) * p.wout + ox + jx;
-                            if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + gp * p.pitch_add + co);
-                            *reinterpret_cast<f32x4*>(p.out + gp * p.pitch_out + co) = v;
-                            if (p.stats) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    sf[k] += v[k];
-                                    qf[k] = __builtin_fmaf(v[k], v[k], qf[k]);
-                                }
+                            for (int k = 0; k < 4; ++k) {
+                                sf[k] += v[k];
+                                qf[k] = __builtin_fmaf(v[k], v[k], qf[k]);
                             }
                         }
                     }
                 }
             }
             if (p.stats) {
-                // a thread's 16 values per channel and the 8 lanes (tiles) of the wave that hold the same channel quad are summed in
-                // fp32 (<= 128 values per partial sum), everything from there on is fp64 (as in kernels_conv_wino.hip)
+                // a thread's 8 values per channel and the 8 lanes (tiles) of the wave that hold the same channel quad are summed in
+                // fp32 (<= 64 values per partial sum), everything from there on is fp64 (as in kernels_conv_wino.hip)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
                 if (lane < 8) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        st_s[((tid >> 6) * 32 + 4 * e_q + k) * 2] = (double)sf[k];
-                        st_s[((tid >> 6) * 32 + 4 * e_q + k) * 2 + 1] = (double)qf[k];
+                        st_s[(wave * 32 + 4 * e_q + k) * 2] = (double)sf[k];
+                        st_s[(wave * 32 + 4 * e_q + k) * 2 + 1] = (double)qf[k];
                     }
                 }
             }
@@ -282,14 +282,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
         __syncthreads();
         if (p.stats && tid < 64) {
             const int c = tid >> 1, k = tid & 1;
-            atomicAdd(p.stats + ((size_t)img * p.cout + nt0 * 16 + hf * 32 + c) * 2 + k, st_s[(0 * 32 + c) * 2 + k] + st_s[(1 * 32 + c) * 2 + k]);
+            atomicAdd(p.stats + ((size_t)img * p.cout + nt0 * 16 + hf * 32 + c) * 2 + k,
+                      (st_s[(0 * 32 + c) * 2 + k] + st_s[(1 * 32 + c) * 2 + k]) + (st_s[(2 * 32 + c) * 2 + k] + st_s[(3 * 32 + c) * 2 + k]));
         }
     }
 }
 
 size_t packed_wino4_floats(int cout_total, int cin_total) { return (size_t)(cin_total / 16) * 36 * (cout_total / 16) * 256; }
 
-bool wino4_fits(int cin, int cout, int h, int w) { return cin >= 128 && cin % 32 == 0 && cout % 64 == 0 && h >= 8 && w >= 8; }
+bool wino4_fits(int cin, int cout, int h, int w) { return cin >= WINO4_MIN_CIN && cin % 32 == 0 && cout % 64 == 0 && h >= 8 && w >= 8; }
 
 int launch_conv_wino4(hipStream_t s, const ConvSrc& a, const float* wpack_wino4, const float* bias, float* out, int pitch_out, int cout,
                       double* stats, int n, int h, int w, const ConvOutExtra* ex) {

@@ -116,6 +116,7 @@ class TrainStep:
             self._step_dev = torch.zeros((), dtype=torch.int32, device=dev)
             self._hyper_host = None
         self._step_dev.fill_(int(opt._step))
+        model._pack_state = (model._pack_state[0], True, False)     # the frozen re-pack runs in training mode: inference-only packings go stale
 
     def _push_hyper(self) -> None:
         g = self.optimizer.param_groups[0]
@@ -226,7 +227,9 @@ class TrainStep:
 
     def _step(self, inputs, labels_onehot, dev) -> torch.Tensor:
         model = self.model
-        if self._tensors is None or self._signature() != self._sig or self.optimizer._m is None or int(self.optimizer._step) != self._expected_step:
+        if (self._tensors is None or self._signature() != self._sig or self.optimizer._m is None or int(self.optimizer._step) != self._expected_step
+                or not getattr(model, "_pack_state", (0, False, False))[1]):     # (an inference call in between re-packed without the data-gradient layouts)
+            self._bound = None
             self._bind(dev)
         h = model._engine.handle
         check(lib.cs_unet_set_training(h, 1), "cs_unet_set_training")

@@ -234,7 +234,7 @@ class UNet(nn.Module):
                                        self.in_channels, self.out_channels)
             self._engine_device = p0.device
             self._uploaded.clear()
-            self._pack_state = (False, False)
+            self._pack_state = (0, False, False)
             self._ws.clear()
             self._grad_slots = {}
             for i, (key, shape) in enumerate(self._engine.param_table()):
@@ -256,9 +256,12 @@ class UNet(nn.Module):
         # The engine packs the split-bf16 / data-gradient weight layouts only when asked.  `_pack_state` says which of them
         # EVERY uploaded tensor currently has; a missing one forces a full re-upload under the new flags.
         fmt = 3 if planes == 5 else 2 if planes == 4 else 1 if planes > 0 else 0    # low-precision packing the kernels will read
-        need = (fmt, want_train)
-        state = getattr(self, "_pack_state", (0, False))
-        if (need[0] and state[0] != need[0]) or (need[1] and not state[1]):
+        # third flag: the inference-only packings (Winograd F(4x4,3x3) weights of the fp32 path) are present.  A training-mode upload
+        # skips them - a training step re-packs every weight, and 36 fp64-transformed positions per 3x3 kernel cost more per step than
+        # they save - so the first inference call after training re-uploads once (and the first training call after that again)
+        need = (fmt, want_train, not want_train)
+        state = getattr(self, "_pack_state", (0, False, False))
+        if (need[0] and state[0] != need[0]) or (need[1] and not state[1]) or (need[2] and not state[2]):
             self._uploaded.clear()
             state = need
         uploaded_any = False
@@ -284,7 +287,7 @@ class UNet(nn.Module):
             finally:
                 check(lib.cs_unet_load_end(self._engine.handle, stream), "cs_unet_load_end")   # one kernel packs everything recorded
         del alive
-        self._pack_state = (state[0] and need[0], state[1] and need[1]) if uploaded_any else state
+        self._pack_state = (state[0] and need[0], state[1] and need[1], state[2] and need[2]) if uploaded_any else state
         return self._engine
 
     def invalidate_weights(self) -> None:

@@ -130,7 +130,10 @@ struct ConvW {             // packed weights + bias of one (possibly fused) conv
     float* wd = nullptr;   // the same weights packed for the DATA-GRADIENT launch (see kernels_bwd.hip header)
     float* ww = nullptr;   // 3x3 stride-1 layers: Winograd F(2x2,3x3) weights G g G^T in fragment order (kernels_conv_wino.hip)
     float* wwd = nullptr;  // ... and those of the layer's DATA-GRADIENT convolution (channel roles swapped, taps reversed)
-    float* ww4 = nullptr;  // wide 3x3 stride-1 layers (>= 128 input channels): Winograd F(4x4,3x3) weights (kernels_conv_wino4.hip), forward
+    float* ww4 = nullptr;  // 3x3 stride-1 layers with >= WINO4_MIN_CIN input channels: Winograd F(4x4,3x3) weights (kernels_conv_wino4.hip).
+                           // INFERENCE only: a training step re-packs every weight, and packing 36 positions in fp64 costs more there
+                           // (0.25 ms per step) than the kernel saves on training-sized launches - loads in training mode leave them stale
+    bool ww4_fresh = false; // the F(4x4) weights correspond to the parameter's current value (else the F(2x2) kernel runs)
     unsigned short* wb = nullptr;   // 3 bf16 planes in 16x16x32 fragment order (split-bf16 forward kernels)
     unsigned short* wbd = nullptr;  // the same planes for the layer's DATA-GRADIENT launch (bf16 training): stride-1 conv (roles swapped, taps reversed),
                                     // fused stride-2 pair (as a transposed conv over [dy0 || dr]), transposed conv (as a stride-2 conv)
@@ -303,6 +306,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     float* ww = cw.ww;
     float* wwd = cw.wwd;
     float* ww4 = cw.ww4;
+    bool* const ww4_fresh = &cw.ww4_fresh;
     unsigned short* wb = cw.wb;
     unsigned short* wbd = cw.wbd;
     unsigned char* w8 = cw.w8;
@@ -350,8 +354,11 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             if (w8 && net->planes == 5)
                 if (int rc = pack_conv_weights_fp8(s, d, false, cout, cin, ksize, w8, wsc, cout_off, cout_total, 0)) return rc;
             // 3x3 stride-1 layers: the tile kernel also writes the Winograd weights (forward; data gradient in training mode)
-            if (ww4 && wino_level() >= 2 && net->planes == 0)
-                if (int rc = pack_wino4_weights(net->pack, s, d, cout, cin, ww4)) return rc;
+            if (ww4) {
+                *ww4_fresh = wino_level() >= 2 && net->planes == 0 && !net->training;
+                if (*ww4_fresh)
+                    if (int rc = pack_wino4_weights(net->pack, s, d, cout, cin, ww4)) return rc;
+            }
             float* const wino_f = (ww && wino_enabled()) ? ww : nullptr;
             float* const wino_d = (wwd && wino_enabled() && net->training && dg == DG_S1) ? wwd : nullptr;
             return pack_conv_weights(net->pack, s, d, false, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off,
@@ -501,7 +508,8 @@ static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, co
         return launch_conv_bf16s(s, ksize, stride, net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin, win, a.h16);
     CS_REQUIRE(!a.h16 && !a.q8, "conv: a layer without low-precision weights met bf16 / e4m3 activations");
     // fp32, wide layers: Winograd F(4x4,3x3) - 2.25 multiplies per output pixel and channel pair instead of F(2x2)'s 4 (CS_WINO=1: F(2x2) everywhere)
-    if (net->planes == 0 && cw.ww4 && ksize == 3 && stride == 1 && wino_level() >= 2 && wino4_fits(a.c, cout, hin, win) && wino_fits(hin, win, a.pitch))
+    if (net->planes == 0 && cw.ww4 && cw.ww4_fresh && ksize == 3 && stride == 1 && wino_level() >= 2 && wino4_fits(a.c, cout, hin, win) &&
+        wino_fits(hin, win, a.pitch))
         return launch_conv_wino4(s, a, cw.ww4, cw.bias, out, pitch_out, cout, stats, n, hin, win);
     if (net->planes == 0 && cw.ww && ksize == 3 && stride == 1 && wino_enabled() && wino_fits(hin, win, a.pitch))   // fp32: Winograd F(2x2,3x3), 2.25x fewer multiplies
         return launch_conv_wino(s, a, cw.ww, cw.bias, out, pitch_out, cout, stats, n, hin, win);

@@ -64,7 +64,8 @@ int pack_wino_weights(PackCtx* pc, hipStream_t s, const float* w, bool dgrad, in
 struct ConvOutExtra;
 constexpr int WINO4_MIN_CIN = 64;   // layers with at least this many input channels (and cout % 64 == 0) take the F(4x4,3x3) form
 size_t packed_wino4_floats(int cout_total, int cin_total);
-int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed);
+int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed, bool dgrad = false);   // dgrad: (cout, cin) of the
+                                                                                          // DATA-GRADIENT convolution (= the layer's cin, cout)
 bool wino4_fits(int cin, int cout, int h, int w);
 int launch_conv_wino4(hipStream_t s, const ConvSrc& a, const float* wpack_wino4, const float* bias, float* out, int pitch_out, int cout,
                       double* stats, int n, int h, int w, const ConvOutExtra* ex = nullptr);

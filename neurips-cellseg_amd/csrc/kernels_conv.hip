@@ -1443,9 +1443,10 @@ int pack_wino_weights(PackCtx* pc, hipStream_t s, const float* w, bool dgrad, in
     return pack_submit(pc, s, jb);
 }
 
-int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed) {
+int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed, bool dgrad) {
     CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0, "pack(winograd 4x4): bad channel counts");
     PackJob jb{};
+    jb.transposed = dgrad ? 1 : 0; jb.flip = dgrad ? 1 : 0;
     jb.src = w; jb.dst = packed; jb.kind = PK_WINO4; jb.cout = cout; jb.cin = cin; jb.ntile_total = cout / 16;
     return pack_submit(pc, s, jb);
 }

@@ -166,7 +166,8 @@ __device__ __forceinline__ void pack_wino4_elem(const PackJob& jb, int64_t e) {
     const int pos = (int)(r % 36);
     const int chunk = (int)(r / 36);
     const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
-    const float* src = jb.src + ((size_t)co * cin + ci) * 9;
+    // transposed + flip = the data-gradient convolution of the same tensor (channel roles swapped, taps reversed)
+    const float* src = jb.transposed ? jb.src + ((size_t)ci * cout + co) * 9 : jb.src + ((size_t)co * cin + ci) * 9;
     const int xi = pos / 6, nu = pos - xi * 6;
     // row xi of G: {1/4, 0, 0}, {-1/6, -1/6, -1/6}, {-1/6, 1/6, -1/6}, {1/24, 1/12, 1/6}, {1/24, -1/12, 1/6}, {0, 0, 1}
     auto grow = [](int k, double (&o)[3]) {
@@ -186,7 +187,7 @@ __device__ __forceinline__ void pack_wino4_elem(const PackJob& jb, int64_t e) {
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) u += ga[a] * (double)src[a * 3 + b] * gb[b];
+        for (int b = 0; b < 3; ++b) u += ga[a] * (double)src[jb.flip ? 8 - (a * 3 + b) : a * 3 + b] * gb[b];
     reinterpret_cast<float*>(jb.dst)[(((size_t)chunk * 36 + pos) * jb.ntile_total + ntl) * 256 + lane * 4 + j] = (float)u;
 }
 

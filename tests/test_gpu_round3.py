@@ -350,3 +350,43 @@ def test_bf16_training_tracks_the_fp32_loss_curve_with_bf16_weight_gradients():
         worst = max(abs(a - b) for a, b in zip(curves[prec], curves["fp32"]))
         assert worst <= (0.03 if prec == "bf16" else 2e-3), (prec, worst, curves[prec][-1], curves["fp32"][-1])
         assert curves[prec][-1] < 0.8 * curves[prec][0]
+
+
+# ------------------------------------------------------------------------------------------- inference-only weight packings stay in step
+def test_inference_after_training_steps_uses_the_updated_weights_in_every_kernel_family():
+    """The Winograd F(4x4,3x3) weights are packed for inference only (a training step skips them).  After training steps - eager or
+    through TrainStep's frozen re-pack - an eval-mode call must see the UPDATED weights in every kernel it dispatches: its logits
+    equal, bit for bit, those of a fresh model loaded with the same state dict; and training continues afterwards."""
+    import cellseg_amd as ca
+    dev = _dev()
+    torch.manual_seed(31)
+    model = ca.UNet(channels=(32, 64, 128, 256), strides=(2, 2, 2), num_res_units=2).to(dev).train()       # 64-, 128-, 256-channel layers take F(4x4)
+    loss_fn, opt = ca.DiceCELoss(softmax=True), ca.AdamW(model, 1e-2)
+    step = ca.TrainStep(model, loss_fn, opt)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 64, 64, generator=g).to(dev)
+    y = ca.one_hot(torch.randint(0, 3, (2, 1, 64, 64), generator=g).to(dev), 3)
+    probe = torch.rand(1, 3, 64, 96, generator=g).to(dev)
+
+    def fresh_logits():
+        twin = ca.UNet(channels=(32, 64, 128, 256), strides=(2, 2, 2), num_res_units=2)
+        twin.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        with torch.no_grad():
+            return twin.to(dev).eval()(probe)
+
+    with torch.no_grad():
+        before = model.eval()(probe).clone()
+    model.train()
+    for _ in range(3):
+        step(x, y)
+    with torch.no_grad():
+        after = model.eval()(probe).clone()
+    assert not torch.equal(after, before) and torch.equal(after, fresh_logits())
+    model.train()
+    l1 = step(x, y).item()                                   # the step notices that inference re-packed without the data-gradient layouts
+    opt.zero_grad()
+    loss_fn(model(x), y).backward()                          # and the eager path does, too
+    opt.step()
+    with torch.no_grad():
+        assert torch.equal(model.eval()(probe), fresh_logits())
+    assert l1 == l1 and l1 < 3.0

@@ -737,8 +737,8 @@ def main():
             # output pixel: SURVEY 8(d)'s figure)
             f4 = name.endswith("wino4")
             factor = 144 / 36 if f4 else 36 / 16
-            rl["algorithm"] = ("Winograd F(4x4,3x3), fp32: 36 instead of 144 multiplies per 4x4 output tile and channel pair (the layers with "
-                               ">= 128 input channels)" if f4 else
+            rl["algorithm"] = ("Winograd F(4x4,3x3), fp32: 36 instead of 144 multiplies per 4x4 output tile and channel pair (every stride-1 3x3 "
+                               "layer with >= 32 input channels)" if f4 else
                                "Winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per output tile and channel pair")
             rl["direct_conv_equivalent"] = round(rl["achieved"] * factor, 3)
             rl["frac_direct_conv_equivalent"] = round(rl["achieved"] * factor / rl["peak"], 4)

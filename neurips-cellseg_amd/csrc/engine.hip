@@ -387,7 +387,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     const int dg0 = u.first ? DG_NONE : (stride == 2 ? DG_S2_AS_CONVT : DG_S1);
     if (dg0 != DG_NONE) u.unit0.wd = ar.take(packed_conv_floats(cin, u.unit0.cout, 3));
     if (stride == 1 && !u.first && cin % 16 == 0 && c % 32 == 0) u.unit0.ww = ar.take(packed_wino_floats(c, cin));
-    if (stride == 1 && !u.first && cin >= WINO4_MIN_CIN && cin % 32 == 0 && c % 64 == 0) u.unit0.ww4 = ar.take(packed_wino4_floats(c, cin));
+    if (stride == 1 && !u.first && cin >= WINO4_MIN_CIN && cin % 32 == 0 && c % 32 == 0) u.unit0.ww4 = ar.take(packed_wino4_floats(c, cin));
     if (stride == 1 && !u.first && c % 16 == 0 && cin % 32 == 0) u.unit0.wwd = ar.take(packed_wino_floats(cin, c));
     if (!u.first) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(u.unit0.cout, cin, 0, 3) + 1) / 2);
     if (stride == 1 && !u.first) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cin, c, 0, 3) + 1) / 2);
@@ -403,7 +403,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         cw.bias = ar.take(c);
         cw.wd = ar.take(packed_conv_floats(c, c, 3));
         if (c % 32 == 0) cw.ww = ar.take(packed_wino_floats(c, c));
-        if (c >= WINO4_MIN_CIN && c % 64 == 0) cw.ww4 = ar.take(packed_wino4_floats(c, c));
+        if (c >= WINO4_MIN_CIN && c % 32 == 0) cw.ww4 = ar.take(packed_wino4_floats(c, c));
         if (c % 32 == 0) cw.wwd = ar.take(packed_wino_floats(c, c));
         cw.wb = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
         cw.wbd = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
@@ -445,7 +445,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     u.unit0.bias = ar.take(cout);
     if (!small) u.unit0.wd = ar.take(packed_conv_floats(cout, cout, 3));
     if (!small && cout % 32 == 0) u.unit0.ww = ar.take(packed_wino_floats(cout, cout));
-    if (!small && cout >= WINO4_MIN_CIN && cout % 64 == 0) u.unit0.ww4 = ar.take(packed_wino4_floats(cout, cout));
+    if (!small && cout >= WINO4_MIN_CIN && cout % 32 == 0) u.unit0.ww4 = ar.take(packed_wino4_floats(cout, cout));
     if (!small && cout % 32 == 0) u.unit0.wwd = ar.take(packed_wino_floats(cout, cout));
     if (!small) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
     if (!small) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);

@@ -62,7 +62,7 @@ int pack_wino_weights(PackCtx* pc, hipStream_t s, const float* w, bool dgrad, in
 // Winograd F(4x4, 3x3) (kernels_conv_wino4.hip): the wide (>= 128 input channels) 3x3 stride-1 layers of the fp32 path, forward only;
 // packed[cin/16][36 positions][cout/16][64 lanes][4]
 struct ConvOutExtra;
-constexpr int WINO4_MIN_CIN = 64;   // layers with at least this many input channels (and cout % 64 == 0) take the F(4x4,3x3) form
+constexpr int WINO4_MIN_CIN = 32;   // layers with at least this many input channels (cin, cout multiples of 32) take the F(4x4,3x3) form
 size_t packed_wino4_floats(int cout_total, int cin_total);
 int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed, bool dgrad = false);   // dgrad: (cout, cin) of the
                                                                                           // DATA-GRADIENT convolution (= the layer's cin, cout)

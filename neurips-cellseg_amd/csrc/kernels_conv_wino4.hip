@@ -30,7 +30,6 @@ constexpr int W4_PS = 20;                          // floats per staged raw pixe
 constexpr int RAW4_FLOATS = W4_IH * W4_IW * W4_PS; // 6480
 constexpr int V4_FLOATS = 36 * 4 * 16 * 4;         // 9216
 constexpr int M4_FLOATS = 36 * 16 * 32;            // 18432: one 32-channel half of the products
-constexpr int NTW4 = 4;                            // channel tiles per block (64 output channels)
 
 // y = B^T x for one 6-vector (F(4x4,3x3) input transform, Lavin & Gray)
 __device__ __forceinline__ void bt6(const float (&x)[6], float (&y)[6]) {
@@ -53,7 +52,8 @@ __device__ __forceinline__ void at6(const f32x4 (&m)[6], f32x4 (&o)[4]) {
 }
 }  // namespace
 
-template <bool LAZY>
+// NTW4: channel tiles per block - 4 (64 output channels) or 2 (the 32-channel layers)
+template <bool LAZY, int NTW4>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
     constexpr int IN_ITERS = (W4_IH * W4_IW * 4 + 255) / 256;                 // 6: (pixel, channel quad) items per thread
     constexpr int MAIN_FLOATS = RAW4_FLOATS + V4_FLOATS;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
     const int e_ty = e_tile >> 2, e_tx = e_tile & 3;
     const int e_sw = ((e_tile >> 2) & 1) << 4;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+    for (int hf = 0; hf < NTW4 / 2; ++hf) {
         // C layout of an accumulator tile: row (tile) = 4 g + r, column (channel) = pl
 #pragma unroll
         for (int ps = 0; ps < 9; ++ps)
@@ -290,11 +290,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvParams p) {
 
 size_t packed_wino4_floats(int cout_total, int cin_total) { return (size_t)(cin_total / 16) * 36 * (cout_total / 16) * 256; }
 
-bool wino4_fits(int cin, int cout, int h, int w) { return cin >= WINO4_MIN_CIN && cin % 32 == 0 && cout % 64 == 0 && h >= 8 && w >= 8; }
+bool wino4_fits(int cin, int cout, int h, int w) { return cin >= WINO4_MIN_CIN && cin % 32 == 0 && cout % 32 == 0 && h >= 8 && w >= 8; }
 
 int launch_conv_wino4(hipStream_t s, const ConvSrc& a, const float* wpack_wino4, const float* bias, float* out, int pitch_out, int cout,
                       double* stats, int n, int h, int w, const ConvOutExtra* ex) {
-    CS_REQUIRE(a.c % 32 == 0 && a.c > 0 && cout % 64 == 0, "conv(winograd 4x4): channels (%d -> %d) unsupported", a.c, cout);
+    CS_REQUIRE(a.c % 32 == 0 && a.c > 0 && cout % 32 == 0, "conv(winograd 4x4): channels (%d -> %d) unsupported", a.c, cout);
     CS_REQUIRE((a.pitch % 4) == 0 && (pitch_out % 4) == 0, "conv(winograd 4x4): pixel pitch must be a multiple of 4 floats");
     CS_REQUIRE(!a.h16 && !a.q8 && !a.ptr2, "conv(winograd 4x4): plain fp32 activations only");
     CS_REQUIRE((size_t)h * w * a.pitch * 4 < ((size_t)1 << 32), "conv(winograd 4x4): one image's activation tensor must stay below 4 GB");
@@ -321,9 +321,15 @@ int launch_conv_wino4(hipStream_t s, const ConvSrc& a, const float* wpack_wino4,
     const double flops = 2.0 * n * (double)ceil_div(h, 4) * ceil_div(w, 4) * 36.0 * (double)cout * a.c;
     const double bytes = 4.0 * n * (double)h * w * (a.c + cout);
     ProfScope prof(K_CONV3_WINO4, s, flops, bytes);
-    const dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * n, p.ntile_total / NTW4));
-    if (a.tab) hipLaunchKernelGGL((conv_wino4_kernel<true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_wino4_kernel<false>), grid, dim3(256), 0, s, p);
+    const int ntw = cout % 64 == 0 ? 4 : 2;
+    const dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * n, p.ntile_total / ntw));
+    if (ntw == 4) {
+        if (a.tab) hipLaunchKernelGGL((conv_wino4_kernel<true, 4>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_wino4_kernel<false, 4>), grid, dim3(256), 0, s, p);
+    } else {
+        if (a.tab) hipLaunchKernelGGL((conv_wino4_kernel<true, 2>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_wino4_kernel<false, 2>), grid, dim3(256), 0, s, p);
+    }
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -152,7 +152,7 @@ int main(int argc, char** argv) {
             printf("      F(4x4): %7.1f us (%5.1f TF issued = %4.1f%% of 157.3; %5.1f TF direct-equivalent)   max|dy| %.2e (at img %zu y %zu x %zu ch %zu), stats rel %.1e\n",
                    us_4, f4_gf / us_4 * 1e3, f4_gf / us_4 * 1e3 / 157.3 * 100, direct_gf / us_4 * 1e3, err4, wpix / ((size_t)L.hw * L.hw),
                    (wpix / L.hw) % L.hw, wpix % L.hw, worst % L.cout, serr4);
-            hipFree(w4);
+            (void)hipFree(w4);
         }
         if (getenv("WINO_STAMPS")) {       // one more launch with in-kernel stamps: cycles per phase, block 0, per wave
             long long* sb;
@@ -176,10 +176,10 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < 7; ++k) printf("  %s %.1f%%", v1 ? names_1[k] : wv < 4 ? names_m[k] : names_s[k], 100.0 * hs[wv * 8 + k] / (tot ? tot : 1));
                 printf("\n");
             }
-            hipFree(sb);
+            (void)hipFree(sb);
         }
         if (tab) { (void)hipFree(tab); (void)hipFree(slope); }
-        hipFree(x); hipFree(w); hipFree(b); hipFree(ww); hipFree(wd); hipFree(y1); hipFree(y2); hipFree(st1); hipFree(st2);
+        for (void* ptr : {(void*)x, (void*)w, (void*)b, (void*)ww, (void*)wd, (void*)y1, (void*)y2, (void*)st1, (void*)st2}) (void)hipFree(ptr);
     }
     cs::pack_ctx_destroy(pc);
     return 0;

@@ -211,6 +211,22 @@ int cs_normalize_image(const void* image, int bytes_per_sample, int h, int w, in
                        uint8_t* u8_hwc, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Label-map writer  -  replaces the compression half of
+ *   tif.imwrite(join(output_path, name + '_label.tiff'), test_pred_mask, compression='zlib')
+ *   (baseline/predict.py:114, inside the per-image timer :106-116).
+ * labels: int32 [h][w] in HBM.  The map is cut into TIFF strips of rows_per_strip rows; every strip becomes one zlib
+ * stream (RFC 1950, TIFF compression 8: fixed-Huffman run-length coding of the labels, chunks joined by sync-flush
+ * markers).  out: the streams back to back, each on an even offset; meta (device, uint32 [2 n_strips + 2]):
+ * (offset in out, byte count) per strip, then the total byte count and an overflow flag (1: out_capacity too small,
+ * nothing written).  cs_label_deflate_bound() is the worst-case total; typical label maps need 1-2 % of h*w*4.
+ * The host writes header + out[0:total] + IFD (cellseg_amd.preprocess.write_label_tiff does).
+ * ---------------------------------------------------------------------------------------------- */
+size_t cs_label_deflate_workspace_bytes(int h, int w, int rows_per_strip);
+size_t cs_label_deflate_bound(int h, int w, int rows_per_strip);
+int cs_label_deflate(const int32_t* labels, int h, int w, int rows_per_strip, uint8_t* out, size_t out_capacity,
+                     uint32_t* meta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Connected-component post-process  -  replaces
  *   measure.label(morphology.remove_small_objects(morphology.remove_small_holes(mask), 16))
  *   (baseline/predict.py:113): 4-connected holes < 64 filled, 4-connected objects < 16 removed,

@@ -82,8 +82,10 @@ def main(argv=None):
     reader, writer = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
     pending_writes = []
 
-    def save(img_name, img_data, labels):
-        preprocess.write_label_tiff(join(args.output_path, preprocess.label_name(img_name)), labels)
+    def save(img_name, img_data, strips, labels):
+        # the label map was deflated on the device (csrc/kernels_deflate.hip): the writer thread only wraps the strips into a TIFF
+        data, sizes, (h, w), rps = strips
+        preprocess.write_tiff_strips(join(args.output_path, preprocess.label_name(img_name)), h, w, 1, np.dtype("<i4"), rps, data, sizes)
         if args.show_overlay:
             # predict.py:118-122: inner boundaries of the instances, dilated by disk(2), painted 255 into the image as read,
             # saved as overlay_<img_name> in the input's own format
@@ -121,8 +123,12 @@ def main(argv=None):
                 x = torch.from_numpy(preprocess.to_unit_float(pre_img_data)).to(device)      # [H,W,3]: NHWC, no copy needed
                 shape = pre_img_data.shape
             _, _, mask = ca.swi_infer_image(model, x.permute(2, 0, 1), roi_size, args.overlap, want_logits=False, want_mask=True)
-            labels = _to_host(ca.mask_to_instances(mask)).copy()          # the staging buffer is reused by the next image
-            pending_writes.append((img_name, writer.submit(save, img_name, img_data, labels)))
+            lab = ca.mask_to_instances(mask)
+            rps = min(64, lab.shape[0])
+            buf, sizes = preprocess.deflate_labels_gpu(lab, rps)
+            strips = (bytes(memoryview(buf.numpy())), sizes, tuple(lab.shape), rps)   # the staging buffer is reused by the next image
+            labels = _to_host(lab).copy() if args.show_overlay else None             # the overlay is drawn on the host
+            pending_writes.append((img_name, writer.submit(save, img_name, img_data, strips, labels)))
             t1 = time.time()
             print(f"Prediction finished: {img_name}; img size = {shape}; costing: {t1 - t0:.2f}s")
     for img_name, f in pending_writes:

@@ -238,13 +238,61 @@ def _read_pillow(path: str) -> np.ndarray:
 # ----------------------------------------------------------------------------------------------------------------------
 # writers
 # ----------------------------------------------------------------------------------------------------------------------
+def write_tiff_strips(path: str, h: int, w: int, spp: int, dtype: np.dtype, rps: int, strips, sizes=None) -> None:
+    """Baseline TIFF around already deflated strips.  `strips`: a list of bytes-like zlib streams, or ONE buffer that holds them
+    back to back on even offsets together with `sizes` (the device encoder's layout).  Layout: header, strip data, then the IFD
+    (little endian; tags 256-259, 262, 273, 277-279, 284, 338, 339)."""
+    import struct
+    if sizes is None:
+        sizes = [len(st) for st in strips]
+    offsets, pos = [], 8
+    for sz in sizes:
+        offsets.append(pos)
+        pos += sz + (sz & 1)                                           # word-align every strip
+    SHORT, LONG = 3, 4
+    extra = bytearray()                                                # out-of-line tag values, placed before the IFD
+
+    def field(tag, typ, values):
+        values = list(values)
+        data = struct.pack("<" + ("H" if typ == SHORT else "I") * len(values), *values)
+        if len(data) <= 4:
+            return (tag, typ, len(values), data.ljust(4, b"\0"))
+        at = pos + len(extra)
+        extra.extend(data)
+        if len(extra) & 1:
+            extra.append(0)
+        return (tag, typ, len(values), struct.pack("<I", at))
+    bits = dtype.itemsize * 8
+    entries = [field(256, LONG, [w]), field(257, LONG, [h]), field(258, SHORT, [bits] * spp), field(259, SHORT, [8]),
+               field(262, SHORT, [2 if spp >= 3 else 1]), field(273, LONG, offsets), field(277, SHORT, [spp]), field(278, LONG, [rps]),
+               field(279, LONG, sizes), field(284, SHORT, [1])]
+    n_extra = spp - 3 if spp >= 3 else spp - 1
+    if n_extra > 0:
+        entries.append(field(338, SHORT, [0] * n_extra))               # ExtraSamples: unspecified
+    entries.append(field(339, SHORT, [{"u": 1, "i": 2, "f": 3}[dtype.kind]] * spp))
+    ifd_at = pos + len(extra)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<2sHI", b"II", 42, ifd_at))
+        if isinstance(strips, (list, tuple)):
+            for st in strips:
+                f.write(st)
+                if len(st) & 1:
+                    f.write(b"\0")
+        else:
+            f.write(strips)                                            # one buffer, pad bytes already in place
+        f.write(bytes(extra))
+        f.write(struct.pack("<H", len(entries)))
+        for tag, typ, cnt, v in entries:
+            f.write(struct.pack("<HHI", tag, typ, cnt) + v)
+        f.write(struct.pack("<I", 0))
+
+
 def write_tiff(path: str, image: np.ndarray, rows_per_strip: int = 64, level: int = 6, threads: int = 0) -> None:
     """Single-page TIFF with deflate compression for [H,W] or [H,W,C] arrays of uint8/16/32, int8/16/32 or float32/64.
 
     Own baseline-TIFF writer: the image is cut into strips of `rows_per_strip` rows which are deflated in parallel (zlib
     releases the GIL), because the single-threaded deflate of a 4096^2 label map (170 ms through Pillow) is 3x the whole
-    GPU path.  Layout: header, strip data, then the IFD (little endian; tags 256-259, 262, 273, 277-279, 284, 338, 339)."""
-    import struct
+    GPU path.  (Label maps that are still on the device take `write_label_tiff`'s device encoder instead.)"""
     import zlib
     from concurrent.futures import ThreadPoolExecutor
     a = np.asarray(image)
@@ -264,48 +312,77 @@ def write_tiff(path: str, image: np.ndarray, rows_per_strip: int = 64, level: in
             strips = list(ex.map(compress, bounds))
     else:
         strips = [compress(b) for b in bounds]
-    n = len(strips)
-    offsets, pos = [], 8
-    for st in strips:
-        offsets.append(pos)
-        pos += len(st) + (len(st) & 1)                                # word-align every strip
-    SHORT, LONG = 3, 4
-    extra = bytearray()                                                # out-of-line tag values, placed before the IFD
-
-    def field(tag, typ, values):
-        values = list(values)
-        data = struct.pack("<" + ("H" if typ == SHORT else "I") * len(values), *values)
-        if len(data) <= 4:
-            return (tag, typ, len(values), data.ljust(4, b"\0"))
-        at = pos + len(extra)
-        extra.extend(data)
-        if len(extra) & 1:
-            extra.append(0)
-        return (tag, typ, len(values), struct.pack("<I", at))
-    bits = a.dtype.itemsize * 8
-    entries = [field(256, LONG, [w]), field(257, LONG, [h]), field(258, SHORT, [bits] * spp), field(259, SHORT, [8]),
-               field(262, SHORT, [2 if spp >= 3 else 1]), field(273, LONG, offsets), field(277, SHORT, [spp]), field(278, LONG, [rps]),
-               field(279, LONG, [len(st) for st in strips]), field(284, SHORT, [1])]
-    n_extra = spp - 3 if spp >= 3 else spp - 1
-    if n_extra > 0:
-        entries.append(field(338, SHORT, [0] * n_extra))               # ExtraSamples: unspecified
-    entries.append(field(339, SHORT, [{"u": 1, "i": 2, "f": 3}[a.dtype.kind]] * spp))
-    ifd_at = pos + len(extra)
-    with open(path, "wb") as f:
-        f.write(struct.pack("<2sHI", b"II", 42, ifd_at))
-        for st in strips:
-            f.write(st)
-            if len(st) & 1:
-                f.write(b"\0")
-        f.write(bytes(extra))
-        f.write(struct.pack("<H", len(entries)))
-        for tag, typ, cnt, v in entries:
-            f.write(struct.pack("<HHI", tag, typ, cnt) + v)
-        f.write(struct.pack("<I", 0))
+    write_tiff_strips(path, h, w, spp, a.dtype, rps, strips)
 
 
-def write_label_tiff(path: str, labels: np.ndarray, rows_per_strip: int = 64, level: int = 6, threads: int = 0) -> None:
-    """int32 single-page TIFF with deflate compression (`tif.imwrite(..., compression='zlib')`, predict.py:114)."""
+_deflate_cache = {}
+
+
+def deflate_labels_gpu(labels, rows_per_strip: int = 64):
+    """zlib streams of an int32 label map that lives on the GPU, one per TIFF strip (csrc/kernels_deflate.hip).
+
+    labels: torch int32 [H,W] on the device -> (buffer, sizes): a pinned uint8 host tensor that holds the strips back to back,
+    each on an even offset (views of a cached buffer: valid until the next call for the same device), and the byte count per
+    strip.  Two small synchronisations: the strip table, then exactly the compressed bytes (typically 1-2 % of H*W*4)."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    from ._lib import check, lib
+    _lib.require_gpu(labels)
+    if labels.dim() != 2 or labels.dtype != torch.int32:
+        raise ValueError(f"deflate_labels_gpu expects an int32 [H,W] tensor (got {tuple(labels.shape)} {labels.dtype})")
+    labels = labels.contiguous()
+    h, w = labels.shape
+    if h == 0 or w == 0:
+        raise ValueError("deflate_labels_gpu: empty label map")
+    rps = max(1, min(int(rows_per_strip), h))
+    n_strips = (h + rps - 1) // rps
+    key = (labels.device.index, h, w, rps)
+    with torch.cuda.device(labels.device):
+        st = _deflate_cache.get(key)
+        if st is None:
+            _deflate_cache.clear()                                     # one shape at a time: the scratch is ~1.1x the label map
+            bound = lib.cs_label_deflate_bound(h, w, rps)
+            st = {"ws": torch.empty(lib.cs_label_deflate_workspace_bytes(h, w, rps), dtype=torch.uint8, device=labels.device),
+                  "out": torch.empty(bound, dtype=torch.uint8, device=labels.device),
+                  "meta": torch.empty(2 * n_strips + 2, dtype=torch.int32, device=labels.device),
+                  "meta_h": torch.empty(2 * n_strips + 2, dtype=torch.int32).pin_memory(),
+                  "host": torch.empty(max(1 << 20, bound // 16), dtype=torch.uint8).pin_memory()}
+            _deflate_cache[key] = st
+        check(lib.cs_label_deflate(C.c_void_p(labels.data_ptr()), h, w, rps, C.c_void_p(st["out"].data_ptr()), st["out"].numel(),
+                                   C.c_void_p(st["meta"].data_ptr()), C.c_void_p(st["ws"].data_ptr()), st["ws"].numel(),
+                                   _lib.stream_ptr()), "cs_label_deflate")
+        st["meta_h"].copy_(st["meta"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        meta = st["meta_h"].numpy().view(np.uint32)
+        if meta[2 * n_strips + 1]:
+            raise RuntimeError("cs_label_deflate: output buffer too small (internal bound violated)")
+        total = int(meta[2 * n_strips])
+        if total > st["host"].numel():
+            st["host"] = torch.empty(total + (total >> 2), dtype=torch.uint8).pin_memory()
+        buf = st["host"][:total]
+        buf.copy_(st["out"][:total], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    return buf, [int(v) for v in meta[1:2 * n_strips:2]]
+
+
+def write_label_tiff(path: str, labels, rows_per_strip: int = 64, level: int = 6, threads: int = 0) -> None:
+    """int32 single-page TIFF with deflate compression (`tif.imwrite(..., compression='zlib')`, predict.py:114).
+
+    A label map that is still on the GPU (a torch CUDA tensor) is deflated THERE and only the compressed strips come to the host;
+    a host array goes through zlib on `threads` threads at `level`."""
+    if hasattr(labels, "is_cuda") and labels.is_cuda:
+        import torch
+        if labels.dim() != 2:
+            raise ValueError("write_label_tiff expects an [H,W] label map")
+        lab = labels if labels.dtype == torch.int32 else labels.to(torch.int32)
+        h, w = lab.shape
+        rps = max(1, min(int(rows_per_strip), h))
+        buf, sizes = deflate_labels_gpu(lab, rps)
+        write_tiff_strips(path, h, w, 1, np.dtype("<i4"), rps, memoryview(buf.numpy()), sizes)
+        return
     a = np.asarray(labels)
     if a.ndim != 2:
         raise ValueError("write_label_tiff expects an [H,W] label map")

@@ -33,7 +33,8 @@ static const char* kNames[K_NUM_IDS] = {
     "conv3x3_s1_mfma", "conv3x3_s2_mfma", "conv1x1_mfma", "conv_first_mfma", "convT3x3s2_mfma", "convT_top_mfma",
     "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
     "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset", "norm_bwd",
-    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric", "wgrad_unpack", "conv3x3_s1_wino", "dice_ce_loss", "conv3x3_s1_wino4"};
+    "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric", "wgrad_unpack", "conv3x3_s1_wino", "dice_ce_loss", "conv3x3_s1_wino4",
+    "label_deflate"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
 
 struct ProfRecord {
@@ -1725,6 +1726,16 @@ int cs_remove_boundary_cells(const int32_t* labels, int h, int w, int border, in
                              void* workspace, size_t workspace_bytes, void* stream) {
     CS_REQUIRE(labels && out && workspace && h >= 0 && w >= 0 && border >= 0 && n_labels >= 0, "remove_boundary_cells: bad argument");
     return cs::remove_boundary_cells((hipStream_t)stream, labels, h, w, border, n_labels, out, n_out, workspace, workspace_bytes);
+}
+
+size_t cs_label_deflate_workspace_bytes(int h, int w, int rows_per_strip) { return cs::label_deflate_workspace_bytes(h, w, rows_per_strip); }
+
+size_t cs_label_deflate_bound(int h, int w, int rows_per_strip) { return cs::label_deflate_bound(h, w, rows_per_strip); }
+
+int cs_label_deflate(const int32_t* labels, int h, int w, int rows_per_strip, uint8_t* out, size_t out_capacity, uint32_t* meta,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(labels && out && meta && workspace, "label_deflate: null argument");
+    return cs::label_deflate((hipStream_t)stream, labels, h, w, rows_per_strip, out, out_capacity, meta, workspace, workspace_bytes);
 }
 
 size_t cs_ccl_workspace_bytes(int h, int w) { return cs::ccl_workspace_bytes(h, w); }

@@ -280,6 +280,11 @@ int normalize_image(hipStream_t s, const void* img, int is_u16, int h, int w, in
 
 // ---- F1 harness pieces (kernels_metric.hip) -----------------------------------------------------
 int label_max(hipStream_t s, const int32_t* a, const int32_t* b, int64_t n, int32_t* out2);
+// kernels_deflate.hip: zlib streams of the label TIFF's strips, on the device
+size_t label_deflate_bound(int h, int w, int rps);
+size_t label_deflate_workspace_bytes(int h, int w, int rps);
+int label_deflate(hipStream_t s, const int* labels, int h, int w, int rps, unsigned char* out, size_t out_capacity, unsigned* meta,
+                  void* workspace, size_t ws_bytes);
 int label_overlap(hipStream_t s, const int32_t* x, const int32_t* y, int64_t n, int32_t nx1, int32_t ny1, unsigned int* overlap);
 size_t remove_boundary_workspace_bytes(int32_t n_labels);
 int remove_boundary_cells(hipStream_t s, const int32_t* lab, int h, int w, int border, int32_t n_labels, int32_t* out, int32_t* n_out,

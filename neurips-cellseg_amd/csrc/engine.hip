@@ -786,13 +786,24 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     const bool side_on = side != nullptr && n_side > 0 && n_side_ev > 0 && !dry;
     hipStream_t sw = s;                        // stream of the current weight-gradient group (the groups alternate over the side streams)
     int side_used = 0, groups = 0;
+    // bias gradients (column sums of a finished dy) are nobody's input: with side streams they wait for the next weight-gradient group and
+    // run in front of it, off the main chain (5 x 20 us of the 1.1 ms backward chain of the batch-8 reference-width step)
+    struct PendingColsum { const float* dy; int pitch, c; int64_t npix; float* partial; float* dst; };
+    PendingColsum pending[8];
+    int n_pending = 0;
+    auto flush_colsums = [&](hipStream_t st) -> int {
+        for (int i = 0; i < n_pending; ++i)
+            CS_TRY(launch_colsum(st, pending[i].dy, pending[i].pitch, pending[i].c, pending[i].npix, pending[i].partial, pending[i].dst));
+        n_pending = 0;
+        return CS_OK;
+    };
     auto wg_begin = [&]() -> int {
         if (!side_on) return CS_OK;
         sw = side[groups++ % n_side];
         const hipEvent_t ev = side_ev[side_used++ % n_side_ev];
         CS_HIP(hipEventRecord(ev, s));
         CS_HIP(hipStreamWaitEvent(sw, ev, 0));
-        return CS_OK;
+        return flush_colsums(sw);
     };
 
     // fp64 accumulators that end up as fp32 gradients (slope gradients, the last conv's weight / bias sums) are handed over by ONE
@@ -811,6 +822,10 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         float* partial = buf.take<float>((size_t)colsum_blocks(npix_total) * c);
         if (dry) return CS_OK;
         if (!buf.ok()) return oom();
+        if (side_on && n_pending < (int)(sizeof(pending) / sizeof(pending[0]))) {
+            pending[n_pending++] = PendingColsum{dy, pitch, c, npix_total, partial, gptr(pidx)};
+            return CS_OK;
+        }
         return launch_colsum(s, dy, pitch, c, npix_total, partial, gptr(pidx));
     };
     // Weight gradients of the 3x3 layers on the 16-bit matrix pipe (kernels_bwd16.hip) when the handle's precision asks for it:
@@ -1054,6 +1069,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         CS_TRY(unpack3(sw, gf, c0, cin, 0, c, cin, gptr(u.unit0.p_w[0]), ax_dY0, nullptr));
         CS_TRY(unpack3(sw, gf, c0, cin, c, c, cin, gptr(u.unit0.p_w[1]), ax_dXd, nullptr));
     }
+    if (!dry) CS_TRY(flush_colsums(s));        // column sums no weight-gradient group picked up
     if (!dry) CS_TRY(launch_f64_jobs(s, f64_jobs));
     if (side_on) {                             // join: the caller's stream continues behind the last weight gradients
         for (int i = 0; i < n_side; ++i) {

@@ -62,6 +62,7 @@ int pack_wino_weights(PackCtx* pc, hipStream_t s, const float* w, bool dgrad, in
 // Winograd F(4x4, 3x3) (kernels_conv_wino4.hip): the wide (>= 128 input channels) 3x3 stride-1 layers of the fp32 path, forward only;
 // packed[cin/16][36 positions][cout/16][64 lanes][4]
 struct ConvOutExtra;
+constexpr int SMALL_GRID_BLOCKS = 256;   // launches with fewer blocks than CUs take narrower channel blocks (same kernels, more blocks)
 constexpr int WINO4_MIN_CIN = 32;   // layers with at least this many input channels (cin, cout multiples of 32) take the F(4x4,3x3) form
 size_t packed_wino4_floats(int cout_total, int cin_total);
 int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed, bool dgrad = false);   // dgrad: (cout, cin) of the
@@ -249,6 +250,7 @@ int launch_wgrad16(hipStream_t s, int mode, int stride, const float* a, int a_pi
                    const float* b_amax, float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo,
                    int hi, int wi);
 int launch_amax(hipStream_t s, const float* src, int64_t numel, float* out);   // out[AMAX_SLOTS]: partial maxima of |src|; zero before the first use
+constexpr int NORM_BWD_FUSED_MAX_PIX = 1024;   // InstanceNorm backward of images with at most this many pixels: one launch (norm_bwd_fused_kernel)
 constexpr int NORM_DSLOPE_SLOTS = 64;          // partial accumulators of one PReLU slope gradient (launch_norm_bwd's `dslope`)
 struct F64Job { const double* src; float* dst; int count, slots; };
 struct F64Jobs { F64Job j[96]; int n = 0; };   // passed by value as a kernel argument (2.3 KB)

@@ -179,6 +179,73 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p) {
     if (p.amax) amax_commit(p.amax, amax);           // (block-uniform branch: every thread of the block gets here)
 }
 
+// One-launch form for the small tensors of the deep levels (InstanceNorm, npix <= NORM_BWD_FUSED_MAX_PIX): a block OWNS (image,
+// QB channel quads), so the sums of the reduce pass need no atomics and no second launch - pass 1 sums over the image's pixels, the
+// waves meet through LDS, pass 2 re-reads the same (L2-resident) elements and writes dy.  The two-kernel form spends ~19 us per norm
+// site on such tensors (launch + atomics + a dependent launch); 10 of the 16 sites of the reference-width batch-8 step qualify.
+template <int QB>
+__global__ __launch_bounds__(256) void norm_bwd_fused_kernel(NormBwdParams p) {
+    constexpr int LANES = 256 / QB;                      // pixel lanes per quad
+    __shared__ double sh[4][QB][9];
+    const int quad_l = threadIdx.x % QB, pl = threadIdx.x / QB;
+    const int quad = blockIdx.x * QB + quad_l, img = blockIdx.y;
+    const int wave = threadIdx.x >> 6;
+    const f32x4* t = reinterpret_cast<const f32x4*>(p.tab + (size_t)img * p.tab_c + p.tab_off + 4 * quad);
+    const f32x4 t0 = t[0], t1 = t[1];
+    const float sc[4] = {t0.x, t0.z, t1.x, t1.z}, sf[4] = {t0.y, t0.w, t1.y, t1.w};
+    const float slope = p.slope ? *p.slope : 0.f;
+    const float* const da0 = p.da + (size_t)img * p.npix * p.da_pitch + 4 * quad;
+    const float* const y0 = p.y + (size_t)img * p.npix * p.y_pitch + 4 * quad;
+    float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // s1[4], s2[4], ds
+    for (int px = pl; px < p.npix; px += LANES) {
+        const f32x4 da = *reinterpret_cast<const f32x4*>(da0 + (size_t)px * p.da_pitch);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(y0 + (size_t)px * p.y_pitch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = y[j] * sc[j] + sf[j];
+            const float dz = z >= 0.f ? da[j] : da[j] * slope;
+            if (z < 0.f) v[8] += da[j] * z;
+            v[j] += dz;
+            v[4 + j] += dz * z;
+        }
+    }
+    // lanes of a wave that share a quad sit QB apart
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int off = QB; off < 64; off <<= 1) v[k] += __shfl_xor(v[k], off);
+    if ((threadIdx.x & 63) < QB)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sh[wave][quad_l][k] = (double)v[k];
+    __syncthreads();
+    float m1[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m1[j] = (float)(((sh[0][quad_l][j] + sh[1][quad_l][j]) + (sh[2][quad_l][j] + sh[3][quad_l][j])) * p.inv_m);
+        m2[j] = (float)(((sh[0][quad_l][4 + j] + sh[1][quad_l][4 + j]) + (sh[2][quad_l][4 + j] + sh[3][quad_l][4 + j])) * p.inv_m);
+    }
+    if (p.dslope && threadIdx.x < QB) {
+        const double ds = (sh[0][quad_l][8] + sh[1][quad_l][8]) + (sh[2][quad_l][8] + sh[3][quad_l][8]);
+        atomicAdd(p.dslope + ((blockIdx.x * QB + quad_l + 13 * blockIdx.y) & (NORM_DSLOPE_SLOTS - 1)), ds);
+    }
+    float amax = 0.f;
+    float* const dy0 = p.dy + (size_t)img * p.npix * p.dy_pitch + 4 * quad;
+    for (int px = pl; px < p.npix; px += LANES) {
+        const f32x4 da = *reinterpret_cast<const f32x4*>(da0 + (size_t)px * p.da_pitch);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(y0 + (size_t)px * p.y_pitch);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = y[j] * sc[j] + sf[j];
+            const float dz = z >= 0.f ? da[j] : da[j] * slope;
+            o[j] = sc[j] * (dz - m1[j] - z * m2[j]);
+        }
+        *reinterpret_cast<f32x4*>(dy0 + (size_t)px * p.dy_pitch) = o;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+    if (p.amax) amax_commit(p.amax, amax);           // (block-uniform branch)
+}
+
 // narrow (c <= 4, any pitch): one thread per pixel
 template <int C>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_small_kernel(NormBwdParams p) {
@@ -296,6 +363,16 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
         // ... but never so many that a block's share shrinks to a handful of elements per thread: at 8 x 128^2 x 16 channels 2048 blocks
         // held 4 elements per thread and the pass was nothing but 65 k fp64 atomics on 256 addresses (70 us for 17 MB; 16 of the 172
         // launches of the reference-width training step were a fifth of its time) - at least `min_elems` elements per thread
+        if (!batch && npix <= NORM_BWD_FUSED_MAX_PIX) {
+            // widest channel group that still gives the launch >= 128 blocks
+            const int qb = (c4n % 4 == 0 && (c4n / 4) * n >= 128) ? 4 : (c4n % 2 == 0 && (c4n / 2) * n >= 128) ? 2 : 1;
+            const dim3 grid((unsigned)(c4n / qb), (unsigned)n);
+            if (qb == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<4>), grid, dim3(256), 0, s, p);
+            else if (qb == 2) hipLaunchKernelGGL((norm_bwd_fused_kernel<2>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((norm_bwd_fused_kernel<1>), grid, dim3(256), 0, s, p);
+            CS_HIP(hipGetLastError());
+            return CS_OK;
+        }
         auto chunk = [&](int64_t target_blocks, int min_elems) {
             int64_t ppb = (npix * n + target_blocks - 1) / target_blocks;
             const int64_t ppb_min = (int64_t)min_elems * 256 / y.c;

@@ -497,14 +497,22 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
         case 2: return launch_conv_t<S_, KS_, 2, MT_>(s, p);                   \
         default: return launch_conv_t<S_, KS_, 1, MT_>(s, p);                  \
     }
+    auto blocks_of = [&](int th, int ch_tiles) {
+        return (long long)xcd_grid(ceil_div(p.wout, 16) * ceil_div(p.hout, th) * n, p.ntile_total / ch_tiles);
+    };
     // 64-channel blocks of the 3x3 layers take the register-weights kernel (measured: s1 31.9 -> 30.3 ms, s2 9.8 -> 8.3 ms per
     // 4096^2 slide; the 32-channel and 1x1 layers were not faster with it and keep the LDS-weights kernel)
     if (nt == 4 && ksize == 3 && stride == 1) return launch_conv_wreg<1, 3, 4, 8, 3, 1>(s, p);
     if (nt == 4 && ksize == 3 && stride == 2) {
         // 128-channel blocks (two channel tiles per wave: every A fragment feeds 8 MFMAs, 288 MFMAs per barrier) when the
-        // channel count and the (out, out2) split allow it
-        const bool wide = cout % 128 == 0;
+        // channel count and the (out, out2) split allow it - and the grid still covers the chip (small training launches do not)
+        const bool wide = cout % 128 == 0 && blocks_of(4, 8) >= SMALL_GRID_BLOCKS;
         return wide ? launch_conv_wreg<2, 3, 4, 4, 3, 2>(s, p) : launch_conv_wreg<2, 3, 4, 4, 3, 1>(s, p);
+    }
+    // LDS-weights kernels: narrower channel blocks for launches that would not cover the chip once (same kernel, same order)
+    {
+        const int th = ksize == 3 && stride == 2 ? 4 : 8;
+        while (nt > 1 && blocks_of(th, nt) < SMALL_GRID_BLOCKS) nt /= 2;
     }
     // (a register-weights form of the 32-channel stride-1 layers with a 16-row tile was measured in round 2: 30.9 vs 30.6 ms per
     // slide for the stride-1 group - not kept)
@@ -1143,6 +1151,9 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
     p.tiles_y = ceil_div(hin, 4);
     int nt = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
     if (int rc = apply_extra(p, ex, cout, &nt)) return rc;
+    // small launches (the deep levels of a batch-8 training step: 32 blocks of 64 channels with K = 384) take narrower channel blocks
+    // until the grid covers the chip once: the same kernel, the same accumulation order, 2-4 x the blocks
+    while (nt > 1 && xcd_grid(p.tiles_x * p.tiles_y * n, p.ntile_total / nt) < SMALL_GRID_BLOCKS) nt /= 2;
     // two input rows per wave for the 64-channel blocks when the grid still fills the chip at two blocks per CU
     if (nt == 4 && !b.ptr2 && hin >= 8 && xcd_grid(p.tiles_x * ceil_div(hin, 8) * n, p.ntile_total / nt) >= 1024) {
         p.tiles_y = ceil_div(hin, 8);

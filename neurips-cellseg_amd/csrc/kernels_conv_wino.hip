@@ -664,7 +664,7 @@ int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, c
         const dim3 grid1(xcd_grid(nsp, p.ntile_total / 8));
         if (lazy) hipLaunchKernelGGL((conv_wino1_kernel<true>), grid1, dim3(256), 0, s, p, g_wino_stamps);
         else hipLaunchKernelGGL((conv_wino1_kernel<false>), grid1, dim3(256), 0, s, p, g_wino_stamps);
-    } else if (cout % 64 == 0) {
+    } else if (cout % 64 == 0 && (long long)xcd_grid(nsp, p.ntile_total / 4) >= SMALL_GRID_BLOCKS) {     // (else: 32-channel blocks, twice the grid)
         if (lazy) CS_WINO_LAUNCH(4, 2, true);
         else CS_WINO_LAUNCH(4, 2, false);
     } else {

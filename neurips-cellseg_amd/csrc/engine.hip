@@ -1166,6 +1166,11 @@ int cs_unet_create(cs_unet** out, int in_channels, int out_channels, const int* 
     ArenaPlan real;
     real.base = net->arena;
     build_net(net, real);
+    if (real.off != net->arena_floats) {       // a build step whose allocations depend on pointers would overrun the arena silently
+        cs::set_error("unet_create: the two planning passes disagree (%zu vs %zu floats)", real.off, net->arena_floats);
+        cs_unet_destroy(net);
+        return CS_ERR_INVALID;
+    }
     int64_t off = 0;
     for (auto& p : net->params) {
         p.grad_off = off;

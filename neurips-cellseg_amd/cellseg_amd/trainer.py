@@ -156,25 +156,25 @@ class TrainStep:
         return sh
 
     # ---- the launch sequence (identical eager and under capture) ----------------------------------------------------------
-    def _front(self, sh: _Shape) -> None:
+    def _front(self, sh: _Shape, x: torch.Tensor, t: torch.Tensor) -> None:
         """forward -> (BatchNorm: running statistics back to the module) -> DiceCE -> its gradient -> backward into the flat bucket."""
         model, lf = self.model, self.loss_function
         h = model._engine.handle
-        n, _, hh, ww = sh.x.shape
+        n, _, hh, ww = x.shape
         s = _lib.stream_ptr()
-        sn, sc, shh, sww = sh.x.stride()
-        check(lib.cs_unet_forward(h, C.c_void_p(sh.x.data_ptr()), sn, sc, shh, sww, n, hh, ww, C.c_void_p(sh.logits.data_ptr()),
+        sn, sc, shh, sww = x.stride()
+        check(lib.cs_unet_forward(h, C.c_void_p(x.data_ptr()), sn, sc, shh, sww, n, hh, ww, C.c_void_p(sh.logits.data_ptr()),
                                   C.c_void_p(sh.ws_f.data_ptr()), sh.ws_f.numel(), s), "cs_unet_forward")
         if model.norm_name == "batch":
             check(lib.cs_unet_readback(h, s), "cs_unet_readback")
         lg = sh.logits.permute(0, 3, 1, 2)                         # the NCHW view the loss is defined on
         ls = (C.c_int64 * 4)(*[int(v) for v in lg.stride()])
-        ts = (C.c_int64 * 4)(*[int(v) for v in sh.t.stride()])
+        ts = (C.c_int64 * 4)(*[int(v) for v in t.stride()])
         cls = model.out_channels
-        check(lib.cs_dice_ce_forward(C.c_void_p(sh.logits.data_ptr()), ls, C.c_void_p(sh.t.data_ptr()), ts, n, cls, hh, ww, lf.smooth_nr,
+        check(lib.cs_dice_ce_forward(C.c_void_p(sh.logits.data_ptr()), ls, C.c_void_p(t.data_ptr()), ts, n, cls, hh, ww, lf.smooth_nr,
                                      lf.smooth_dr, lf.lambda_dice, lf.lambda_ce, C.c_void_p(sh.loss.data_ptr()), C.c_void_p(sh.ws_l.data_ptr()),
                                      sh.ws_l.numel(), s), "cs_dice_ce_forward")
-        check(lib.cs_dice_ce_backward(C.c_void_p(sh.logits.data_ptr()), ls, C.c_void_p(sh.t.data_ptr()), ts, n, cls, hh, ww, lf.smooth_nr,
+        check(lib.cs_dice_ce_backward(C.c_void_p(sh.logits.data_ptr()), ls, C.c_void_p(t.data_ptr()), ts, n, cls, hh, ww, lf.smooth_nr,
                                       lf.smooth_dr, lf.lambda_dice, lf.lambda_ce, C.c_void_p(), C.c_void_p(sh.ws_l.data_ptr()), sh.ws_l.numel(),
                                       C.c_void_p(sh.dlogits.data_ptr()), s), "cs_dice_ce_backward")
         check(lib.cs_unet_backward(h, C.c_void_p(sh.dlogits.data_ptr()), C.c_void_p(sh.ws_b.data_ptr()), sh.ws_b.numel(),
@@ -214,6 +214,10 @@ class TrainStep:
             raise ValueError(f"one-hot labels {tuple(labels_onehot.shape)} do not match inputs {tuple(inputs.shape)}")
         dev = inputs.device
         with torch.cuda.device(dev):
+            if not self.capture:
+                # the lean launch sequence runs on the caller's stream and reads the caller's tensors in place: no event round trips
+                # between steps, no staging copies (40 us of the 1.5 ms batch-8 step)
+                return self._step(inputs, labels_onehot, dev)
             if self._stream is None or self._stream.device != dev:
                 self._stream = torch.cuda.Stream(dev)
             caller = torch.cuda.current_stream(dev)
@@ -236,14 +240,19 @@ class TrainStep:
         if model.norm_name == "batch":
             check(lib.cs_unet_set_batch_stats(h, 1), "cs_unet_set_batch_stats")
         sh = self._buffers(tuple(inputs.shape), dev)
-        sh.x.copy_(inputs, non_blocking=True)
-        sh.t.copy_(labels_onehot, non_blocking=True)
+        if self.capture:                                        # a captured step replays fixed addresses: stage the batch
+            sh.x.copy_(inputs, non_blocking=True)
+            sh.t.copy_(labels_onehot, non_blocking=True)
+            x, t = sh.x, sh.t
+        else:                                                   # (any strides; other dtypes are converted once)
+            x = inputs if inputs.dtype == torch.float32 else inputs.float()
+            t = labels_onehot if labels_onehot.dtype == torch.float32 else labels_onehot.float()
         self._push_hyper()
         model._generation += 1                                  # an eager backward of an older forward must not run on this tape
         collective = self._collective()
         use_graph = self.capture and sh.eager_steps >= 1 and not lib.cs_prof_is_enabled()
         if not use_graph:
-            self._front(sh)                                     # (the first step of a shape runs eagerly: it creates the engine's
+            self._front(sh, x, t)                               # (the first step of a shape runs eagerly: it creates the engine's
             if collective:                                      # side streams, which a capture must not do)
                 self._exchange()
             self._back()
@@ -251,9 +260,9 @@ class TrainStep:
         else:
             if sh.graph_a is None:
                 if collective:
-                    sh.graph_a, sh.graph_b = self._record(lambda: self._front(sh)), self._record(self._back)
+                    sh.graph_a, sh.graph_b = self._record(lambda: self._front(sh, x, t)), self._record(self._back)
                 else:
-                    sh.graph_a = self._record(lambda: (self._front(sh), self._back()))
+                    sh.graph_a = self._record(lambda: (self._front(sh, x, t), self._back()))
             s = _lib.stream_ptr()
             check(lib.cs_graph_launch(sh.graph_a, s), "cs_graph_launch")
             if collective:

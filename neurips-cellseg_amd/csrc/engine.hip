@@ -901,7 +901,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         if (!buf.ok()) return oom();
         if (u.top) {
             double* dw_last = acc.take<double>(84);                   // [81 weights | 3 biases]
-            float* last_part = buf.take<float>(conv_last_bwd_partial_floats(n));
+            float* last_part = buf.take<float>(conv_last_bwd_partial_floats(n, oh, ow));
             if (!buf.ok()) return oom();
             if (!dry) {
                 CS_TRY(launch_conv_last_bwd(s, dlogits, lu, u.unit0.w, d_au, dw_last, last_part, n, oh, ow));

@@ -255,8 +255,8 @@ constexpr int NORM_DSLOPE_SLOTS = 64;          // partial accumulators of one PR
 struct F64Job { const double* src; float* dst; int count, slots; };
 struct F64Jobs { F64Job j[96]; int n = 0; };   // passed by value as a kernel argument (2.3 KB)
 int launch_f64_jobs(hipStream_t s, const F64Jobs& jobs);   // dst[i] = (float) sum over slots of src[slot * count + i], one block per job
-// dw_db: 84 doubles = [81 weight gradients | 3 bias gradients]; partial: conv_last_bwd_partial_floats(n) floats of scratch
-size_t conv_last_bwd_partial_floats(int n);
+// dw_db: 84 doubles = [81 weight gradients | 3 bias gradients]; partial: conv_last_bwd_partial_floats(n, h, w) floats of scratch
+size_t conv_last_bwd_partial_floats(int n, int h, int w);
 int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw_db,
                          float* partial, int n, int h, int w);
 int launch_convt_small_bwd_data(hipStream_t s, const float* du, const float* w_torch, int cin_total, int c_begin, int c_count,

@@ -959,13 +959,21 @@ int launch_f64_jobs(hipStream_t s, const F64Jobs& jobs) {
 // last layer backward: logits = conv3x3(T(u); W) + b + T(u)
 //   d_au[p][ci] = dl[p][ci] + sum_{co,k} dl[p - (k - 1)][co] * W[co][ci][k]
 //   dW[co][ci][k] = sum_p dl[p][co] * T(u)[p + k - 1][ci] ;  db[co] = sum_p dl[p][co]
+// Block = a 16 x 64 pixel tile.  The tile's gradient rows and ACTIVATED inputs go to LDS once, with a one-pixel halo that holds zeros
+// outside the image (zero padding comes after the activation, and a neighbour outside the image contributes nothing) - so the
+// 18 neighbour reads of a pixel are plain 16-byte LDS loads without bounds checks, and the norm + PReLU of an input pixel is
+// evaluated once instead of once per tap.  (The first form read every neighbour from global memory - 54 scalar loads per pixel - and
+// took 0.1 ms at batch 32.)  A thread keeps the 81 + 3 sums of its four pixels in registers; the block's sums meet below.
 template <int C>
 __global__ __launch_bounds__(256) void conv_last_bwd_kernel(const float* dl, const float* u, const float2* tab, const float* slope_p,
-                                                            const float* w, float* d_au, float* partial, int h, int wd) {
-    __shared__ float w_s[C * C * 9];
-    for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) w_s[i] = w[i];
-    __syncthreads();
+                                                            const float* __restrict__ w, float* d_au, float* partial, int h, int wd,
+                                                            int tiles_x) {
+    static_assert(C == 3, "pixel records below are float4 = 3 channels + pad");
+    constexpr int TH = 16, TW = 64, IH = TH + 2, IW = TW + 2;
+    __shared__ f32x4 dl_s[IH * IW], a_s[IH * IW];
     const int img = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
     const float slope = slope_p ? *slope_p : 0.f;
     float sc[C], sf[C];
 #pragma unroll
@@ -973,19 +981,42 @@ __global__ __launch_bounds__(256) void conv_last_bwd_kernel(const float* dl, con
         const float2 t = tab[img * C + c];
         sc[c] = t.x; sf[c] = t.y;
     }
+    const float* dlb = dl + (size_t)img * h * wd * C;
+    const float* ub = u + (size_t)img * h * wd * C;
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        const int iy = i / IW, ix = i - iy * IW;
+        const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f}, a = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < h && gx >= 0 && gx < wd) {
+            const size_t o = ((size_t)gy * wd + gx) * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                d[c] = dlb[o + c];
+                a[c] = prelu_b(ub[o + c] * sc[c] + sf[c], slope);
+            }
+        }
+        dl_s[i] = d;
+        a_s[i] = a;
+    }
+    float wr[C * C * 9];                       // uniform: scalar registers
+#pragma unroll
+    for (int i = 0; i < C * C * 9; ++i) wr[i] = w[i];
+    __syncthreads();
     float gw[C * C * 9], gb[C];
 #pragma unroll
     for (int i = 0; i < C * C * 9; ++i) gw[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) gb[c] = 0.f;
-    const float* dlb = dl + (size_t)img * h * wd * C;
-    const float* ub = u + (size_t)img * h * wd * C;
-    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < h * wd; pix += gridDim.x * blockDim.x) {
-        const int y = pix / wd, x = pix - y * wd;
-        float g[C], acc[C];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        const int ly = (threadIdx.x >> 6) * 4 + k4, lx = threadIdx.x & 63;       // a wave walks four rows of the tile
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= h || x >= wd) continue;
+        const int ctr = (ly + 1) * IW + lx + 1;
+        const f32x4 g = dl_s[ctr];
+        float acc[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            g[c] = dlb[(size_t)pix * C + c];
             acc[c] = g[c];
             gb[c] += g[c];
         }
@@ -994,38 +1025,22 @@ __global__ __launch_bounds__(256) void conv_last_bwd_kernel(const float* dl, con
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int k = ky * 3 + kx;
-                // data gradient: neighbour q = p - (k - 1) contributed to by this pixel's activation
-                const int qy = y - (ky - 1), qx = x - (kx - 1);
-                if (qy >= 0 && qy < h && qx >= 0 && qx < wd) {
-                    const float* dq = dlb + ((size_t)qy * wd + qx) * C;
+                const f32x4 dq = dl_s[ctr - (ky - 1) * IW - (kx - 1)];      // data gradient: the neighbour this pixel's activation fed
+                const f32x4 av = a_s[ctr + (ky - 1) * IW + (kx - 1)];       // weight gradient: the activation under tap k
 #pragma unroll
-                    for (int co = 0; co < C; ++co) {
-                        const float d = dq[co];
-#pragma unroll
-                        for (int ci = 0; ci < C; ++ci) acc[ci] += d * w_s[(co * C + ci) * 9 + k];
-                    }
-                }
-                // weight gradient: activation at p + (k - 1)
-                const int ay = y + ky - 1, ax = x + kx - 1;
-                if (ay >= 0 && ay < h && ax >= 0 && ax < wd) {
-                    const float* up = ub + ((size_t)ay * wd + ax) * C;
+                for (int co = 0; co < C; ++co)
 #pragma unroll
                     for (int ci = 0; ci < C; ++ci) {
-                        const float a = prelu_b(up[ci] * sc[ci] + sf[ci], slope);
-#pragma unroll
-                        for (int co = 0; co < C; ++co) gw[(co * C + ci) * 9 + k] += g[co] * a;
+                        acc[ci] += dq[co] * wr[(co * C + ci) * 9 + k];
+                        gw[(co * C + ci) * 9 + k] += g[co] * av[ci];
                     }
-                }
             }
 #pragma unroll
-        for (int c = 0; c < C; ++c) d_au[((size_t)img * h * wd + pix) * C + c] = acc[c];
+        for (int c = 0; c < C; ++c) d_au[((size_t)img * h * wd + (size_t)y * wd + x) * C + c] = acc[c];
     }
-    // block reduction of the C*C*9 weight gradients and C bias gradients -> one partial row per block (no atomics:
-    // thousands of waves adding into the same 84 doubles serialised at the memory side and cost 1.5 ms)
     // Wave reduction as a halving butterfly: at every step a lane keeps one half of its list and hands the other half to its partner, so
-    // the 84 sums cost 64 + 32 + ... + 2 = 126 cross-lane moves instead of 84 x 6 = 504 (the one-value-at-a-time form was 504
-    // ds_bpermute round trips per wave: 100 of the kernel's 130 us at batch 32).  After the six steps lane l holds the wave totals of
-    // entries 2 l and 2 l + 1 of the list (padded with zeros to 128).
+    // the 84 sums cost 64 + 32 + ... + 2 = 126 cross-lane moves instead of 84 x 6 = 504.  After the six steps lane l holds the wave
+    // totals of entries 2 l and 2 l + 1 of the list (padded with zeros to 128).
     constexpr int NV = C * C * 9 + C;
     static_assert(NV <= 128, "the butterfly below reduces at most 128 values per wave");
     __shared__ float red_s[4][128];
@@ -1073,22 +1088,18 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* partial, int
     }
 }
 
-// blocks per image of the last-layer backward: ~1024 blocks over the batch, 8...64 per image.  (64 per image at batch 32 left every
-// thread 4 pixels and the block an 84-value shuffle-and-LDS reduction behind them: 161 us for 75 MB of traffic.)
-static inline int last_bwd_blocks(int n) {
-    int b = 1024 / (n > 0 ? n : 1);
-    b = b < 8 ? 8 : (b > 64 ? 64 : b);
-    return b;
-}
-size_t conv_last_bwd_partial_floats(int n) { return (size_t)n * last_bwd_blocks(n) * 84; }
+// one partial row of 84 sums per 16 x 64 pixel tile
+static inline int last_bwd_tiles(int h, int w) { return ceil_div(h, 16) * ceil_div(w, 64); }
+size_t conv_last_bwd_partial_floats(int n, int h, int w) { return (size_t)n * last_bwd_tiles(h, w) * 84; }
 
 int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, const float* w_torch, float* d_au, double* dw_db,
                          float* partial, int n, int h, int w) {
     CS_REQUIRE(u.c == 3 && u.pitch == 3 && u.tab, "conv_last_bwd: 3-class contract");
     ProfScope prof(K_TOP_BWD, s, 4.0 * n * h * w * 81.0, 4.0 * n * (double)h * w * 9);
-    const int blocks = last_bwd_blocks(n);
+    const int blocks = last_bwd_tiles(h, w);
     dim3 grid((unsigned)blocks, (unsigned)n);
-    hipLaunchKernelGGL((conv_last_bwd_kernel<3>), grid, dim3(256), 0, s, dlogits, u.ptr, u.tab, u.slope, w_torch, d_au, partial, h, w);
+    hipLaunchKernelGGL((conv_last_bwd_kernel<3>), grid, dim3(256), 0, s, dlogits, u.ptr, u.tab, u.slope, w_torch, d_au, partial, h, w,
+                       ceil_div(w, 64));
     hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(84, 8)), dim3(256), 0, s, partial, n * blocks, 84, dw_db);   // [81 weights | 3 biases]
     CS_HIP(hipGetLastError());
     return CS_OK;

@@ -1202,7 +1202,7 @@ static inline int64_t pack_job_elems(const PackJob& jb) {
         case PK_CONV: return (int64_t)(jb.cin / 16) * (jb.cout / 16);       // BLOCKS: one per (chunk, channel tile)
         case PK_FIRST: return (int64_t)jb.ksteps * (jb.cout / 16) * 64;
         case PK_FIRST16: return (int64_t)(jb.cout / 16) * 512;
-        case PK_BF16: return (int64_t)jb.chunks_total * jb.taps * (jb.cout / 16) * 512;
+        case PK_BF16: return (int64_t)jb.chunks_total * jb.taps * (jb.cout / 16) * 64;     // OCTETS: 8 halfs of 3 planes per thread
         case PK_WINO: return (int64_t)(jb.cin / 16) * 16 * (jb.cout / 16) * 256;
         case PK_WINO4: return (int64_t)(jb.cin / 16) * 36 * (jb.cout / 16) * 256;
         default: return jb.cout;                              // PK_COPY: cout = element count
@@ -1221,9 +1221,23 @@ __device__ __forceinline__ int find_job(const PackJob* jobs, int n_jobs, T e) {
 }
 
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* jobs, int n_jobs, long long total) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    // a block's 256 work items almost always belong to one job: one thread searches the table and the descriptor is read from LDS (every
+    // thread searching the global table and copying its 120-byte descriptor was most of this kernel's time)
+    __shared__ PackJob jb_s;
+    __shared__ int single_s;
+    const long long e0 = (long long)blockIdx.x * 256;
+    if (threadIdx.x == 0) {
+        const long long e1 = e0 + 255 < total ? e0 + 255 : total - 1;
+        const int j0 = find_job(jobs, n_jobs, e0);
+        single_s = j0 == find_job(jobs, n_jobs, e1) ? 1 : 0;
+        jb_s = jobs[j0];
+    }
+    __syncthreads();
+    const long long e = e0 + threadIdx.x;
     if (e >= total) return;
-    const PackJob jb = jobs[find_job(jobs, n_jobs, e)];
+    PackJob own;
+    if (!single_s) own = jobs[find_job(jobs, n_jobs, e)];
+    const PackJob& jb = single_s ? jb_s : own;
     const int64_t le = e - jb.begin;
     switch (jb.kind) {
         case PK_FIRST: pack_first_elem(jb, le); break;

@@ -72,39 +72,61 @@ __device__ __forceinline__ void pack_first16_elem(const PackJob& jb, int64_t e) 
 // packed[chunk][tap][ntile_total][plane][lane][j]: cout = ntile*16 + (lane & 15), k = chunk*32 + 8*(lane>>4) + j.
 // Input channels >= cin_split (second concat source) start a fresh 32-channel chunk, as the kernel stages them.
 constexpr float PACK_F16_W_SCALE = 256.f;                     // == F16_W_SCALE of kernels_conv_bf16.hip
-__device__ __forceinline__ void pack_bf16_elem(const PackJob& jb, int64_t e) {
+// one thread = one OCTET: the 8 consecutive k of a lane's fragment register pair, i.e. 16 bytes per plane
+__device__ __forceinline__ void pack_bf16_elem(const PackJob& jb, int64_t o) {
     const int cout = jb.cout, cin = jb.cin, taps = jb.taps, cin_split = jb.cin_split, chunks_total = jb.chunks_total;
-    const int j = e & 7, lane = (e >> 3) & 63;
-    int64_t r = e >> 9;
+    const int lane = o & 63;
+    int64_t r = o >> 6;
     const int ntl = r % (cout / 16);
     r /= (cout / 16);
     const int tap = r % taps;
     const int chunk = r / taps;
     const int chunks_a = cin_split > 0 ? (cin_split + 31) / 32 : chunks_total;
-    const int k = (chunk < chunks_a ? chunk * 32 : (chunk - chunks_a) * 32) + 8 * (lane >> 4) + j;
-    const int ci = chunk < chunks_a ? k : cin_split + k;
-    const bool valid = chunk < chunks_a ? k < (cin_split > 0 ? cin_split : cin) : ci < cin;
+    const int k0 = (chunk < chunks_a ? chunk * 32 : (chunk - chunks_a) * 32) + 8 * (lane >> 4);
     const int co = ntl * 16 + (lane & 15);
-    float v = 0.f;
     const int ts = jb.flip ? taps - 1 - tap : tap;            // data-gradient packing of a stride-1 conv: taps reversed
-    if (valid) v = jb.transposed ? jb.src[((size_t)ci * cout + co) * taps + ts] : jb.src[((size_t)co * cin + ci) * taps + ts];
-    unsigned short* packed = reinterpret_cast<unsigned short*>(jb.dst);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const int ci = chunk < chunks_a ? k : cin_split + k;
+        const bool valid = chunk < chunks_a ? k < (cin_split > 0 ? cin_split : cin) : ci < cin;
+        v[j] = 0.f;
+        if (valid) v[j] = jb.transposed ? jb.src[((size_t)ci * cout + co) * taps + ts] : jb.src[((size_t)co * cin + ci) * taps + ts];
+    }
+    typedef unsigned pk_u32x4 __attribute__((ext_vector_type(4)));
+    pk_u32x4* packed = reinterpret_cast<pk_u32x4*>(jb.dst);
     const size_t base = (((size_t)(chunk + jb.chunk_off) * taps + tap) * jb.ntile_total + jb.cout_off / 16 + ntl) * 3;   // chunk_off: this tensor
                                                             // is the second input-channel source of a fused launch (data-gradient packings)
+    unsigned short h[3][8];
     if (jb.f16) {                                             // fp16x3: planes of w * 2^8: h0, remainder, unused
-        v = __builtin_amdgcn_fmed3f(v * PACK_F16_W_SCALE, -65504.f, 65504.f);   // saturate (|w| >= 255.9 is outside the mode's domain)
-        const _Float16 h0 = (_Float16)v;
-        const _Float16 h1 = (_Float16)(v - (float)h0);
-        packed[((base + 0) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h0);
-        packed[((base + 1) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h1);
-        packed[((base + 2) * 64 + lane) * 8 + j] = 0;
-        return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = __builtin_amdgcn_fmed3f(v[j] * PACK_F16_W_SCALE, -65504.f, 65504.f);   // saturate (|w| >= 255.9 is outside the mode's domain)
+            const _Float16 h0 = (_Float16)w;
+            const _Float16 h1 = (_Float16)(w - (float)h0);
+            h[0][j] = __builtin_bit_cast(unsigned short, h0);
+            h[1][j] = __builtin_bit_cast(unsigned short, h1);
+            h[2][j] = 0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float w = v[j];
+#pragma unroll
+            for (int pn = 0; pn < 3; ++pn) {
+                const __bf16 hb = (__bf16)w;
+                w -= (float)hb;
+                h[pn][j] = __builtin_bit_cast(unsigned short, hb);
+            }
+        }
     }
 #pragma unroll
     for (int pn = 0; pn < 3; ++pn) {
-        const __bf16 h = (__bf16)v;
-        v -= (float)h;
-        packed[((base + pn) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, h);
+        pk_u32x4 q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = (unsigned)h[pn][2 * i] | ((unsigned)h[pn][2 * i + 1] << 16);
+        packed[(base + pn) * 64 + lane] = q;
     }
 }
 

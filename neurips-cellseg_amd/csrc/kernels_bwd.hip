@@ -1069,23 +1069,21 @@ __global__ __launch_bounds__(256) void conv_last_bwd_kernel(const float* dl, con
             red_s[0][threadIdx.x] + red_s[1][threadIdx.x] + red_s[2][threadIdx.x] + red_s[3][threadIdx.x];
 }
 
-// sum of the per-block partial rows in fp64: block = 8 columns x 32 row lanes (one thread walking all the rows of a column was
-// 119 us of pure latency)
+// sum of the per-block partial rows in fp64: one block per column, 256 row lanes, LDS tree (8 columns x 32 row lanes per block
+// walked 2048 rows in 64 dependent trips: 21 us on the serial stretch at the top of the backward pass)
 __global__ __launch_bounds__(256) void rows_sum_kernel(const float* partial, int rows, int cols, double* dst) {
     __shared__ double sh[256];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
+    const int c = blockIdx.x;
     double acc = 0.0;
-    if (c < cols)
-        for (int r = rl; r < rows; r += 32) acc += (double)partial[(size_t)r * cols + c];
+    for (int r = threadIdx.x; r < rows; r += 256) acc += (double)partial[(size_t)r * cols + c];
     sh[threadIdx.x] = acc;
     __syncthreads();
-    if (rl == 0 && c < cols) {
-        double t = 0.0;
 #pragma unroll
-        for (int l = 0; l < 32; ++l) t += sh[l * 8 + cl];
-        dst[c] = t;
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) dst[c] = sh[0];
 }
 
 // one partial row of 84 sums per 16 x 64 pixel tile
@@ -1100,7 +1098,7 @@ int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, 
     dim3 grid((unsigned)blocks, (unsigned)n);
     hipLaunchKernelGGL((conv_last_bwd_kernel<3>), grid, dim3(256), 0, s, dlogits, u.ptr, u.tab, u.slope, w_torch, d_au, partial, h, w,
                        ceil_div(w, 64));
-    hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(84, 8)), dim3(256), 0, s, partial, n * blocks, 84, dw_db);   // [81 weights | 3 biases]
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(84), dim3(256), 0, s, partial, n * blocks, 84, dw_db);   // [81 weights | 3 biases]
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -1135,11 +1133,19 @@ __global__ __launch_bounds__(256) void convt_small_bwd_data_kernel(const float* 
         }
     float* o = dst + ((size_t)img * hin * win + pix) * dst_pitch;
     if ((c_count & 3) == 0 && (dst_pitch & 3) == 0) {          // 16-byte stores: 4 channels at a time
+        static_assert(WROW % 4 == 0, "a weight row is read as 16-byte LDS words");
         for (int ci = 0; ci < c_count; ci += 4) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float* wr = &w_s[(ci + j) * WROW];
+                // the row's 27 weights as seven 16-byte broadcast reads (27 scalar LDS reads per channel made the kernel LDS-issue bound)
+                float wr[WROW];
+                const f32x4* w4 = reinterpret_cast<const f32x4*>(&w_s[(ci + j) * WROW]);
+#pragma unroll
+                for (int i = 0; i < WROW / 4; ++i) {
+                    const f32x4 t = w4[i];
+                    wr[4 * i] = t.x; wr[4 * i + 1] = t.y; wr[4 * i + 2] = t.z; wr[4 * i + 3] = t.w;
+                }
 #pragma unroll
                 for (int co = 0; co < COUT; ++co)
 #pragma unroll

@@ -210,6 +210,30 @@ def test_ccl_stress_masks(kind):
     assert np.array_equal(ca.mask_to_instances(t).cpu().numpy(), mask_postprocess_c(m))
 
 
+@pytest.mark.parametrize("shape", [(17, 2048), (16, 2048), (33, 1024), (5, 8192), (7, 9000), (9, 16384), (3, 20000), (130, 700), (2, 3)])
+def test_ccl_strip_geometries_match_c_oracle(shape):
+    """The row-adjacency unions run strip by strip in LDS first (kernels_ccl.hip: 2...16 rows, as many as fit 128 KB) and only the
+    strips' first rows in the global forest: widths on both sides of every strip-height step, heights that are not a multiple of
+    the strip, the widths where no strip fits (one row = the old path)."""
+    import cellseg_amd as ca
+    from oracle.postprocess_ref import label_c, mask_postprocess_c
+    h, w = shape
+    rng = np.random.default_rng(h * 131 + w)
+    for kind in range(3):
+        if kind == 0:
+            m = rng.random((h, w)) > 0.5                       # noise: thousands of tiny components and holes
+        elif kind == 1:
+            m = np.zeros((h, w), bool)                         # vertical bars + a serpentine through every strip boundary
+            m[:, ::3] = True
+            m[::2, :] = True
+        else:
+            m = rng.random((h, w)) > 0.08                      # one giant component with small holes
+        t = torch.from_numpy(m).to(_dev())
+        assert np.array_equal(ca.label(t, 1).cpu().numpy(), label_c(m, 1)), (shape, kind, 4)
+        assert np.array_equal(ca.label(t, 2).cpu().numpy(), label_c(m, 2)), (shape, kind, 8)
+        assert np.array_equal(ca.mask_to_instances(t).cpu().numpy(), mask_postprocess_c(m)), (shape, kind)
+
+
 def test_ccl_idempotent_and_deterministic():
     import cellseg_amd as ca
     prob = torch.from_numpy(_blob_prob(2048, 7)).to(_dev())

@@ -390,3 +390,24 @@ def test_inference_after_training_steps_uses_the_updated_weights_in_every_kernel
     with torch.no_grad():
         assert torch.equal(model.eval()(probe), fresh_logits())
     assert l1 == l1 and l1 < 3.0
+
+
+def test_small_launches_take_narrower_blocks_and_stay_bitwise_identical():
+    """Launches with fewer blocks than CUs halve their channel block (SMALL_GRID_BLOCKS, csrc/kernels.h): the same kernels, the same
+    accumulation order.  A window evaluated alone (every deep layer is a small launch) equals the same window inside a batch of 24,
+    bit for bit, in eval mode (F(4x4) / F(2x2) / strided / transposed kernels) and in train mode (tape recording, F(2x2))."""
+    import cellseg_amd as ca
+    dev = _dev()
+    torch.manual_seed(5)
+    for channels in ((16, 32, 64, 128, 256), (32, 64, 128, 256, 512)):
+        model = ca.UNet(spatial_dims=2, in_channels=3, out_channels=3, channels=channels, strides=(2, 2, 2, 2), num_res_units=2).to(dev)
+        x = torch.rand(24, 3, 128, 128, device=dev)
+        for train in (False, True):
+            model.train(train)
+            with torch.no_grad():
+                big = model(x).clone()
+                for k in (0, 7, 23):
+                    one = model(x[k:k + 1])
+                    assert torch.equal(one[0], big[k]), (channels, train, k, float((one[0] - big[k]).abs().max()))
+                pair = model(x[3:5])
+                assert torch.equal(pair, big[3:5]), (channels, train)

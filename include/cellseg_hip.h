@@ -227,6 +227,37 @@ int cs_label_deflate(const int32_t* labels, int h, int w, int rows_per_strip, ui
                      uint32_t* meta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training augmentations on the device  -  replaces the per-sample work of the MONAI transform chain
+ *   SpatialPadd, RandSpatialCropd, RandAxisFlipd, RandRotate90d, RandGaussianNoised, RandAdjustContrastd,
+ *   RandGaussianSmoothd, RandHistogramShiftd, RandZoomd   (baseline/model_training_3class.py:119-162)
+ * for a whole batch, from a dataset resident in HBM.  The host draws one parameter record per sample (which transforms
+ * fire and with what values); the library does everything that touches pixels.
+ * img_arena: float32, every image [channels][src_h][src_w] (already intensity-scaled, :126) at element offset img_off;
+ * lab_arena: uint8 labels [src_h][src_w] at lab_off.  out_img: [n][channels][size][size] float32, out_lab: [n][size][size].
+ * ---------------------------------------------------------------------------------------------- */
+#define CS_AUG_MAX_TAPS 17
+typedef struct cs_aug_params {
+    int64_t img_off, lab_off;      /* element offsets of the sample inside the arenas                                         */
+    int32_t src_h, src_w;
+    int32_t pad_top, pad_left;     /* SpatialPadd: zero rows / columns in front of the image (symmetric padding's first half)   */
+    int32_t crop_y, crop_x;        /* RandSpatialCropd: window origin in the padded image                                      */
+    int32_t flip_axis;             /* RandAxisFlipd: 0 none, 1 rows, 2 columns                                                 */
+    int32_t rot_k;                 /* RandRotate90d: number of counter-clockwise quarter turns                                 */
+    float noise_std;               /* RandGaussianNoised: < 0 = off                                                            */
+    uint32_t noise_seed;
+    float gamma;                   /* RandAdjustContrastd: <= 0 = off                                                          */
+    int32_t taps_y_n, taps_x_n;    /* RandGaussianSmoothd: erf taps along rows / columns (odd counts, 0 = axis untouched)      */
+    float taps_y[CS_AUG_MAX_TAPS], taps_x[CS_AUG_MAX_TAPS];
+    int32_t hist_n;                /* RandHistogramShiftd: control points (0 = off, at most 4)                                 */
+    double hist_y[4];              /*   their images as fractions of [min, max]; the reference points are evenly spaced        */
+    float zoom;                    /* RandZoomd: <= 0 = off                                                                    */
+    int32_t zoom_h, zoom_w;        /*   size of the resampled image: floor(size * zoom)                                        */
+} cs_aug_params;
+size_t cs_augment_workspace_bytes(int n, int channels, int size);
+int cs_augment_batch(const float* img_arena, const uint8_t* lab_arena, const cs_aug_params* params_device, int n, int channels,
+                     int size, float* out_img, uint8_t* out_lab, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Connected-component post-process  -  replaces
  *   measure.label(morphology.remove_small_objects(morphology.remove_small_holes(mask), 16))
  *   (baseline/predict.py:113): 4-connected holes < 64 filled, 4-connected objects < 16 removed,

@@ -131,32 +131,58 @@ class CellDataset(Dataset):
                 "name": os.path.basename(self.files[i][0])}
 
     def _augment(self, img, lab):
-        s, rng = self.size, self.rng
-        ph, pw = max(s - img.shape[1], 0), max(s - img.shape[2], 0)
-        if ph or pw:                                                    # SpatialPad: symmetric
-            pad = ((0, 0), (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2))
-            img, lab = np.pad(img, pad), np.pad(lab, pad)
-        y0 = rng.integers(0, img.shape[1] - s + 1)
-        x0 = rng.integers(0, img.shape[2] - s + 1)
-        img, lab = img[:, y0:y0 + s, x0:x0 + s], lab[:, y0:y0 + s, x0:x0 + s]
-        if rng.random() < 0.5:
-            ax = 1 + int(rng.integers(0, 2))
-            img, lab = np.flip(img, ax), np.flip(lab, ax)
-        if rng.random() < 0.5:
-            k = int(rng.integers(1, 4))
-            img, lab = np.rot90(img, k, (1, 2)), np.rot90(lab, k, (1, 2))
-        if rng.random() < 0.25:
-            img = img + rng.normal(0.0, rng.uniform(0, 0.1), img.shape).astype(np.float32)
-        if rng.random() < 0.25:
-            lo, hi = img.min(), img.max()
-            img = ((img - lo) / (hi - lo + 1e-7)) ** rng.uniform(1, 2) * (hi - lo) + lo
-        if rng.random() < 0.25:                                         # RandGaussianSmoothd(sigma_x=(1,2)); sigma_y default (0.25,1.5)
-            img = gaussian_smooth(img, rng.uniform(1.0, 2.0), rng.uniform(0.25, 1.5))
-        if rng.random() < 0.25:                                         # RandHistogramShiftd(num_control_points=3)
-            img = histogram_shift(img, random_control_points(rng, 3))
-        if rng.random() < 0.15:                                         # RandZoomd(0.8, 1.5)
-            img, lab = zoom_keep_size(np.ascontiguousarray(img, dtype=np.float32), np.ascontiguousarray(lab), rng.uniform(0.8, 1.5))
-        return img.astype(np.float32), lab
+        return apply_params(img, lab, draw_params(self.rng, img.shape[1], img.shape[2], self.size), self.size)
+
+
+def draw_params(rng, src_h: int, src_w: int, size: int) -> dict:
+    """One sample's random decisions of the reference's transform chain (model_training_3class.py:119-162), in its order.  The same
+    record drives the host pipeline (`apply_params`, DataLoader workers) and the device pipeline (`cellseg_amd.gpu_data`,
+    csrc/kernels_augment.hip)."""
+    s = size
+    ph, pw = max(s - src_h, 0), max(s - src_w, 0)                      # SpatialPadd: symmetric
+    p = {"src_h": src_h, "src_w": src_w, "pad_top": ph // 2, "pad_left": pw // 2, "pad_h": ph, "pad_w": pw}
+    p["crop_y"] = int(rng.integers(0, src_h + ph - s + 1))
+    p["crop_x"] = int(rng.integers(0, src_w + pw - s + 1))
+    p["flip_axis"] = 1 + int(rng.integers(0, 2)) if rng.random() < 0.5 else 0
+    p["rot_k"] = int(rng.integers(1, 4)) if rng.random() < 0.5 else 0
+    if rng.random() < 0.25:                                            # RandGaussianNoised(prob 0.25, std 0.1): std ~ U(0, 0.1)
+        p["noise_std"], p["noise_seed"] = float(rng.uniform(0, 0.1)), int(rng.integers(0, 2 ** 32))
+    else:
+        p["noise_std"], p["noise_seed"] = -1.0, 0
+    p["gamma"] = float(rng.uniform(1, 2)) if rng.random() < 0.25 else 0.0
+    if rng.random() < 0.25:                                            # RandGaussianSmoothd(sigma_x=(1,2)); sigma_y default (0.25,1.5)
+        p["sigma_y"], p["sigma_x"] = float(rng.uniform(1.0, 2.0)), float(rng.uniform(0.25, 1.5))
+    else:
+        p["sigma_y"] = p["sigma_x"] = 0.0
+    p["hist"] = random_control_points(rng, 3) if rng.random() < 0.25 else None        # RandHistogramShiftd(num_control_points=3)
+    p["zoom"] = float(rng.uniform(0.8, 1.5)) if rng.random() < 0.15 else 0.0          # RandZoomd(0.8, 1.5)
+    return p
+
+
+def apply_params(img: np.ndarray, lab: np.ndarray, p: dict, size: int):
+    """The host implementation of one parameter record (numpy / scipy / torch-CPU primitives)."""
+    s = size
+    if p["pad_h"] or p["pad_w"]:
+        pad = ((0, 0), (p["pad_top"], p["pad_h"] - p["pad_top"]), (p["pad_left"], p["pad_w"] - p["pad_left"]))
+        img, lab = np.pad(img, pad), np.pad(lab, pad)
+    y0, x0 = p["crop_y"], p["crop_x"]
+    img, lab = img[:, y0:y0 + s, x0:x0 + s], lab[:, y0:y0 + s, x0:x0 + s]
+    if p["flip_axis"]:
+        img, lab = np.flip(img, p["flip_axis"]), np.flip(lab, p["flip_axis"])
+    if p["rot_k"]:
+        img, lab = np.rot90(img, p["rot_k"], (1, 2)), np.rot90(lab, p["rot_k"], (1, 2))
+    if p["noise_std"] >= 0:
+        img = img + np.random.default_rng(p["noise_seed"]).normal(0.0, p["noise_std"], img.shape).astype(np.float32)
+    if p["gamma"] > 0:
+        lo, hi = img.min(), img.max()
+        img = ((img - lo) / (hi - lo + 1e-7)) ** p["gamma"] * (hi - lo) + lo
+    if p["sigma_y"] > 0 or p["sigma_x"] > 0:
+        img = gaussian_smooth(img, p["sigma_y"], p["sigma_x"])
+    if p["hist"] is not None:
+        img = histogram_shift(img, p["hist"])
+    if p["zoom"] > 0:
+        img, lab = zoom_keep_size(np.ascontiguousarray(img, dtype=np.float32), np.ascontiguousarray(lab), p["zoom"])
+    return img.astype(np.float32), lab
 
 
 class SyntheticCells(Dataset):

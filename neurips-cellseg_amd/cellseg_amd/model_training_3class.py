@@ -46,6 +46,8 @@ def main(argv=None):
     parser.add_argument("--initial_lr", type=float, default=6e-4, help="learning rate")
     parser.add_argument("--synthetic", type=int, default=0, help="train on N seeded synthetic images instead of --data_path")
     parser.add_argument("--val_start_epoch", type=int, default=20, help="validate only after this epoch (reference: 20)")
+    parser.add_argument("--gpu_data", action="store_true", help="keep the decoded training set in HBM and run the augmentation chain there "
+                        "(cellseg_amd.gpu_data, csrc/kernels_augment.hip) instead of in DataLoader workers")
     parser.add_argument("--eager", action="store_true", help="run the training step through autograd as the reference writes it instead of "
                                                               "cellseg_amd.TrainStep (the same launches on static buffers)")
     parser.add_argument("--graph", action="store_true", help="replay the training step as a captured hipGraph (cellseg_amd.TrainStep(capture=True))")
@@ -89,9 +91,37 @@ def main(argv=None):
     if rank == 0:
         print(f"training image num: {len(train_ds)}, validation image num: {len(val_ds)}")
     sampler = torch.utils.data.distributed.DistributedSampler(train_ds, world, rank, shuffle=True, seed=args.seed) if world > 1 else None
-    train_loader = DataLoader(train_ds, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
-                              num_workers=args.num_workers, pin_memory=True, drop_last=world > 1,
-                              worker_init_fn=data.seed_worker, persistent_workers=args.num_workers > 0)
+    if args.gpu_data:
+        # the rank's share of the training set decoded once into HBM; every batch is cropped / augmented there from records the host draws
+        from cellseg_amd import gpu_data
+        if args.synthetic:
+            samples = [(train_ds[i]["img"].numpy(), train_ds[i]["label"].numpy()) for i in range(len(train_ds))]
+            dev_ds = gpu_data.DeviceCellDataset(samples, device)
+        else:
+            dev_ds = gpu_data.DeviceCellDataset.from_files(train_files, device)
+        augmenter = gpu_data.GpuAugmenter(dev_ds, args.input_size, seed=args.seed + rank)
+        if rank == 0:
+            print(f"training set resident in HBM: {len(dev_ds)} images, {dev_ds.nbytes() / 2 ** 20:.1f} MiB")
+
+        class _DeviceLoader:
+            """Epoch iterator with the DataLoader's contract for this loop: shuffled (sampler-sharded) index batches -> device tensors."""
+
+            def __iter__(self):
+                if sampler is not None:
+                    order = list(iter(sampler))
+                else:
+                    order = list(np.random.permutation(len(dev_ds)))
+                bs = args.batch_size
+                stop_at = len(order) - (len(order) % bs if world > 1 else 0)          # drop_last under data parallel, as below
+                for b in range(0, stop_at, bs):
+                    img, lab = augmenter.batch(order[b:b + bs])
+                    yield {"img": img, "label": lab}
+
+        train_loader = _DeviceLoader()
+    else:
+        train_loader = DataLoader(train_ds, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
+                                  num_workers=args.num_workers, pin_memory=True, drop_last=world > 1,
+                                  worker_init_fn=data.seed_worker, persistent_workers=args.num_workers > 0)
     val_loader = DataLoader(val_ds, batch_size=1, shuffle=False, num_workers=1)
 
     model = ca.UNet(spatial_dims=2, in_channels=3, out_channels=args.num_class, channels=(16, 32, 64, 128, 256),

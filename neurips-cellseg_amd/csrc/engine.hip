@@ -1749,6 +1749,15 @@ int cs_remove_boundary_cells(const int32_t* labels, int h, int w, int border, in
     return cs::remove_boundary_cells((hipStream_t)stream, labels, h, w, border, n_labels, out, n_out, workspace, workspace_bytes);
 }
 
+size_t cs_augment_workspace_bytes(int n, int channels, int size) { return cs::augment_workspace_bytes(n, channels, size); }
+
+int cs_augment_batch(const float* img_arena, const uint8_t* lab_arena, const cs_aug_params* params_device, int n, int channels, int size,
+                     float* out_img, uint8_t* out_lab, void* workspace, size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(img_arena && lab_arena && params_device && out_img && out_lab && workspace, "augment_batch: null argument");
+    return cs::augment_batch((hipStream_t)stream, img_arena, lab_arena, params_device, n, channels, size, out_img, out_lab, workspace,
+                             workspace_bytes);
+}
+
 size_t cs_label_deflate_workspace_bytes(int h, int w, int rows_per_strip) { return cs::label_deflate_workspace_bytes(h, w, rows_per_strip); }
 
 size_t cs_label_deflate_bound(int h, int w, int rows_per_strip) { return cs::label_deflate_bound(h, w, rows_per_strip); }

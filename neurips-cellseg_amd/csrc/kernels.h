@@ -282,6 +282,10 @@ int normalize_image(hipStream_t s, const void* img, int is_u16, int h, int w, in
 
 // ---- F1 harness pieces (kernels_metric.hip) -----------------------------------------------------
 int label_max(hipStream_t s, const int32_t* a, const int32_t* b, int64_t n, int32_t* out2);
+// kernels_augment.hip: the training augmentations of a batch, from an HBM-resident dataset
+size_t augment_workspace_bytes(int n, int c, int s);
+int augment_batch(hipStream_t st, const float* img_arena, const unsigned char* lab_arena, const ::cs_aug_params* params_dev, int n, int c, int s,
+                  float* out_img, unsigned char* out_lab, void* workspace, size_t ws_bytes);
 // kernels_deflate.hip: zlib streams of the label TIFF's strips, on the device
 size_t label_deflate_bound(int h, int w, int rps);
 size_t label_deflate_workspace_bytes(int h, int w, int rps);

@@ -24,6 +24,43 @@ def test_library_exports_every_declared_symbol():
     assert ca.lib.cs_version() >= 100
 
 
+def test_augmentation_record_layout_matches_the_c_header(tmp_path):
+    """`cs_aug_params` is filled by ctypes on the host and read by the kernels: same size and the same offset for every field (gcc)."""
+    import ctypes as C
+    import subprocess
+    from cellseg_amd import gpu_data
+    fields = [f[0] for f in gpu_data.AugParams._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cellseg_hip.h"\nint main(void) {\n  printf("%zu", sizeof(cs_aug_params));\n'
+                   + "".join(f'  printf(" %zu", offsetof(cs_aug_params, {f}));\n' for f in fields) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got[0] == C.sizeof(gpu_data.AugParams)
+    assert got[1:] == [getattr(gpu_data.AugParams, f).offset for f in fields]
+
+
+def test_draw_params_follows_the_reference_chain_and_is_reproducible():
+    """One record per sample, drawn in the order of the reference's transform list (model_training_3class.py:119-162) with its
+    probabilities; the host pipeline applies it to the crop size whatever the source size."""
+    from cellseg_amd import data
+    a = [data.draw_params(np.random.default_rng(4), 300, 200, 256) for _ in range(2)]
+    assert a[0].keys() == a[1].keys() and all(np.array_equal(a[0][k], a[1][k]) if k == "hist" else a[0][k] == a[1][k] for k in a[0])
+    rng = np.random.default_rng(0)
+    recs = [data.draw_params(rng, 300, 200, 256) for _ in range(4000)]
+    frac = lambda f: np.mean([bool(f(r)) for r in recs])          # noqa: E731
+    assert abs(frac(lambda r: r["flip_axis"]) - 0.5) < 0.03 and abs(frac(lambda r: r["rot_k"]) - 0.5) < 0.03
+    for key, prob in (("gamma", 0.25), ("sigma_y", 0.25), ("zoom", 0.15)):
+        assert abs(frac(lambda r: r[key] > 0) - prob) < 0.03, key
+    assert abs(frac(lambda r: r["noise_std"] >= 0) - 0.25) < 0.03 and abs(frac(lambda r: r["hist"] is not None) - 0.25) < 0.03
+    assert all(r["pad_w"] == 56 and r["pad_left"] == 28 and r["pad_h"] == 0 and 0 <= r["crop_y"] <= 44 and r["crop_x"] == 0 for r in recs)
+    assert all(1.0 <= r["gamma"] < 2.0 for r in recs if r["gamma"] > 0) and all(0.8 <= r["zoom"] < 1.5 for r in recs if r["zoom"] > 0)
+    img, lab = np.random.default_rng(1).random((3, 300, 200), dtype=np.float32), np.ones((1, 300, 200), np.uint8)
+    for r in recs[:40]:
+        oi, ol = data.apply_params(img, lab, r, 256)
+        assert oi.shape == (3, 256, 256) and ol.shape == (1, 256, 256) and oi.dtype == np.float32 and ol.dtype == np.uint8
+
+
 @pytest.mark.parametrize("hw", [(4096, 4096), (1024, 1000), (512, 512), (200, 200), (256, 300), (257, 255), (2000, 333)])
 @pytest.mark.parametrize("overlap", [0.25, 0.5, 0.0])
 def test_plan_matches_oracle_tiler(hw, overlap):

@@ -59,4 +59,13 @@ for b in range(160, 960, 8):
     loss.item()                                    # the reference loop reads the loss every step (model_training_3class.py:263)
 dt = time.perf_counter() - t0
 out["training_loop_batch_8_with_loss_item"] = {"images_per_s": round(800 / dt), "ms_per_step": round(dt / 100 * 1e3, 3)}
+acc = torch.zeros((), dtype=torch.float64, device=dev)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for b in range(160, 960, 8):
+    img, lab = aug.batch(order[b:b + 8])
+    acc += step(img, ca.one_hot(lab, 3)).double()   # what cellseg_amd.model_training_3class does: the epoch's sum stays on the device
+acc.item()
+dt = time.perf_counter() - t0
+out["training_loop_batch_8_loss_summed_on_device"] = {"images_per_s": round(800 / dt), "ms_per_step": round(dt / 100 * 1e3, 3)}
 print(json.dumps(out, indent=1))

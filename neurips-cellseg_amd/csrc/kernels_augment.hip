@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void aug_gather_kernel(const float* img_arena,
 // min / max of a sample's image: one block per sample, result in stats[sample] = (min, max)
 __global__ __launch_bounds__(1024) void aug_minmax_kernel(const float* img, const AugParams* params, int which, int count, float2* stats) {
     const AugParams& p = params[blockIdx.x];
-    if (which == 0 ? !(p.gamma > 0.f) : p.hist_n == 0) return;
+    if (which == 0 ? !(p.gamma > 0.f) : p.hist_n < 2) return;
     __shared__ float lo_s[16], hi_s[16];
     const float* a = img + (size_t)blockIdx.x * count;
     float lo = INFINITY, hi = -INFINITY;
@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256) void aug_gamma_kernel(float* img, const AugPar
 template <int AXIS>   // 0: along y (sigma_y taps), 1: along x
 __global__ __launch_bounds__(256) void aug_smooth_kernel(const float* src, float* dst, const AugParams* params, int c, int s) {
     const AugParams& p = params[blockIdx.y];
-    const int nt = AXIS == 0 ? p.taps_y_n : p.taps_x_n;
-    if (p.taps_y_n == 0 && p.taps_x_n == 0) return;                  // smoothing does not fire: the data stays where it is
+    const int nt_raw = AXIS == 0 ? p.taps_y_n : p.taps_x_n;
+    const int nt = nt_raw > CS_AUG_MAX_TAPS ? CS_AUG_MAX_TAPS : (nt_raw < 0 ? 0 : nt_raw);   // (records come from the host: never index past the arrays)
+    if (p.taps_y_n <= 0 && p.taps_x_n <= 0) return;                  // smoothing does not fire: the data stays where it is
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= c * s * s) return;
     const size_t base = (size_t)blockIdx.y * c * s * s;
@@ -140,12 +141,12 @@ __global__ __launch_bounds__(256) void aug_smooth_kernel(const float* src, float
 // stage 4: histogram shift, in place: np.interp(x, ref * (hi - lo) + lo, floating * (hi - lo) + lo) in fp64, ref = linspace(0, 1, n)
 __global__ __launch_bounds__(256) void aug_hist_kernel(float* img, const AugParams* params, int count, const float2* stats) {
     const AugParams& p = params[blockIdx.y];
-    if (p.hist_n == 0) return;
+    if (p.hist_n < 2) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     const float lo = stats[blockIdx.y].x, hi = stats[blockIdx.y].y;
     const double range = (double)(hi - lo), lod = (double)lo;
-    const int n = p.hist_n;
+    const int n = p.hist_n > 4 ? 4 : p.hist_n;
     float* a = img + (size_t)blockIdx.y * count;
     const double x = (double)a[i];
     double xp0 = lod, fp0 = (double)p.hist_y[0] * range + lod, r = fp0;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void aug_zoom_kernel(const float* src, const u
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= s * s) return;
     const size_t ibase = (size_t)blockIdx.y * c * s * s, lbase = (size_t)blockIdx.y * s * s;
-    if (!(p.zoom > 0.f)) {
+    if (!(p.zoom > 0.f) || p.zoom_h <= 0 || p.zoom_w <= 0) {
         for (int ch = 0; ch < c; ++ch) out[ibase + (size_t)ch * s * s + i] = src[ibase + (size_t)ch * s * s + i];
         lab_out[lbase + i] = lab_src[lbase + i];
         return;
@@ -185,8 +186,10 @@ __global__ __launch_bounds__(256) void aug_zoom_kernel(const float* src, const u
     zy = zy < 0 ? 0 : (zy > oh - 1 ? oh - 1 : zy);
     zx = zx < 0 ? 0 : (zx > ow - 1 ? ow - 1 : zx);
     // adaptive average: rows [floor(zy * s / oh), ceil((zy + 1) * s / oh)), torch's float formulas
-    const int y0 = (int)floorf((float)(zy * s) / (float)oh), y1 = (int)ceilf((float)((zy + 1) * s) / (float)oh);
-    const int x0 = (int)floorf((float)(zx * s) / (float)ow), x1 = (int)ceilf((float)((zx + 1) * s) / (float)ow);
+    int y0 = (int)floorf((float)(zy * s) / (float)oh), y1 = (int)ceilf((float)((zy + 1) * s) / (float)oh);
+    int x0 = (int)floorf((float)(zx * s) / (float)ow), x1 = (int)ceilf((float)((zx + 1) * s) / (float)ow);
+    y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0; y1 = y1 > s ? s : y1; x1 = x1 > s ? s : x1;
+    // (floor / ceil of exact small-integer quotients: always inside [0, s]; the clamps only guard against a malformed record)
     const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
     for (int ch = 0; ch < c; ++ch) {
         const float* a = src + ibase + (size_t)ch * s * s;

@@ -92,8 +92,15 @@ def main(argv=None):
             preprocess.save_image(join(args.output_path, "overlay_" + img_name), preprocess.overlay_boundaries(img_data, labels))
 
     def read(k):
+        """Reader thread: decode, and stage integer images in PINNED memory so that the main thread's upload is an asynchronous 2 ms
+        DMA instead of a synchronous 10 ms copy out of pageable memory (50 MB for a 4096^2 RGB image)."""
         try:
-            return preprocess.read_image(join(args.input_path, img_names[k]))
+            img = preprocess.read_image(join(args.input_path, img_names[k]))
+            staged = None
+            if img.dtype in (np.uint8, np.uint16) and img.ndim in (2, 3):
+                flat = np.ascontiguousarray(img)
+                staged = torch.from_numpy(flat.view(np.int16) if flat.dtype == np.uint16 else flat).pin_memory()
+            return img, staged
         except Exception as e:                                   # one undecodable file must not end the run (reader thread)
             return e
 
@@ -102,12 +109,13 @@ def main(argv=None):
     with torch.no_grad():
         for pos, k in enumerate(todo):
             img_name = img_names[k]
-            img_data = nxt.result()
+            got = nxt.result()
             nxt = reader.submit(read, todo[pos + 1]) if pos + 1 < len(todo) else None
-            if isinstance(img_data, Exception):
-                print(f"Prediction FAILED: {img_name}: {img_data}")
+            if isinstance(got, Exception):
+                print(f"Prediction FAILED: {img_name}: {got}")
                 failed.append(img_name)
                 continue
+            img_data, staged = got
             t0 = time.time()
             if img_data.ndim not in (2, 3) or (img_data.ndim == 3 and img_data.shape[-1] < 3):
                 print(f"Prediction FAILED: {img_name}: unsupported image shape {img_data.shape} ({img_data.dtype})")
@@ -115,8 +123,7 @@ def main(argv=None):
                 continue
             if img_data.dtype in (np.uint8, np.uint16):
                 # integer images: percentile normalisation on the device (bit-exact with the host path below)
-                raw = torch.from_numpy(np.ascontiguousarray(img_data).view(np.int16) if img_data.dtype == np.uint16 else np.ascontiguousarray(img_data))
-                x = preprocess.normalize_image_gpu(raw.to(device))                             # [H,W,3] float32
+                x = preprocess.normalize_image_gpu(staged.to(device, non_blocking=True))      # [H,W,3] float32
                 shape = tuple(x.shape)
             else:
                 pre_img_data = preprocess.prepare_image(img_data)

@@ -134,11 +134,11 @@ def cpu_baseline(size, roi, overlap, channels, seed):
     t_reps = []
     with torch.no_grad():
         sliding_window_inference_ref(img[:, :, :roi, :roi], (roi, roi), 4, net, overlap)          # warm up
-        while sum(t_reps) < 3.0 or len(t_reps) < 3:                                               # >= 3 s of windows, >= 3 repeats
+        while sum(t_reps) < 10.0 or len(t_reps) < 3:                                              # >= 10 s of windows, >= 3 repeats
             t0 = time.perf_counter()
             logits = sliding_window_inference_ref(img, (roi, roi), 4, net, overlap)
             t_reps.append(time.perf_counter() - t0)
-            if len(t_reps) >= 12:
+            if len(t_reps) >= 24:
                 break
     t_net = sorted(t_reps)[len(t_reps) // 2]                                                      # median repeat
     prob = softmax_interior_ref(logits[0].numpy())
@@ -160,6 +160,51 @@ def cpu_baseline(size, roi, overlap, channels, seed):
         out["skimage_chain_s"] = round(t_sk, 3)
         out["sample"] += f"; value_skimage_chain replaces the C oracle by real scikit-image 0.18.3 remove_small_holes/objects + label on the same mask ({t_sk:.2f}s, {CONDA_PY})"
     return out
+
+
+def _median_seconds(fn, min_s, min_reps=3, max_reps=12):
+    ts = []
+    while (sum(ts) < min_s or len(ts) < min_reps) and len(ts) < max_reps:
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2], len(ts), sum(ts)
+
+
+def cpu_baseline_tiles_and_train(seed):
+    """BASELINE.md 3 (i) and (iv) on the host cores beside the GPU legs: the oracle net's forward on N x 3 x 256 x 256 tiles (N = 4:
+    the reference's sw_batch_size; N = 32: configs[1]) and one oracle training step (forward + DiceCE + backward + AdamW,
+    oracle/train_ref.py) at batch 8, for the BASELINE.json width (32...512) and the reference's own (16...256)."""
+    from oracle.train_ref import dice_ce_ref, one_hot_ref
+    from oracle.unet_ref import make_reference_unet
+    threads = effective_cpus()
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(seed)
+    x32 = torch.rand(32, 3, 256, 256, generator=g)
+    y8 = torch.randint(0, 3, (8, 1, 256, 256), generator=g)
+    tiles, train = {}, {}
+    for wname in ("baseline32", "reference16"):
+        net = make_reference_unet(seed, channels=WIDTHS[wname]).eval()
+        with torch.no_grad():
+            net(x32[:1])                                                                        # warm up
+            for n, min_s in ((4, 1.0), (32, 2.0)):
+                t, reps, total = _median_seconds(lambda: net(x32[:n]), min_s)
+                tiles[f"{wname}_n{n}"] = {"value": round(n * 65536 / 1e6 / t, 3), "unit": "Mpixels/s (tile pixels, forward only)",
+                                          "ms": round(t * 1e3, 2), "reps": reps, "timed_s": round(total, 2)}
+        net.train()
+        opt = torch.optim.AdamW(net.parameters(), 6e-4)
+
+        def one_step():
+            opt.zero_grad()
+            loss = dice_ce_ref(net(x32[:8]), one_hot_ref(y8, 3))
+            loss.backward()
+            opt.step()
+
+        one_step()
+        t, reps, total = _median_seconds(one_step, 3.0, min_reps=3, max_reps=6)
+        train[wname] = {"images_per_s": round(8 / t, 2), "ms_per_step": round(t * 1e3, 1), "batch": 8, "reps": reps, "timed_s": round(total, 2)}
+    note = (f"torch-CPU oracle (oracle/unet_ref.py, oracle/train_ref.py), {threads} threads, fp32, seeded uniform tiles; median of the repeats")
+    return {"tiles": dict(tiles, cores=threads, kind="port", note=note), "train_step": dict(train, cores=threads, kind="port", note=note)}
 
 
 def lowprec_accuracy(dev, steps=150, n_images=2, size=1024, precisions=("fp16x3", "bf16x6", "bf16", "fp8"), seed=7):
@@ -294,10 +339,11 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="internal streams the window chunks are dealt to (1 = serial)")
     ap.add_argument("--precision", choices=sorted(MFMA_PEAK), default="fp32",
                     help="matrix-core arithmetic of the convolutions")
-    ap.add_argument("--shard", choices=["slides", "strips"], default="slides",
-                    help="headline multi-GPU partition: one slide per rank (weak scaling, no collective) or ONE slide cut into row "
-                         "strips with an all-gather of the uint8 mask strips before the connected-component pass (strong scaling); "
-                         "the other partition is reported as a secondary object")
+    ap.add_argument("--shard", choices=["slides", "strips"], default=None,
+                    help="headline multi-GPU partition: ONE slide split by window rows over the ranks with the seam exchange and the "
+                         "all-gather of the uint8 mask strips before the connected-component pass (strong scaling; the default for "
+                         "--gpus N > 1: north_star's '>= 6x at 8 GPUs' is about one WSI) or one slide per rank (weak scaling, no "
+                         "collective); the other partition is reported as a secondary object")
     ap.add_argument("--strip-batch", type=int, default=64, help="engine batch of the strips leg (a rank holds ~1/N of the windows; smaller "
                                                                 "chunks keep both internal streams busy)")
     ap.add_argument("--train-batch", type=int, default=32, help="tiles per GPU of the training step (BASELINE configs[1]/[3]: 32)")
@@ -315,6 +361,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.shard is None:
+        args.shard = "strips" if world > 1 else "slides"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the hot path")
     # BENCH_DEVICE / BENCH_BACKEND exist only to exercise the multi-rank code path on a 1-GPU box (ranks share cuda:0, gloo)
@@ -389,8 +437,14 @@ def main():
 
     no_labels, no_num = torch.zeros((1, 1), dtype=torch.int32, device=dev), torch.zeros((), dtype=torch.int32, device=dev)
 
+    # before the strips leg: a 1 KB ring of batched send/recv; when the library's point-to-point path fails the seam halves go
+    # through one all-gather instead (reported as seam_transport) - the job does not end there
+    seam_transport = None
+    if dist is not None:
+        seam_transport = os.environ.get("BENCH_SEAM_TRANSPORT") or ("p2p" if parallel.p2p_selfcheck(dev) else "allgather")
+
     def seam_exchange(win, pl, r, w):
-        return parallel.exchange_seam(win, pl, r, w)
+        return parallel.exchange_seam(win, pl, r, w, transport=seam_transport or "p2p")
 
     def make_step(model, strips, d2h, cc_overlap=True, sim=None):
         imgs = slide_pair(strips)
@@ -440,13 +494,14 @@ def main():
             def fake_exchange(win, pl, rr, ww):
                 me = ca.strip_partition(pl, rr, ww)
                 for src, dst, j, r0 in parallel.seam_transfers(pl, ww):
-                    if dst == rr:
-                        win[j - me.halo_begin, :, r0:].copy_(win[me.win_row_end - 1 - me.halo_begin, :, r0:].contiguous())
+                    if dst == rr:                # pack (sender's side, stood in for locally), a device-local copy in place of the link, unpack
+                        win[j - me.halo_begin, :, r0:].copy_(win[me.win_row_end - 1 - me.halo_begin, :, r0:].contiguous().clone())
                     elif src == rr:
-                        win[j - me.halo_begin, :, r0:].contiguous()
+                        win[j - me.halo_begin, :, r0:].contiguous().clone()
             ca.swi_infer_strip(model, image, roi, args.overlap, r, w, engine_batch=args.strip_batch, streams=args.streams,
                                exchange=fake_exchange)
-            return labelled(full_mask) if r == 0 else (no_labels, no_num)
+            gathered = full_mask.clone()         # a device-local copy of the gathered mask's size in place of the all-gather
+            return labelled(gathered) if r == 0 else (no_labels, no_num)
 
         inner = step_sim if sim else (step_strips if (strips and dist is not None) else step_slide)
         if not d2h:
@@ -562,7 +617,43 @@ def main():
                 "ms_per_slide": worst, "full_slide_ms": round(full_s * 1e3, 3), "ratio": round(full_s * 1e3 / worst, 3),
                 "note": "one GPU doing one rank's share of the 8-rank strips leg (its windows, the seam pack / unpack copies, its finalize; "
                         "rank 0 also the CC pass over a full mask on the CC stream); ms_per_slide = the slower of the simulated ranks; the seam "
-                        "transfer (12 MB over one xGMI link) and the 2 MB-per-rank mask all-gather are not included"}
+                        "transfer (12 MB over one xGMI link) and the mask all-gather (16 MB gathered) are stood in for by device-local copies of "
+                        "the same sizes, so `ratio` is an UPPER bound of the 8-GPU speed-up: link latency, RCCL launch cost and rank skew are not in it"}
+
+    def measure_tiles(width, precision, n, k=20):
+        """SURVEY.md 8(d) 'tile throughput': forward-only U-Net on N x 3 x 256 x 256 synthetic tiles (the predictor call of
+        model_training_3class.py:255 / :291), logits left in HBM; Mpixels/s of tile pixels + the dominant kernel's roofline."""
+        model = make_model(WIDTHS[width], seed).to(dev)
+        model.precision = precision
+        x = torch.rand(n, 3, 256, 256, generator=torch.Generator().manual_seed(seed)).to(dev)
+        with torch.no_grad():
+            for _ in range(3):
+                model(x)
+            dt, _ = time_steps(lambda: model(x), k, barrier)
+            _lib.lib.cs_prof_reset()
+            _lib.lib.cs_prof_enable(1)
+            time_steps(lambda: model(x), k, barrier)
+            _lib.lib.cs_prof_enable(0)
+            prof = _lib.prof_collect()
+        ms = dt / k * 1e3
+        return {"value": round(n * 65536 / 1e6 / (dt / k), 1), "unit": "Mpixels/s (tile pixels, forward only)", "ms_per_forward": round(ms, 4),
+                "tiles": n, "tflops": round(n * WINDOW_GFLOP[width] / ms, 2), "roofline": roofline({"prof": prof}, precision)}
+
+    def measure_configs4():
+        """BASELINE.json configs[4] on ONE GPU as a child process of this bench (its own slide size, window and net): 64...1024 U-Net,
+        512 x 512 windows, fp8 weights / e4m3-staged activations, one 8192 x 8192 slide, 3 timed steps."""
+        cmd = [sys.executable, os.path.abspath(__file__), "--precision", "fp8", "--width", "deep64", "--roi", "512", "--size", "8192",
+               "--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline"]
+        try:
+            cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                                env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_FORCE_DIST")})
+            line = json.loads(cp.stdout.strip().splitlines()[-1])
+        except (subprocess.SubprocessError, ValueError, IndexError, OSError) as e:
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+        return {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "value_device", "roofline") if k in line} | {
+            "workload": line["config"]["workload"], "windows": line["config"]["windows"],
+            "kernels": dict(list(line["kernels"].items())[:8]),
+            "note": "python bench.py --precision fp8 --width deep64 --roi 512 --size 8192 --steps 3 --warmup 1 as a child process on the same GPU"}
 
     def infer_summary(res, strips):
         slides = 1 if strips else world
@@ -645,7 +736,8 @@ def main():
                "global_batch": world * b, "per_gpu_batch": b, "width": list(WIDTHS[width]),
                "dtype": {"fp32": "f32", "fp16x3": "f32-grade split fp16 (2 planes x 3 terms): forward convolutions and 3x3 weight gradients on "
                                                    "v_mfma_f32_16x16x32_f16, data gradients f32",
-                         "bf16": "bf16 forward convolutions and 3x3 weight gradients (fp32 activations, data gradients and master weights)"
+                         "bf16": "bf16 forward convolutions, weight gradients and data gradients (v_mfma_f32_16x16x32_bf16; fp32 activations on the tape, fp32 "
+                                 "norm / loss / optimiser arithmetic and master weights)"
                          }.get(precision, f"{precision} forward convolutions (fp32 activations), f32 backward"),
                "loss": round(float(loss.item()), 5), "grad_bucket_bytes": int(model.flat_grad.numel() * 4),
                "allreduce_ms": allreduce_ms,
@@ -703,16 +795,18 @@ def main():
             dist.destroy_process_group()
         return
 
-    def roofline(res):
+    def roofline(res, precision=None):
         prof = res.get("prof")
         if not prof:
             return None
+        precision = precision or args.precision
         name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
         mfma = k["flops"] > 0 and ("mfma" in name or "wino" in name)
         sec = k["ms"] / 1e3
         if mfma:
             achieved = k["flops"] / sec / 1e12
-            peak = round(MFMA_PEAK[args.precision], 1)
+            # the fp32 Winograd / direct kernels run on the fp32 matrix instruction whatever the mode of the other layers
+            peak = round(MFMA_PEAK["fp32" if ("wino" in name or precision == "fp32") else precision], 1)
             rl = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                   "frac": round(achieved / peak, 4), "traffic": None}
         else:
@@ -796,7 +890,8 @@ def main():
         "roofline": roofline(main_res),
         "kernels": kernel_table(main_res),
     }
-    strips_info = {"window_rows_per_rank": [st.win_row_end - st.win_row_begin for st in strip_parts],
+    strips_info = {"seam_transport": seam_transport,
+                   "window_rows_per_rank": [st.win_row_end - st.win_row_begin for st in strip_parts],
                    "windows_per_rank": [(st.win_row_end - st.win_row_begin) * plan.n_w for st in strip_parts],
                    "output_rows_per_rank": [st.row_end - st.row_begin for st in strip_parts], "strip_batch": args.strip_batch,
                    "equal_to_single_gpu_labels": strips_equal}
@@ -836,8 +931,17 @@ def main():
     if train_ref:
         out["train_step_reference"] = dict(train_ref, note="the reference's own training setting: channels 16...256, batch 8 x 3 x 256 x 256 "
                                                             "(baseline/model_training_3class.py:201-208, 247-267)")
+    if world == 1 and dist is None and not args.no_secondary and args.width in WINDOW_GFLOP and args.roi == 256:
+        # forward-only tile throughput (N = 8: configs[0]'s batch, N = 32: configs[1]'s), exact fp32 and the bf16 datapath
+        out["tiles"] = {prec: {f"n{n}": measure_tiles(args.width, prec, n) for n in (8, 32)} for prec in ("fp32", "bf16")}
+        out["tiles"]["note"] = ("forward-only U-Net on N x 3 x 256 x 256 synthetic tiles (torch.rand, seed 2022), logits left in HBM; value = tile "
+                                "pixels / time; roofline = the dominant kernel of that forward (HIP events on the launch stream)")
+        if args.precision == "fp32" and args.size == 4096:
+            out["configs4_fp8"] = measure_configs4()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.overlap, WIDTHS[args.width], seed)
+        if not args.no_secondary:
+            out["cpu_baseline"].update(cpu_baseline_tiles_and_train(seed))
     print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

@@ -84,18 +84,80 @@ def seam_transfers(plan, world: int) -> List[Tuple[int, int, int, int]]:
     return out
 
 
-def exchange_seam(win: torch.Tensor, plan, rank: int, world: int, group=None) -> int:
+def p2p_selfcheck(device, group=None) -> bool:
+    """A 1 KB ring of batched point-to-point calls (every rank sends to rank + 1, receives from rank - 1): True when it completes
+    and the payload arrives.  `bench.py` runs it before the strips leg so that a point-to-point failure of the collective library
+    shows up here, and the seam exchange then takes its all-gather transport instead of ending the job.  Collective: every rank
+    calls it; the verdict is agreed over the group (one failing rank switches all of them)."""
+    import torch.distributed as dist
+    if not _collectives_on(group):
+        return True
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ok = 1
+    if world > 1:
+        try:
+            bounce = dist.get_backend(group) == "gloo"
+            dev = torch.device("cpu") if bounce else device
+            out = torch.full((256,), float(rank), dtype=torch.float32, device=dev)
+            inp = torch.full((256,), -1.0, dtype=torch.float32, device=dev)
+            ops = [dist.P2POp(dist.isend, out, (rank + 1) % world, group), dist.P2POp(dist.irecv, inp, (rank - 1) % world, group)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if inp.is_cuda:
+                torch.cuda.synchronize(inp.device)
+            ok = int(bool((inp == float((rank - 1) % world)).all().item()))
+        except Exception:                                           # noqa: BLE001  (any failure of the library = "use the other transport")
+            ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if dist.get_backend(group) == "gloo" else device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
+def exchange_seam(win: torch.Tensor, plan, rank: int, world: int, group=None, transport: str = "p2p") -> int:
     """Seam exchange of the window-row partition ("exchange seam partial sums with one neighbour send/recv").
     win: this rank's window logits [(win_row_end - halo_begin), n_w, roi_h, roi_w, C] with its own rows behind the halo slots
     (``inferers.swi_infer_strip``).  Sends the lower part of its last window row(s) to the rank(s) below and receives its halo
-    from the rank above: batched point-to-point (RCCL send/recv over the direct xGMI link of the pair; 12 MB per seam at 4096^2 /
-    stride 128).  Returns the number of transfers this rank took part in."""
+    from the rank above.  transport "p2p": batched point-to-point (RCCL send/recv over the direct xGMI link of the pair; 12 MB per
+    seam at 4096^2 / stride 128).  transport "allgather": the same halves through ONE all-gather of equally sized slots (every
+    rank contributes the halves it owes, zero padded; a receiver copies its halves out of the sender's slot) - world x the bytes,
+    for a collective library whose point-to-point path fails (``p2p_selfcheck``).  Returns the number of transfers this rank
+    took part in."""
     import torch.distributed as dist
     from .inferers import strip_partition
+    if transport not in ("p2p", "allgather"):
+        raise ValueError(f"exchange_seam: unknown transport {transport!r}")
     me = strip_partition(plan, rank, world)
+    transfers = [t for t in seam_transfers(plan, world) if t[0] != t[1]]
+    if transport == "allgather":
+        if not transfers or not _collectives_on(group):
+            return 0
+        bounce = _host_bounce(win, group)
+        numel = lambda r0: plan.n_w * (plan.roi_h - r0) * plan.roi_w * win.shape[-1]      # noqa: E731
+        # slot layout, identical on every rank: the transfers of one source back to back, in seam_transfers order
+        offs, fill = {}, [0] * world
+        for src, dst, j, r0 in transfers:
+            offs[(src, dst, j)] = fill[src]
+            fill[src] += numel(r0)
+        slot = max(fill)
+        mine = torch.zeros(slot, dtype=win.dtype, device="cpu" if bounce else win.device)
+        n = 0
+        for src, dst, j, r0 in transfers:
+            if src == rank:
+                view = win[j - me.halo_begin, :, r0:]
+                mine[offs[(src, dst, j)]: offs[(src, dst, j)] + view.numel()].copy_(view.reshape(-1))
+                n += 1
+        out = mine.new_empty(world * slot)
+        dist.all_gather_into_tensor(out, mine, group=group)
+        for src, dst, j, r0 in transfers:
+            if dst == rank:
+                view = win[j - me.halo_begin, :, r0:]
+                o = src * slot + offs[(src, dst, j)]
+                view.copy_(out[o: o + view.numel()].view(view.shape), non_blocking=True)
+                n += 1
+        return n
     ops, landing = [], []
-    for src, dst, j, r0 in seam_transfers(plan, world):
-        if rank not in (src, dst) or src == dst:
+    for src, dst, j, r0 in transfers:
+        if rank not in (src, dst):
             continue
         view = win[j - me.halo_begin, :, r0:]                       # [n_w, roi_h - r0, roi_w, C]: contiguous per window
         if rank == src:
@@ -131,10 +193,15 @@ def sync_gradients(model, group=None, reduce: bool = True, rebind: bool = True) 
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
             flat.copy_(host)
+            if world > 1:
+                flat.mul_(1.0 / world)
+        elif dist.get_backend(group) == "nccl":
+            # RCCL divides inside the reduction: one call, no separate scaling launch behind it (AVG at world size 1 is the identity)
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if world > 1:
-            flat.mul_(1.0 / world)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)      # gloo has no AVG
+            if world > 1:
+                flat.mul_(1.0 / world)
     if not rebind:
         return
     for key, p in model.named_parameters():

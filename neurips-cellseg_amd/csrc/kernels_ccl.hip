@@ -328,13 +328,19 @@ int forest(hipStream_t s, const uint8_t* m, int want, int h, int w, int conn, co
         int rows = 1;
         while (rows < 16 && 2 * rows * w <= CCL_STRIP_PIXELS && 2 * rows <= h) rows *= 2;
         if (rows > 1) {
-            static const bool lds_ok = [] {
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl_merge_local_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           CCL_STRIP_PIXELS * 4) == hipSuccess &&
-                       hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl_merge_local_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           CCL_STRIP_PIXELS * 4) == hipSuccess;
-            }();
-            CS_REQUIRE(lds_ok, "ccl: the strip kernel could not reserve %d bytes of LDS", CCL_STRIP_PIXELS * 4);
+            // the > 64 KB dynamic-LDS opt-in is an attribute of the function ON THE CURRENT DEVICE: remembered per device
+            static unsigned long long lds_set = 0ull;
+            int dev = 0;
+            CS_HIP(hipGetDevice(&dev));
+            CS_REQUIRE(dev >= 0 && dev < 64, "ccl: device index %d out of range", dev);
+            if (!((lds_set >> dev) & 1ull)) {
+                const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl_merge_local_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    CCL_STRIP_PIXELS * 4) == hipSuccess &&
+                                hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl_merge_local_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    CCL_STRIP_PIXELS * 4) == hipSuccess;
+                CS_REQUIRE(ok, "ccl: the strip kernel could not reserve %d bytes of LDS on device %d", CCL_STRIP_PIXELS * 4, dev);
+                lds_set |= 1ull << dev;
+            }
             const dim3 gl((unsigned)ceil_div(h, rows));
             const size_t lds = (size_t)rows * w * sizeof(int);
             if (conn == 8) hipLaunchKernelGGL((ccl_merge_local_kernel<8>), gl, dim3(1024), lds, s, m, want, h, w, ws.L, rows);

@@ -1473,6 +1473,7 @@ int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int
     PackJob jb{};
     jb.transposed = dgrad ? 1 : 0; jb.flip = dgrad ? 1 : 0;
     jb.src = w; jb.dst = packed; jb.kind = PK_WINO4; jb.cout = cout; jb.cin = cin; jb.ntile_total = cout / 16;
+    jb.f16 = wino4_layout32(cin, cout) ? 1 : 0;      // (field reused) 1: the 32x32x2 fragment order of kernels_conv_wino4x.hip
     return pack_submit(pc, s, jb);
 }
 

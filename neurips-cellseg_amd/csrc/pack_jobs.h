@@ -177,17 +177,33 @@ __device__ __forceinline__ void pack_wino_elem(const PackJob& jb, int64_t e) {
     reinterpret_cast<float*>(jb.dst)[(((size_t)chunk * 16 + pos) * jb.ntile_total + ntl) * 256 + lane * 4 + j] = (float)u;
 }
 
-// Winograd F(4x4, 3x3) weights U = G g G^T (6 x 6 positions, fp64, rounded once) in fp32 MFMA fragment order (kernels_conv_wino4.hip):
-// packed[chunk][position xi*6+nu][ntile_total][lane][j]: cout = ntile*16 + (lane & 15), cin = chunk*16 + 4*(lane>>4) + j.
+// Winograd F(4x4, 3x3) weights U = G g G^T (6 x 6 positions, fp64, rounded once) in fp32 MFMA fragment order:
+//   jb.f16 == 0 (kernels_conv_wino4.hip, 16x16x4): packed[chunk][position xi*6+nu][ntile_total][lane][j],
+//                cout = ntile*16 + (lane & 15), cin = chunk*16 + 4*(lane>>4) + j;
+//   jb.f16 == 1 (kernels_conv_wino4x.hip, 32x32x2): packed[chunk][position][cout/32][u 2][lane][j],
+//                cout = nt32*32 + (lane & 31), cin = chunk*16 + 2*(4u + j) + (lane>>5)  (k-step 4u + j of the chunk).
 __device__ __forceinline__ void pack_wino4_elem(const PackJob& jb, int64_t e) {
     const int cout = jb.cout, cin = jb.cin;
     const int j = e & 3, lane = (e >> 2) & 63;
     int64_t r = e >> 8;
-    const int ntl = r % (cout / 16);
-    r /= (cout / 16);
-    const int pos = (int)(r % 36);
-    const int chunk = (int)(r / 36);
-    const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
+    int co, ci, pos, chunk;
+    if (jb.f16) {
+        const int u = (int)(r & 1);
+        r >>= 1;
+        const int nt32 = (int)(r % (cout / 32));
+        r /= (cout / 32);
+        pos = (int)(r % 36);
+        chunk = (int)(r / 36);
+        co = nt32 * 32 + (lane & 31);
+        ci = chunk * 16 + 2 * (4 * u + j) + (lane >> 5);
+    } else {
+        const int ntl = (int)(r % (cout / 16));
+        r /= (cout / 16);
+        pos = (int)(r % 36);
+        chunk = (int)(r / 36);
+        co = ntl * 16 + (lane & 15);
+        ci = chunk * 16 + 4 * (lane >> 4) + j;
+    }
     // transposed + flip = the data-gradient convolution of the same tensor (channel roles swapped, taps reversed)
     const float* src = jb.transposed ? jb.src + ((size_t)ci * cout + co) * 9 : jb.src + ((size_t)co * cin + ci) * 9;
     const int xi = pos / 6, nu = pos - xi * 6;
@@ -210,7 +226,8 @@ __device__ __forceinline__ void pack_wino4_elem(const PackJob& jb, int64_t e) {
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) u += ga[a] * (double)src[jb.flip ? 8 - (a * 3 + b) : a * 3 + b] * gb[b];
-    reinterpret_cast<float*>(jb.dst)[(((size_t)chunk * 36 + pos) * jb.ntile_total + ntl) * 256 + lane * 4 + j] = (float)u;
+    // both orders are a permutation of the same element range: the flattened element index IS the destination
+    reinterpret_cast<float*>(jb.dst)[e] = (float)u;
 }
 
 }  // namespace cs

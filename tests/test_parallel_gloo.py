@@ -148,7 +148,7 @@ def test_window_row_partition_covers_every_pixel_once(world, h, overlap):
         assert [(s, d) for s, d, _, _ in transfers] == [(r, r + 1) for r in range(7)] and all(r0 == 128 for *_, r0 in transfers)
 
 
-def _seam_worker(rank, world, port, h, overlap, q):
+def _seam_worker(rank, world, port, h, overlap, q, transport="p2p"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -162,8 +162,8 @@ def _seam_worker(rank, world, port, h, overlap, q):
         me = ca.strip_partition(plan, rank, world)
         win = torch.full((me.win_row_end - me.halo_begin, plan.n_w, roi, roi, 3), float("nan"))
         win[me.win_row_begin - me.halo_begin:] = every[me.win_row_begin:me.win_row_end]
-        n = parallel.exchange_seam(win, plan, rank, world)
-        ok = True
+        ok = parallel.p2p_selfcheck(torch.device("cpu"))                      # the 1 KB ring bench.py runs before the strips leg
+        n = parallel.exchange_seam(win, plan, rank, world, transport=transport)
         for j in range(me.halo_begin, me.win_row_begin):
             r0 = max(0, me.row_begin + plan.pad_top - hs[j])
             ok &= bool(torch.equal(win[j - me.halo_begin, :, r0:], every[j, :, r0:]))
@@ -176,12 +176,15 @@ def _seam_worker(rank, world, port, h, overlap, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["p2p", "allgather"])
 @pytest.mark.parametrize("world,h,overlap", [(2, 200, 0.5), (3, 200, 0.5), (3, 171, 0.25), (4, 97, 0.5), (1, 120, 0.5)])
-def test_seam_exchange_and_unequal_strip_gather(world, h, overlap):
+def test_seam_exchange_and_unequal_strip_gather(world, h, overlap, transport):
+    """Both transports of the seam exchange (batched send/recv; the all-gather fallback bench.py takes when the point-to-point
+    self-check fails) deliver exactly the halo rows the partition asks for."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_seam_worker, args=(r, world, port, h, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_seam_worker, args=(r, world, port, h, overlap, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

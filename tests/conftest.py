@@ -29,3 +29,30 @@ try:   # the GPU box shows 256 logical CPUs under a 16-CPU cgroup quota: keep th
     torch.set_num_threads(min(_effective_cpus(), 16))
 except ImportError:
     pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one short run of the training CLI per test session (GPU tests): work_dir + its console log, shared by the CLI tests
+# ----------------------------------------------------------------------------------------------------------------------
+import subprocess  # noqa: E402
+
+import pytest  # noqa: E402
+
+
+def cli_env(**extra):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG, ROOT, os.environ.get("PYTHONPATH", "")]), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update({k: str(v) for k, v in extra.items()})
+    return env
+
+
+def run_module(mod, *args, **env):
+    return subprocess.run([sys.executable, "-m", mod, *args], capture_output=True, text=True, timeout=900, env=cli_env(**env))
+
+
+@pytest.fixture(scope="session")
+def trained_cli(tmp_path_factory):
+    work = tmp_path_factory.mktemp("work")
+    out = run_module("cellseg_amd.model_training_3class", "--synthetic", "24", "--max_epochs", "4", "--val_start_epoch", "1",
+                     "--val_interval", "1", "--batch_size", "8", "--num_workers", "2", "--work_dir", str(work))
+    assert out.returncode == 0, out.stderr[-2000:]
+    return work, out.stdout

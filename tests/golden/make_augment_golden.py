@@ -83,6 +83,19 @@ def main():
     for i, (s0, s1) in enumerate(sig):
         out[f"gauss_out_{i}"] = monai_gaussian_smooth(gimg, float(s0), float(s1)).astype(np.float32)
         out[f"gauss_taps_{i}"] = monai_gaussian_1d(float(s0)).numpy()
+    # the same primitives on SQUARE inputs: what the device chain (cs_augment_batch works on size x size crops) is fed directly in
+    # tests/test_gpu_round4.py - drawn AFTER everything above, so the earlier arrays keep their values
+    simg = rng.random((3, 48, 48), dtype=np.float32)
+    simg[:, :16] *= 0.3
+    slab = rng.integers(0, 3, (1, 48, 48)).astype(np.uint8)
+    out["sq_img"], out["sq_lab"] = simg, slab
+    for i, z in enumerate(zs):
+        out[f"sq_zoom_area_{i}"] = monai_zoom(simg, float(z), "area").astype(np.float32)
+        out[f"sq_zoom_nearest_{i}"] = monai_zoom(slab.astype(np.float32), float(z), "nearest").astype(np.uint8)
+    for i, fl in enumerate(fls):
+        out[f"sq_hist_out_{i}"] = monai_hist_shift(simg, fl).astype(np.float32)
+    for i, (s0, s1) in enumerate(sig):
+        out[f"sq_gauss_out_{i}"] = monai_gaussian_smooth(simg, float(s0), float(s1)).astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "augment_golden.npz"), **out)
     print("wrote augment_golden.npz with", len(out), "arrays")
 

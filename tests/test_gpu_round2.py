@@ -239,12 +239,15 @@ def _bench(*args, **env):
 
 
 def test_bench_gpus2_launches_two_ranks():
-    """`python bench.py --gpus 2` starts its own ranks (here sharing the one GPU over gloo): n_gpus 2, all three legs present."""
+    """`python bench.py --gpus 2` starts its own ranks (here sharing the one GPU over gloo): n_gpus 2, all three legs present.  For
+    N > 1 the headline is the STRONG-scaling leg (one slide split by window rows, seam exchange, mask all-gather); the one-slide-per-rank
+    leg is the secondary `slides` object."""
     line = _bench("--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1", "--train-batch", "2", "--train-steps", "2",
                   BENCH_DEVICE=0, BENCH_BACKEND="gloo")
-    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak"
-    assert line["strips"]["scaling"] == "strong" and line["strips"]["value"] > 0
-    assert line["strips"]["instances_found"] > 0
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "strong"
+    assert line["slides"]["scaling"] == "weak" and line["slides"]["value"] > 0 and line["value_strips"] == line["value"]
+    assert line["config"]["seam_transport"] in ("p2p", "allgather") and line["config"]["equal_to_single_gpu_labels"] is True
+    assert line["config"]["instances_found"] > 0
     assert line["train_step"]["global_batch"] == 4 and line["train_step"]["images_per_s"] > 0
     assert line["roofline"]["frac"] > 0
 
@@ -264,12 +267,8 @@ def _run_module(mod, *args, **env):
 
 
 @pytest.fixture(scope="module")
-def trained(tmp_path_factory):
-    work = tmp_path_factory.mktemp("work")
-    out = _run_module("cellseg_amd.model_training_3class", "--synthetic", "24", "--max_epochs", "4", "--val_start_epoch", "1",
-                      "--val_interval", "1", "--batch_size", "8", "--num_workers", "2", "--work_dir", str(work))
-    assert out.returncode == 0, out.stderr[-2000:]
-    return work, out.stdout
+def trained(trained_cli):
+    return trained_cli                      # one training-CLI run per session (tests/conftest.py), shared with tests/test_gpu_round4.py
 
 
 def test_training_cli_checkpoint_contract(trained):
@@ -606,8 +605,10 @@ def test_winograd_and_direct_kernels_agree_forward_and_backward(tmp_path):
     for k, g0 in outs["0"]["g"].items():
         g1 = outs["1"]["g"][k]
         assert (g0 - g1).abs().max().item() <= 2e-4 * max(g0.abs().max().item(), 1e-3 * scale), k
-    # CS_WINO=2 (the default since round 3): the layers with >= 128 input channels in F(4x4,3x3) form in the forward pass (larger
-    # transform constants: a few 1e-5 on the logits, measured 2e-5 ... 4e-5 against fp64), the backward as in mode 1
+    # CS_WINO=2: this is a TRAINING-mode forward + backward, where the F(4x4,3x3) weights are not packed (an inference-only packing,
+    # engine.hip: ww4_fresh), so this leg re-checks the F(2x2) kernels under the other switch value; the F(4x4) kernels themselves
+    # (layers with >= 32 input channels, eval mode) are A/B-tested against the direct form in
+    # tests/test_gpu_round4.py::test_winograd_f4_on_32x32_mfmas_agrees_with_the_other_forms_in_eval_mode
     y2 = outs["2"]["y"]
     assert (y0 - y2).abs().max().item() <= 1e-4
     for k, g0 in outs["0"]["g"].items():

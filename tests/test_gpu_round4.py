@@ -1,0 +1,189 @@
+"""Round-4 GPU tests (run on the MI355X box with ``pytest -m gpu``; everything goes through the C-ABI of libcellseg_hip.so).
+
+* the predict CLI end to end against the ORACLE chain (not the product's own API): oracle.normalize_ref ->
+  sliding_window_inference_ref(unet_ref) -> softmax_interior_ref -> the plain-C post-process, on a folder with a uint8 RGB PNG, a
+  uint16 gray TIFF smaller than the window (the pad-to-256 path), a uint16 RGB TIFF and a multi-window image
+  (reference: baseline/predict.py:87-116);
+* the device kernels on the reference's own three sample pairs (tests/golden/sample_golden.npz: outputs of the imported reference
+  functions on data/Train_Labeled): normalisation, 3-class label map, F1 counts, post-process
+  (baseline/predict.py:94-113, data/pre_process_3class.py:31-56, baseline/compute_metric.py:107-122, 225-241);
+* the device augmentation kernels fed the INPUTS of tests/golden/augment_golden.npz directly, against the stored outputs of the
+  primitives MONAI calls (baseline/model_training_3class.py:119-162);
+* the F(4x4,3x3) kernels on 32x32x2 MFMAs (CS_WINO=3) against the 16x16x4 form and the direct kernels in eval mode, on spatial sizes that
+  leave partial and odd tile pairs.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "neurips-cellseg_amd")
+G = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, PKG)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------- predict CLI == the oracle chain
+def test_predict_cli_matches_the_oracle_chain_end_to_end(trained_cli, tmp_path):
+    from conftest import run_module
+    from cellseg_amd import preprocess              # only to WRITE the input files and READ the label files back
+    from oracle import f1_ref, normalize_ref
+    from oracle.postprocess_ref import mask_postprocess_c, softmax_interior_ref
+    from oracle.sliding_window_ref import sliding_window_inference_ref
+    from oracle.unet_ref import make_reference_unet
+    from scipy.ndimage import gaussian_filter
+    work, _ = trained_cli
+    inp, outp = tmp_path / "in", tmp_path / "out"
+    inp.mkdir()
+    rng = np.random.default_rng(17)
+    imgs = {}
+    for name, (h, w), dt, rgb in (("cells_rgb8.png", (300, 420), np.uint8, True), ("gray16.tif", (200, 180), np.uint16, False),
+                                  ("rgb16.tiff", (260, 256), np.uint16, True), ("multi_window.png", (600, 520), np.uint8, True)):
+        g = gaussian_filter(rng.random((h, w)), 5)
+        g = (g - g.min()) / (g.max() - g.min())
+        top = 255 if dt == np.uint8 else 60000
+        if rgb:       # three DIFFERENT channels, so that a channel-order slip between the pieces cannot hide
+            a = np.stack([(np.clip(g * s + o, 0, 1) * top).astype(dt) for s, o in ((1.0, 0.0), (0.8, 0.1), (0.6, 0.25))], -1)
+        else:
+            a = (g * top).astype(dt)
+        preprocess.save_image(str(inp / name), a)
+        imgs[name] = a
+    out = run_module("cellseg_amd.predict", "-i", str(inp), "-o", str(outp), "--model_path", os.path.join(work, "unet_3class"),
+                     "--model_name", "unet")
+    assert out.returncode == 0, out.stderr[-2000:]
+    ck = torch.load(os.path.join(work, "unet_3class", "best_Dice_model.pth"), map_location="cpu")
+    ref = make_reference_unet(0)
+    ref.load_state_dict(ck["model_state_dict"])
+    ref.eval()
+    for name, a in imgs.items():
+        got = preprocess.read_image(str(outp / (name.split(".")[0] + "_label.tiff")))          # predict.py:114's name rule
+        assert got.dtype == np.int32 and got.shape == a.shape[:2]
+        x = torch.from_numpy(normalize_ref.to_network_input_ref(normalize_ref.preprocess_image_ref(a)))       # predict.py:94-108
+        with torch.no_grad():
+            logits = sliding_window_inference_ref(x, (256, 256), 4, ref)                                    # predict.py:109 (overlap 0.25)
+        prob = softmax_interior_ref(logits[0].numpy())                                                       # predict.py:110-111
+        want = mask_postprocess_c(prob > 0.5)                                                                # predict.py:113
+        near = np.abs(prob - 0.5) <= 1e-5
+        if not near.any():
+            assert np.array_equal(got, want), name          # no pixel near the threshold: the label maps are the same, ids included
+        else:                                               # a pixel within rounding of 0.5 may flip: same instances to F1 >= 0.999
+            tp, fp, fn = f1_ref.eval_tp_fp_fn_ref(want, got)
+            assert 2 * tp / max(2 * tp + fp + fn, 1) >= 0.999, (name, tp, fp, fn, int(near.sum()))
+        assert int(want.max()) > 0, name                    # the trained net does find cells: the comparison is not vacuous
+
+
+# ------------------------------------------------------------------------------------------- the reference's own sample pairs
+SAMPLES = np.load(os.path.join(G, "sample_golden.npz"))
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in SAMPLES.files}))
+def test_device_kernels_on_the_reference_sample_pairs(name):
+    import cellseg_amd as ca
+    from cellseg_amd import metrics, preprocess
+    dev = _dev()
+    img, gt = SAMPLES[name + "/img"], SAMPLES[name + "/gt"]
+    t = torch.from_numpy(img.view(np.int16) if img.dtype == np.uint16 else img).to(dev)
+    unit, u8 = preprocess.normalize_image_gpu(t, return_uint8=True)                                    # cs_normalize_image
+    pre = SAMPLES[name + "/pre"]
+    assert np.array_equal(u8.cpu().numpy(), pre)
+    assert np.array_equal(unit.cpu().numpy(), (pre / np.max(pre)).astype(np.float32))                  # predict.py:107
+    inst = torch.from_numpy(gt.astype(np.int32)).to(dev)
+    interior = ca.create_interior_map(inst)                                                              # cs_interior_map
+    assert np.array_equal(interior.cpu().numpy(), SAMPLES[name + "/interior"])
+    seg = ca.label((interior == 1).to(torch.uint8), connectivity=2)                                      # cs_ccl_label, 8-connected
+    assert np.array_equal(seg.cpu().numpy(), SAMPLES[name + "/seg"])
+    assert tuple(metrics.eval_tp_fp_fn(inst, seg)) == tuple(SAMPLES[name + "/tpfpfn"])                   # overlap histogram on the device
+    gt_rb, seg_rb = metrics.remove_boundary_cells(inst), metrics.remove_boundary_cells(seg)
+    assert tuple(metrics.eval_tp_fp_fn(gt_rb, seg_rb)) == tuple(SAMPLES[name + "/tpfpfn_rb"])
+    lab = ca.mask_to_instances((interior == 1).to(torch.uint8))                                          # cs_ccl_postprocess
+    assert np.array_equal(lab.cpu().numpy(), SAMPLES[name + "/label_m"])
+
+
+# ------------------------------------------------------------------------------------------- augmentation kernels vs the golden primitives
+def _aug_noop(s):
+    return {"src_h": s, "src_w": s, "pad_top": 0, "pad_left": 0, "pad_h": 0, "pad_w": 0, "crop_y": 0, "crop_x": 0, "flip_axis": 0, "rot_k": 0,
+            "noise_std": -1.0, "noise_seed": 0, "gamma": 0.0, "sigma_y": 0.0, "sigma_x": 0.0, "hist": None, "zoom": 0.0}
+
+
+def test_augment_kernels_reproduce_the_golden_primitive_outputs():
+    """cs_augment_batch fed the stored INPUTS of augment_golden.npz (square set), compared with the stored outputs of the primitives
+    MONAI's transforms call - no product code on the checking side."""
+    from cellseg_amd import gpu_data
+    g = np.load(os.path.join(G, "augment_golden.npz"))
+    img, lab = g["sq_img"], g["sq_lab"]
+    s = img.shape[1]
+    ds = gpu_data.DeviceCellDataset([(img, lab)], _dev())
+    aug = gpu_data.GpuAugmenter(ds, s, seed=1)
+    params, want = [], []
+    for i, z in enumerate(g["zoom_factors"]):
+        p = _aug_noop(s)
+        p["zoom"] = float(z)
+        params.append(p)
+        want.append(("zoom %g" % z, g[f"sq_zoom_area_{i}"], g[f"sq_zoom_nearest_{i}"]))
+    for i, fl in enumerate(g["hist_floating"]):
+        p = _aug_noop(s)
+        p["hist"] = np.asarray(fl, np.float64)            # the floating control points; the reference points are linspace(0, 1, n)
+        params.append(p)
+        want.append(("hist %d" % i, g[f"sq_hist_out_{i}"], lab))
+    for i, (s0, s1) in enumerate(g["gauss_sigmas"]):
+        p = _aug_noop(s)
+        p["sigma_y"], p["sigma_x"] = float(s0), float(s1)
+        params.append(p)
+        want.append(("gauss %g %g" % (s0, s1), g[f"sq_gauss_out_{i}"], lab))
+    out_img, out_lab = aug.batch([0] * len(params), params)
+    out_img, out_lab = out_img.cpu().numpy(), out_lab.cpu().numpy()
+    for k, (what, wi, wl) in enumerate(want):
+        assert np.array_equal(out_lab[k], wl), what
+        err = float(np.abs(out_img[k] - wi).max())
+        assert err <= 2e-6, (what, err)
+
+
+# ------------------------------------------------------------------------------------------- F(4x4) on 32x32x2 MFMAs, eval mode
+_WINO_EVAL = r"""
+import sys, torch
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {root!r})
+import cellseg_amd as ca
+dev = torch.device("cuda:0")
+outs = {{}}
+for tag, channels, strides, shape, norm in (("a", (32, 64, 128, 256, 512), (2, 2, 2, 2), (3, 3, 272, 208), "instance"),
+                                            ("b", (64, 128, 256), (2, 2), (5, 3, 100, 76), "instance"),
+                                            ("c", (32, 64, 128), (2, 2), (2, 3, 136, 72), "batch")):
+    torch.manual_seed(11)
+    kw = dict(norm="batch", act="relu") if norm == "batch" else {{}}
+    m = ca.UNet(channels=channels, strides=strides, num_res_units=2, **kw).to(dev).eval()
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():
+        outs[tag] = m(x).cpu()
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_winograd_f4_on_32x32_mfmas_agrees_with_the_other_forms_in_eval_mode(tmp_path):
+    """Eval-mode forward (the only mode in which the F(4x4) weights are packed) in three processes: CS_WINO=0 direct kernels, CS_WINO=2
+    F(4x4) on 16x16x4 MFMAs, CS_WINO=3 (default) F(4x4) on 32x32x2 MFMAs with two 16x16 sub-tiles per block.  Shapes: 272x208 (17x13
+    pixels at the bottom: partial tiles at every level, an ODD number of 16x16 tiles at several), 5 images of 100x76 with a 64-base
+    net (tile pairs that straddle two images: 25x19 at the bottom = 4 tiles per image... 5 images -> an odd total), and a BatchNorm
+    net (eval-mode running statistics as the lazy table).  Logits within 5e-5 of the direct kernels."""
+    res = {}
+    for mode in ("0", "2", "3"):
+        path = str(tmp_path / f"w{mode}.pt")
+        env = dict(os.environ, CS_WINO=mode, PYTHONPATH=os.pathsep.join([PKG, ROOT]))
+        subprocess.run([sys.executable, "-c", _WINO_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
+        res[mode] = torch.load(path)
+    for tag in res["0"]:
+        scale = float(res["0"][tag].abs().max())
+        for mode in ("2", "3"):
+            err = float((res[mode][tag] - res["0"][tag]).abs().max())
+            assert err <= 5e-5 * max(scale, 1.0), (tag, mode, err, scale)
+        assert not torch.equal(res["3"][tag], res["0"][tag])          # the Winograd path really ran (it is not bitwise the direct form)

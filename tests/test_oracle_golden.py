@@ -78,3 +78,32 @@ LC = np.load(os.path.join(G, "label_contract_golden.npz"))
 @pytest.mark.parametrize("name", _cases(LC))
 def test_label_contract_matches_reference(name):
     assert np.array_equal(label_contract_ref.create_interior_map_ref(LC[name + "/inst"]), LC[name + "/interior"])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference's own three sample pairs (data/Train_Labeled): outputs of the IMPORTED reference functions on real data
+# (tests/golden/make_sample_golden.py); SURVEY 8(c) G6 measured cell_00849 -> 143/13/8 and cell_00225 -> 5/0/0 with the boundary rule
+# ----------------------------------------------------------------------------------------------------------------------
+SAMPLES = np.load(os.path.join(G, "sample_golden.npz"))
+
+
+def test_sample_goldens_hold_the_surveyed_counts():
+    assert tuple(SAMPLES["cell_00849/tpfpfn_rb"]) == (143, 13, 8) and tuple(SAMPLES["cell_00225/tpfpfn_rb"]) == (5, 0, 0)
+    assert SAMPLES["cell_00528/img"].dtype == np.uint16 and SAMPLES["cell_00528/img"].shape == (200, 200)      # the pad-to-256 input
+    assert int(SAMPLES["cell_00849/gt"].max()) == 187
+
+
+@pytest.mark.parametrize("name", _cases(SAMPLES))
+def test_oracle_matches_reference_on_its_own_samples(name):
+    img, gt = SAMPLES[name + "/img"], SAMPLES[name + "/gt"]
+    pre = normalize_ref.preprocess_image_ref(img)                                    # predict.py:94-104 == pre_process_3class.py:84-95
+    assert pre.dtype == np.uint8 and np.array_equal(pre, SAMPLES[name + "/pre"])
+    interior = label_contract_ref.create_interior_map_ref(gt)                        # pre_process_3class.py:31-56
+    assert np.array_equal(interior, SAMPLES[name + "/interior"])
+    seg = SAMPLES[name + "/seg"]
+    assert np.array_equal(P.label_scipy(interior == 1, 2), seg) and np.array_equal(P.label_c(interior == 1, 2), seg)   # measure.label
+    assert tuple(f1_ref.eval_tp_fp_fn_ref(gt, seg)) == tuple(SAMPLES[name + "/tpfpfn"])                                 # compute_metric.py
+    gt_rb, seg_rb = f1_ref.remove_boundary_cells_ref(gt), f1_ref.remove_boundary_cells_ref(seg)
+    assert tuple(f1_ref.eval_tp_fp_fn_ref(gt_rb, seg_rb)) == tuple(SAMPLES[name + "/tpfpfn_rb"])
+    for post in (P.mask_postprocess_scipy, P.mask_postprocess_c):                    # predict.py:113 on a real interior mask
+        assert np.array_equal(post(interior == 1), SAMPLES[name + "/label_m"])

@@ -304,6 +304,9 @@ int cs_dice_ce_backward(const float* logits, const int64_t* logit_strides, const
  * table: device int64 [n_tensors][3] = (device pointer of the parameter tensor, float offset of the tensor in the flat buffers,
  * element count), offsets ascending (cs_unet_grad_offset); grad: the flat gradient bucket cs_unet_backward wrote (`total` =
  * cs_unet_grad_numel floats); exp_avg / exp_avg_sq: flat moment buffers of the same size (zero before step 1); step = 1, 2, ...
+ * Limits: n_tensors <= 256 (the offset table is staged in LDS; the reference net has 63 tensors) - more is refused with an error.
+ * ONE step count for all tensors: torch keeps a step per parameter, which differs only for a tensor whose first gradient arrives
+ * after step 1 (its bias correction then uses the global count); cellseg_amd.AdamW refuses that case (the active set must not grow).
  * ---------------------------------------------------------------------------------------------- */
 int cs_adamw_step(const int64_t* table, int n_tensors, int64_t total, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream);

@@ -92,7 +92,9 @@ def main(argv=None):
         print(f"training image num: {len(train_ds)}, validation image num: {len(val_ds)}")
     sampler = torch.utils.data.distributed.DistributedSampler(train_ds, world, rank, shuffle=True, seed=args.seed) if world > 1 else None
     if args.gpu_data:
-        # the rank's share of the training set decoded once into HBM; every batch is cropped / augmented there from records the host draws
+        # the training set decoded once into HBM - on EVERY rank the whole set (the DistributedSampler deals a different share of the
+        # indices to a rank each epoch, so a rank needs every image over time; 288 GB hold thousands of images many times over);
+        # every batch is cropped / augmented there from records the host draws
         from cellseg_amd import gpu_data
         if args.synthetic:
             samples = [(train_ds[i]["img"].numpy(), train_ds[i]["label"].numpy()) for i in range(len(train_ds))]
@@ -106,11 +108,14 @@ def main(argv=None):
         class _DeviceLoader:
             """Epoch iterator with the DataLoader's contract for this loop: shuffled (sampler-sharded) index batches -> device tensors."""
 
+            epoch = 0
+
             def __iter__(self):
+                self.epoch += 1
                 if sampler is not None:
                     order = list(iter(sampler))
-                else:
-                    order = list(np.random.permutation(len(dev_ds)))
+                else:                                  # reproducible from --seed alone (not from the global numpy state)
+                    order = list(np.random.default_rng(args.seed + self.epoch).permutation(len(dev_ds)))
                 bs = args.batch_size
                 stop_at = len(order) - (len(order) % bs if world > 1 else 0)          # drop_last under data parallel, as below
                 for b in range(0, stop_at, bs):

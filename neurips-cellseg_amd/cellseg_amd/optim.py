@@ -60,6 +60,12 @@ class AdamW:
             rows.sort()
             self._table = torch.tensor([[ptr, off, numel] for off, numel, ptr in rows], dtype=torch.int64).reshape(-1, 3).to(flat.device)
             self._ptrs = ptrs
+        late = set(active) - self._touched
+        if self._step > 0 and self._touched and late:
+            # torch keeps a step count per parameter; this optimiser keeps ONE (cs_adamw_step): a tensor whose first gradient arrives
+            # after step 1 would get the bias correction of the global count - refused rather than silently different
+            raise _lib.CellSegHipError("AdamW: " + ", ".join(sorted(late)[:3]) + f" receive(s) a first gradient after step {self._step}; "
+                                       "cellseg_amd.AdamW keeps one step count for all tensors (the set of updated tensors must not grow)")
         self._touched.update(active)
         if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
             self._m = torch.zeros_like(flat)

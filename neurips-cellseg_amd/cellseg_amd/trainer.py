@@ -60,6 +60,7 @@ class TrainStep:
         self._sync = sync_gradients
         self._shapes: Dict[Tuple, _Shape] = {}
         self._bound = None                 # (param pointers, precision, training) the engine's frozen re-pack table was recorded for
+        self._opt_bound = None             # (moment buffers, offset table) of the optimiser the launch sequence was bound to
         self._hyper = self._step_dev = None
         self._hyper_host = None
         self.flat = None
@@ -97,6 +98,14 @@ class TrainStep:
         self._sig = self._signature()
         tag = (tuple(t.data_ptr() for t in self._tensors), model.precision)
         if tag == self._bound:
+            # the parameters did not move - but the optimiser's state may have (AdamW.load_state_dict re-allocates the moments and drops
+            # its offset table): re-bind it, and forget captured graphs, which replay the OLD moment addresses
+            if self.flat is not None and self._opt_tag() != self._opt_bound:
+                opt._bind(self.flat, frozenset(model._param_keys))
+                self._opt_bound = self._opt_tag()
+                for sh in self._shapes.values():
+                    self._drop_graphs(sh)
+                self._step_dev.fill_(int(opt._step))
             return
         arr = (C.c_void_p * len(self._tensors))(*[t.data_ptr() for t in self._tensors])
         check(lib.cs_unet_bind_params(eng.handle, arr, len(self._tensors), _lib.stream_ptr()), "cs_unet_bind_params")
@@ -111,12 +120,19 @@ class TrainStep:
             off, numel, shape = model._grad_slots[key]
             p.grad = self.flat[off:off + numel].view(shape)
         opt._bind(self.flat, frozenset(model._param_keys))
+        self._opt_bound = self._opt_tag()
         if self._hyper is None or self._hyper.device != dev:
             self._hyper = torch.zeros(16, dtype=torch.float32, device=dev)
             self._step_dev = torch.zeros((), dtype=torch.int32, device=dev)
             self._hyper_host = None
         self._step_dev.fill_(int(opt._step))
         model._pack_state = (model._pack_state[0], True, False)     # the frozen re-pack runs in training mode: inference-only packings go stale
+
+    def _opt_tag(self):
+        """Identity of the optimiser state a recorded launch sequence reads and writes: the two moment buffers and the offset table."""
+        o = self.optimizer
+        return (None if o._m is None else o._m.data_ptr(), None if o._v is None else o._v.data_ptr(),
+                None if o._table is None else o._table.data_ptr())
 
     def _push_hyper(self) -> None:
         g = self.optimizer.param_groups[0]
@@ -232,6 +248,7 @@ class TrainStep:
     def _step(self, inputs, labels_onehot, dev) -> torch.Tensor:
         model = self.model
         if (self._tensors is None or self._signature() != self._sig or self.optimizer._m is None or int(self.optimizer._step) != self._expected_step
+                or self._opt_tag() != self._opt_bound        # load_state_dict at the SAME step count: new moment buffers, no offset table
                 or not getattr(model, "_pack_state", (0, False, False))[1]):     # (an inference call in between re-packed without the data-gradient layouts)
             self._bound = None
             self._bind(dev)

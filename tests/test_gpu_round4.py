@@ -187,3 +187,54 @@ def test_winograd_f4_on_32x32_mfmas_agrees_with_the_other_forms_in_eval_mode(tmp
             err = float((res[mode][tag] - res["0"][tag]).abs().max())
             assert err <= 5e-5 * max(scale, 1.0), (tag, mode, err, scale)
         assert not torch.equal(res["3"][tag], res["0"][tag])          # the Winograd path really ran (it is not bitwise the direct form)
+
+
+# ------------------------------------------------------------------------------------------- TrainStep after AdamW.load_state_dict
+@pytest.mark.parametrize("capture", [False, True])
+def test_train_step_notices_an_optimizer_reload_at_the_same_step_count(capture):
+    """AdamW.load_state_dict re-allocates the moment buffers and drops the offset table; at an unchanged step count the step counter
+    alone does not show it.  The next TrainStep call must re-bind (and forget captured graphs, which replay the old moment
+    addresses): twin models, one of which reloads its own optimiser state between steps, stay bitwise equal."""
+    import copy
+    import cellseg_amd as ca
+    dev = _dev()
+    torch.manual_seed(3)
+    a = ca.UNet(channels=(16, 32, 64), strides=(2, 2), num_res_units=2).to(dev).train()
+    b = copy.deepcopy(a)
+    x = torch.rand(2, 3, 64, 64, device=dev)
+    y = ca.one_hot(torch.randint(0, 3, (2, 1, 64, 64), device=dev), 3)
+    steps = []
+    for m in (a, b):
+        opt = ca.AdamW(m, 6e-4)
+        steps.append((ca.TrainStep(m, ca.DiceCELoss(softmax=True), opt, capture=capture), opt))
+    for it in range(6):
+        for k, (st, opt) in enumerate(steps):
+            if k == 1 and it in (3, 5):
+                opt.load_state_dict(copy.deepcopy(opt.state_dict()))          # same values, same step count, NEW buffers
+            st(x, y)
+    torch.cuda.synchronize()
+    for (ka, pa), (kb, pb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(pa, pb), ka
+
+
+def test_native_adamw_refuses_a_tensor_whose_first_gradient_arrives_late():
+    """cs_adamw_step keeps ONE step count (include/cellseg_hip.h); torch would start such a tensor's bias correction at its own
+    step 1.  Rather than silently differ, cellseg_amd.AdamW raises."""
+    import cellseg_amd as ca
+    from cellseg_amd import _lib
+    dev = _dev()
+    torch.manual_seed(7)
+    m = ca.UNet(channels=(16, 32), strides=(2,), num_res_units=1).to(dev).train()
+    x = torch.rand(2, 3, 32, 32, device=dev)
+    y = ca.one_hot(torch.randint(0, 3, (2, 1, 32, 32), device=dev), 3)
+    opt, loss_fn = ca.AdamW(m, 1e-3), ca.DiceCELoss(softmax=True)
+    skip = m._param_keys[4]
+    for it in range(2):
+        opt.zero_grad()
+        loss_fn(m(x), y).backward()
+        if it == 0:
+            dict(m.named_parameters())[skip].grad = None
+            opt.step()
+        else:
+            with pytest.raises(_lib.CellSegHipError, match="first gradient after step"):
+                opt.step()

@@ -47,7 +47,8 @@ MFMA_PEAK = {"fp32": PEAK_F32_MFMA_TFLOPS, "fp16x3": PEAK_BF16_MFMA_TFLOPS / 3, 
              "bf16": PEAK_BF16_MFMA_TFLOPS, "fp8": PEAK_FP8_MFMA_TFLOPS}
 DTYPE = {"fp32": "f32", "fp16x3": "f32 (split-fp16, 2 planes x 3 MFMA terms, fp32 accumulate)", "bf16x6": "f32 (split-bf16, 3 planes x 6 MFMA terms, fp32 accumulate)",
          "bf16x3": "split-bf16 (2 planes x 3 terms)", "bf16": "bf16 (weights, activations in HBM; fp32 accumulate)",
-         "fp8": "fp8 e4m3 (weights with per-channel scales; every conv input materialised once as activated e4m3, conv outputs bf16; fp32 accumulate)"}
+         "fp8": "fp8 e4m3 for the layers with >= 128 channels (weights with per-channel scales; their inputs materialised once as activated e4m3, "
+                "v_mfma_scale_f32_16x16x128_f8f6f4), bf16 for the narrower ones; conv outputs bf16; fp32 accumulate"}
 PEAK_HBM_GBS = 8000.0
 WIDTHS = {"baseline32": (32, 64, 128, 256, 512), "reference16": (16, 32, 64, 128, 256),
           "deep64": (64, 128, 256, 512, 1024)}          # BASELINE.json configs[4] width (use with --roi 512)
@@ -207,7 +208,7 @@ def cpu_baseline_tiles_and_train(seed):
     return {"tiles": dict(tiles, cores=threads, kind="port", note=note), "train_step": dict(train, cores=threads, kind="port", note=note)}
 
 
-def lowprec_accuracy(dev, steps=150, n_images=2, size=1024, precisions=("fp16x3", "bf16x6", "bf16", "fp8"), seed=7):
+def lowprec_accuracy(dev, steps=150, n_images=8, size=1024, precisions=("fp16x3", "bf16x6", "bf16", "fp8"), seed=7):
     """Accuracy of the low-precision datapaths where it means something: on a TRAINED net (random-init logits sit at the 0.5
     threshold).  A 32-base U-Net is trained for `steps` AdamW steps on seeded synthetic cells (fp32 engine, ca.TrainStep), then
     `n_images` held-out synthetic images of size^2 are segmented in fp32 and in every mode: instance F1@0.5 against the fp32

@@ -140,12 +140,22 @@ struct ConvW {             // packed weights + bias of one (possibly fused) conv
                                     // fused stride-2 pair (as a transposed conv over [dy0 || dr]), transposed conv (as a stride-2 conv)
     unsigned char* w8 = nullptr;    // e4m3 weights in 16x16x128 fragment order (fp8 forward kernels)
     float* wscale = nullptr;        // their per-output-channel scales [cout]
+    bool f8 = false;                // fp8 mode: THIS layer runs on the fp8 kernels (else on the bf16 kernels from `wb`): see fp8_layer()
     float* bias = nullptr;
     int cin = 0, cout = 0; // cout = total (fused) output channels
     int p_w[2] = {-1, -1}, p_b[2] = {-1, -1};   // parameter indices (slot 1 = fused residual conv)
 };
 
 enum DgradKind { DG_NONE = 0, DG_S1, DG_S2_AS_CONVT, DG_CONVT_AS_S2, DG_1X1 };
+
+// fp8 mode ("mixed fp8 weights / bf16", BASELINE.json configs[4]): a layer takes the e4m3 kernels (K = 128 channels per matrix
+// instruction) when both its channel counts reach CS_FP8_MIN_C (default 128); narrower layers - where most of a K = 128 step is
+// padding and whose e4m3 rounding sits closest to the logits - run on the bf16 kernels of the bf16 datapath, reading bf16 tensors.
+static int fp8_min_channels() {
+    static const int v = [] { const char* e = getenv("CS_FP8_MIN_C"); return e ? atoi(e) : 128; }();
+    return v;
+}
+static bool fp8_layer(int cin, int cout) { return cin >= fp8_min_channels() && cout >= fp8_min_channels(); }
 
 struct DownUnit {          // ResidualUnit in the encoder / bottom
     int cin = 0, c = 0, stride = 2, subunits = 2;
@@ -312,6 +322,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     unsigned short* wbd = cw.wbd;
     unsigned char* w8 = cw.w8;
     float* wsc = cw.wscale;
+    const bool* const f8p = &cw.f8;
     float* bdst = cw.bias + cout_off;
     const int cout_total = cw.cout;
     // the data-gradient layout of the same tensor (channel axes swapped; see pack_conv_weights) is written by the same tile
@@ -323,13 +334,13 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     if (transposed) {
         cw.p_w[slot] = add_param(net, conv + ".weight", {cin, cout, ksize, ksize}, [=](const float* d, hipStream_t s) {
             if (mode == 2) return copy_param(net, wdst, d, (size_t)cin * cout * ksize * ksize, s);
-            if (wb && net->planes > 0 && net->planes <= 4)
+            if (wb && ((net->planes > 0 && net->planes <= 4) || (net->planes == 5 && !*f8p)))
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, true, cout, cin, ksize, wb, cout_off, cout_total, cin_split, net->planes == 4)) return rc;
             // bf16 training: the data gradient of a transposed conv is a stride-2 conv of dy with the SAME tensor read as conv weights
             // W[cin_t][cout_t] (no flip)
             if (wbd && net->training && dg == DG_CONVT_AS_S2 && net->planes == 1)
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, false, cin, cout, ksize, wbd, 0, cin, 0, false)) return rc;
-            if (w8 && net->planes == 5)
+            if (w8 && net->planes == 5 && *f8p)
                 if (int rc = pack_conv_weights_fp8(s, d, true, cout, cin, ksize, w8, wsc, cout_off, cout_total, cin_split)) return rc;
             return pack_conv_weights(net->pack, s, d, true, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off);
         });
@@ -341,7 +352,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
                     if (int rc = pack_first_weights16(net->pack, s, d, cout, cin, wb, cout_off)) return rc;
                 return pack_first_weights(net->pack, s, d, cout, cin, wdst, cout_off, cout_total);
             }
-            if (wb && net->planes > 0 && net->planes <= 4)
+            if (wb && ((net->planes > 0 && net->planes <= 4) || (net->planes == 5 && !*f8p)))
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, false, cout, cin, ksize, wb, cout_off, cout_total, 0, net->planes == 4)) return rc;
             // training on the 16-bit pipe (fp16x3 / bf16): the data-gradient convolution of a 3x3 stride-1 layer is a 3x3 stride-1
             // convolution with the channel roles swapped and the taps reversed - the same kernel family, its own weight planes
@@ -352,7 +363,7 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
             if (wbd && net->training && dg == DG_S2_AS_CONVT && net->planes == 1)
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, true, cin, cout, ksize, wbd, 0, cin, 0, false, false, cout_off ? (cout + 31) / 32 : 0))
                     return rc;
-            if (w8 && net->planes == 5)
+            if (w8 && net->planes == 5 && *f8p)
                 if (int rc = pack_conv_weights_fp8(s, d, false, cout, cin, ksize, w8, wsc, cout_off, cout_total, 0)) return rc;
             // 3x3 stride-1 layers: the tile kernel also writes the Winograd weights (forward; data gradient in training mode)
             if (ww4) {
@@ -395,6 +406,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
     if (stride == 2 && !u.first && u.fused_res) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cin, c, c, 3) + 1) / 2);
     if (u.first) u.unit0.wb = (unsigned short*)ar.take((size_t)(u.unit0.cout / 16) * 512 / 2);      // one bf16 K-step (bf16 / fp8 datapaths)
     if (!u.first) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(u.unit0.cout, cin, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(u.unit0.cout); }
+    u.unit0.f8 = !u.first && fp8_layer(cin, c);
     add_conv_params(net, pfx + ".conv.unit0.conv", u.unit0, c, cin, 3, 0, false, u.first ? 1 : 0, dg0, 0);
     add_norm_params(net, ar, pfx + ".conv.unit0.adn", u.norms[0], c);
     for (int su = 1; su < u.subunits; ++su) {
@@ -410,6 +422,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         cw.wbd = (unsigned short*)ar.take((packed_bf16_elems(c, c, 0, 3) + 1) / 2);
         cw.w8 = (unsigned char*)ar.take((packed_fp8_bytes(c, c, 0, 3) + 3) / 4);
         cw.wscale = ar.take(c);
+        cw.f8 = fp8_layer(c, c);
         const std::string un = pfx + ".conv.unit" + std::to_string(su);
         add_conv_params(net, un + ".conv", cw, c, c, 3, 0, false, 0, DG_S1, 0);
         add_norm_params(net, ar, un + ".adn", u.norms[su], c);
@@ -423,6 +436,7 @@ static void build_down(cs_unet* net, ArenaPlan& ar, DownUnit& u, const std::stri
         u.res1x1.wb = (unsigned short*)ar.take((packed_bf16_elems(c, cin, 0, 1) + 1) / 2);
         u.res1x1.w8 = (unsigned char*)ar.take((packed_fp8_bytes(c, cin, 0, 1) + 3) / 4);
         u.res1x1.wscale = ar.take(c);
+        u.res1x1.f8 = fp8_layer(cin, c);
         u.res1x1.bias = ar.take(c);
         add_conv_params(net, pfx + ".residual", u.res1x1, c, cin, 1, 0, false, 0, DG_1X1, 0);
     }
@@ -439,6 +453,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     if (!small) u.convt.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cin_skip, cin_sub, 3) + 1) / 2);
     if (!small) u.convt.wbd = (unsigned short*)ar.take((packed_bf16_elems(cin, cout, 0, 3) + 1) / 2);
     if (!small) { u.convt.w8 = (unsigned char*)ar.take((packed_fp8_bytes(cout, cin_skip, cin_sub, 3) + 3) / 4); u.convt.wscale = ar.take(cout); }
+    u.convt.f8 = !small && fp8_layer(cin_skip < cin_sub ? cin_skip : cin_sub, cout);
     add_conv_params(net, pfx + ".0.conv", u.convt, cout, cin, 3, 0, true, small ? 2 : 0, small ? DG_NONE : DG_CONVT_AS_S2, 0, cin_skip);
     add_norm_params(net, ar, pfx + ".0.adn", u.norm_t, cout);
     u.unit0.cin = cout; u.unit0.cout = cout;
@@ -451,6 +466,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     if (!small) u.unit0.wb = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
     if (!small) u.unit0.wbd = (unsigned short*)ar.take((packed_bf16_elems(cout, cout, 0, 3) + 1) / 2);
     if (!small) { u.unit0.w8 = (unsigned char*)ar.take((packed_fp8_bytes(cout, cout, 0, 3) + 3) / 4); u.unit0.wscale = ar.take(cout); }
+    u.unit0.f8 = !small && fp8_layer(cout, cout);
     add_conv_params(net, pfx + ".1.conv.unit0.conv", u.unit0, cout, cout, 3, 0, false, small ? 2 : 0, small ? DG_NONE : DG_S1, 0);
     if (!top) add_norm_params(net, ar, pfx + ".1.conv.unit0.adn", u.norm_u, cout);
 }
@@ -503,10 +519,15 @@ static const float* act_off(const float* p, size_t elems, bool h16) {
 // forward conv on the matrix cores: fp32 MFMA or split-bf16, by net->planes
 static int conv_fwd(hipStream_t s, const cs_unet* net, int ksize, int stride, const ConvSrc& a, const ConvW& cw, float* out,
                     int pitch_out, int cout, double* stats, int n, int hin, int win) {
-    if (net->planes == 5 && cw.w8)
+    if (net->planes == 5 && cw.w8 && cw.f8) {
+        CS_REQUIRE(a.q8, "conv(fp8): the layer's input was not materialised as e4m3");
         return launch_conv_fp8(s, ksize, stride, a, ConvSrc(), cw.w8, cw.wscale, cw.bias, out, pitch_out, cout, stats, n, hin, win);
-    if (net->planes > 0 && net->planes <= 4 && cw.wb)
-        return launch_conv_bf16s(s, ksize, stride, net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin, win, a.h16);
+    }
+    if (net->planes > 0 && net->planes <= 5 && cw.wb) {         // (fp8 mode: the layers below CS_FP8_MIN_C channels, on the bf16 kernels)
+        CS_REQUIRE(!a.q8, "conv(bf16): a layer on the bf16 kernels met an e4m3 input");
+        return launch_conv_bf16s(s, ksize, stride, net->planes == 5 ? 1 : net->planes, a, ConvSrc(), cw.wb, cw.bias, out, pitch_out, cout, stats, n, hin,
+                                 win, a.h16);
+    }
     CS_REQUIRE(!a.h16 && !a.q8, "conv: a layer without low-precision weights met bf16 / e4m3 activations");
     // fp32, wide layers: Winograd F(4x4,3x3) - 2.25 multiplies per output pixel and channel pair instead of F(2x2)'s 4 (CS_WINO=1: F(2x2) everywhere)
     if (net->planes == 0 && cw.ww4 && cw.ww4_fresh && ksize == 3 && stride == 1 && wino_level() >= 2 && wino4_fits(a.c, cout, hin, win) &&
@@ -613,10 +634,15 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         float* E = take_act((size_t)n * oh * ow * c0);          // [y0 || r]
         std::vector<float*> Y(u.subunits, nullptr);
         for (int su = 1; su < u.subunits; ++su) Y[su] = take_act((size_t)n * oh * ow * c);
-        // X[d] as bf16 / fp32: everywhere except the fp8 mode, where only the top transposed conv (level 0) still reads it as bf16
-        X[d] = (!q8 || d == 0) ? take_act((size_t)n * oh * ow * c) : nullptr;
-        Xq[d] = take_q8((size_t)n * oh * ow * c);
-        unsigned char* Aq = (q8 && u.subunits > 1) ? take_q8((size_t)n * oh * ow * c) : nullptr;   // activated input of the next subunit
+        // X[d] as bf16 / fp32: everywhere except the fp8 mode, where each consumer (the next level's unit0, this level's transposed conv)
+        // reads the form its kernel family takes: bf16 for the bf16 kernels and the 3-channel top layer, e4m3 for the fp8 kernels
+        const bool next8 = q8 && (d + 1 < nl ? net->down[d + 1].unit0.f8 : net->bottom.unit0.f8);
+        const bool skip8 = q8 && net->up[d].convt.f8;
+        X[d] = (!q8 || d == 0 || !next8 || !skip8) ? take_act((size_t)n * oh * ow * c) : nullptr;
+        Xq[d] = (next8 || skip8) ? take_q8((size_t)n * oh * ow * c) : nullptr;
+        bool any8 = false;
+        for (int su = 1; su < u.subunits; ++su) any8 = any8 || u.units[su - 1].f8;
+        unsigned char* Aq = (q8 && any8) ? take_q8((size_t)n * oh * ow * c) : nullptr;   // activated input of the next subunit
         for (int su = 0; su < u.subunits; ++su) new_tab(rt_down[d][su], su == 0 ? c0 : c);
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
@@ -626,15 +652,16 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 else
                     CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, a16, c));   // statistics for the unit0 half only
             } else {
-                CS_TRY(conv_fwd(s, net, 3, 2, q8 ? raw8_src(prevq, pc) : raw_src(prev, pc, pc, a16), u.unit0, E, c0, c0, rt_down[d][0].stats, n, ph, pw));
+                CS_TRY(conv_fwd(s, net, 3, 2, (q8 && u.unit0.f8) ? raw8_src(prevq, pc) : raw_src(prev, pc, pc, a16), u.unit0, E, c0, c0, rt_down[d][0].stats, n, ph, pw));
             }
             CS_TRY(finish_norm(s, net, u.norms[0], rt_down[d][0], n, c0, oh * ow, dry));
             const float* cur = E;
             int cur_pitch = c0, cur_tabc = c0;
             for (int su = 1; su < u.subunits; ++su) {
                 const ConvSrc lz = lazy_src(cur, c, cur_pitch, rt_down[d][su - 1], u.norms[su - 1], cur_tabc, a16);
-                if (q8) CS_TRY(launch_act_quant(s, lz, Aq, c, (int64_t)oh * ow, n));
-                CS_TRY(conv_fwd(s, net, 3, 1, q8 ? raw8_src(Aq, c) : lz, u.units[su - 1], Y[su], c, c, rt_down[d][su].stats, n, oh, ow));
+                const bool in8 = q8 && u.units[su - 1].f8;
+                if (in8) CS_TRY(launch_act_quant(s, lz, Aq, c, (int64_t)oh * ow, n));
+                CS_TRY(conv_fwd(s, net, 3, 1, in8 ? raw8_src(Aq, c) : lz, u.units[su - 1], Y[su], c, c, rt_down[d][su].stats, n, oh, ow));
                 CS_TRY(finish_norm(s, net, u.norms[su], rt_down[d][su], n, c, oh * ow, dry));
                 cur = Y[su];
                 cur_pitch = c;
@@ -665,22 +692,26 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         std::vector<float*> Y(u.subunits);
         for (int su = 0; su < u.subunits; ++su) Y[su] = take_act((size_t)n * ph * pw * c);
         float* R = u.res_conv ? take_act((size_t)n * ph * pw * c) : nullptr;
-        S = (!q8 || nl == 1) ? take_act((size_t)n * ph * pw * c) : nullptr;     // bf16 form only where the top transposed conv reads it
-        Sq = (q8 && nl > 1) ? take_q8((size_t)n * ph * pw * c) : nullptr;
-        unsigned char* Aq = (q8 && u.subunits > 1) ? take_q8((size_t)n * ph * pw * c) : nullptr;
+        const bool up8 = q8 && net->up[nl - 1].convt.f8;               // the consumer of the bottom unit's sum
+        S = !up8 ? take_act((size_t)n * ph * pw * c) : nullptr;        // bf16 form where the consumer is a bf16 kernel (or the 3-channel top layer)
+        Sq = up8 ? take_q8((size_t)n * ph * pw * c) : nullptr;
+        bool any8 = false;
+        for (int su = 1; su < u.subunits; ++su) any8 = any8 || u.units[su - 1].f8;
+        unsigned char* Aq = (q8 && any8) ? take_q8((size_t)n * ph * pw * c) : nullptr;
         for (int su = 0; su < u.subunits; ++su) new_tab(rt_bottom[su], c);
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         CS_REQUIRE(!q8 || u.res_conv, "unet(fp8): an identity residual at the bottom is not supported");
         if (!dry) {
-            const ConvSrc in = q8 ? raw8_src(prevq, pc) : raw_src(prev, pc, pc, a16);
+            const ConvSrc in = (q8 && u.unit0.f8) ? raw8_src(prevq, pc) : raw_src(prev, pc, pc, a16);      // (res1x1 has the same channel counts: same family)
             CS_TRY(conv_fwd(s, net, 3, 1, in, u.unit0, Y[0], c, c, rt_bottom[0].stats, n, ph, pw));
             CS_TRY(finish_norm(s, net, u.norms[0], rt_bottom[0], n, c, ph * pw, dry));
             if (u.res_conv)
                 CS_TRY(conv_fwd(s, net, 1, 1, in, u.res1x1, R, c, c, nullptr, n, ph, pw));
             for (int su = 1; su < u.subunits; ++su) {
                 const ConvSrc lz = lazy_src(Y[su - 1], c, c, rt_bottom[su - 1], u.norms[su - 1], c, a16);
-                if (q8) CS_TRY(launch_act_quant(s, lz, Aq, c, (int64_t)ph * pw, n));
-                CS_TRY(conv_fwd(s, net, 3, 1, q8 ? raw8_src(Aq, c) : lz, u.units[su - 1], Y[su], c, c, rt_bottom[su].stats, n, ph, pw));
+                const bool in8 = q8 && u.units[su - 1].f8;
+                if (in8) CS_TRY(launch_act_quant(s, lz, Aq, c, (int64_t)ph * pw, n));
+                CS_TRY(conv_fwd(s, net, 3, 1, in8 ? raw8_src(Aq, c) : lz, u.units[su - 1], Y[su], c, c, rt_bottom[su].stats, n, ph, pw));
                 CS_TRY(finish_norm(s, net, u.norms[su], rt_bottom[su], n, c, ph * pw, dry));
             }
             const int last = u.subunits - 1;
@@ -705,20 +736,21 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         unsigned char *Dq = nullptr, *Uq = nullptr;
         if (!u.top) {
             V = take_act((size_t)n * oh * ow * c);
-            D = (!q8 || d == 1) ? take_act((size_t)n * oh * ow * c) : nullptr;   // fp8 mode: bf16 only for the level the top conv reads
-            Dq = (q8 && d > 1) ? take_q8((size_t)n * oh * ow * c) : nullptr;
-            Uq = take_q8((size_t)n * oh * ow * c);
+            const bool up8 = q8 && net->up[d - 1].convt.f8;               // the consumer of this level's sum: the transposed conv above
+            D = !up8 ? take_act((size_t)n * oh * ow * c) : nullptr;       // fp8 mode: bf16 where a bf16 kernel (or the top layer) reads it
+            Dq = up8 ? take_q8((size_t)n * oh * ow * c) : nullptr;
+            Uq = (q8 && u.unit0.f8) ? take_q8((size_t)n * oh * ow * c) : nullptr;
             new_tab(rt_upu[d], c);
         }
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         if (!dry) {
-            const bool in8 = q8 && !u.top;
+            const bool in8 = q8 && !u.top && u.convt.f8;
             const ConvSrc a = in8 ? raw8_src(Xq[d], u.cin_skip) : raw_src(X[d], u.cin_skip, u.cin_skip, a16);
             const ConvSrc b = in8 ? raw8_src(Sq, sc) : sub;
-            if (c % 16 == 0 && net->planes == 5 && u.convt.w8) {
+            if (c % 16 == 0 && net->planes == 5 && u.convt.w8 && u.convt.f8) {
                 CS_TRY(launch_convt_fp8(s, a, b, u.convt.w8, u.convt.wscale, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
-            } else if (c % 16 == 0 && net->planes > 0 && net->planes <= 4 && u.convt.wb) {
-                CS_TRY(launch_convt_bf16s(s, net->planes, a, b, u.convt.wb, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw, a16));
+            } else if (c % 16 == 0 && net->planes > 0 && net->planes <= 5 && u.convt.wb) {
+                CS_TRY(launch_convt_bf16s(s, net->planes == 5 ? 1 : net->planes, a, b, u.convt.wb, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw, a16));
             } else if (c % 16 == 0) {
                 CS_REQUIRE(!a16, "convT: a layer without 16-bit weights met bf16 activations");
                 CS_TRY(launch_convt_mfma(s, a, b, u.convt.w, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
@@ -730,8 +762,9 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             if (u.top) {
                 CS_TRY(launch_conv_last(s, lu, u.unit0.w, u.unit0.bias, logits, c, n, oh, ow));
             } else {
-                if (q8) CS_TRY(launch_act_quant(s, lu, Uq, c, (int64_t)oh * ow, n));
-                CS_TRY(conv_fwd(s, net, 3, 1, q8 ? raw8_src(Uq, c) : lu, u.unit0, V, c, c, rt_upu[d].stats, n, oh, ow));
+                const bool v8 = q8 && u.unit0.f8;
+                if (v8) CS_TRY(launch_act_quant(s, lu, Uq, c, (int64_t)oh * ow, n));
+                CS_TRY(conv_fwd(s, net, 3, 1, v8 ? raw8_src(Uq, c) : lu, u.unit0, V, c, c, rt_upu[d].stats, n, oh, ow));
                 CS_TRY(finish_norm(s, net, u.norm_u, rt_upu[d], n, c, oh * ow, dry));
                 const ConvSrc lv = lazy_src(V, c, c, rt_upu[d], u.norm_u, c, a16);
                 // (consumers with 64-channel blocks are left alone: the second tensor costs that kernel variant a third of its occupancy -

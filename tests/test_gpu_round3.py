@@ -287,21 +287,21 @@ def test_captured_training_step_notices_outside_changes_and_new_shapes():
 # ------------------------------------------------------------------------------------------- low precision: the accuracy target itself
 def test_low_precision_modes_against_the_fp32_path_and_the_ground_truth():
     """north_star: "F1 within 1e-3 of reference on held-out tuning set".  On the synthetic-trained 32-base net (bench.lowprec_accuracy:
-    150 AdamW steps, held-out 1024^2 synthetic images with known ground truth) the fp32-grade modes must reproduce the fp32 instances
-    and stay within 1e-3 of the fp32 path's F1 against the ground truth; the throughput modes keep F1 >= 0.99 (bf16) / 0.98 (fp8)
-    against the fp32 instances (measured 0.9986 / 0.9959 over four images, profiles/lowprec_accuracy_r03.json)."""
+    150 AdamW steps, EIGHT held-out 1024^2 synthetic images with known ground truth, ~3 600 cells: one cell is < 3e-4 of F1) the
+    fp32-grade modes must reproduce the fp32 instances and stay within 1e-3 of the fp32 path's F1 against the ground truth; the bf16
+    datapath within 1e-3 and the fp8 mode - layers below 128 channels on the bf16 kernels, "mixed fp8 weights / bf16" - within 2e-3
+    (measured +2.7e-4 / +2.2e-4 and F1 0.9988 / 0.9986 against the fp32 instances, profiles/fp8_mix_accuracy_r04.json; with EVERY
+    layer in e4m3, as in rounds 2-3, the same images give -4.3e-4 and 0.9934)."""
     sys.path[:0] = [ROOT, PKG]
     from bench import lowprec_accuracy
-    res = lowprec_accuracy(_dev(), n_images=4)
-    assert res["trained_net"]["cells_found_fp32"] > 500 and res["trained_net"]["f1_vs_truth_fp32"] > 0.6
+    res = lowprec_accuracy(_dev(), n_images=8)
+    assert res["trained_net"]["cells_found_fp32"] > 3000 and res["trained_net"]["f1_vs_truth_fp32"] > 0.6
     for prec in ("fp16x3", "bf16x6"):
         assert res[prec]["f1_vs_fp32"] >= 1.0 - 1e-3 and abs(res[prec]["delta_f1_vs_truth"]) <= 1e-3, (prec, res[prec])
-    assert res["bf16"]["f1_vs_fp32"] >= 0.99 and res["bf16"]["pixel_agreement"] >= 0.998, res["bf16"]
-    assert res["fp8"]["f1_vs_fp32"] >= 0.98 and res["fp8"]["pixel_agreement"] >= 0.995, res["fp8"]
-    # the throughput modes move a handful of the ~900 cells either way (measured over several runs: bf16 -6.5e-4 ... +1e-3, fp8 -1.7e-4 ...
-    # +2.5e-3; the sign is not systematic): gated at a few cells' worth, reported per run by bench.py
-    assert abs(res["bf16"]["delta_f1_vs_truth"]) <= 3e-3, res["bf16"]
-    assert abs(res["fp8"]["delta_f1_vs_truth"]) <= 5e-3, res["fp8"]
+    assert res["bf16"]["f1_vs_fp32"] >= 0.995 and res["bf16"]["pixel_agreement"] >= 0.998, res["bf16"]
+    assert res["fp8"]["f1_vs_fp32"] >= 0.995 and res["fp8"]["pixel_agreement"] >= 0.998, res["fp8"]
+    assert abs(res["bf16"]["delta_f1_vs_truth"]) <= 1e-3, res["bf16"]
+    assert abs(res["fp8"]["delta_f1_vs_truth"]) <= 2e-3, res["fp8"]
 
 
 def test_predict_cli_accepts_fp8(tmp_path):

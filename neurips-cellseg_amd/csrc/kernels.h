@@ -68,7 +68,7 @@ size_t packed_wino4_floats(int cout_total, int cin_total);
 int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed, bool dgrad = false);   // dgrad: (cout, cin) of the
                                                                                           // DATA-GRADIENT convolution (= the layer's cin, cout)
 bool wino4_fits(int cin, int cout, int h, int w);
-// layers with cout % 64 == 0 take the 32x32x2-MFMA form of the same algorithm (kernels_conv_wino4x.hip, CS_WINO >= 3): its weight
+// layers with cout % 64 == 0 (CS_WINO >= 3) or cout % 32 == 0 (CS_WINO >= 4) take the 32x32x2-MFMA form (kernels_conv_wino4x.hip): its weight
 // fragments are packed[cin/16][36 positions][cout/32][2][64 lanes][4] (same size, other order) - pack and launch ask this predicate
 bool wino4_layout32(int cin, int cout);
 int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4x, const float* bias, float* out, int pitch_out, int cout,
@@ -99,8 +99,8 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
 // 3x3 stride-1 pad-1 convolution as Winograd F(2x2, 3x3) on the fp32 matrix pipe (kernels_conv_wino.hip): 16 instead of 36
 // multiplies per 2x2 output tile; fp32 throughout, same outputs / statistics contract as launch_conv_mfma.  cout % 32 == 0.
 bool wino_enabled();           // CS_WINO=0 disables it (A/B against the direct kernels)
-int wino_level();              // CS_WINO: 0 direct kernels, 1 F(2x2,3x3) everywhere, 2 F(4x4,3x3) on 16x16x4 MFMAs, 3 (default) F(4x4,3x3)
-                               // on 32x32x2 MFMAs where the layer has >= 64 output channels
+int wino_level();              // CS_WINO: 0 direct kernels, 1 F(2x2,3x3) everywhere, 2 F(4x4,3x3) on 16x16x4 MFMAs, 3 F(4x4,3x3) on 32x32x2
+                               // MFMAs where the layer has >= 64 output channels, 4 (default) also its 32-channel form
 // the kernel addresses one image's input tensor with 32-bit byte offsets; larger tensors (a plain forward over a > 4 GB image
 // level) take the direct kernels
 static inline bool wino_fits(int h, int w, int pitch) { return (size_t)h * w * pitch * 4 < ((size_t)1 << 32); }

@@ -614,15 +614,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long l
 long long* g_wino_stamps = nullptr;    // diagnostics: device buffer of 8 x 8 counters (tests/diagnostics/wino_layer_bench.hip)
 void wino_set_stamp_buffer(long long* dev) { g_wino_stamps = dev; }
 
-int g_wino = 3;   // A/B switch (CS_WINO): 0 = direct kernels, 1 = Winograd F(2x2,3x3) everywhere, 2 = F(4x4,3x3) on 16x16x4 MFMAs,
-                  // 3 (default) = F(4x4,3x3) on 32x32x2 MFMAs for the layers with >= 64 output channels (kernels_conv_wino4x.hip)
+int g_wino = 4;   // A/B switch (CS_WINO): 0 = direct kernels, 1 = Winograd F(2x2,3x3) everywhere, 2 = F(4x4,3x3) on 16x16x4 MFMAs,
+                  // 3 = F(4x4,3x3) on 32x32x2 MFMAs for the layers with >= 64 output channels (kernels_conv_wino4x.hip),
+                  // 4 (default) = ... and its 32-channel form for the 32-channel layers
 static const int g_wino_init = [] {
     if (const char* e = getenv("CS_WINO")) g_wino = atoi(e);
     return 0;
 }();
 bool wino_enabled() { return g_wino != 0; }
 int wino_level() { return g_wino; }
-bool wino4_layout32(int cin, int cout) { return g_wino >= 3 && cin % 32 == 0 && cout % 64 == 0; }
+bool wino4_layout32(int cin, int cout) { return g_wino >= 3 && cin % 32 == 0 && (cout % 64 == 0 || (g_wino >= 4 && cout % 32 == 0)); }
 
 size_t packed_wino_floats(int cout_total, int cin_total) { return (size_t)(cin_total / 16) * 16 * (cout_total / 16) * 256; }
 

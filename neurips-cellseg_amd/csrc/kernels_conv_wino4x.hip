@@ -360,11 +360,286 @@ __global__ __launch_bounds__(512, 2) void conv_wino4x_kernel(ConvParams p, long 
         for (int k = 0; k < 8; ++k) stamps[(blockIdx.x ? 64 : 0) + wave * 8 + k] = tsum[k];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The 32-output-channel form (the 32 -> 32 layers at 128 x 128: K = 2 sixteen-channel chunks).  kernels_conv_wino4.hip's block for
+// them (16 tiles x 32 channels) lives 11 us for 2 us of matrix work: first patch's round trip, two stagings, exchange, output
+// transform, store tail.  Here a block is 256 threads = 4 waves, TWO sub-tiles (32 tiles = the M of the 32x32x2 instruction) x 32 output
+// channels (ONE N tile): wave w owns positions 9 w ... 9 w + 8, 144 accumulator registers, half the MFMA instructions and weight
+// fragments per tile, and a prologue / epilogue per 32 tiles instead of per 16.  The K loop walks EIGHT-channel chunks (four k-steps
+// of the instruction: one ds_read_b128 of A and one buffer load of B per position), which keeps raw (31 KB) + V (37 KB) and the
+// per-sub-tile exchange (74 KB) small enough for two blocks per CU - the second block's matrix phase covers this one's staging,
+// barriers and epilogue.  Same arithmetic, weights in the 32x32x2 fragment order of the kernel above.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int Z_PS = 12;                               // floats per staged raw pixel (8 + 4: keeps the 16-byte stores aligned)
+constexpr int Z_RAW1 = X_IH * X_IW * Z_PS;             // 3888 floats per sub-tile
+constexpr int Z_RAW = 2 * Z_RAW1;
+constexpr int Z_V = 36 * 2 * 32 * 4;                   // 9216: V[36 positions][h][32 tiles][4 k-steps]
+constexpr int Z_M = 36 * 16 * 32;                      // 18432: the products of one sub-tile
+constexpr int Z_MAIN = Z_RAW + Z_V;
+constexpr int Z_BODY = Z_MAIN > Z_M ? Z_MAIN : Z_M;
+constexpr int Z_ST = 4 * 32 * 2 * 2;                   // fp64 statistics of the four waves (as floats)
+constexpr size_t Z_LDS_BYTES = (size_t)(Z_BODY + Z_ST) * 4;
+}  // namespace
+
+template <bool LAZY>
+__global__ __launch_bounds__(256, 2) void conv_wino4z_kernel(ConvParams p) {
+    constexpr int IN_ITERS = 6;                                  // (pixel, channel quad) items per thread; the sixth only for 8 threads of a half
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const vs = smem + Z_RAW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = wave >> 1;                                   // staging half of this thread (wave-uniform): threads 0..127 / 128..255
+    const int htid = tid & 127;
+    const int n_spatial = p.tiles_x * p.tiles_y * p.n;
+    const WorkId wk = decode_work((n_spatial + 1) >> 1, p.ntile_total >> 1);
+    if (!wk.valid) return;
+    const int sp0 = 2 * wk.spatial;
+    const bool has1 = sp0 + 1 < n_spatial;
+    const int per_img = p.tiles_x * p.tiles_y;
+    auto tile_of = [&](int sp, int& img, int& oy0, int& ox0) {
+        img = sp / per_img;
+        const int r = sp - img * per_img;
+        const int ty = r / p.tiles_x;
+        oy0 = ty * 16;
+        ox0 = (r - ty * p.tiles_x) * 16;
+    };
+    int img_a, oy_a, ox_a, img_b, oy_b, ox_b;
+    tile_of(sp0, img_a, oy_a, ox_a);
+    tile_of(has1 ? sp0 + 1 : sp0, img_b, oy_b, ox_b);
+    const int my_img = sub ? img_b : img_a, my_oy = sub ? oy_b : oy_a, my_ox = sub ? ox_b : ox_a;
+    const bool my_valid = sub ? has1 : true;
+    const int nt0 = wk.ct * 2;                                   // first 16-channel tile of the block's 32 output channels
+    const int q = tid & 1;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int ps = 0; ps < 9; ++ps)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ps][r] = 0.f;
+
+    unsigned boff[IN_ITERS], inb = 0;
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (htid >> 1) + 64 * it;
+        const int iy = pix / X_IW, ix = pix - iy * X_IW;
+        const int gy = my_oy - 1 + iy, gx = my_ox - 1 + ix;
+        const bool ok = my_valid && pix < X_IH * X_IW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win;
+        inb |= ok ? (1u << it) : 0u;
+        boff[it] = ok ? ((unsigned)(gy * p.win + gx) * (unsigned)p.a.pitch + 4u * q) * 4u : 16u * q;
+    }
+    const char* const img_base = reinterpret_cast<const char*>(p.a.ptr + (size_t)my_img * p.hin * p.win * p.a.pitch);
+    const int chunks = p.a.c >> 3;                               // 8-channel chunks
+    const bool tail_wave = (wave & 1) == 0;                      // the waves whose first 8 lanes own pixels 320..323 of their half
+    f32x4 rin[3];
+    Lazy4 lz;
+    float* const my_raw = smem + sub * Z_RAW1;
+    auto load_half = [&](auto hc, int ch) {
+        constexpr int H = decltype(hc)::value;
+        const char* base = img_base + (size_t)(ch << 3) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rin[k] = *reinterpret_cast<const f32x4*>(base + boff[3 * H + k]);   // unconditional (clamped)
+    };
+    auto store_one = [&](int it, const f32x4& r) {
+        const int pix = (htid >> 1) + 64 * it;
+        const f32x4 a = LAZY ? lz.apply_on(r) : r;
+        const f32x4 v = (inb >> it) & 1u ? a : f32x4{0.f, 0.f, 0.f, 0.f};           // padding stays 0 after the activation
+        *reinterpret_cast<f32x4*>(&my_raw[pix * Z_PS + 4 * q]) = v;
+    };
+    auto store_half = [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        if (H == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) store_one(k, rin[k]);
+        } else {
+            store_one(3, rin[0]);
+            store_one(4, rin[1]);
+            if (tail_wave && (htid >> 1) + 64 * 5 < X_IH * X_IW) store_one(5, rin[2]);
+        }
+    };
+    const std::integral_constant<int, 0> H0;
+    const std::integral_constant<int, 1> H1;
+    // input transform of one (tile, channel): tile = tid >> 3 (0..31: sub-tile = tile >> 4), channel = tid & 7
+    const int t_tile = tid >> 3, t_lt = t_tile & 15, t_c = tid & 7;
+    const float* const t_src = smem + (t_tile >> 4) * Z_RAW1 + (((t_lt >> 2) * 4) * X_IW + (t_lt & 3) * 4) * Z_PS + t_c;
+    // V[position][h = c & 1][tile][e = c >> 1]: channel 2 e + h of the chunk is k-step e of lane half h
+    float* const t_dst = vs + ((t_c & 1) * 32 + t_tile) * 4 + (t_c >> 1);            // + position * 256
+    auto transform = [&]() {
+        float t[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float x[6], y[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = t_src[(i * X_IW + j) * Z_PS];
+            xbt6(x, y);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][j] = y[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float y[6];
+            xbt6(t[i], y);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) t_dst[(i * 6 + j) * 256] = y[j];
+        }
+    };
+
+    // B fragments: packed[chunk16][position 36][cout / 32][u 2][64 lanes][4]; the 8-channel chunk c8 is (chunk16, u) = (c8 >> 1, c8 & 1)
+    const int nt32_total = p.ntile_total >> 1;
+    const unsigned wpos = (unsigned)nt32_total * 2u * 64u * 16u;      // bytes between positions
+    const unsigned wblock = (unsigned)wk.ct * 2u * 64u * 16u + (unsigned)wave * 9u * wpos;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpack), 0, (int)((size_t)(p.a.c >> 4) * 36 * wpos), 0x00020000);
+    const unsigned wlane = (unsigned)lane * 16u;
+    f32x4 wc[3];                                                 // three-slot ring, fragments requested two positions ahead
+    const int last_step = chunks * 9 - 1;
+    auto wload = [&](int step, f32x4& dst) {
+        const int ch = step / 9, ps = step - ch * 9;
+        const unsigned so = wblock + (unsigned)((ch >> 1) * 36 + ps) * wpos + (unsigned)(ch & 1) * 1024u;
+        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
+    };
+
+    if (LAZY) lz.load(p.a, my_img, 4 * q, p.wpack);
+    load_half(H0, 0);
+    wload(0, wc[0]);
+    wload(last_step < 1 ? last_step : 1, wc[1]);
+    store_half(H0);
+    load_half(H1, 0);
+    store_half(H1);
+    __syncthreads();
+    transform();
+    __syncthreads();
+    const int a_i = lane & 31, a_h = lane >> 5;
+    const float* const a_src = vs + (wave * 9) * 256 + (a_h * 32 + a_i) * 4;           // + position * 256
+#pragma unroll 1
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        const int nch = more ? ch + 1 : ch;        // (the last trip re-reads its own chunk: a skipped load group would mis-size the ring's waits)
+        f32x4 av[2];
+        av[0] = *reinterpret_cast<const f32x4*>(a_src);
+#pragma unroll
+        for (int ps = 0; ps < 9; ++ps) {
+            {
+                const int step = ch * 9 + ps + 2;
+                wload(step < last_step ? step : last_step, wc[(ps + 2) % 3]);
+            }
+            if (ps == 0) {
+                if (LAZY) lz.load(p.a, my_img, (nch << 3) + 4 * q, p.wpack);
+                load_half(H0, nch);
+            }
+            if (ps == 3) {
+                if (more) store_half(H0);
+                load_half(H1, nch);
+            }
+            if (ps == 7 && more) store_half(H1);
+            if (ps < 8) av[(ps + 1) & 1] = *reinterpret_cast<const f32x4*>(a_src + (ps + 1) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[ps] = mfma32(av[ps & 1][e], wc[ps % 3][e], acc[ps]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (more) {
+            transform();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: one sub-tile (16 tiles x 32 channels) at a time through LDS; registers 0..7 / 8..15 of every accumulator ----
+    float* const ms = smem;                                     // [36 positions][16 tiles][32 channels]
+    double* const st_s = reinterpret_cast<double*>(smem + Z_BODY);           // [4 waves][32 channels][2]
+    const int e_grp = tid >> 7;                                 // output rows 2 e_grp, 2 e_grp + 1 of the tile
+    const int e_lt = (tid >> 3) & 15, e_q = tid & 7;
+    const int e_ty = e_lt >> 2, e_tx = e_lt & 3;
+    const int co = nt0 * 16 + 4 * e_q;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+    auto pass = [&](auto sbc) {
+        constexpr int SB = decltype(sbc)::value;
+        const int e_img = SB ? img_b : img_a, e_oy0 = SB ? oy_b : oy_a, e_ox0 = SB ? ox_b : ox_a;
+        const bool e_valid = SB ? has1 : true;
+#pragma unroll
+        for (int ps = 0; ps < 9; ++ps)
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int tile = (r8 & 3) + 8 * (r8 >> 2) + 4 * a_h;
+                ms[((wave * 9 + ps) * 16 + tile) * 32 + a_i] = acc[ps][8 * SB + r8];
+            }
+        __syncthreads();
+        {
+            const float* src = ms + e_lt * 32 + 4 * e_q;
+            float sf[4] = {0.f, 0.f, 0.f, 0.f}, qf[4] = {0.f, 0.f, 0.f, 0.f};
+            const int ox = e_ox0 + 4 * e_tx;
+            f32x4 tm[2][6];
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                f32x4 m[6];
+#pragma unroll
+                for (int xi = 0; xi < 6; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(src + (xi * 6 + nu) * 512);
+                f32x4 o[4];
+                xat6(m, o);
+                tm[0][nu] = e_grp ? o[2] : o[0];
+                tm[1][nu] = e_grp ? o[3] : o[1];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                f32x4 y[4];
+                xat6(tm[ii], y);
+                const int oy = e_oy0 + 4 * e_ty + 2 * e_grp + ii;
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    f32x4 v = y[jx] + bias4;
+                    if (e_valid && oy < p.hout && ox + jx < p.wout) {
+                        const size_t gp = ((size_t)e_img * p.hout + oy) * p.wout + ox + jx;
+                        if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + gp * p.pitch_add + co);
+                        *reinterpret_cast<f32x4*>(p.out + gp * p.pitch_out + co) = v;
+                        if (p.stats) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                sf[k] += v[k];
+                                qf[k] = __builtin_fmaf(v[k], v[k], qf[k]);
+                            }
+                        }
+                    }
+                }
+            }
+            if (p.stats) {
+                // a thread's 8 values per channel and the 8 lanes (tiles) of the wave that hold the same channel quad are summed in fp32
+                // (<= 64 values per partial sum), everything from there on is fp64
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int sh = 8; sh < 64; sh <<= 1) {
+                        sf[k] += __shfl_xor(sf[k], sh);
+                        qf[k] += __shfl_xor(qf[k], sh);
+                    }
+                }
+                if (lane < 8) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        st_s[(wave * 32 + 4 * e_q + k) * 2] = (double)sf[k];
+                        st_s[(wave * 32 + 4 * e_q + k) * 2 + 1] = (double)qf[k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (p.stats && tid < 64 && e_valid) {
+            const int c = tid >> 1, k = tid & 1;
+            const double v = (st_s[(0 * 32 + c) * 2 + k] + st_s[(1 * 32 + c) * 2 + k]) + (st_s[(2 * 32 + c) * 2 + k] + st_s[(3 * 32 + c) * 2 + k]);
+            atomicAdd(p.stats + ((size_t)e_img * p.cout + nt0 * 16 + c) * 2 + k, v);
+        }
+    };
+    pass(std::integral_constant<int, 0>());
+    pass(std::integral_constant<int, 1>());
+}
+
 extern long long* g_wino_stamps;       // diagnostics (tests/diagnostics/wino_layer_bench.hip); null in production
 
 int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4x, const float* bias, float* out, int pitch_out, int cout,
                        double* stats, int n, int h, int w, const ConvOutExtra* ex) {
-    CS_REQUIRE(a.c % 32 == 0 && a.c > 0 && cout % 64 == 0, "conv(winograd 4x4, 32x32): channels (%d -> %d) unsupported", a.c, cout);
+    CS_REQUIRE(a.c % 32 == 0 && a.c > 0 && cout % 32 == 0, "conv(winograd 4x4, 32x32): channels (%d -> %d) unsupported", a.c, cout);
     CS_REQUIRE((a.pitch % 4) == 0 && (pitch_out % 4) == 0, "conv(winograd 4x4, 32x32): pixel pitch must be a multiple of 4 floats");
     CS_REQUIRE(!a.h16 && !a.q8 && !a.ptr2, "conv(winograd 4x4, 32x32): plain fp32 activations only");
     CS_REQUIRE((size_t)h * w * a.pitch * 4 < ((size_t)1 << 32), "conv(winograd 4x4, 32x32): one image's activation tensor must stay below 4 GB");
@@ -388,24 +663,41 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
         p.pitch_add = ex->pitch_add;
     }
     const int n_spatial = p.tiles_x * p.tiles_y * n;
-    const dim3 grid(xcd_grid((n_spatial + 1) / 2, p.ntile_total / 4));
     const double flops = 2.0 * n * (double)ceil_div(h, 4) * ceil_div(w, 4) * 36.0 * (double)cout * a.c;
     const double bytes = 4.0 * n * (double)h * w * (a.c + cout);
     ProfScope prof(K_CONV3_WINO4, s, flops, bytes);
     // opt-in to > 64 KB of dynamic LDS: an attribute of the function ON THE CURRENT DEVICE, so it is remembered per (kernel, device)
-    static unsigned long long lds_set[2] = {0ull, 0ull};
+    static unsigned long long lds_set[4] = {0ull, 0ull, 0ull, 0ull};
     int dev = 0;
     CS_HIP(hipGetDevice(&dev));
     CS_REQUIRE(dev >= 0 && dev < 64, "conv(winograd 4x4, 32x32): device index %d out of range", dev);
-    auto go = [&](auto kern, int which) -> int {
+    const bool wide = cout % 64 == 0;          // 64-channel blocks of 512 threads; else the 32-channel form (256 threads, two blocks per CU)
+    const size_t lds = wide ? X_LDS_BYTES : Z_LDS_BYTES;
+    const dim3 grid(wide ? xcd_grid((n_spatial + 1) / 2, p.ntile_total / 4) : xcd_grid((n_spatial + 1) / 2, p.ntile_total / 2));
+    auto ensure = [&](const void* kern, int which) -> int {
         if (!((lds_set[which] >> dev) & 1ull)) {
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS_BYTES));
+            CS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_set[which] |= 1ull << dev;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(512), X_LDS_BYTES, s, p, g_wino_stamps);
         return CS_OK;
     };
-    if (int rc = a.tab ? go(conv_wino4x_kernel<true>, 1) : go(conv_wino4x_kernel<false>, 0)) return rc;
+    if (wide) {
+        if (a.tab) {
+            if (int rc = ensure(reinterpret_cast<const void*>(&conv_wino4x_kernel<true>), 1)) return rc;
+            hipLaunchKernelGGL(conv_wino4x_kernel<true>, grid, dim3(512), lds, s, p, g_wino_stamps);
+        } else {
+            if (int rc = ensure(reinterpret_cast<const void*>(&conv_wino4x_kernel<false>), 0)) return rc;
+            hipLaunchKernelGGL(conv_wino4x_kernel<false>, grid, dim3(512), lds, s, p, g_wino_stamps);
+        }
+    } else {
+        if (a.tab) {
+            if (int rc = ensure(reinterpret_cast<const void*>(&conv_wino4z_kernel<true>), 3)) return rc;
+            hipLaunchKernelGGL(conv_wino4z_kernel<true>, grid, dim3(256), lds, s, p);
+        } else {
+            if (int rc = ensure(reinterpret_cast<const void*>(&conv_wino4z_kernel<false>), 2)) return rc;
+            hipLaunchKernelGGL(conv_wino4z_kernel<false>, grid, dim3(256), lds, s, p);
+        }
+    }
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -240,3 +240,19 @@ def test_native_adamw_refuses_a_tensor_whose_first_gradient_arrives_late():
         else:
             with pytest.raises(_lib.CellSegHipError, match="first gradient after step"):
                 opt.step()
+
+
+# ------------------------------------------------------------------------------------------- bench.py --gpus N: strips leg guarded
+def test_bench_reports_the_slides_leg_when_the_strips_leg_fails():
+    """`bench.py --gpus N` makes the strong-scaling strips leg the headline; its collectives (seam send/recv, mask all-gather) have never
+    run on real multi-GPU hardware here, so a failure there must not cost the whole line: the collective-free slides leg is measured
+    first and reported (scaling weak, strips_error set).  The failure is provoked with an unknown seam transport (two gloo ranks
+    sharing the GPU)."""
+    from conftest import cli_env
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1",
+                          "--no-secondary"], capture_output=True, text=True, timeout=900,
+                         env=cli_env(BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_SEAM_TRANSPORT="bogus"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert "unknown transport" in line["strips_error"]

@@ -135,6 +135,8 @@ struct ConvW {             // packed weights + bias of one (possibly fused) conv
                            // INFERENCE only: a training step re-packs every weight, and packing 36 positions in fp64 costs more there
                            // (0.25 ms per step) than the kernel saves on training-sized launches - loads in training mode leave them stale
     bool ww4_fresh = false; // the F(4x4) weights correspond to the parameter's current value (else the F(2x2) kernel runs)
+    float* wtw = nullptr;   // transposed convs: the 25 F(2,2) products' weights (kernels_convt_wino.hip) - an inference-only packing too
+    bool wtw_fresh = false;
     unsigned short* wb = nullptr;   // 3 bf16 planes in 16x16x32 fragment order (split-bf16 forward kernels)
     unsigned short* wbd = nullptr;  // the same planes for the layer's DATA-GRADIENT launch (bf16 training): stride-1 conv (roles swapped, taps reversed),
                                     // fused stride-2 pair (as a transposed conv over [dy0 || dr]), transposed conv (as a stride-2 conv)
@@ -318,6 +320,8 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
     float* wwd = cw.wwd;
     float* ww4 = cw.ww4;
     bool* const ww4_fresh = &cw.ww4_fresh;
+    float* wtw = cw.wtw;
+    bool* const wtw_fresh = &cw.wtw_fresh;
     unsigned short* wb = cw.wb;
     unsigned short* wbd = cw.wbd;
     unsigned char* w8 = cw.w8;
@@ -342,6 +346,11 @@ static void add_conv_params(cs_unet* net, const std::string& conv, ConvW& cw, in
                 if (int rc = pack_conv_weights_bf16(net->pack, s, d, false, cin, cout, ksize, wbd, 0, cin, 0, false)) return rc;
             if (w8 && net->planes == 5 && *f8p)
                 if (int rc = pack_conv_weights_fp8(s, d, true, cout, cin, ksize, w8, wsc, cout_off, cout_total, cin_split)) return rc;
+            if (wtw) {                                       // fp32 inference: the F(2,2) form of the transposed conv
+                *wtw_fresh = convt_wino_enabled() && net->planes == 0 && !net->training && cout_off == 0 && cout == cout_total;
+                if (*wtw_fresh)
+                    if (int rc = pack_convt_wino_weights(net->pack, s, d, cout, cin, wtw)) return rc;
+            }
             return pack_conv_weights(net->pack, s, d, true, cout, cin, ksize, wdst, cout_off, cout_total, dgrad_dst(), dg_flip, dg_chunk_off);
         });
     } else {
@@ -454,6 +463,7 @@ static void build_up(cs_unet* net, ArenaPlan& ar, UpUnit& u, const std::string& 
     if (!small) u.convt.wbd = (unsigned short*)ar.take((packed_bf16_elems(cin, cout, 0, 3) + 1) / 2);
     if (!small) { u.convt.w8 = (unsigned char*)ar.take((packed_fp8_bytes(cout, cin_skip, cin_sub, 3) + 3) / 4); u.convt.wscale = ar.take(cout); }
     u.convt.f8 = !small && fp8_layer(cin_skip < cin_sub ? cin_skip : cin_sub, cout);
+    if (!small && cout % 32 == 0 && cin_skip % 16 == 0 && cin_sub % 16 == 0) u.convt.wtw = ar.take(packed_convt_wino_floats(cout, cin));
     add_conv_params(net, pfx + ".0.conv", u.convt, cout, cin, 3, 0, true, small ? 2 : 0, small ? DG_NONE : DG_CONVT_AS_S2, 0, cin_skip);
     add_norm_params(net, ar, pfx + ".0.adn", u.norm_t, cout);
     u.unit0.cin = cout; u.unit0.cout = cout;
@@ -753,7 +763,10 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 CS_TRY(launch_convt_bf16s(s, net->planes == 5 ? 1 : net->planes, a, b, u.convt.wb, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw, a16));
             } else if (c % 16 == 0) {
                 CS_REQUIRE(!a16, "convT: a layer without 16-bit weights met bf16 activations");
-                CS_TRY(launch_convt_mfma(s, a, b, u.convt.w, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
+                if (net->planes == 0 && u.convt.wtw && u.convt.wtw_fresh && convt_wino_fits(a.c, b.c, c, ph, pw) && !a.tab && (b.ptr2 || !b.tab))
+                    CS_TRY(launch_convt_wino(s, a, b, u.convt.wtw, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));   // 25 instead of 36 multiplies per 2 x 2 pixels
+                else
+                    CS_TRY(launch_convt_mfma(s, a, b, u.convt.w, u.convt.bias, U, c, c, rt_upt[d].stats, n, ph, pw));
             } else {
                 CS_TRY(launch_convt_small(s, a, b, u.convt.w, u.convt.bias, U, c, rt_upt[d].stats, n, ph, pw));
             }

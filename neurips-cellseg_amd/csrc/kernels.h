@@ -76,6 +76,15 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
 int launch_conv_wino4(hipStream_t s, const ConvSrc& a, const float* wpack_wino4, const float* bias, float* out, int pitch_out, int cout,
                       double* stats, int n, int h, int w, const ConvOutExtra* ex = nullptr);
 size_t packed_first_floats(int cout_total, int cin);
+// Transposed conv k3 s2 p1 op1 in Winograd form F(2,2) (kernels_convt_wino.hip; inference): 25 instead of 36 multiplies per 2 x 2 input
+// pixels; weights W[cin][cout][3][3] -> packed[cin/16][25 products][cout/16][64 lanes][4].  CS_CONVT_WINO=0 keeps the direct kernels.
+struct ConvSrc;
+size_t packed_convt_wino_floats(int cout_total, int cin_total);
+int pack_convt_wino_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed);
+bool convt_wino_enabled();
+bool convt_wino_fits(int cin_a, int cin_b, int cout, int h, int w);
+int launch_convt_wino(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* wpack_tw, const float* bias, float* out, int pitch_out,
+                      int cout, double* stats, int n, int hin, int win);
 
 // Extras used by the backward pass when a forward kernel computes a data gradient:
 //   out = conv(...) + bias + addend ; output channels >= `split` are written to out2 (+ addend2) instead.

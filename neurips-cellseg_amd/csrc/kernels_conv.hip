@@ -1205,6 +1205,7 @@ static inline int64_t pack_job_elems(const PackJob& jb) {
         case PK_BF16: return (int64_t)jb.chunks_total * jb.taps * (jb.cout / 16) * 64;     // OCTETS: 8 halfs of 3 planes per thread
         case PK_WINO: return (int64_t)(jb.cin / 16) * 16 * (jb.cout / 16) * 256;
         case PK_WINO4: return (int64_t)(jb.cin / 16) * 36 * (jb.cout / 16) * 256;
+        case PK_CONVTW: return (int64_t)(jb.cin / 16) * 25 * (jb.cout / 16) * 256;
         default: return jb.cout;                              // PK_COPY: cout = element count
     }
 }
@@ -1245,6 +1246,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* jobs, int
         case PK_BF16: pack_bf16_elem(jb, le); break;
         case PK_WINO: pack_wino_elem(jb, le); break;
         case PK_WINO4: pack_wino4_elem(jb, le); break;
+        case PK_CONVTW: pack_convt_wino_elem(jb, le); break;
         default: reinterpret_cast<float*>(jb.dst)[le] = jb.src[le]; break;
     }
 }
@@ -1474,6 +1476,13 @@ int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int
     jb.transposed = dgrad ? 1 : 0; jb.flip = dgrad ? 1 : 0;
     jb.src = w; jb.dst = packed; jb.kind = PK_WINO4; jb.cout = cout; jb.cin = cin; jb.ntile_total = cout / 16;
     jb.f16 = wino4_layout32(cin, cout) ? 1 : 0;      // (field reused) 1: the 32x32x2 fragment order of kernels_conv_wino4x.hip
+    return pack_submit(pc, s, jb);
+}
+
+int pack_convt_wino_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed) {
+    CS_REQUIRE(cout % 16 == 0 && cin % 16 == 0, "pack(transposed conv, winograd): bad channel counts");
+    PackJob jb{};
+    jb.src = w; jb.dst = packed; jb.kind = PK_CONVTW; jb.cout = cout; jb.cin = cin; jb.ntile_total = cout / 16; jb.transposed = 1;
     return pack_submit(pc, s, jb);
 }
 

@@ -6,7 +6,7 @@
 
 namespace cs {
 
-enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3, PK_FIRST16 = 4, PK_WINO = 5, PK_WINO4 = 6 };
+enum PackKind { PK_CONV = 0, PK_FIRST = 1, PK_BF16 = 2, PK_COPY = 3, PK_FIRST16 = 4, PK_WINO = 5, PK_WINO4 = 6, PK_CONVTW = 7 };
 struct PackJob {
     const float* src;
     void* dst;
@@ -228,6 +228,44 @@ __device__ __forceinline__ void pack_wino4_elem(const PackJob& jb, int64_t e) {
         for (int b = 0; b < 3; ++b) u += ga[a] * (double)src[jb.flip ? 8 - (a * 3 + b) : a * 3 + b] * gb[b];
     // both orders are a permutation of the same element range: the flattened element index IS the destination
     reinterpret_cast<float*>(jb.dst)[e] = (float)u;
+}
+
+
+// The F(2,2) forms of the stride-2 layers: the 25 products (row form a) x (column form b), U[a][b] = sum over (ky, kx) of
+// rho_a[ky] rho_b[kx] W[ky][kx], summed in fp64, rounded once.
+//   transposed conv k3 s2 p1 op1 (kernels_convt_wino.hip; jb.transposed = 1: W[cin][cout][3][3], jb.flip = 0):
+//       rho_0 = rho_1 = e_1 (one-tap phase), rho_2 = e_2, rho_3 = e_2 + e_0, rho_4 = e_0     (two-tap phase: g0 = w[2], g1 = w[0])
+//   (jb.transposed = 0, jb.flip = 1 gives the forms of the ADJOINT, a stride-2 conv k3 p1 with W[cout][cin][3][3]: g0 = w[0], g1 = w[2].
+//    A kernel for it was built and measured in round 4 - 7.55 vs 7.80 ms per slide for the fused stride-2 layers, no gain on the slide,
+//    3.6e-5 on the logits - and not kept: DESIGN.md 3.1c.)
+// packed[chunk][product a * 5 + b][ntile_total][lane][j]: cout = cout_off + ntile*16 + (lane & 15), cin = chunk*16 + 4*(lane>>4) + j.
+__device__ __forceinline__ void pack_convt_wino_elem(const PackJob& jb, int64_t e) {
+    const int cout = jb.cout, cin = jb.cin;
+    const int j = e & 3, lane = (e >> 2) & 63;
+    int64_t r = e >> 8;
+    const int ntl = (int)(r % (cout / 16));
+    r /= (cout / 16);
+    const int prod = (int)(r % 25);
+    const int chunk = (int)(r / 25);
+    const int co = ntl * 16 + (lane & 15), ci = chunk * 16 + 4 * (lane >> 4) + j;
+    const float* src = jb.transposed ? jb.src + ((size_t)ci * cout + co) * 9 : jb.src + ((size_t)co * cin + ci) * 9;
+    const int a = prod / 5, b = prod - a * 5;
+    const int k_first = jb.flip ? 0 : 2, k_second = jb.flip ? 2 : 0;        // tap of g0 / of g1 on the two-tap phase
+    auto rho = [&](int f, double (&o)[3]) {
+        o[0] = o[1] = o[2] = 0.0;
+        if (f == 0 || f == 1) o[1] = 1.0;
+        if (f == 2 || f == 3) o[k_first] = 1.0;
+        if (f == 3 || f == 4) o[k_second] = 1.0;
+    };
+    double ra[3], rb[3];
+    rho(a, ra);
+    rho(b, rb);
+    double u = 0.0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) u += ra[ky] * rb[kx] * (double)src[ky * 3 + kx];
+    reinterpret_cast<float*>(jb.dst)[(((size_t)chunk * 25 + prod) * jb.ntile_total + jb.cout_off / 16 + ntl) * 256 + lane * 4 + j] = (float)u;
 }
 
 }  // namespace cs

@@ -256,3 +256,21 @@ def test_bench_reports_the_slides_leg_when_the_strips_leg_fails():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert "unknown transport" in line["strips_error"]
+
+
+def test_transposed_conv_winograd_form_agrees_with_the_direct_kernels(tmp_path):
+    """The decoder's transposed convs in F(2,2) form (kernels_convt_wino.hip: 25 instead of 36 multiplies per 2 x 2 input pixels, eval mode)
+    against the direct fp32 MFMA kernels, everything else equal (CS_WINO=0 in both processes): logits within 5e-5 on shapes with partial
+    8 x 8 input blocks (17 x 13 / 34 x 26 pixels at the levels that take the kernel), odd sizes and a BatchNorm net; and the kernel
+    really ran (the results are not bitwise the direct ones)."""
+    res = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"ct{mode}.pt")
+        env = dict(os.environ, CS_WINO="0", CS_CONVT_WINO=mode, PYTHONPATH=os.pathsep.join([PKG, ROOT]))
+        subprocess.run([sys.executable, "-c", _WINO_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
+        res[mode] = torch.load(path)
+    for tag in res["0"]:
+        scale = float(res["0"][tag].abs().max())
+        err = float((res["1"][tag] - res["0"][tag]).abs().max())
+        assert err <= 5e-5 * max(scale, 1.0), (tag, err, scale)
+    assert not torch.equal(res["1"]["a"], res["0"]["a"]) and not torch.equal(res["1"]["b"], res["0"]["b"])

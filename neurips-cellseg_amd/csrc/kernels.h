@@ -71,6 +71,7 @@ bool wino4_fits(int cin, int cout, int h, int w);
 // layers with cout % 64 == 0 (CS_WINO >= 3) or cout % 32 == 0 (CS_WINO >= 4) take the 32x32x2-MFMA form (kernels_conv_wino4x.hip): its weight
 // fragments are packed[cin/16][36 positions][cout/32][2][64 lanes][4] (same size, other order) - pack and launch ask this predicate
 bool wino4_layout32(int cin, int cout);
+int wino4_form(int cin, int cout);     // 0: kernels_conv_wino4.hip; 1 / 2 / 3: the 64-channel, 32-channel and register-epilogue kernels of kernels_conv_wino4x.hip
 int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4x, const float* bias, float* out, int pitch_out, int cout,
                        double* stats, int n, int h, int w, const ConvOutExtra* ex = nullptr);
 int launch_conv_wino4(hipStream_t s, const ConvSrc& a, const float* wpack_wino4, const float* bias, float* out, int pitch_out, int cout,

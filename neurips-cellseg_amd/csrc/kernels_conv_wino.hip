@@ -614,16 +614,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long l
 long long* g_wino_stamps = nullptr;    // diagnostics: device buffer of 8 x 8 counters (tests/diagnostics/wino_layer_bench.hip)
 void wino_set_stamp_buffer(long long* dev) { g_wino_stamps = dev; }
 
-int g_wino = 4;   // A/B switch (CS_WINO): 0 = direct kernels, 1 = Winograd F(2x2,3x3) everywhere, 2 = F(4x4,3x3) on 16x16x4 MFMAs,
+int g_wino = 5;   // A/B switch (CS_WINO): 0 = direct kernels, 1 = Winograd F(2x2,3x3) everywhere, 2 = F(4x4,3x3) on 16x16x4 MFMAs,
                   // 3 = F(4x4,3x3) on 32x32x2 MFMAs for the layers with >= 64 output channels (kernels_conv_wino4x.hip),
-                  // 4 (default) = ... and its 32-channel form for the 32-channel layers
+                  // 4 = ... and its 32-channel form for the 32-channel layers, 5 (default) = ... and the register-epilogue form for cin <= 128
 static const int g_wino_init = [] {
     if (const char* e = getenv("CS_WINO")) g_wino = atoi(e);
     return 0;
 }();
 bool wino_enabled() { return g_wino != 0; }
 int wino_level() { return g_wino; }
-bool wino4_layout32(int cin, int cout) { return g_wino >= 3 && cin % 32 == 0 && (cout % 64 == 0 || (g_wino >= 4 && cout % 32 == 0)); }
+static const int g_wino4y_max_cin = [] { const char* e = getenv("CS_WINO4Y_MAX_CIN"); return e ? atoi(e) : 128; }();
+// which F(4x4) kernel a layer takes: 0 = kernels_conv_wino4.hip (16x16x4, a wave owns positions), 1 / 2 = the 32x32x2 forms of
+// kernels_conv_wino4x.hip (64- / 32-channel blocks), 3 = its 16x16x4 form with the output transform in registers (short K loops)
+int wino4_form(int cin, int cout) {
+    if (g_wino < 3 || cin % 32 != 0) return 0;
+    if (cout % 64 == 0) return (g_wino >= 5 && cin <= g_wino4y_max_cin) ? 3 : 1;
+    return (g_wino >= 4 && cout % 32 == 0) ? 2 : 0;
+}
+bool wino4_layout32(int cin, int cout) { const int f = wino4_form(cin, cout); return f == 1 || f == 2; }
 
 size_t packed_wino_floats(int cout_total, int cin_total) { return (size_t)(cin_total / 16) * 16 * (cout_total / 16) * 256; }
 

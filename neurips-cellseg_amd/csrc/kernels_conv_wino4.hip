@@ -294,7 +294,7 @@ bool wino4_fits(int cin, int cout, int h, int w) { return cin >= WINO4_MIN_CIN &
 
 int launch_conv_wino4(hipStream_t s, const ConvSrc& a, const float* wpack_wino4, const float* bias, float* out, int pitch_out, int cout,
                       double* stats, int n, int h, int w, const ConvOutExtra* ex) {
-    if (wino4_layout32(a.c, cout)) return launch_conv_wino4x(s, a, wpack_wino4, bias, out, pitch_out, cout, stats, n, h, w, ex);   // (weights packed to match)
+    if (wino4_form(a.c, cout) != 0) return launch_conv_wino4x(s, a, wpack_wino4, bias, out, pitch_out, cout, stats, n, h, w, ex);   // (weights packed to match)
     CS_REQUIRE(a.c % 32 == 0 && a.c > 0 && cout % 32 == 0, "conv(winograd 4x4): channels (%d -> %d) unsupported", a.c, cout);
     CS_REQUIRE((a.pitch % 4) == 0 && (pitch_out % 4) == 0, "conv(winograd 4x4): pixel pitch must be a multiple of 4 floats");
     CS_REQUIRE(!a.h16 && !a.q8 && !a.ptr2, "conv(winograd 4x4): plain fp32 activations only");

@@ -362,6 +362,290 @@ __global__ __launch_bounds__(512, 2) void conv_wino4x_kernel(ConvParams p, long 
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The same block (512 threads, two sub-tiles, 64 output channels, the staging and transform above) with the point-wise GEMMs on
+// v_mfma_f32_16x16x4_f32 and the ownership turned round: wave w = (channel tile w & 3) x (sub-tile w >> 2) x ALL 36 positions.  The C
+// layout then keeps every product of an output pixel block in one lane, so the output transform, bias and statistics run in registers -
+// no exchange through LDS, no epilogue barriers (the two-pass exchange of the kernel above is 20 k cycles of a block that is alone on its
+// CU: 40 % of a 64 -> 64 block's life).  A weight fragment feeds 4 instead of 8 MFMAs' worth of work; the two waves of a channel tile
+// read the same fragments (one fetch from L2, two from the vector L1).  Used where the K loop is short (cin <= 128); the deep layers keep
+// the 32x32x2 form, whose halved fragment stream weighs more there.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool LAZY>
+__global__ __launch_bounds__(512, 2) void conv_wino4y_kernel(ConvParams p, long long* stamps) {
+    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long treal0 = stamps ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    long long tlast = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    auto stamp = [&](int k) {
+        if (stamps) {
+            const long long t = (long long)__builtin_amdgcn_s_memtime();
+            tsum[k] += t - tlast;
+            tlast = t;
+        }
+    };
+    constexpr int IN_ITERS = 6;                                  // (pixel, channel quad) items per thread; the sixth only for 16 threads of a half
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const vs = smem + X_RAW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = wave >> 2;                                   // staging / transform half of this thread (wave-uniform)
+    const int htid = tid & 255;
+    const int n_spatial = p.tiles_x * p.tiles_y * p.n;
+    const WorkId wk = decode_work((n_spatial + 1) >> 1, p.ntile_total >> 2);
+    if (!wk.valid) return;
+    // the two sub-tiles: items 2 s, 2 s + 1 of the tile list (the second may not exist)
+    const int sp0 = 2 * wk.spatial;
+    const bool has1 = sp0 + 1 < n_spatial;
+    const int per_img = p.tiles_x * p.tiles_y;
+    auto tile_of = [&](int sp, int& img, int& oy0, int& ox0) {
+        img = sp / per_img;
+        const int r = sp - img * per_img;
+        const int ty = r / p.tiles_x;
+        oy0 = ty * 16;
+        ox0 = (r - ty * p.tiles_x) * 16;
+    };
+    int img_a, oy_a, ox_a, img_b, oy_b, ox_b;
+    tile_of(sp0, img_a, oy_a, ox_a);
+    tile_of(has1 ? sp0 + 1 : sp0, img_b, oy_b, ox_b);
+    const int my_img = sub ? img_b : img_a, my_oy = sub ? oy_b : oy_a, my_ox = sub ? ox_b : ox_a;
+    const bool my_valid = sub ? has1 : true;
+    const int nt0 = wk.ct * 4;                                   // first 16-channel tile of the block's 64 output channels
+    const int q = tid & 3;
+
+    f32x4 acc[36];                                               // every position of (16 tiles, 16 channels): the wave's own output tile
+#pragma unroll
+    for (int ps = 0; ps < 36; ++ps) acc[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging geometry of this thread's half, fixed for the K loop
+    unsigned boff[IN_ITERS], inb = 0;
+#pragma unroll
+    for (int it = 0; it < IN_ITERS; ++it) {
+        const int pix = (htid >> 2) + 64 * it;
+        const int iy = pix / X_IW, ix = pix - iy * X_IW;
+        const int gy = my_oy - 1 + iy, gx = my_ox - 1 + ix;
+        const bool ok = my_valid && pix < X_IH * X_IW && gy >= 0 && gy < p.hin && gx >= 0 && gx < p.win;
+        inb |= ok ? (1u << it) : 0u;
+        boff[it] = ok ? ((unsigned)(gy * p.win + gx) * (unsigned)p.a.pitch + 4u * q) * 4u : 16u * q;
+    }
+    const char* const img_base = reinterpret_cast<const char*>(p.a.ptr + (size_t)my_img * p.hin * p.win * p.a.pitch);
+    const int chunks = p.a.c >> 4;
+    const bool tail_wave = (wave & 3) == 0;                      // the waves whose first 16 lanes own pixels 320..323 of their half
+    // the staged patch travels in two halves of three (pixel, quad) items: half 0 = items 0..2, half 1 = items 3..5 (the last one only
+    // for 16 threads of each staging half); inside the K loop both halves pass through the same three registers
+    f32x4 rin[3];
+    Lazy4 lz;
+    float* const my_raw = smem + sub * X_RAW1;
+    auto load_half = [&](auto hc, int ch) {
+        constexpr int H = decltype(hc)::value;
+        const char* base = img_base + (size_t)(ch << 4) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rin[k] = *reinterpret_cast<const f32x4*>(base + boff[3 * H + k]);   // unconditional (clamped)
+    };
+    auto store_one = [&](int it, const f32x4& r) {
+        const int pix = (htid >> 2) + 64 * it;
+        const f32x4 a = LAZY ? lz.apply_on(r) : r;
+        const f32x4 v = (inb >> it) & 1u ? a : f32x4{0.f, 0.f, 0.f, 0.f};           // padding stays 0 after the activation
+        *reinterpret_cast<f32x4*>(&my_raw[pix * X_PS + 4 * q]) = v;
+    };
+    auto store_half = [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        if (H == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) store_one(k, rin[k]);
+        } else {
+            store_one(3, rin[0]);
+            store_one(4, rin[1]);
+            if (tail_wave && (htid >> 2) + 64 * 5 < X_IH * X_IW) store_one(5, rin[2]);
+        }
+    };
+    const std::integral_constant<int, 0> H0;
+    const std::integral_constant<int, 1> H1;
+    // input transform of one (tile, channel): tile = tid >> 4 (0..31: sub-tile = tile >> 4), channel = tid & 15
+    const int t_tile = tid >> 4, t_lt = t_tile & 15, t_c = tid & 15;
+    const float* const t_src = my_raw + (((t_lt >> 2) * 4) * X_IW + (t_lt & 3) * 4) * X_PS + t_c;
+    // V[position][k-group c >> 2][tile ^ 2 (c >> 2)][c & 3] - the A-fragment order of v_mfma_f32_16x16x4_f32 for 32 tiles; the XOR spreads the
+    // four k-groups a 32-lane store group holds over all banks, the A-fragment read applies the same permutation
+    float* const t_dst = vs + ((t_c >> 2) * 32 + (t_tile ^ (2 * (t_c >> 2)))) * 4 + (t_c & 3);                // + position * 512
+    auto transform = [&]() {
+        float t[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float x[6], y[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = t_src[(i * X_IW + j) * X_PS];
+            xbt6(x, y);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][j] = y[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float y[6];
+            xbt6(t[i], y);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) t_dst[(i * 6 + j) * 512] = y[j];
+        }
+    };
+
+    // wave w: channel tile nt0 + (w & 3) (16 channels) x tile half w >> 2 (= sub-tile) x ALL 36 positions: 144 accumulator registers whose C
+    // layout puts every position of (tile 4 g + r, channel pl) into one lane - the output transform needs no exchange.
+    // B fragments: packed[chunk][position 36][cout / 16][64 lanes][4] (the order of kernels_conv_wino4.hip), buffer loads as in the kernel above
+    const int th = wave >> 2, ntw = wave & 3;
+    const int pl = lane & 15, g = lane >> 4;
+    const unsigned wpos = (unsigned)p.ntile_total * 64u * 16u;        // bytes between positions
+    const unsigned wblock = (unsigned)(nt0 + ntw) * 64u * 16u;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpack), 0, (int)((size_t)chunks * 36 * wpos), 0x00020000);
+    const unsigned wlane = (unsigned)lane * 16u;
+    // positions are contracted in PAIRS (two independent accumulator chains: the 16x16x4 instruction has a 40-cycle dependent latency on a
+    // 32-cycle issue); six-slot ring: the fragments of a pair are requested two pairs ahead (18 pairs per chunk: slot = pair % 3)
+    f32x4 wc[3][2];
+    const int last_pair = chunks * 18 - 1;
+    auto wload = [&](int pair, f32x4 (&dst)[2]) {
+        const unsigned so = wblock + (unsigned)(2 * pair) * wpos;        // (pair index runs over chunks: 36 positions per chunk, consecutive)
+        dst[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
+        dst[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so + wpos, 0));
+    };
+
+    if (LAZY) lz.load(p.a, my_img, 4 * q, p.wpack);
+    load_half(H0, 0);
+    wload(0, wc[0]);
+    wload(last_pair < 1 ? last_pair : 1, wc[1]);
+    store_half(H0);
+    load_half(H1, 0);
+    store_half(H1);
+    __syncthreads();
+    transform();
+    __syncthreads();
+    stamp(0);
+    const float* const a_src = vs + (g * 32 + th * 16 + (pl ^ (2 * g))) * 4;               // + position * 512
+#pragma unroll 1
+    for (int ch = 0; ch < chunks; ++ch) {
+        const bool more = ch + 1 < chunks;
+        const int nch = more ? ch + 1 : ch;        // the loads of the last trip re-read its own chunk: a skipped load group would mis-size the ring's waits
+        f32x4 av[2][2];                            // A fragments of the current and the next pair of positions
+        av[0][0] = *reinterpret_cast<const f32x4*>(a_src);
+        av[0][1] = *reinterpret_cast<const f32x4*>(a_src + 512);
+        // the next chunk's patch is staged INSIDE the MFMA phase (raw is free while V is being contracted): half 0 requested at pair 0 and
+        // stored at pair 6, half 1 requested at 6 and stored at 14
+#pragma unroll
+        for (int pr = 0; pr < 18; ++pr) {
+            {
+                const int pair = ch * 18 + pr + 2;
+                wload(pair < last_pair ? pair : last_pair, wc[(pr + 2) % 3]);
+            }
+            if (pr == 0) {
+                if (LAZY) lz.load(p.a, my_img, (nch << 4) + 4 * q, p.wpack);
+                load_half(H0, nch);
+            }
+            if (pr == 6) {
+                if (more) store_half(H0);
+                load_half(H1, nch);
+            }
+            if (pr == 14 && more) store_half(H1);
+            if (pr < 17) {
+                av[(pr + 1) & 1][0] = *reinterpret_cast<const f32x4*>(a_src + (2 * pr + 2) * 512);
+                av[(pr + 1) & 1][1] = *reinterpret_cast<const f32x4*>(a_src + (2 * pr + 3) * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * pr] = mfma4(av[pr & 1][0][j], wc[pr % 3][0][j], acc[2 * pr]);
+                acc[2 * pr + 1] = mfma4(av[pr & 1][1][j], wc[pr % 3][1][j], acc[2 * pr + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp(1);
+        __syncthreads();
+        stamp(3);
+        if (more) {
+            transform();
+            stamp(4);
+            __syncthreads();
+            stamp(5);
+        }
+    }
+
+    // ---- epilogue, all in registers: lane (pl, g) holds the 36 products of tiles 4 g ... 4 g + 3 of sub-tile `th` for channel 16 (nt0 + ntw) + pl ----
+    {
+        const int e_img = th ? img_b : img_a, e_oy0 = th ? oy_b : oy_a, e_ox0 = th ? ox_b : ox_a;
+        const bool e_valid = th ? has1 : true;
+        const int co = (nt0 + ntw) * 16 + pl;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        // outputs leave as buffer stores: descriptor of the image's output plane + the pixel's byte offset (i, jx, r: wave-uniform) in SGPRs,
+        // ONE per-lane offset (tile row g, channel) - no 64-bit vector address arithmetic per store
+        const size_t img_bytes = (size_t)p.hout * p.wout * p.pitch_out * 4;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)e_img * p.hout * p.wout * p.pitch_out, 0, (int)img_bytes, 0x00020000);
+        const unsigned ovoff = (((unsigned)(e_oy0 + 4 * g) * (unsigned)p.wout + (unsigned)e_ox0) * (unsigned)p.pitch_out + (unsigned)co) * 4u;
+        const unsigned prow = (unsigned)p.wout * (unsigned)p.pitch_out * 4u, ppix = (unsigned)p.pitch_out * 4u;
+        const bool inside = e_oy0 + 16 <= p.hout && e_ox0 + 16 <= p.wout;          // wave-uniform: the whole sub-tile lies inside the image
+        float sf = 0.f, qf = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // tile 4 g + r of the sub-tile: tile row g, tile column r
+            const int oyt = e_oy0 + 4 * g, oxt = e_ox0 + 4 * r;
+            float t[4][6];                                       // A^T M: rows of the output tile x position columns
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                const float m0 = acc[0 * 6 + nu][r], m1 = acc[1 * 6 + nu][r], m2 = acc[2 * 6 + nu][r], m3 = acc[3 * 6 + nu][r],
+                            m4 = acc[4 * 6 + nu][r], m5 = acc[5 * 6 + nu][r];
+                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                t[0][nu] = (m0 + s1) + s2;
+                t[1][nu] = d1 + 2.f * d2;
+                t[2][nu] = s1 + 4.f * s2;
+                t[3][nu] = (d1 + 8.f * d2) + m5;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s1 = t[i][1] + t[i][2], d1 = t[i][1] - t[i][2], s2 = t[i][3] + t[i][4], d2 = t[i][3] - t[i][4];
+                float y[4];
+                y[0] = ((t[i][0] + s1) + s2) + bias;
+                y[1] = (d1 + 2.f * d2) + bias;
+                y[2] = (s1 + 4.f * s2) + bias;
+                y[3] = ((d1 + 8.f * d2) + t[i][5]) + bias;
+                if (p.addend) {                                  // (data-gradient use: the residual path's gradient joins here)
+                    const size_t rowbase = ((size_t)e_img * p.hout + oyt + i) * p.wout + oxt;
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx)
+                        if (e_valid && oyt + i < p.hout && oxt + jx < p.wout) y[jx] += p.addend[(rowbase + jx) * p.pitch_add + co];
+                }
+                if (e_valid && inside) {
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[jx]), orsrc, ovoff, (unsigned)i * prow + (unsigned)(4 * r + jx) * ppix, 0);
+                        sf += y[jx];
+                        qf = __builtin_fmaf(y[jx], y[jx], qf);
+                    }
+                } else if (e_valid && oyt + i < p.hout) {
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx)
+                        if (oxt + jx < p.wout) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[jx]), orsrc, ovoff, (unsigned)i * prow + (unsigned)(4 * r + jx) * ppix, 0);
+                            sf += y[jx];
+                            qf = __builtin_fmaf(y[jx], y[jx], qf);
+                        }
+                }
+            }
+        }
+        if (p.stats && e_valid) {
+            // a lane's <= 64 values of one channel in fp32, the four lane groups and everything from there on in fp64; the two waves that hold the
+            // same channel tile (the two sub-tiles) add to their own images' slots
+            double s = (double)sf, qq = (double)qf;
+            s += __shfl_xor(s, 16);
+            qq += __shfl_xor(qq, 16);
+            s += __shfl_xor(s, 32);
+            qq += __shfl_xor(qq, 32);
+            if (lane < 16) {
+                atomicAdd(p.stats + ((size_t)e_img * p.cout + co) * 2, s);
+                atomicAdd(p.stats + ((size_t)e_img * p.cout + co) * 2 + 1, qq);
+            }
+        }
+    }
+    stamp(6);
+    if (stamps) tsum[7] = (long long)__builtin_amdgcn_s_memrealtime() - treal0;
+    if (stamps && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0)
+        for (int k = 0; k < 8; ++k) stamps[(blockIdx.x ? 64 : 0) + wave * 8 + k] = tsum[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // The 32-output-channel form (the 32 -> 32 layers at 128 x 128: K = 2 sixteen-channel chunks).  kernels_conv_wino4.hip's block for
 // them (16 tiles x 32 channels) lives 11 us for 2 us of matrix work: first patch's round trip, two stagings, exchange, output
 // transform, store tail.  Here a block is 256 threads = 4 waves, TWO sub-tiles (32 tiles = the M of the 32x32x2 instruction) x 32 output
@@ -667,11 +951,13 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
     const double bytes = 4.0 * n * (double)h * w * (a.c + cout);
     ProfScope prof(K_CONV3_WINO4, s, flops, bytes);
     // opt-in to > 64 KB of dynamic LDS: an attribute of the function ON THE CURRENT DEVICE, so it is remembered per (kernel, device)
-    static unsigned long long lds_set[4] = {0ull, 0ull, 0ull, 0ull};
+    static unsigned long long lds_set[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     int dev = 0;
     CS_HIP(hipGetDevice(&dev));
     CS_REQUIRE(dev >= 0 && dev < 64, "conv(winograd 4x4, 32x32): device index %d out of range", dev);
-    const bool wide = cout % 64 == 0;          // 64-channel blocks of 512 threads; else the 32-channel form (256 threads, two blocks per CU)
+    const int form = wino4_form(a.c, cout);
+    CS_REQUIRE(form != 0, "conv(winograd 4x4, 32x32): the layer %d -> %d belongs to kernels_conv_wino4.hip", a.c, cout);
+    const bool wide = form != 2;               // 64-channel blocks of 512 threads; else the 32-channel form (256 threads, two blocks per CU)
     const size_t lds = wide ? X_LDS_BYTES : Z_LDS_BYTES;
     const dim3 grid(wide ? xcd_grid((n_spatial + 1) / 2, p.ntile_total / 4) : xcd_grid((n_spatial + 1) / 2, p.ntile_total / 2));
     auto ensure = [&](const void* kern, int which) -> int {
@@ -681,7 +967,16 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
         }
         return CS_OK;
     };
-    if (wide) {
+    if (form == 3) {                           // 16x16x4 MFMAs, a wave = channel tile x sub-tile x all positions, output transform in registers
+        const size_t lds_y = (size_t)X_MAIN * 4;
+        if (a.tab) {
+            if (!((lds_set[4] >> dev) & 1ull)) { CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4y_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_y)); lds_set[4] |= 1ull << dev; }
+            hipLaunchKernelGGL(conv_wino4y_kernel<true>, grid, dim3(512), lds_y, s, p, g_wino_stamps);
+        } else {
+            if (!((lds_set[5] >> dev) & 1ull)) { CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4y_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_y)); lds_set[5] |= 1ull << dev; }
+            hipLaunchKernelGGL(conv_wino4y_kernel<false>, grid, dim3(512), lds_y, s, p, g_wino_stamps);
+        }
+    } else if (wide) {
         if (a.tab) {
             if (int rc = ensure(reinterpret_cast<const void*>(&conv_wino4x_kernel<true>), 1)) return rc;
             hipLaunchKernelGGL(conv_wino4x_kernel<true>, grid, dim3(512), lds, s, p, g_wino_stamps);

@@ -172,23 +172,25 @@ torch.save(outs, sys.argv[1])
 def test_winograd_f4_on_32x32_mfmas_agrees_with_the_other_forms_in_eval_mode(tmp_path):
     """Eval-mode forward (the only mode in which the F(4x4) weights are packed) in three processes: CS_WINO=0 direct kernels, CS_WINO=2
     F(4x4) on 16x16x4 MFMAs, CS_WINO=3 F(4x4) on 32x32x2 MFMAs with two 16x16 sub-tiles per block for the layers with >= 64 output
-    channels, CS_WINO=4 (default) also the 32-channel layers in that form.  Shapes: 272x208 (17x13
+    channels, CS_WINO=4 also the 32-channel layers in that form, CS_WINO=5 (default) the layers with <= 128 input channels in the form
+    whose output transform runs in registers (a wave = channel tile x sub-tile x all 36 positions).  Shapes: 272x208 (17x13
     pixels at the bottom: partial tiles at every level, an ODD number of 16x16 tiles at several), 5 images of 100x76 with a 64-base
     net (tile pairs that straddle two images: 25x19 at the bottom = 4 tiles per image... 5 images -> an odd total), and a BatchNorm
     net (eval-mode running statistics as the lazy table).  Logits within 5e-5 of the direct kernels."""
     res = {}
-    for mode in ("0", "2", "3", "4"):
+    for mode in ("0", "2", "3", "4", "5"):
         path = str(tmp_path / f"w{mode}.pt")
         env = dict(os.environ, CS_WINO=mode, PYTHONPATH=os.pathsep.join([PKG, ROOT]))
         subprocess.run([sys.executable, "-c", _WINO_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
         res[mode] = torch.load(path)
     for tag in res["0"]:
         scale = float(res["0"][tag].abs().max())
-        for mode in ("2", "3", "4"):
+        for mode in ("2", "3", "4", "5"):
             err = float((res[mode][tag] - res["0"][tag]).abs().max())
             assert err <= 5e-5 * max(scale, 1.0), (tag, mode, err, scale)
-        assert not torch.equal(res["4"][tag], res["0"][tag])          # the Winograd path really ran (it is not bitwise the direct form)
-    assert not torch.equal(res["4"]["a"], res["3"]["a"])              # ... and the 32-channel form differs from the 16x16x4 one it replaces
+        assert not torch.equal(res["5"][tag], res["0"][tag])          # the Winograd path really ran (it is not bitwise the direct form)
+    assert not torch.equal(res["4"]["a"], res["3"]["a"])              # the 32-channel form differs from the 16x16x4 one it replaces ...
+    assert not torch.equal(res["5"]["a"], res["4"]["a"])              # ... and so does the register-epilogue form of the short-K layers
 
 
 # ------------------------------------------------------------------------------------------- TrainStep after AdamW.load_state_dict

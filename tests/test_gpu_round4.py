@@ -276,3 +276,18 @@ def test_transposed_conv_winograd_form_agrees_with_the_direct_kernels(tmp_path):
         err = float((res["1"][tag] - res["0"][tag]).abs().max())
         assert err <= 5e-5 * max(scale, 1.0), (tag, err, scale)
     assert not torch.equal(res["1"]["a"], res["0"]["a"]) and not torch.equal(res["1"]["b"], res["0"]["b"])
+
+
+# ------------------------------------------------------------------------------------------- fp8 mode: the all-e4m3 setting of rounds 2-3
+def test_fp8_mode_with_every_layer_in_e4m3_still_runs():
+    """CS_FP8_MIN_C=0 puts every layer on the e4m3 kernels (rounds 2-3); the default 128 keeps the narrow layers on the bf16 kernels.  Both
+    settings segment the held-out images of the trained net; the mixed default is the more accurate one (profiles/fp8_mix_accuracy_r04.json)."""
+    child = ("import json, sys, torch\nsys.path[:0] = [%r, %r]\nfrom bench import lowprec_accuracy\n"
+             "print(json.dumps(lowprec_accuracy(torch.device('cuda:0'), n_images=2, precisions=('fp8',))))" % (ROOT, PKG))
+    res = {}
+    for min_c in ("0", "128"):
+        out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=dict(os.environ, CS_FP8_MIN_C=min_c))
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[min_c] = json.loads(out.stdout.strip().splitlines()[-1])["fp8"]
+    assert res["0"]["f1_vs_fp32"] >= 0.98 and res["128"]["f1_vs_fp32"] >= 0.995, res
+    assert res["128"]["pixel_agreement"] >= res["0"]["pixel_agreement"], res

@@ -783,8 +783,14 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 // (consumers with 64-channel blocks are left alone: the second tensor costs that kernel variant a third of its occupancy -
                 // measured on the 32-base slide: level 2 fused -0.47 ms, level 3 fused -0.06 ms, CS_FUSE_SUM=2 fuses every level)
                 const int c_up = net->up[d - 1].cout;
-                const bool fused = fuse_sum && d >= 2 && c_up % 16 == 0 && rt_upt[d].tab && rt_upu[d].tab &&
-                                   (a16 ? (c % 32 == 0 && net->up[d - 1].convt.wb != nullptr) : (c_up % 64 != 0 || fuse_env == 2));
+                const bool fused_mid = fuse_sum && d >= 2 && c_up % 16 == 0 && rt_upt[d].tab && rt_upu[d].tab &&
+                                       (a16 ? (c % 32 == 0 && net->up[d - 1].convt.wb != nullptr) : (c_up % 64 != 0 || fuse_env == 2));
+                // ... and the 3-channel top layer (fp32 path): its GEMM + gather kernel stages act(norm(V)) + act(norm(U)) itself for the
+                // 32 channels that come from below - measured -0.9 ms of norm_act_add for +0.3 ms in that kernel per slide
+                const int cin_top = net->up[0].cin_skip + c;
+                const bool fused_top = fuse_sum && d == 1 && !a16 && net->up[0].top && rt_upt[d].tab && rt_upu[d].tab && c % 4 == 0 &&
+                                       net->up[0].cin_skip == c && (cin_top == 64 || cin_top == 128);
+                const bool fused = fused_mid || fused_top;
                 if (fused) {
                     sub = lv;
                     sub.ptr2 = U; sub.tab2 = rt_upt[d].tab; sub.slope2 = u.norm_t.slope;

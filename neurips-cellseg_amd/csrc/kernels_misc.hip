@@ -344,10 +344,24 @@ struct __attribute__((packed, aligned(4))) Px3 {             // one 3-channel pi
     float c0, c1, c2;
 };
 
-template <int CIN, bool IN16>
+// SUM2 (fp32 inference): the `b` source is the decoder's residual sum D = act(norm(V)) + act(norm(U)) of the level below the top, read as its
+// two raw tensors with their lazy InstanceNorm tables + PReLU slopes - the norm_act_add pass that materialised D (two reads and one write of
+// a 32-channel 128 x 128 tensor per window) is not launched.
+struct SumExtra {
+    const float* ptr2;             // U (same pitch / channel count as b.ptr = V)
+    const float2* tab;             // table of V: [n][tab_c] (scale, shift), + tab_off
+    const float2* tab2;            // table of U
+    const float* slope;            // PReLU slopes (device scalars; null = ReLU)
+    const float* slope2;
+    int tab_c, tab_off;
+};
+
+template <int CIN, bool IN16, bool SUM2 = false>
 __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSrc b, const float* __restrict__ w, const float* bias,
                                                              float* out, double* stats, int hin, int win, int tiles_x, int tiles_y,
-                                                             int n_tiles) {
+                                                             int n_tiles, SumExtra sx) {
+    static_assert(!(SUM2 && IN16), "sum sources are implemented for fp32 activations");
+    static_assert(!SUM2 || CIN == 64 || CIN == 128, "sum sources: the items of each tensor must divide evenly over the four waves");
     constexpr int TH = 8, TW = 16, IH = TH + 1, IW = TW + 1, NPIX = IH * IW, MPAD = 160;   // 10 M-tiles of 16 rows
     constexpr int PP = 33;                                                              // P pitch (27 used, 32 computed)
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -378,10 +392,26 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
     // tile-invariant part of the staging addresses (element offsets; bf16 sources are addressed through a 16-bit pointer)
     const float* sptr[ITERS];
     int rel[ITERS], spitch[ITERS], liy[ITERS], lix[ITERS];
+    // item -> (pixel, channel quad).  Plain launches: item = tid + 256 it, quads fastest.  SUM2 launches (a.c == b.c): a wave instruction
+    // covers 8 pixels x the 8 quads of ONE tensor, and every wave takes the skip tensor's quads in its first ITERS / 2 items and the sum's
+    // in the rest - which items pay for the second tensor's loads and the two lazy activations is then known at compile time, and the four
+    // waves carry equal shares of that work (all lanes predicated: 350 instructions per wave and tile; a / b waves: 60 / 350; this: 205)
+    constexpr int HALF = ITERS / 2;
+    auto item_of = [&](int it, int& pix, int& c4) {
+        if constexpr (SUM2) {
+            const int sec = it >= HALF ? 1 : 0, k = it - sec * HALF;
+            c4 = sec * (c4n / 2) + (lane % (c4n / 2));
+            pix = lane / (c4n / 2) + (64 / (c4n / 2)) * (wave + 4 * k);
+        } else {
+            const int i = tid + 256 * it;
+            pix = i / c4n;
+            c4 = i - pix * c4n;
+        }
+    };
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int i = tid + 256 * it;
-        const int pix = i / c4n, c4 = i - pix * c4n;
+        int pix, c4;
+        item_of(it, pix, c4);
         const int iy = pix / IW, ix = pix - iy * IW;
         const int c = 4 * c4;
         const bool in_a = c < a.c;
@@ -394,6 +424,17 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
     }
     unsigned okmask = 0;                                     // padding is zeroed at LDS-store time: consuming a loaded value
                                                              // earlier would make hipcc wait for the prefetch before the GEMM
+    // SUM2: a thread's channel quad is the same for all its items (256 % c4n == 0), so it is a `b` thread or an `a` thread throughout;
+    // `b` threads also fetch the second tensor and, per tile, the two lazy-norm tables of the tile's image (4 channels each)
+    const int cb = SUM2 ? 4 * (lane % (c4n / 2)) : 0;                     // channel of this lane's sum-source items inside b
+    const ptrdiff_t delta2 = SUM2 ? sx.ptr2 - b.ptr : 0;                  // second tensor: same offsets, other base
+    f32x4m rx2[SUM2 ? ITERS - HALF : 1];
+    f32x4m tA0, tA1, tB0, tB1;                               // (scale, shift) x 4 channels of V's and of U's table
+    float slA = 0.f, slB = 0.f;
+    if constexpr (SUM2) {
+        slA = sx.slope ? *sx.slope : 0.f;
+        slB = sx.slope2 ? *sx.slope2 : 0.f;
+    }
     auto prefetch = [&](int img, int iy0, int ix0) {
         okmask = 0;
         const int base_px = (img * hin + iy0) * win + ix0;
@@ -403,8 +444,27 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
             const int off = ok ? base_px * spitch[it] + rel[it] : 0;
             if constexpr (IN16) rx[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(sptr[it]) + off);
             else rx[it] = *reinterpret_cast<const f32x4m*>(sptr[it] + off);
+            if constexpr (SUM2)
+                if (it >= HALF) rx2[it - HALF] = *reinterpret_cast<const f32x4m*>(sptr[it] + delta2 + off);
             okmask |= ok ? (1u << it) : 0u;
         }
+        if constexpr (SUM2) {
+            const f32x4m* ta = reinterpret_cast<const f32x4m*>(sx.tab + (size_t)img * sx.tab_c + sx.tab_off + cb);
+            const f32x4m* tb = reinterpret_cast<const f32x4m*>(sx.tab2 + (size_t)img * sx.tab_c + sx.tab_off + cb);
+            tA0 = ta[0];
+            tA1 = ta[1];
+            tB0 = tb[0];
+            tB1 = tb[1];
+        }
+    };
+    auto act4 = [](f32x4m v, f32x4m t0, f32x4m t1, float slope) {      // lazy InstanceNorm + PReLU on 4 channels (conv_common.h: Lazy4::apply_on)
+        f32x4m r;
+        const float x0 = v.x * t0.x + t0.y, x1 = v.y * t0.z + t0.w, x2 = v.z * t1.x + t1.y, x3 = v.w * t1.z + t1.w;
+        r.x = __builtin_fmaf(slope, __builtin_fminf(x0, 0.f), __builtin_fmaxf(x0, 0.f));
+        r.y = __builtin_fmaf(slope, __builtin_fminf(x1, 0.f), __builtin_fmaxf(x1, 0.f));
+        r.z = __builtin_fmaf(slope, __builtin_fminf(x2, 0.f), __builtin_fmaxf(x2, 0.f));
+        r.w = __builtin_fmaf(slope, __builtin_fminf(x3, 0.f), __builtin_fmaxf(x3, 0.f));
+        return r;
     };
     int xo[5], wo[5];
 #pragma unroll
@@ -468,11 +528,13 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
         const int iy0 = ty * TH, ix0 = tx * TW, cur_img = img;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int i = tid + 256 * it;
-            const int pix = i / c4n, c4 = i - pix * c4n;
+            int pix, c4;
+            item_of(it, pix, c4);
             f32x4m xv;
             if constexpr (IN16) xv = bf16x4_to_f32(rx[it]);
             else xv = rx[it];
+            if constexpr (SUM2)
+                if (it >= HALF) xv = act4(xv, tA0, tA1, slA) + act4(rx2[it - HALF], tB0, tB1, slB);    // same operations, same order as norm_act_add
             *reinterpret_cast<f32x4m*>(&x_s[pix * XP + 4 * c4]) = ((okmask >> it) & 1u) ? xv : f32x4m{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
@@ -727,7 +789,10 @@ __global__ __launch_bounds__(256) void convt_top_gemm16_kernel(SmallSrc a, Small
 int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const float* w_torch, const float* bias, float* out,
                        int cout, double* stats, int n, int hin, int win) {
     CS_REQUIRE(cout == 3, "convT(small): cout %d unsupported (3-class contract)", cout);
-    CS_REQUIRE(a.tab == nullptr && b.tab == nullptr, "convT(small): lazy inputs unsupported");
+    const bool sum2 = b.ptr2 != nullptr;
+    CS_REQUIRE(a.tab == nullptr && (b.tab == nullptr || sum2), "convT(small): lazy inputs only as a sum source (second operand)");
+    CS_REQUIRE(!sum2 || (b.tab && b.tab2 && !a.h16 && !b.h16 && a.c == b.c && (a.c + b.c == 64 || a.c + b.c == 128)),
+               "convT(small): a sum source needs both lazy tables, fp32 activations, 64 / 128 input channels and as many skip channels as summed ones");
     CS_REQUIRE(a.c % 4 == 0 && b.c % 4 == 0, "convT(small): channels must be multiples of 4");
     CS_REQUIRE(a.h16 == b.h16 || b.c == 0, "convT(small): mixed activation element types");
     const int cin = a.c + b.c;
@@ -742,7 +807,14 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
         const int resident = 256 * (int)((160 * 1024) / (sm + 64));           // persistent blocks: as many as the LDS lets live at once
         const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
         const SmallSrc sa{a.ptr, a.c, a.pitch}, sb{b.ptr, b.c, b.pitch};
-#define CS_TOP(CIN_, H_) hipLaunchKernelGGL((convt_top_gemm_kernel<CIN_, H_>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles)
+        const SumExtra sx{b.ptr2, b.tab, b.tab2, b.slope, b.slope2, b.tab_c ? b.tab_c : b.c, b.tab_off};
+#define CS_TOP(CIN_, H_) hipLaunchKernelGGL((convt_top_gemm_kernel<CIN_, H_>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles, sx)
+#define CS_TOPS(CIN_) hipLaunchKernelGGL((convt_top_gemm_kernel<CIN_, false, true>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles, sx)
+        if (sum2) {
+            if (cin == 64) CS_TOPS(64); else CS_TOPS(128);
+            CS_HIP(hipGetLastError());
+            return CS_OK;
+        }
         if (a.h16 && a.c % 8 == 0 && b.c % 8 == 0) {           // bf16 inputs: bf16 matrix pipe, plain-copy staging
             const size_t xb = (size_t)160 * (cin + 8) * 2, pb = (size_t)160 * 33 * 4;
             const size_t sm16 = (xb > pb ? xb : pb) + (size_t)cin * 32 * 2;
@@ -757,9 +829,11 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
             if (cin == 32) CS_TOP(32, false); else if (cin == 64) CS_TOP(64, false); else CS_TOP(128, false);
         }
 #undef CS_TOP
+#undef CS_TOPS
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
+    CS_REQUIRE(!sum2, "convT(small): the VALU form takes plain tensors");
     dim3 grid((unsigned)ceil_div(hin * win, 256), (unsigned)n);
     if (a.h16)
         hipLaunchKernelGGL((convt_small_kernel<3, true>), grid, dim3(256), lds, s, SmallSrc{a.ptr, a.c, a.pitch},

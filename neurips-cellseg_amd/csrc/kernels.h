@@ -154,7 +154,9 @@ struct WindowSrc {
     int roi_h = 0, roi_w = 0;                // window size = conv input size
 };
 int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
-                      float* out, int pitch_out, int cout, double* stats, int n, bool out16 = false, int stats_c = 0);   // stats_c: statistics for channels [0, stats_c) only (0 = all)
+                      float* out, int pitch_out, int cout, double* stats, int n, bool out16 = false, int stats_c = 0,   // stats_c: statistics for channels [0, stats_c) only (0 = all)
+                      int cout_pack = 0, int cout_off = 0,     // channels [cout_off, cout_off + cout) of a pack of cout_pack channels (0 = the whole pack)
+                      const ConvSrc* add = nullptr);           // out = conv + bias + act(norm(*add)): the ResidualUnit's sum, fp32
 // bf16 / fp8 datapaths: the image is converted to bf16 while it is staged, one v_mfma_f32_16x16x32_bf16 per 16 x 16 output tile
 // (the fp32 form needs seven 16x16x4 steps = 14x the matrix-pipe cycles), bf16 out
 int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsigned short* wpack16, const float* bias, float* out,

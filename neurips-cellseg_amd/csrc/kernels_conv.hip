@@ -537,10 +537,54 @@ struct FirstParams {
     double* stats;
     int pitch_out, cout, ntile_total, n, hout, wout, tiles_x, tiles_y;
     int stats_c;       // statistics only for channels [0, stats_c): the residual half of a fused [unit0 || residual] launch feeds no norm
+    int nt_pack, nt_off;   // the packed weights hold nt_pack channel tiles per K step; this launch computes tiles [nt_off, nt_off + NT)
+    SrcDev add;        // ADD launches: out = conv + bias + act(norm(add)) (the unit's last conv output with its lazy norm table)
 };
 
-template <int S, int CIN, int NT, int MT, bool OUT16>
+// epilogue_store with the ResidualUnit's sum folded in: every stored quad gets act(norm(y)) of the same pixel and channels added
+// (y raw, its InstanceNorm / BatchNorm table and PReLU slope as in the consumers' lazy staging).  A lane's channel quad is the same
+// in every pass (64 % (4 NT) == 0): one table fetch per lane.
+template <int NT, int ROWS>
+__device__ __forceinline__ void epilogue_store_lazy_add(float* ep, const f32x4 (&vals)[ROWS][NT], int lane, float* out, int64_t elem0,
+                                                        int64_t row_stride, int pitch, int n_rows_valid, int n_cols_valid,
+                                                        const SrcDev& y, int img, int64_t y_elem0, int64_t y_row_stride, const float* dummy) {
+    constexpr int EPS = 16 * NT + 4;
+    constexpr int F4_PER_PIX = NT * 4;
+    static_assert(64 % F4_PER_PIX == 0 && (ROWS * 16 * F4_PER_PIX) % 64 == 0, "a lane keeps its channel quad; whole passes of the wave");
+    const int pl = lane & 15, g = lane >> 4;
+    const int c4 = lane % F4_PER_PIX;
+    Lazy4 lz;
+    lz.load(y, img, c4 * 4, dummy);
+    f32x4 yv[ROWS * 16 * F4_PER_PIX / 64];
+#pragma unroll
+    for (int it = 0; it < ROWS * 16 * F4_PER_PIX / 64; ++it) {       // requested before the slab round trip
+        const int pix = (lane + 64 * it) / F4_PER_PIX;
+        const int m = pix >> 4, x = pix & 15;
+        const bool ok = m < n_rows_valid && x < n_cols_valid;
+        yv[it] = *reinterpret_cast<const f32x4*>(y.ptr + (ok ? y_elem0 + m * y_row_stride + (int64_t)x * y.pitch + c4 * 4 : 0));
+    }
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ep[(m * 16 + g * 4 + r) * EPS + nt * 16 + pl] = vals[m][nt][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the slab is wave-private
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < ROWS * 16 * F4_PER_PIX / 64; ++it) {
+        const int pix = (lane + 64 * it) / F4_PER_PIX;
+        const int m = pix >> 4, x = pix & 15;
+        if (m < n_rows_valid && x < n_cols_valid) {
+            const f32x4 v = lz.apply(yv[it]) + *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);     // (a + b as norm_act_add forms it)
+            *reinterpret_cast<f32x4*>(out + elem0 + m * row_stride + (int64_t)x * pitch + c4 * 4) = v;
+        }
+    }
+}
+
+template <int S, int CIN, int NT, int MT, bool OUT16, bool ADD = false>
 __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
+    static_assert(!(ADD && OUT16), "the fused sum is an fp32 epilogue");
     constexpr int TH = 4 * MT, TW = 16;
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int KSTEPS = (9 * CIN + 3) / 4;
@@ -576,7 +620,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
 #pragma unroll
     for (int it = 0; it < W_ITERS; ++it) {
         const int i = tid + 256 * it;
-        rwt[it] = reinterpret_cast<const f32x4*>(p.wpack)[(W4 % 256 == 0 || i < W4) ? i : 0];
+        const int j = (W4 % 256 == 0 || i < W4) ? i : 0;
+        // (ks, nt, quad) of the block's slice inside packed[ks][nt_pack][16 quads]; the whole pack when nt_pack == NT
+        rwt[it] = reinterpret_cast<const f32x4*>(p.wpack)[((j / (NT * 16)) * p.nt_pack + p.nt_off) * 16 + j % (NT * 16)];
     }
     // unconditional (clamped) loads, fully unrolled: a load under a branch makes hipcc wait for it before issuing the next
     // (a row-per-wave gather with the row arithmetic on the scalar unit - 13 half-empty loads instead of 7 full ones, ~50 fewer VALU
@@ -640,9 +686,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 16 + pl;
-        const float bias = p.bias ? p.bias[co] : 0.f;
+        const float bias = p.bias ? p.bias[p.nt_off * 16 + co] : 0.f;
         double s = 0.0, qq = 0.0;
-        const bool want = p.stats && nt * 16 < p.stats_c;        // block-uniform: the fp64 work is skipped for channels nobody normalises
+        const bool want = !ADD && p.stats && nt * 16 < p.stats_c;        // block-uniform: the fp64 work is skipped for channels nobody normalises
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int oy = oy0 + wave * MT + m;
@@ -671,10 +717,15 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
     {
         const int oy = oy0 + wave * MT;
         const int64_t elem0 = (((int64_t)img * p.hout + oy) * p.wout + ox0) * p.pitch_out;
-        epilogue_store<NT, MT, OUT16>(smem + wave * EPW, acc, lane, p.out, (int64_t)p.wout * p.pitch_out, p.pitch_out,
-                                      p.hout - oy, p.wout - ox0, nullptr, 0, 0, elem0);
+        if constexpr (ADD)
+            epilogue_store_lazy_add<NT, MT>(smem + wave * EPW, acc, lane, p.out, elem0, (int64_t)p.wout * p.pitch_out, p.pitch_out, p.hout - oy,
+                                            p.wout - ox0, p.add, img, (((int64_t)img * p.hout + oy) * p.wout + ox0) * p.add.pitch,
+                                            (int64_t)p.wout * p.add.pitch, p.wpack);
+        else
+            epilogue_store<NT, MT, OUT16>(smem + wave * EPW, acc, lane, p.out, (int64_t)p.wout * p.pitch_out, p.pitch_out,
+                                          p.hout - oy, p.wout - ox0, nullptr, 0, 0, elem0);
     }
-    if (p.stats) {
+    if (!ADD && p.stats) {
         __syncthreads();
         if (tid < 32 * NT && (tid >> 1) < p.stats_c) {
             const int c = tid >> 1, k = tid & 1;
@@ -686,10 +737,17 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstParams p) {
 }
 
 int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
-                      float* out, int pitch_out, int cout, double* stats, int n, bool out16, int stats_c) {
+                      float* out, int pitch_out, int cout, double* stats, int n, bool out16, int stats_c, int cout_pack, int cout_off,
+                      const ConvSrc* add) {
     CS_REQUIRE(cin == 3, "first conv: in_channels %d unsupported (the reference always feeds 3)", cin);
     CS_REQUIRE(stride == 2, "first conv: stride %d unsupported", stride);
     CS_REQUIRE(cout == 16 || cout == 32 || cout == 64 || cout == 128, "first conv: fused cout %d unsupported", cout);
+    if (cout_pack <= 0) cout_pack = cout;
+    CS_REQUIRE(cout_pack % 16 == 0 && cout_off % 16 == 0 && cout_off >= 0 && cout_off + cout <= cout_pack,
+               "first conv: channels [%d, %d) of a %d-channel pack", cout_off, cout_off + cout, cout_pack);
+    CS_REQUIRE(!add || (!out16 && !stats && add->ptr && !add->h16 && !add->q8 && !add->ptr2 && add->c == cout && add->pitch % 4 == 0 &&
+                        pitch_out % 4 == 0),
+               "first conv: the fused residual sum takes a plain fp32 tensor of %d channels and writes fp32", cout);
     FirstParams p{};
     p.image = src.image;
     p.sn = src.sn; p.sc = src.sc; p.sh = src.sh; p.sw = src.sw;
@@ -698,6 +756,9 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
     p.wpack = wpack; p.bias = bias; p.out = out; p.stats = stats;
     p.pitch_out = pitch_out; p.cout = cout; p.ntile_total = cout / 16; p.n = n;
     p.stats_c = stats_c > 0 ? stats_c : cout;
+    p.nt_pack = cout_pack / 16;
+    p.nt_off = cout_off / 16;
+    if (add) p.add = SrcDev{add->ptr, add->tab, add->slope, add->c, add->pitch, add->tab_c ? add->tab_c : add->c, add->tab_off, nullptr, nullptr, nullptr};
     p.hout = (src.roi_h + 2 - 3) / 2 + 1;
     p.wout = (src.roi_w + 2 - 3) / 2 + 1;
     constexpr int MT = 2;
@@ -705,10 +766,11 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
     p.tiles_y = ceil_div(p.hout, 4 * MT);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * n));
     const double flops = 2.0 * n * p.hout * p.wout * (double)cout * cin * 9;
-    const double bytes = n * (4.0 * src.roi_h * src.roi_w * cin + (out16 ? 2.0 : 4.0) * p.hout * p.wout * cout);
+    const double bytes = n * (4.0 * src.roi_h * src.roi_w * cin + (out16 ? 2.0 : 4.0) * p.hout * p.wout * cout * (add ? 2.0 : 1.0));
     ProfScope prof(K_CONV_FIRST, s, flops, bytes);
 #define CS_FIRST(NT_)                                                                                          \
-    if (out16) hipLaunchKernelGGL((conv_first_kernel<2, 3, NT_, MT, true>), grid, dim3(256), 0, s, p);         \
+    if (add) hipLaunchKernelGGL((conv_first_kernel<2, 3, NT_, MT, false, true>), grid, dim3(256), 0, s, p);    \
+    else if (out16) hipLaunchKernelGGL((conv_first_kernel<2, 3, NT_, MT, true>), grid, dim3(256), 0, s, p);    \
     else hipLaunchKernelGGL((conv_first_kernel<2, 3, NT_, MT, false>), grid, dim3(256), 0, s, p);
     switch (cout / 16) {
         case 1: CS_FIRST(1) break;
@@ -829,9 +891,9 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(FirstParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 16 + pl;
-        const float bias = p.bias ? p.bias[co] : 0.f;
+        const float bias = p.bias ? p.bias[p.nt_off * 16 + co] : 0.f;
         double s = 0.0, qq = 0.0;
-        const bool want = p.stats && nt * 16 < p.stats_c;        // block-uniform: the fp64 work is skipped for channels nobody normalises
+        const bool want = !ADD && p.stats && nt * 16 < p.stats_c;        // block-uniform: the fp64 work is skipped for channels nobody normalises
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int oy = oy0 + wave * MT + m;

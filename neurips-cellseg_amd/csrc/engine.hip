@@ -655,10 +655,17 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         unsigned char* Aq = (q8 && any8) ? take_q8((size_t)n * oh * ow * c) : nullptr;   // activated input of the next subunit
         for (int su = 0; su < u.subunits; ++su) new_tab(rt_down[d][su], su == 0 ? c0 : c);
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
+        // fp32 inference: the residual branch of the first unit (a 3 -> c conv of the image, 27 multiplies per output) is not written
+        // by the unit0 launch and read back by norm_act_add: a second first-layer launch computes it from the image and adds
+        // act(norm(Y)) in its epilogue (one c-channel tensor less written and read; CS_FUSE_FIRST=0 restores the [y0 || r] launch)
+        static const int fuse_first_env = getenv("CS_FUSE_FIRST") ? atoi(getenv("CS_FUSE_FIRST")) : 1;
+        const bool fuse_first = fuse_first_env && u.first && !tape && !a16 && u.subunits >= 2 && c0 == 2 * c && (c == 16 || c == 32 || c == 64);
         if (!dry) {
             if (u.first) {
                 if (a16 && u.unit0.wb)
                     CS_TRY(launch_conv_first16(s, src, pc, u.unit0.wb, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, c));
+                else if (fuse_first)
+                    CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c, rt_down[d][0].stats, n, false, c, c0, 0));
                 else
                     CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, a16, c));   // statistics for the unit0 half only
             } else {
@@ -678,6 +685,10 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 cur_tabc = c;
             }
             const int last = u.subunits - 1;
+            if (fuse_first) {
+                const ConvSrc ly = lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc, false);
+                CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, X[d], c, c, nullptr, n, false, 0, c0, c, &ly));
+            } else
             CS_TRY(launch_norm_act_add(s, lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc, a16),
                                        raw_src(act_off(E, c, a16), c, c0, a16), X[d], c, (int64_t)oh * ow, n, a16, Xq[d], c));
         }

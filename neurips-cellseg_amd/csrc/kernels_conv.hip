@@ -758,6 +758,7 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
     p.stats_c = stats_c > 0 ? stats_c : cout;
     p.nt_pack = cout_pack / 16;
     p.nt_off = cout_off / 16;
+    p.cout = cout_pack;           // (the kernel's only use: the stride of the statistics rows, laid out for the whole pack)
     if (add) p.add = SrcDev{add->ptr, add->tab, add->slope, add->c, add->pitch, add->tab_c ? add->tab_c : add->c, add->tab_off, nullptr, nullptr, nullptr};
     p.hout = (src.roi_h + 2 - 3) / 2 + 1;
     p.wout = (src.roi_w + 2 - 3) / 2 + 1;
@@ -891,9 +892,9 @@ __global__ __launch_bounds__(256) void conv_first16_kernel(FirstParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 16 + pl;
-        const float bias = p.bias ? p.bias[p.nt_off * 16 + co] : 0.f;
+        const float bias = p.bias ? p.bias[co] : 0.f;
         double s = 0.0, qq = 0.0;
-        const bool want = !ADD && p.stats && nt * 16 < p.stats_c;        // block-uniform: the fp64 work is skipped for channels nobody normalises
+        const bool want = p.stats && nt * 16 < p.stats_c;        // block-uniform: the fp64 work is skipped for channels nobody normalises
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int oy = oy0 + wave * MT + m;

@@ -278,6 +278,52 @@ def test_transposed_conv_winograd_form_agrees_with_the_direct_kernels(tmp_path):
     assert not torch.equal(res["1"]["a"], res["0"]["a"]) and not torch.equal(res["1"]["b"], res["0"]["b"])
 
 
+_FIRST_EVAL = r"""
+import sys, torch
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {root!r})
+import cellseg_amd as ca
+from cellseg_amd import _lib
+dev = torch.device("cuda:0")
+outs = {{}}
+for tag, channels, strides, shape, norm in (("a", (32, 64, 128, 256, 512), (2, 2, 2, 2), (3, 3, 272, 208), "instance"),
+                                            ("b", (64, 128, 256), (2, 2), (5, 3, 100, 76), "instance"),
+                                            ("c", (16, 32, 64), (2, 2), (2, 3, 136, 72), "batch")):
+    torch.manual_seed(11)
+    kw = dict(norm="batch", act="relu") if norm == "batch" else {{}}
+    m = ca.UNet(channels=channels, strides=strides, num_res_units=2, **kw).to(dev).eval()
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():
+        m(x)
+        _lib.lib.cs_prof_enable(1); _lib.lib.cs_prof_reset()
+        outs[tag] = m(x).cpu()
+        prof = _lib.prof_collect()
+        _lib.lib.cs_prof_enable(0)
+    outs[tag + "_first"] = int(prof["conv_first_mfma"]["launches"])
+    outs[tag + "_adds"] = int(prof["norm_act_add"]["launches"])
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_first_unit_residual_recomputed_in_the_sum_launch_agrees_with_the_materialised_one(tmp_path):
+    """fp32 inference: the first ResidualUnit's residual branch (3 -> c conv of the image) is computed by a second first-layer launch
+    whose epilogue adds act(norm(Y)) (engine.hip: fuse_first) instead of being written by the [y0 || r] launch and read back by
+    norm_act_add.  Against CS_FUSE_FIRST=0 on partial tiles (136x104 / 50x38 / 68x36 outputs), 32-, 64- and 16-channel first layers, an
+    InstanceNorm and a BatchNorm(eval) table: the same products in the same order and a commutative sum - logits equal to 1e-6; the
+    launch counts show which path ran (two first-layer launches, one norm_act_add less)."""
+    res = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"ff{mode}.pt")
+        env = dict(os.environ, CS_FUSE_FIRST=mode, PYTHONPATH=os.pathsep.join([PKG, ROOT]))
+        subprocess.run([sys.executable, "-c", _FIRST_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
+        res[mode] = torch.load(path)
+    for tag in ("a", "b", "c"):
+        scale = float(res["0"][tag].abs().max())
+        err = float((res["1"][tag] - res["0"][tag]).abs().max())
+        assert err <= 1e-6 * max(scale, 1.0), (tag, err, scale)
+        assert res["0"][tag + "_first"] == 1 and res["1"][tag + "_first"] == 2, (tag, res["0"][tag + "_first"], res["1"][tag + "_first"])
+        assert res["1"][tag + "_adds"] == res["0"][tag + "_adds"] - 1
+
+
 # ------------------------------------------------------------------------------------------- fp8 mode: the all-e4m3 setting of rounds 2-3
 def test_fp8_mode_with_every_layer_in_e4m3_still_runs():
     """CS_FP8_MIN_C=0 puts every layer on the e4m3 kernels (rounds 2-3); the default 128 keeps the narrow layers on the bf16 kernels.  Both

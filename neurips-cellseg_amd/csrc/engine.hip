@@ -641,7 +641,15 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     for (int d = 0; d < nl; ++d) {
         const DownUnit& u = net->down[d];
         const int oh = ph / 2, ow = pw / 2, c = u.c, c0 = u.unit0.cout;
-        float* E = take_act((size_t)n * oh * ow * c0);          // [y0 || r]
+        // fp32 inference / bf16 datapath with pixel records: the first unit's residual branch is recomputed by the sum launch (below),
+        // E then holds y0 alone
+        static const int fuse_first_env = getenv("CS_FUSE_FIRST") ? atoi(getenv("CS_FUSE_FIRST")) : 1;
+        const bool use_rec = u.first && !tape && src.rec && src.rec16 == a16 && pc == 3;
+        const bool fuse_first_shape = fuse_first_env && u.first && !tape && u.subunits >= 2 && c0 == 2 * c && (c == 16 || c == 32 || c == 64);
+        // (the sizing pass may stand for a training forward: it takes c0)
+        const int ec = !dry && fuse_first_shape && (!a16 || use_rec) && !(q8 && ((d + 1 < nl ? net->down[d + 1].unit0.f8 : net->bottom.unit0.f8) || net->up[d].convt.f8))
+                           ? c : c0;                            // channels (= pixel pitch) of E
+        float* E = take_act((size_t)n * oh * ow * ec);          // [y0 || r], or y0
         std::vector<float*> Y(u.subunits, nullptr);
         for (int su = 1; su < u.subunits; ++su) Y[su] = take_act((size_t)n * oh * ow * c);
         // X[d] as bf16 / fp32: everywhere except the fp8 mode, where each consumer (the next level's unit0, this level's transposed conv)
@@ -655,17 +663,20 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         unsigned char* Aq = (q8 && any8) ? take_q8((size_t)n * oh * ow * c) : nullptr;   // activated input of the next subunit
         for (int su = 0; su < u.subunits; ++su) new_tab(rt_down[d][su], su == 0 ? c0 : c);
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
-        // fp32 inference: the residual branch of the first unit (a 3 -> c conv of the image, 27 multiplies per output) is not written
-        // by the unit0 launch and read back by norm_act_add: a second first-layer launch computes it from the image and adds
-        // act(norm(Y)) in its epilogue (one c-channel tensor less written and read; CS_FUSE_FIRST=0 restores the [y0 || r] launch)
-        static const int fuse_first_env = getenv("CS_FUSE_FIRST") ? atoi(getenv("CS_FUSE_FIRST")) : 1;
-        const bool fuse_first = fuse_first_env && u.first && !tape && !a16 && u.subunits >= 2 && c0 == 2 * c && (c == 16 || c == 32 || c == 64);
+        // the residual branch of the first unit (a 3 -> c conv of the image, 27 multiplies per output) is not written by the unit0 launch
+        // and read back by norm_act_add: a second first-layer launch computes it from the image and adds act(norm(Y)) in its epilogue
+        // (one c-channel tensor less written and read; CS_FUSE_FIRST=0 restores the [y0 || r] launch).  With pixel records from the
+        // window pass (swi_run_windows) both launches run on the record kernels of kernels_first.hip (fp32 and the bf16 datapath; at
+        // most 64 channels per launch)
+        const bool fuse_first = ec == c && c0 != c;
         if (!dry) {
             if (u.first) {
-                if (a16 && u.unit0.wb)
+                if (use_rec && ec <= 64)
+                    CS_TRY(launch_conv_first_rec(s, src, u.unit0.w, u.unit0.bias, E, ec, ec, rt_down[d][0].stats, n, c, c0, 0));
+                else if (a16 && u.unit0.wb)
                     CS_TRY(launch_conv_first16(s, src, pc, u.unit0.wb, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, c));
                 else if (fuse_first)
-                    CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c, rt_down[d][0].stats, n, false, c, c0, 0));
+                    CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, ec, c, rt_down[d][0].stats, n, false, c, c0, 0));
                 else
                     CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, E, c0, c0, rt_down[d][0].stats, n, a16, c));   // statistics for the unit0 half only
             } else {
@@ -673,7 +684,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             }
             CS_TRY(finish_norm(s, net, u.norms[0], rt_down[d][0], n, c0, oh * ow, dry));
             const float* cur = E;
-            int cur_pitch = c0, cur_tabc = c0;
+            int cur_pitch = u.first ? ec : c0, cur_tabc = c0;
             for (int su = 1; su < u.subunits; ++su) {
                 const ConvSrc lz = lazy_src(cur, c, cur_pitch, rt_down[d][su - 1], u.norms[su - 1], cur_tabc, a16);
                 const bool in8 = q8 && u.units[su - 1].f8;
@@ -686,8 +697,9 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             }
             const int last = u.subunits - 1;
             if (fuse_first) {
-                const ConvSrc ly = lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc, false);
-                CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, X[d], c, c, nullptr, n, false, 0, c0, c, &ly));
+                const ConvSrc ly = lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc, a16);
+                if (use_rec) CS_TRY(launch_conv_first_rec(s, src, u.unit0.w, u.unit0.bias, X[d], c, c, nullptr, n, 0, c0, c, &ly));
+                else CS_TRY(launch_conv_first(s, 2, src, pc, u.unit0.w, u.unit0.bias, X[d], c, c, nullptr, n, false, 0, c0, c, &ly));
             } else
             CS_TRY(launch_norm_act_add(s, lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc, a16),
                                        raw_src(act_off(E, c, a16), c, c0, a16), X[d], c, (int64_t)oh * ow, n, a16, Xq[d], c));
@@ -1631,7 +1643,8 @@ size_t cs_swi_windows_workspace_bytes(const cs_unet* net, const cs_swi_plan* pl,
     const size_t eb = (size_t)engine_batch < nwin ? (size_t)engine_batch : nwin;
     const size_t unet = cs_unet_workspace_bytes(net, (int)eb, pl->roi_h, pl->roi_w) * (size_t)net->n_streams;
     if (unet == 0) return 0;
-    return unet + (nwin * 8 + 255) / 256 * 256 + 512;
+    const size_t records = ((size_t)pl->img_h * pl->img_w * 16 + 255) / 256 * 256;      // the image as pixel records (swi_run_windows)
+    return unet + (nwin * 8 + 255) / 256 * 256 + records + 512;
 }
 
 size_t cs_swi_workspace_bytes(const cs_unet* net, const cs_swi_plan* pl, int engine_batch) {
@@ -1653,6 +1666,15 @@ static int swi_run_windows(cs_unet* net, const cs_swi_plan* pl, const float* ima
     WindowSrc src;
     src.image = image; src.sn = 0; src.sc = sc; src.sh = sh; src.sw = sw;
     src.img_h = pl->img_h; src.img_w = pl->img_w; src.roi_h = pl->roi_h; src.roi_w = pl->roi_w;
+    // the image once more as (r, g, b, 0) pixel records: every window's first layer gathers its patches from these (kernels_first.hip)
+    if (cs::first_rec_enabled() && net->in_ch == 3 && (int64_t)pl->img_h * pl->img_w < ((int64_t)1 << 31)) {
+        const bool rec16 = (net->planes == 1 || net->planes == 5) && !net->training;       // unet_forward_impl's bf16 datapath
+        void* rec = b.take<char>((size_t)pl->img_h * pl->img_w * 16);
+        if (!b.ok()) { cs::set_error("swi: workspace too small"); return CS_ERR_WORKSPACE; }
+        if (int rc0 = cs::launch_image_records(s, image, 0, sc, sh, sw, 1, pl->img_h, pl->img_w, rec, rec16)) return rc0;
+        src.rec = rec;
+        src.rec16 = rec16;
+    }
     // sliding-window inference is an inference call: BatchNorm layers use their running statistics whatever mode the handle was
     // left in (a train-mode handle would otherwise normalise every window chunk with that chunk's own statistics and update the
     // running ones once per chunk, from several streams)

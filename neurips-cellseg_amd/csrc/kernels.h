@@ -152,11 +152,22 @@ struct WindowSrc {
     const int2* origins = nullptr;           // [n] (y0, x0) or nullptr
     int img_h = 0, img_w = 0;                // bounds of the image (or of each batch item)
     int roi_h = 0, roi_w = 0;                // window size = conv input size
+    // inference: the same image as (r, g, b, 0) pixel records (launch_image_records) - float4, or 4 x bf16 when rec16 - [img_h][img_w]
+    // with origins, [n][img_h][img_w] without; the record kernels of kernels_first.hip read these instead of `image`
+    const void* rec = nullptr;
+    bool rec16 = false;
 };
 int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, const float* wpack, const float* bias,
                       float* out, int pitch_out, int cout, double* stats, int n, bool out16 = false, int stats_c = 0,   // stats_c: statistics for channels [0, stats_c) only (0 = all)
                       int cout_pack = 0, int cout_off = 0,     // channels [cout_off, cout_off + cout) of a pack of cout_pack channels (0 = the whole pack)
                       const ConvSrc* add = nullptr);           // out = conv + bias + act(norm(*add)): the ResidualUnit's sum, fp32
+// first layer from pixel records (kernels_first.hip; inference): wave-private tiles walked along the row, no block barrier; fp32 or,
+// with src.rec16, the bf16 datapath (bf16 out); `add`: out = conv + bias + act(norm(*add)) in the datapath's own format
+int launch_image_records(hipStream_t s, const float* image, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n, int h, int w, void* rec,
+                         bool as16);
+bool first_rec_enabled();
+int launch_conv_first_rec(hipStream_t s, const WindowSrc& src, const float* wpack, const float* bias, void* out, int pitch_out, int cout,
+                          double* stats, int n, int stats_c = 0, int cout_pack = 0, int cout_off = 0, const ConvSrc* add = nullptr);
 // bf16 / fp8 datapaths: the image is converted to bf16 while it is staged, one v_mfma_f32_16x16x32_bf16 per 16 x 16 output tile
 // (the fp32 form needs seven 16x16x4 steps = 14x the matrix-pipe cycles), bf16 out
 int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsigned short* wpack16, const float* bias, float* out,

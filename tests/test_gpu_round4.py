@@ -324,6 +324,56 @@ def test_first_unit_residual_recomputed_in_the_sum_launch_agrees_with_the_materi
         assert res["1"][tag + "_adds"] == res["0"][tag + "_adds"] - 1
 
 
+_REC_EVAL = r"""
+import sys, torch
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {root!r})
+import cellseg_amd as ca
+dev = torch.device("cuda:0")
+outs = {{}}
+cases = (("a", (32, 64, 128, 256, 512), (2, 2, 2, 2), (3, 700, 530), (256, 256), 0.5, "instance"),     # the slide setting, partial last windows
+         ("b", (16, 32, 64, 128, 256), (2, 2, 2, 2), (3, 200, 611), (256, 256), 0.25, "instance"),     # image lower than the window: padded rows, negative origins
+         ("c", (64, 128, 256), (2, 2), (3, 300, 420), (128, 192), 0.5, "instance"),                    # 64-channel first layer, non-square window
+         ("d", (32, 64, 128), (2, 2), (3, 333, 277), (100, 76), 0.25, "batch"))                        # 50 x 38 outputs: partial tiles and row groups, BatchNorm table
+for precision in ("fp32", "bf16"):
+    for tag, channels, strides, shape, roi, overlap, norm in cases:
+        torch.manual_seed(11)
+        kw = dict(norm="batch", act="relu") if norm == "batch" else {{}}
+        m = ca.UNet(channels=channels, strides=strides, num_res_units=2, **kw).to(dev).eval()
+        m.precision = precision
+        x = torch.rand(1, *shape, generator=torch.Generator().manual_seed(4)).to(dev)
+        with torch.no_grad():
+            outs[precision + "/" + tag] = ca.sliding_window_inference(x, roi, 4, m, overlap=overlap).cpu()
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_first_layer_from_pixel_records_agrees_with_the_planar_gather(tmp_path):
+    """The window pass rewrites the image once as (r, g, b, 0) records and runs the first layer on kernels_first.hip (wave-private tiles
+    walked along the row; fp32 and the bf16 datapath, with and without the fused residual sum).  Against the planar-gather kernels
+    (CS_FIRST_REC=0) through sliding_window_inference: windows that overhang the image on every side (negative origins, padded rows),
+    16- / 32- / 64-channel first layers, partial 16-column tiles and 8-row groups, an InstanceNorm and a BatchNorm net.  fp32: the same
+    products in the same order, only the statistics are summed differently - logits within 2e-5; bf16: K is walked as 3 x 16 instead of
+    1 x 32 and the fused sum adds an unrounded residual - logits within the datapath's own tolerance (0.5 % of the range + 2 % mean)."""
+    res = {}
+    for rec, fuse in (("0", "0"), ("1", "1"), ("1", "0")):
+        path = str(tmp_path / f"rec{rec}{fuse}.pt")
+        env = dict(os.environ, CS_FIRST_REC=rec, CS_FUSE_FIRST=fuse, PYTHONPATH=os.pathsep.join([PKG, ROOT]))
+        subprocess.run([sys.executable, "-c", _REC_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=900)
+        res[rec + fuse] = torch.load(path)
+    base = res["00"]
+    for key, want in base.items():
+        scale = max(float(want.abs().max()), 1.0)
+        for mode in ("11", "10"):
+            got = res[mode][key]
+            assert got.shape == want.shape and torch.isfinite(got).all(), (key, mode)
+            err = float((got - want).abs().max())
+            if key.startswith("fp32"):
+                assert err <= 2e-5 * scale, (key, mode, err, scale)
+            else:
+                assert err <= 0.05 * scale and float((got - want).abs().mean()) <= 0.005 * scale, (key, mode, err, scale)
+    assert not torch.equal(res["11"]["bf16/a"], base["bf16/a"])            # the record kernels really ran
+
+
 # ------------------------------------------------------------------------------------------- fp8 mode: the all-e4m3 setting of rounds 2-3
 def test_fp8_mode_with_every_layer_in_e4m3_still_runs():
     """CS_FP8_MIN_C=0 puts every layer on the e4m3 kernels (rounds 2-3); the default 128 keeps the narrow layers on the bf16 kernels.  Both

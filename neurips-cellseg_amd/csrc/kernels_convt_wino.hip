@@ -270,7 +270,10 @@ size_t packed_convt_wino_floats(int cout_total, int cin_total) { return (size_t)
 static int g_convt_wino = [] { const char* e = getenv("CS_CONVT_WINO"); return e ? atoi(e) : 1; }();
 bool convt_wino_enabled() { return g_convt_wino != 0; }
 bool convt_wino_fits(int cin_a, int cin_b, int cout, int h, int w) {
-    // (32-channel blocks of two waves measured slower than the direct kernel: 847 vs 736 us for 64 + 64 -> 32 at 64 x 64)
+    // (32-channel blocks measured no faster than the direct kernel for 64 + 64 -> 32 at 64 x 64 over 256 windows: two waves with 16-channel
+    // chunks 847 vs 736 us; four waves as 2 channel tiles x 2 tile groups with 8-channel chunks - three blocks per CU, one barrier per
+    // 50 MFMAs - 705 vs 727 us, and 862 vs 750 us when the tensor from below is a SUM source, as it is in the slide: the input
+    // transform is shared by half as many output channels, 48 % / 40 % matrix-pipe busy against 61 % for the 64-channel blocks)
     return g_convt_wino != 0 && cin_a % 16 == 0 && cin_b % 16 == 0 && cin_a > 0 && cout % 64 == 0 && h >= 4 && w >= 4;
 }
 

@@ -435,6 +435,184 @@ static int launch_b(hipStream_t s, ConvBParams p) {
     return CS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 datapath, 3x3 stride 1, 32 -> 32 channels (the two widest tensors of the 32-base net: 128 x 128 x 32 per window), inference.
+// conv_bf16s_kernel<1, 3, 1, 2, 1, 2> runs these layers as blocks of ONE K chunk: gather -> barrier -> 72 MFMAs per wave -> epilogue,
+// nothing of a block overlaps anything else of it (13 % matrix busy, 2.5 TB/s for a layer whose floor is its 537 MB of traffic).
+// Here a WAVE streams a strip of 16 output columns down RW_RS rows:
+//   * its 9 x 2 weight fragments (18 x 16 bytes per lane) stay in registers for the whole strip;
+//   * a rolling window of input rows lives in wave-private LDS (4 slots of 18 pixels x 96 bytes): per output row ONE new input row is
+//     loaded (two rows ahead, in registers), normalised + activated + rounded to bf16 and stored - no halo rows are staged twice, only
+//     the 2 halo columns (18 / 16);
+//   * 18 MFMAs per row, A fragments as 16-byte reads of the window (conflict-free at 96 bytes per pixel);
+//   * bias, statistics (fp32 per lane over 8 rows, fp64 beyond), and the row leaves through a wave-private slab as one 16-byte store
+//     per lane (64 lanes = 16 pixels x 64 bytes);
+//   * no block barrier until the statistics of the block's four strips meet at the end.
+// Same products in the same order as conv_bf16s_kernel (tap-major, one K = 32 step per tap): the conv results are bit-identical, the
+// statistics are summed in another order.
+// ------------------------------------------------------------------------------------------------
+constexpr int RW_RS = 32;                                   // output rows of a wave's strip segment
+constexpr int RW_PITCH = 96;                                // bytes per staged pixel: 32 bf16 + pad
+constexpr int RW_ROW = 18 * RW_PITCH;
+constexpr int RW_SLOTS = 4;
+constexpr int RW_EPS = 36;                                  // floats per slab pixel: 32 channels + pad
+constexpr int RW_WAVE_BYTES = RW_SLOTS * RW_ROW + 16 * RW_EPS * 4;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool LAZY>
+__global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p, int strips, int strip_groups, int segs) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * RW_WAVE_BYTES];
+    __shared__ double red[4 * 32 * 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+    char* const ring = smem + wave * RW_WAVE_BYTES;
+    float* const ep = reinterpret_cast<float*>(ring + RW_SLOTS * RW_ROW);
+    int bid = blockIdx.x;
+    const int sg = bid % strip_groups;
+    bid /= strip_groups;
+    const int seg = bid % segs;
+    const int img = bid / segs;
+    const int strip = sg * 4 + wave;
+    const bool active = strip < strips;
+    const int ox0 = strip * 16;
+    const int oy_begin = seg * RW_RS, oy_end = oy_begin + RW_RS < p.hout ? oy_begin + RW_RS : p.hout;
+
+    float sums[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    double dsum[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    if (active) {
+        // weights: fragment (tap, channel tile) of chunk 0, plane 0 of packed[chunk][tap][ntile_total = 2][3][64][8]
+        bf16x8 b[9][2];
+        const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[tap][t] = wbase[(size_t)(tap * 2 + t) * 3 * 64];
+        float bias[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bias[t] = p.bias ? p.bias[t * 16 + pl] : 0.f;
+        // staging items: (pixel px of the 18, channel octet c8): pass A lanes -> pixels 0 ... 15, pass B lanes 0 ... 7 -> pixels 16, 17
+        const int c8 = lane & 3;
+        const int px_a = lane >> 2, px_b = 16 + (lane >> 2);
+        const int gx_a = ox0 - 1 + px_a, gx_b = ox0 - 1 + px_b;
+        const bool ok_a = gx_a >= 0 && gx_a < p.win, ok_b = lane < 8 && gx_b < p.win;
+        f32x4 tb[4];                                               // (scale, shift) of channels 8 c8 ... 8 c8 + 7
+        {
+            const f32x4* t = LAZY ? reinterpret_cast<const f32x4*>(p.a.tab + (size_t)img * p.a.tab_c + p.a.tab_off + 8 * c8)
+                                  : reinterpret_cast<const f32x4*>(p.dummy);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tb[k] = t[k];
+        }
+        float slope = *((LAZY && p.a.slope) ? p.a.slope : p.dummy);
+        if (!(LAZY && p.a.slope)) slope = 0.f;
+        const unsigned short* const src = reinterpret_cast<const unsigned short*>(p.a.ptr) + (size_t)img * p.hin * p.win * p.a.pitch + 8 * c8;
+        const unsigned off_a = (unsigned)(ok_a ? gx_a : 0) * p.a.pitch, off_b = (unsigned)(ok_b ? gx_b : 0) * p.a.pitch;
+        auto load_row = [&](int gy, u32x4& ra, u32x4& rb) {        // clamped: rows outside the image are staged as zeros below
+            const int y = gy < 0 ? 0 : (gy >= p.hin ? p.hin - 1 : gy);
+            const unsigned short* row = src + (size_t)y * p.win * p.a.pitch;
+            ra = *reinterpret_cast<const u32x4*>(row + off_a);
+            rb = *reinterpret_cast<const u32x4*>(row + off_b);
+        };
+        auto activate = [&](u32x4 r, bool ok) -> u32x4 {           // 8 bf16 -> norm + act -> 8 bf16
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float lo = __builtin_bit_cast(float, r[k] << 16), hi = __builtin_bit_cast(float, r[k] & 0xffff0000u);
+                const f32x4 t = tb[k];                             // (scale, shift) of channels 2 k and 2 k + 1 of the octet
+                if constexpr (LAZY) {
+                    lo = prelu_h(lo * t.x + t.y, slope);
+                    hi = prelu_h(hi * t.z + t.w, slope);
+                }
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const bf16x2 h{(__bf16)lo, (__bf16)hi};
+                o[k] = ok ? __builtin_bit_cast(unsigned, h) : 0u;
+            }
+            return o;
+        };
+        auto stage = [&](int gy, u32x4 ra, u32x4 rb) {             // input row gy -> ring slot (gy + 1) & 3
+            char* const slot = ring + ((gy + 1) & 3) * RW_ROW;
+            const bool row_ok = gy >= 0 && gy < p.hin;
+            *reinterpret_cast<u32x4*>(slot + px_a * RW_PITCH + c8 * 16) = activate(ra, row_ok && ok_a);
+            if (lane < 8) *reinterpret_cast<u32x4*>(slot + px_b * RW_PITCH + c8 * 16) = activate(rb, row_ok && ok_b);
+        };
+
+        u32x4 a0, b0, a1, b1, a2, b2;
+        load_row(oy_begin - 1, a0, b0);
+        load_row(oy_begin, a1, b1);
+        stage(oy_begin - 1, a0, b0);
+        stage(oy_begin, a1, b1);
+        load_row(oy_begin + 1, a1, b1);                            // (a1, b1): row oy + 1, (a2, b2): row oy + 2
+        load_row(oy_begin + 2, a2, b2);
+        const size_t out_row = ((size_t)img * p.hout) * p.wout + ox0;
+        unsigned short* const out = reinterpret_cast<unsigned short*>(p.out);
+        const int opix = lane >> 2;                                // the pixel (and channel octet c8) this lane stores
+        const bool ostore = ox0 + opix < p.wout;
+        const bool full = ox0 + 16 <= p.wout;
+        float cmask[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cmask[r] = ox0 + g * 4 + r < p.wout ? 1.f : 0.f;
+#pragma unroll 1
+        for (int oy = oy_begin; oy < oy_end; ++oy) {
+            stage(oy + 1, a1, b1);
+            a1 = a2;
+            b1 = b2;
+            load_row(oy + 3, a2, b2);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the window is wave-private, no block barrier
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const char* const arow = ring + ((oy + ky) & 3) * RW_ROW + pl * RW_PITCH + g * 16;        // input row oy - 1 + ky
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + kx * RW_PITCH);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[ky * 3 + kx][t], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[t][r] + bias[t];
+                    ep[(g * 4 + r) * RW_EPS + t * 16 + pl] = v;
+                    const float vm = full ? v : v * cmask[r];      // (wave-uniform: only the last strip of a row has columns beyond the image)
+                    sums[t][0] += vm;
+                    sums[t][1] = fmaf(vm, v, sums[t][1]);
+                }
+            if (((oy - oy_begin) & 7) == 7) {                      // a lane's <= 32 values per channel in fp32, fp64 beyond (stats_commit_b's rule)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        dsum[t][k] += (double)sums[t][k];
+                        sums[t][k] = 0.f;
+                    }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (ostore) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8 + 4]);
+                const bf16x8 h{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w, (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+                *reinterpret_cast<bf16x8*>(out + (out_row + (size_t)oy * p.wout + opix) * p.pitch_out + c8 * 8) = h;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) dsum[t][k] += (double)sums[t][k];
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) stats_stash_b(dsum[t][0], dsum[t][1], red + ((wave * 2 + t) * 16 + pl) * 2, lane);
+        __syncthreads();
+        stats_flush_b<4, 32>(red, p.stats + (size_t)img * p.cout * 2, tid);
+    }
+}
+
+static int g_bf16_rows = [] { const char* e = getenv("CS_BF16_ROWS"); return e ? atoi(e) : 1; }();
+
 int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
                       const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
                       int hin, int win, bool act16, const float* in_amax, const ConvOutExtra* ex) {
@@ -474,6 +652,15 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     const double esz = act16 ? 2.0 : 4.0;
     const double bytes = esz * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
+    // the 32 -> 32 stride-1 layers of the bf16 datapath: a wave streams a 16-column strip (conv_bf16_rows32_kernel)
+    if (g_bf16_rows && act16 && planes == 1 && ksize == 3 && stride == 1 && a.c == 32 && b.c == 0 && cout == 32 && !ex && !in_amax &&
+        a.pitch % 8 == 0 && pitch_out % 8 == 0 && hin >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31)) {
+        const int strips = ceil_div(p.wout, 16), strip_groups = ceil_div(strips, 4), segs = ceil_div(p.hout, RW_RS);
+        if (a.tab) hipLaunchKernelGGL(conv_bf16_rows32_kernel<true>, dim3((unsigned)(strip_groups * segs * n)), dim3(256), 0, s, p, strips, strip_groups, segs);
+        else hipLaunchKernelGGL(conv_bf16_rows32_kernel<false>, dim3((unsigned)(strip_groups * segs * n)), dim3(256), 0, s, p, strips, strip_groups, segs);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
 #define CS_B3(S_, KS_, NP_, A16_)                                                   \
     switch (wn) {                                                                   \
         case 4: if (S_ == 1 && KS_ == 3 && NP_ != 3 && cout % 128 == 0) return launch_b<S_, KS_, 4, 2, (NP_ == 3 ? 4 : NP_), 1, A16_>(s, p); \

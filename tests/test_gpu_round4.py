@@ -374,6 +374,52 @@ def test_first_layer_from_pixel_records_agrees_with_the_planar_gather(tmp_path):
     assert not torch.equal(res["11"]["bf16/a"], base["bf16/a"])            # the record kernels really ran
 
 
+_ROWS_EVAL = r"""
+import sys, torch
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {root!r})
+import cellseg_amd as ca
+dev = torch.device("cuda:0")
+outs = {{}}
+cases = (("a", (32, 64, 128, 256, 512), (2, 2, 2, 2), (3, 3, 272, 208), "instance"),      # 136 x 104 at the 32-channel level: 7 strips (a block with one idle wave), 5 row segments
+         ("b", (32, 64, 128), (2, 2), (5, 3, 100, 76), "instance"),                        # 50 x 38: partial strip, partial segment, 5 images
+         ("c", (32, 64, 128), (2, 2), (2, 3, 136, 72), "batch"),                           # BatchNorm(eval) table + ReLU (no slope)
+         ("d", (32, 64), (2,), (2, 3, 32, 48), "instance"))                                # 16 x 24: one short segment
+for tag, channels, strides, shape, norm in cases:
+    torch.manual_seed(11)
+    kw = dict(norm="batch", act="relu") if norm == "batch" else {{}}
+    m = ca.UNet(channels=channels, strides=strides, num_res_units=2, **kw).to(dev).eval()
+    m.precision = "bf16"
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():
+        outs[tag] = m(x).cpu()
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_bf16_32_channel_layers_streamed_by_waves_agree_with_the_block_kernel(tmp_path):
+    """bf16 datapath: the 3x3 stride-1 32 -> 32 layers run on conv_bf16_rows32_kernel (a wave streams a 16-column strip row by row with a
+    rolling window of input rows in wave-private LDS and its weights in registers) instead of the one-chunk blocks of conv_bf16s_kernel
+    (CS_BF16_ROWS=0).  The convolution itself is the same products in the same order (bit-identical); the InstanceNorm statistics are
+    summed in another order, and a last-bit change of a norm scale can move a bf16 rounding downstream: logits within 2 % of the range at
+    the worst pixel and 0.2 % on average, on strips / row segments that do not divide the image, several images, and a BatchNorm net
+    (whose table does not depend on the statistics: equal logits)."""
+    res = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"rows{mode}.pt")
+        env = dict(os.environ, CS_BF16_ROWS=mode, PYTHONPATH=os.pathsep.join([PKG, ROOT]))
+        subprocess.run([sys.executable, "-c", _ROWS_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
+        res[mode] = torch.load(path)
+    for tag, want in res["0"].items():
+        got = res["1"][tag]
+        scale = max(float(want.abs().max()), 1.0)
+        assert torch.isfinite(got).all(), tag
+        err, mean = float((got - want).abs().max()), float((got - want).abs().mean())
+        if tag == "c":
+            assert err == 0.0, (tag, err)
+        else:
+            assert err <= 0.02 * scale and mean <= 0.002 * scale, (tag, err, mean, scale)
+
+
 # ------------------------------------------------------------------------------------------- fp8 mode: the all-e4m3 setting of rounds 2-3
 def test_fp8_mode_with_every_layer_in_e4m3_still_runs():
     """CS_FP8_MIN_C=0 puts every layer on the e4m3 kernels (rounds 2-3); the default 128 keeps the narrow layers on the bf16 kernels.  Both

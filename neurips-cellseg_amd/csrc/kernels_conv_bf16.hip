@@ -442,8 +442,11 @@ static int launch_b(hipStream_t s, ConvBParams p) {
 // Here a WAVE streams a strip of 16 output columns down RW_RS rows:
 //   * its 9 x 2 weight fragments (18 x 16 bytes per lane) stay in registers for the whole strip;
 //   * a rolling window of input rows lives in wave-private LDS (4 slots of 18 pixels x 96 bytes): per output row ONE new input row is
-//     loaded (two rows ahead, in registers), normalised + activated + rounded to bf16 and stored - no halo rows are staged twice, only
-//     the 2 halo columns (18 / 16);
+//     loaded (three rows ahead, in registers), normalised + activated + rounded to bf16 and stored one step before it is needed (beside
+//     the MFMAs of the current row: the slot it goes to is the one row oy - 2 left) - no halo rows are staged twice, only
+//     the 2 halo columns (18 / 16).  Those two columns of EIGHT rows are one 64-lane load and one activation pass (lane = row of the
+//     group x pixel x channel octet) into a side area of 16 row slots; a row step copies its two pixels from there into the window
+//     (8 lanes, LDS to LDS) - a per-row halo pass of 8 active lanes cost as many instructions as the 64-lane main pass;
 //   * 18 MFMAs per row, A fragments as 16-byte reads of the window (conflict-free at 96 bytes per pixel);
 //   * bias, statistics (fp32 per lane over 8 rows, fp64 beyond), and the row leaves through a wave-private slab as one 16-byte store
 //     per lane (64 lanes = 16 pixels x 64 bytes);
@@ -456,7 +459,8 @@ constexpr int RW_PITCH = 96;                                // bytes per staged 
 constexpr int RW_ROW = 18 * RW_PITCH;
 constexpr int RW_SLOTS = 4;
 constexpr int RW_EPS = 36;                                  // floats per slab pixel: 32 channels + pad
-constexpr int RW_WAVE_BYTES = RW_SLOTS * RW_ROW + 16 * RW_EPS * 4;
+constexpr int RW_HALO = 16 * 2 * RW_PITCH;                  // the halo columns of 16 input rows (two groups of eight)
+constexpr int RW_WAVE_BYTES = RW_SLOTS * RW_ROW + RW_HALO + 16 * RW_EPS * 4;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool LAZY>
@@ -467,7 +471,8 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
     char* const ring = smem + wave * RW_WAVE_BYTES;
-    float* const ep = reinterpret_cast<float*>(ring + RW_SLOTS * RW_ROW);
+    char* const halo = ring + RW_SLOTS * RW_ROW;
+    float* const ep = reinterpret_cast<float*>(halo + RW_HALO);
     int bid = blockIdx.x;
     const int sg = bid % strip_groups;
     bid /= strip_groups;
@@ -491,11 +496,13 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
         float bias[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) bias[t] = p.bias ? p.bias[t * 16 + pl] : 0.f;
-        // staging items: (pixel px of the 18, channel octet c8): pass A lanes -> pixels 0 ... 15, pass B lanes 0 ... 7 -> pixels 16, 17
+        // staging items (pixel, channel octet c8 = lane & 3): the main pass takes pixels 0 ... 15 of one row (lane >> 2), the halo pass
+        // pixels 16, 17 of eight rows (row lane >> 3, pixel (lane >> 2) & 1)
         const int c8 = lane & 3;
-        const int px_a = lane >> 2, px_b = 16 + (lane >> 2);
-        const int gx_a = ox0 - 1 + px_a, gx_b = ox0 - 1 + px_b;
-        const bool ok_a = gx_a >= 0 && gx_a < p.win, ok_b = lane < 8 && gx_b < p.win;
+        const int px_a = lane >> 2;
+        const int gx_a = ox0 - 1 + px_a, gx_h = ox0 + 15 + ((lane >> 2) & 1);
+        const bool ok_a = gx_a >= 0 && gx_a < p.win, ok_h = gx_h < p.win;
+        const int hrow = lane >> 3;
         f32x4 tb[4];                                               // (scale, shift) of channels 8 c8 ... 8 c8 + 7
         {
             const f32x4* t = LAZY ? reinterpret_cast<const f32x4*>(p.a.tab + (size_t)img * p.a.tab_c + p.a.tab_off + 8 * c8)
@@ -506,13 +513,12 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
         float slope = *((LAZY && p.a.slope) ? p.a.slope : p.dummy);
         if (!(LAZY && p.a.slope)) slope = 0.f;
         const unsigned short* const src = reinterpret_cast<const unsigned short*>(p.a.ptr) + (size_t)img * p.hin * p.win * p.a.pitch + 8 * c8;
-        const unsigned off_a = (unsigned)(ok_a ? gx_a : 0) * p.a.pitch, off_b = (unsigned)(ok_b ? gx_b : 0) * p.a.pitch;
-        auto load_row = [&](int gy, u32x4& ra, u32x4& rb) {        // clamped: rows outside the image are staged as zeros below
-            const int y = gy < 0 ? 0 : (gy >= p.hin ? p.hin - 1 : gy);
-            const unsigned short* row = src + (size_t)y * p.win * p.a.pitch;
-            ra = *reinterpret_cast<const u32x4*>(row + off_a);
-            rb = *reinterpret_cast<const u32x4*>(row + off_b);
-        };
+        const unsigned off_a = (unsigned)(ok_a ? gx_a : 0) * p.a.pitch, off_h = (unsigned)(ok_h ? gx_h : 0) * p.a.pitch;
+        auto clamp_row = [&](int gy) { return gy < 0 ? 0 : (gy >= p.hin ? p.hin - 1 : gy); };     // rows outside the image are staged as zeros below
+        auto load_row = [&](int gy, u32x4& ra) { ra = *reinterpret_cast<const u32x4*>(src + (size_t)clamp_row(gy) * p.win * p.a.pitch + off_a); };
+        auto load_halo = [&](int gy0, u32x4& rh) { rh = *reinterpret_cast<const u32x4*>(src + (size_t)clamp_row(gy0 + hrow) * p.win * p.a.pitch + off_h); };
+        // 0 <= slope <= 1 (ReLU, every PReLU near its 0.25 start): act(v) = max(v, slope v), one instruction less per value than the select form
+        const bool slope01 = slope >= 0.f && slope <= 1.f;
         auto activate = [&](u32x4 r, bool ok) -> u32x4 {           // 8 bf16 -> norm + act -> 8 bf16
             u32x4 o;
 #pragma unroll
@@ -520,8 +526,15 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
                 float lo = __builtin_bit_cast(float, r[k] << 16), hi = __builtin_bit_cast(float, r[k] & 0xffff0000u);
                 const f32x4 t = tb[k];                             // (scale, shift) of channels 2 k and 2 k + 1 of the octet
                 if constexpr (LAZY) {
-                    lo = prelu_h(lo * t.x + t.y, slope);
-                    hi = prelu_h(hi * t.z + t.w, slope);
+                    lo = __builtin_fmaf(lo, t.x, t.y);
+                    hi = __builtin_fmaf(hi, t.z, t.w);
+                    if (slope01) {
+                        lo = __builtin_fmaxf(lo, lo * slope);
+                        hi = __builtin_fmaxf(hi, hi * slope);
+                    } else {
+                        lo = prelu_h(lo, slope);
+                        hi = prelu_h(hi, slope);
+                    }
                 }
                 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
                 const bf16x2 h{(__bf16)lo, (__bf16)hi};
@@ -529,36 +542,57 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
             }
             return o;
         };
-        auto stage = [&](int gy, u32x4 ra, u32x4 rb) {             // input row gy -> ring slot (gy + 1) & 3
+        const int r0 = oy_begin - 1;                               // first input row of the segment: halo slots count from it
+        auto stage_halo = [&](int gy0, u32x4 rh) {                 // input rows gy0 ... gy0 + 7 -> halo slots (gy - r0) & 15
+            const int gy = gy0 + hrow;
+            *reinterpret_cast<u32x4*>(halo + ((((gy - r0) & 15) * 2 + ((lane >> 2) & 1)) * RW_PITCH) + c8 * 16) =
+                activate(rh, gy >= 0 && gy < p.hin && ok_h);
+        };
+        auto stage = [&](int gy, u32x4 ra) {                       // input row gy -> ring slot (gy + 1) & 3
             char* const slot = ring + ((gy + 1) & 3) * RW_ROW;
-            const bool row_ok = gy >= 0 && gy < p.hin;
-            *reinterpret_cast<u32x4*>(slot + px_a * RW_PITCH + c8 * 16) = activate(ra, row_ok && ok_a);
-            if (lane < 8) *reinterpret_cast<u32x4*>(slot + px_b * RW_PITCH + c8 * 16) = activate(rb, row_ok && ok_b);
+            u32x4 hv;
+            if (lane < 8) hv = *reinterpret_cast<const u32x4*>(halo + (((gy - r0) & 15) * 2 + (lane >> 2)) * RW_PITCH + c8 * 16);
+            *reinterpret_cast<u32x4*>(slot + px_a * RW_PITCH + c8 * 16) = activate(ra, gy >= 0 && gy < p.hin && ok_a);
+            if (lane < 8) *reinterpret_cast<u32x4*>(slot + (16 + (lane >> 2)) * RW_PITCH + c8 * 16) = hv;
         };
 
-        u32x4 a0, b0, a1, b1, a2, b2;
-        load_row(oy_begin - 1, a0, b0);
-        load_row(oy_begin, a1, b1);
-        stage(oy_begin - 1, a0, b0);
-        stage(oy_begin, a1, b1);
-        load_row(oy_begin + 1, a1, b1);                            // (a1, b1): row oy + 1, (a2, b2): row oy + 2
-        load_row(oy_begin + 2, a2, b2);
+        constexpr int UNR = 3;                                     // rows per trip = registers of the row queue (it rotates without copies)
+        u32x4 aq[UNR], hn;                                         // aq[j]: the input row that step j of a trip stages; reloaded UNR rows ahead
+        {
+            u32x4 h0, a0, a1, a2;
+            load_halo(r0, h0);
+            load_row(r0, a0);
+            load_row(r0 + 1, a1);
+            load_row(r0 + 2, a2);
+            load_halo(r0 + 8, hn);
+            stage_halo(r0, h0);
+            __builtin_amdgcn_wave_barrier();
+            stage(r0, a0);
+            stage(r0 + 1, a1);
+            stage(r0 + 2, a2);
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) load_row(oy_begin + 2 + j, aq[j]);
         const size_t out_row = ((size_t)img * p.hout) * p.wout + ox0;
         unsigned short* const out = reinterpret_cast<unsigned short*>(p.out);
         const int opix = lane >> 2;                                // the pixel (and channel octet c8) this lane stores
         const bool ostore = ox0 + opix < p.wout;
         const bool full = ox0 + 16 <= p.wout;
-        float cmask[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cmask[r] = ox0 + g * 4 + r < p.wout ? 1.f : 0.f;
-#pragma unroll 1
-        for (int oy = oy_begin; oy < oy_end; ++oy) {
-            stage(oy + 1, a1, b1);
-            a1 = a2;
-            b1 = b2;
-            load_row(oy + 3, a2, b2);
-            __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the window is wave-private, no block barrier
+        // a row leaves one step late: its slab is read (other lanes' values: LDS operations of a wave complete in order) while the next
+        // row's MFMAs run, so that nothing in a step waits for the matrix pipe but the slab writes at its end
+        auto store_row = [&](int oy) {
+            if (ostore) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8 + 4]);
+                const bf16x8 h{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w, (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+                *reinterpret_cast<bf16x8*>(out + (out_row + (size_t)oy * p.wout + opix) * p.pitch_out + c8 * 8) = h;
+            }
+        };
+        // output row oy: window rows oy - 1 ... oy + 1 were staged by earlier steps; this step stages input row oy + 2 (areg) into the slot of
+        // row oy - 2 and reloads areg UNR rows further - independent of its MFMAs, the scheduler interleaves the two
+        auto row_step = [&](int oy, u32x4& areg) {
             __builtin_amdgcn_wave_barrier();
+            if (oy > oy_begin) store_row(oy - 1);
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -570,34 +604,43 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
                     for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[ky * 3 + kx][t], acc[t], 0, 0, 0);
                 }
             }
+            stage(oy + 2, areg);
+            load_row(oy + 2 + UNR, areg);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[t][r] + bias[t];
                     ep[(g * 4 + r) * RW_EPS + t * 16 + pl] = v;
-                    const float vm = full ? v : v * cmask[r];      // (wave-uniform: only the last strip of a row has columns beyond the image)
+                    const float vm = full ? v : (ox0 + g * 4 + r < p.wout ? v : 0.f);      // (wave-uniform: only the last strip of a row has columns beyond the image)
                     sums[t][0] += vm;
                     sums[t][1] = fmaf(vm, v, sums[t][1]);
                 }
-            if (((oy - oy_begin) & 7) == 7) {                      // a lane's <= 32 values per channel in fp32, fp64 beyond (stats_commit_b's rule)
+        };
+#pragma unroll 1
+        for (int oy = oy_begin; oy < oy_end; oy += UNR) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+            for (int j = 0; j < UNR; ++j) {
+                if (oy + j >= oy_end) break;
+                const int rel = oy + j - oy_begin;                 // (wave-uniform conditions: scalar unit)
+                if (((rel + 3) & 7) == 0) {                        // input row oy + j + 2 = r0 + 8 k opens a group of eight: its halo columns, then the load of the group after it
+                    stage_halo(oy + j + 2, hn);
+                    load_halo(oy + j + 10, hn);
+                }
+                row_step(oy + j, aq[j]);
+                if ((rel & 7) == 7) {                              // a lane's <= 32 values per channel in fp32, fp64 beyond (stats_commit_b's rule)
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        dsum[t][k] += (double)sums[t][k];
-                        sums[t][k] = 0.f;
-                    }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            if (ostore) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8]);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8 + 4]);
-                const bf16x8 h{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w, (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
-                *reinterpret_cast<bf16x8*>(out + (out_row + (size_t)oy * p.wout + opix) * p.pitch_out + c8 * 8) = h;
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            dsum[t][k] += (double)sums[t][k];
+                            sums[t][k] = 0.f;
+                        }
+                }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        store_row(oy_end - 1);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll

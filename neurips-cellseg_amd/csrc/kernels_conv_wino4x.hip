@@ -370,8 +370,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4x_kernel(ConvParams p, long 
 // read the same fragments (one fetch from L2, two from the vector L1).  Used where the K loop is short (cin <= 128); the deep layers keep
 // the 32x32x2 form, whose halved fragment stream weighs more there.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool LAZY>
-__global__ __launch_bounds__(512, 2) void conv_wino4y_kernel(ConvParams p, long long* stamps) {
+// NSUB = 2: the 512-thread block of the kernel above (two sub-tiles share the staging phases and barriers, ONE block per CU).
+// NSUB = 1: a 256-thread block of ONE sub-tile with the same per-wave work (raw 26 KB + V 37 KB: TWO independent blocks per CU, whose
+// prologues, barriers and epilogues fall into each other's matrix phases instead of onto the same cycles).
+template <bool LAZY, int NSUB>
+__global__ __launch_bounds__(256 * NSUB, 2) void conv_wino4y_kernel(ConvParams p, long long* stamps) {
+    constexpr int TPP = 16 * NSUB;                               // tiles per position plane of V
+    constexpr int VPOS = TPP * 16;                               // floats per position
     long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long treal0 = stamps ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     long long tlast = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -384,18 +389,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino4y_kernel(ConvParams p, long 
     };
     constexpr int IN_ITERS = 6;                                  // (pixel, channel quad) items per thread; the sixth only for 16 threads of a half
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const vs = smem + X_RAW;
+    float* const vs = smem + NSUB * X_RAW1;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = wave >> 2;                                   // staging / transform half of this thread (wave-uniform)
     const int htid = tid & 255;
     const int n_spatial = p.tiles_x * p.tiles_y * p.n;
-    const WorkId wk = decode_work((n_spatial + 1) >> 1, p.ntile_total >> 2);
+    const WorkId wk = decode_work(NSUB == 2 ? (n_spatial + 1) >> 1 : n_spatial, p.ntile_total >> 2);
     if (!wk.valid) return;
     // the two sub-tiles: items 2 s, 2 s + 1 of the tile list (the second may not exist)
-    const int sp0 = 2 * wk.spatial;
-    const bool has1 = sp0 + 1 < n_spatial;
+    const int sp0 = NSUB * wk.spatial;
+    const bool has1 = NSUB == 2 && sp0 + 1 < n_spatial;
     const int per_img = p.tiles_x * p.tiles_y;
     auto tile_of = [&](int sp, int& img, int& oy0, int& ox0) {
         img = sp / per_img;
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4y_kernel(ConvParams p, long 
     const float* const t_src = my_raw + (((t_lt >> 2) * 4) * X_IW + (t_lt & 3) * 4) * X_PS + t_c;
     // V[position][k-group c >> 2][tile ^ 2 (c >> 2)][c & 3] - the A-fragment order of v_mfma_f32_16x16x4_f32 for 32 tiles; the XOR spreads the
     // four k-groups a 32-lane store group holds over all banks, the A-fragment read applies the same permutation
-    float* const t_dst = vs + ((t_c >> 2) * 32 + (t_tile ^ (2 * (t_c >> 2)))) * 4 + (t_c & 3);                // + position * 512
+    float* const t_dst = vs + ((t_c >> 2) * TPP + (t_tile ^ (2 * (t_c >> 2)))) * 4 + (t_c & 3);               // + position * VPOS
     auto transform = [&]() {
         float t[6][6];
 #pragma unroll
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4y_kernel(ConvParams p, long 
             float y[6];
             xbt6(t[i], y);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) t_dst[(i * 6 + j) * 512] = y[j];
+            for (int j = 0; j < 6; ++j) t_dst[(i * 6 + j) * VPOS] = y[j];
         }
     };
 
@@ -516,14 +521,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4y_kernel(ConvParams p, long 
     transform();
     __syncthreads();
     stamp(0);
-    const float* const a_src = vs + (g * 32 + th * 16 + (pl ^ (2 * g))) * 4;               // + position * 512
+    const float* const a_src = vs + (g * TPP + th * 16 + (pl ^ (2 * g))) * 4;              // + position * VPOS
 #pragma unroll 1
     for (int ch = 0; ch < chunks; ++ch) {
         const bool more = ch + 1 < chunks;
         const int nch = more ? ch + 1 : ch;        // the loads of the last trip re-read its own chunk: a skipped load group would mis-size the ring's waits
         f32x4 av[2][2];                            // A fragments of the current and the next pair of positions
         av[0][0] = *reinterpret_cast<const f32x4*>(a_src);
-        av[0][1] = *reinterpret_cast<const f32x4*>(a_src + 512);
+        av[0][1] = *reinterpret_cast<const f32x4*>(a_src + VPOS);
         // the next chunk's patch is staged INSIDE the MFMA phase (raw is free while V is being contracted): half 0 requested at pair 0 and
         // stored at pair 6, half 1 requested at 6 and stored at 14
 #pragma unroll
@@ -542,8 +547,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4y_kernel(ConvParams p, long 
             }
             if (pr == 14 && more) store_half(H1);
             if (pr < 17) {
-                av[(pr + 1) & 1][0] = *reinterpret_cast<const f32x4*>(a_src + (2 * pr + 2) * 512);
-                av[(pr + 1) & 1][1] = *reinterpret_cast<const f32x4*>(a_src + (2 * pr + 3) * 512);
+                av[(pr + 1) & 1][0] = *reinterpret_cast<const f32x4*>(a_src + (2 * pr + 2) * VPOS);
+                av[(pr + 1) & 1][1] = *reinterpret_cast<const f32x4*>(a_src + (2 * pr + 3) * VPOS);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -968,13 +973,24 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
         return CS_OK;
     };
     if (form == 3) {                           // 16x16x4 MFMAs, a wave = channel tile x sub-tile x all positions, output transform in registers
-        const size_t lds_y = (size_t)X_MAIN * 4;
-        if (a.tab) {
-            if (!((lds_set[4] >> dev) & 1ull)) { CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4y_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_y)); lds_set[4] |= 1ull << dev; }
-            hipLaunchKernelGGL(conv_wino4y_kernel<true>, grid, dim3(512), lds_y, s, p, g_wino_stamps);
+        static const int y_half = [] { const char* e = getenv("CS_WINO_YHALF"); return e ? atoi(e) : 1; }();
+        static unsigned long long lds_set_y[4] = {0ull, 0ull, 0ull, 0ull};
+        const int nsub = y_half ? 1 : 2;
+        const size_t lds_y = (size_t)(nsub * X_RAW1 + 36 * 16 * nsub * 16) * 4;
+        const dim3 grid_y(xcd_grid(nsub == 2 ? (n_spatial + 1) / 2 : n_spatial, p.ntile_total / 4));
+        const int which = (nsub == 2 ? 2 : 0) + (a.tab ? 1 : 0);
+        const void* kern = nsub == 2 ? (a.tab ? reinterpret_cast<const void*>(&conv_wino4y_kernel<true, 2>) : reinterpret_cast<const void*>(&conv_wino4y_kernel<false, 2>))
+                                     : (a.tab ? reinterpret_cast<const void*>(&conv_wino4y_kernel<true, 1>) : reinterpret_cast<const void*>(&conv_wino4y_kernel<false, 1>));
+        if (!((lds_set_y[which] >> dev) & 1ull)) {
+            CS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_y));
+            lds_set_y[which] |= 1ull << dev;
+        }
+        if (nsub == 2) {
+            if (a.tab) hipLaunchKernelGGL((conv_wino4y_kernel<true, 2>), grid_y, dim3(512), lds_y, s, p, g_wino_stamps);
+            else hipLaunchKernelGGL((conv_wino4y_kernel<false, 2>), grid_y, dim3(512), lds_y, s, p, g_wino_stamps);
         } else {
-            if (!((lds_set[5] >> dev) & 1ull)) { CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4y_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_y)); lds_set[5] |= 1ull << dev; }
-            hipLaunchKernelGGL(conv_wino4y_kernel<false>, grid, dim3(512), lds_y, s, p, g_wino_stamps);
+            if (a.tab) hipLaunchKernelGGL((conv_wino4y_kernel<true, 1>), grid_y, dim3(256), lds_y, s, p, g_wino_stamps);
+            else hipLaunchKernelGGL((conv_wino4y_kernel<false, 1>), grid_y, dim3(256), lds_y, s, p, g_wino_stamps);
         }
     } else if (wide) {
         if (a.tab) {

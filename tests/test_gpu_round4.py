@@ -191,6 +191,14 @@ def test_winograd_f4_on_32x32_mfmas_agrees_with_the_other_forms_in_eval_mode(tmp
         assert not torch.equal(res["5"][tag], res["0"][tag])          # the Winograd path really ran (it is not bitwise the direct form)
     assert not torch.equal(res["4"]["a"], res["3"]["a"])              # the 32-channel form differs from the 16x16x4 one it replaces ...
     assert not torch.equal(res["5"]["a"], res["4"]["a"])              # ... and so does the register-epilogue form of the short-K layers
+    # the register-epilogue form as 512-thread blocks of two sub-tiles (CS_WINO_YHALF=0) instead of 256-thread blocks of one: the same
+    # per-wave arithmetic in the same order - bitwise equal
+    path = str(tmp_path / "w5full.pt")
+    env = dict(os.environ, CS_WINO="5", CS_WINO_YHALF="0", PYTHONPATH=os.pathsep.join([PKG, ROOT]))
+    subprocess.run([sys.executable, "-c", _WINO_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
+    full = torch.load(path)
+    for tag in full:
+        assert torch.equal(full[tag], res["5"][tag]), tag
 
 
 # ------------------------------------------------------------------------------------------- TrainStep after AdamW.load_state_dict

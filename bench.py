@@ -336,7 +336,8 @@ def main():
     ap.add_argument("--roi", type=int, default=256)
     ap.add_argument("--overlap", type=float, default=0.5, help="0.5 = stride 128 (BASELINE configs[2]); reference default 0.25")
     ap.add_argument("--width", choices=sorted(WIDTHS), default="baseline32")
-    ap.add_argument("--engine-batch", type=int, default=256)
+    ap.add_argument("--engine-batch", type=int, default=0, help="windows per engine call; 0 = the engine's own choice (equal chunks, one per internal "
+                                                                "stream where that fits 512 windows: cellseg_amd.balanced_batch)")
     ap.add_argument("--streams", type=int, default=2, help="internal streams the window chunks are dealt to (1 = serial)")
     ap.add_argument("--precision", choices=sorted(MFMA_PEAK), default="fp32",
                     help="matrix-core arithmetic of the convolutions")
@@ -470,7 +471,7 @@ def main():
         def step_slide():
             image = imgs[it[0] % 2]
             it[0] += 1
-            _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch, want_logits=False,
+            _, _, mask = ca.swi_infer_image(model, image, roi, args.overlap, engine_batch=args.engine_batch or None, want_logits=False,
                                             want_mask=True, streams=args.streams)
             return labelled(mask)
 
@@ -564,7 +565,7 @@ def main():
         for i in range(reps + 1):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            _, _, mask = ca.swi_infer_image(model, imgs[i % 2], roi, args.overlap, engine_batch=args.engine_batch, want_logits=False,
+            _, _, mask = ca.swi_infer_image(model, imgs[i % 2], roi, args.overlap, engine_batch=args.engine_batch or None, want_logits=False,
                                             want_mask=True, streams=args.streams)
             lab = ca.mask_to_instances(mask)
             host.copy_(lab, non_blocking=True)
@@ -588,7 +589,7 @@ def main():
                 t0 = time.perf_counter()
                 u8 = pre[i % 2].to(dev, non_blocking=True)
                 x = (u8.float() / u8.max()).permute(2, 0, 1)                   # [3,H,W] view of the HWC tensor, read in place
-                _, _, mask = ca.swi_infer_image(model, x, roi, args.overlap, engine_batch=args.engine_batch, want_logits=False,
+                _, _, mask = ca.swi_infer_image(model, x, roi, args.overlap, engine_batch=args.engine_batch or None, want_logits=False,
                                                 want_mask=True, streams=args.streams)
                 lab = ca.mask_to_instances(mask)
                 write_label_tiff(os.path.join(td, f"slide{i}_label.tiff"), lab)        # deflated on the device, strips to the host
@@ -602,7 +603,7 @@ def main():
     def measure_strips_sim(model, full_s, sim_world=8):
         """How long ONE rank of the 8-GPU strips leg works per slide, measured on this GPU (see step_sim): rank 0 (smaller share of the
         windows + the connected-component pass) and an interior rank (larger share, no labelling); the job runs at the slower of them."""
-        _, _, full_mask = ca.swi_infer_image(model, slide_pair(True)[0], roi, args.overlap, engine_batch=args.engine_batch,
+        _, _, full_mask = ca.swi_infer_image(model, slide_pair(True)[0], roi, args.overlap, engine_batch=args.engine_batch or None,
                                              want_logits=False, want_mask=True, streams=args.streams)
         parts = [ca.strip_partition(plan, r, sim_world) for r in range(sim_world)]
         ranks = {}
@@ -841,7 +842,7 @@ def main():
         # gfx950 correction applied; tools/pmc_summary.py).  bench.py cannot read PMCs itself, so it quotes the summary.
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name, {})
-            if res is main_res and args.engine_batch == 256 and args.size == 4096 and args.width == "baseline32" and args.precision == "fp32":
+            if res is main_res and args.engine_batch == 0 and args.size == 4096 and args.width == "baseline32" and args.precision == "fp32":
                 rl["traffic"] = pmc.get("hbm_bytes_per_launch")
                 rl["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 PMC passes of the default command)"
                 rl["algorithmic_bytes_per_launch"] = round(k["bytes"] / k["launches"])
@@ -904,7 +905,8 @@ def main():
                                f"num_res_units=2 InstanceNorm+PReLU random-init, softmax + >0.5 + remove_small_holes(64) + "
                                f"remove_small_objects(16) + 8-conn label on GPU, int32 labels copied to pinned host memory; "
                                + ("one slide cut into row strips" if head_strips else "one slide per GPU"),
-                   "windows": n_windows, "engine_batch": args.engine_batch, "streams": args.streams, "precision": args.precision,
+                   "windows": n_windows, "engine_batch": args.engine_batch or ca.balanced_batch(n_windows, args.streams), "engine_batch_auto": not args.engine_batch,
+                   "streams": args.streams, "precision": args.precision,
                    "parallelism": (f"1 slide split by window rows over {world} ranks + seam send/recv + mask all-gather" if head_strips
                                    else f"slides x{world}"),
                    "instances_found": main_res["n_instances"], "foreground_fraction": round(main_res["fg_frac"], 4)},

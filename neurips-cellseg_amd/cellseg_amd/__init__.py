@@ -11,7 +11,7 @@ All arithmetic runs in libcellseg_hip.so; importing this package without the bui
 """
 from ._lib import CellSegHipError, LIB_PATH, lib  # noqa: F401
 from .unet import UNet  # noqa: F401
-from .inferers import (make_plan, rank_rows, sliding_window_inference, strip_partition, swi_infer_image, swi_infer_strip,  # noqa: F401
+from .inferers import (balanced_batch, make_plan, rank_rows, sliding_window_inference, strip_partition, swi_infer_image, swi_infer_strip,  # noqa: F401
                        window_starts)
 from .postprocess import create_interior_map, label, mask_to_instances, prob_to_instances  # noqa: F401
 from .losses import DiceCELoss, one_hot  # noqa: F401

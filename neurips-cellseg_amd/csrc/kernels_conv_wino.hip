@@ -625,7 +625,7 @@ bool wino_enabled() { return g_wino != 0; }
 int wino_level() { return g_wino; }
 // the register-epilogue form takes the layers up to 128 input channels (measured per layer, DESIGN 3.1a''); beyond, its half-size blocks are 4-6 % faster
 // per launch too, but the slide loses what the window pass's two streams overlap (35.3 vs 34.4 ms)
-constexpr int g_wino4y_max_cin = 128;
+static const int g_wino4y_max_cin = [] { const char* e = getenv("CS_WINO4Y_MAX_CIN"); return e ? atoi(e) : 128; }();      // (A/B switch)
 // which F(4x4) kernel a layer takes: 0 = kernels_conv_wino4.hip (16x16x4, a wave owns positions), 1 / 2 = the 32x32x2 forms of
 // kernels_conv_wino4x.hip (64- / 32-channel blocks), 3 = its 16x16x4 form with the output transform in registers (short K loops)
 int wino4_form(int cin, int cout) {

@@ -199,6 +199,15 @@ def test_winograd_f4_on_32x32_mfmas_agrees_with_the_other_forms_in_eval_mode(tmp
     full = torch.load(path)
     for tag in full:
         assert torch.equal(full[tag], res["5"][tag]), tag
+    # ... and with that form on every layer of 64-channel blocks (CS_WINO4Y_MAX_CIN=512: the 256- / 512-channel layers leave the 32x32x2 kernel)
+    path = str(tmp_path / "w5deep.pt")
+    env = dict(os.environ, CS_WINO="5", CS_WINO4Y_MAX_CIN="512", PYTHONPATH=os.pathsep.join([PKG, ROOT]))
+    subprocess.run([sys.executable, "-c", _WINO_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
+    deep = torch.load(path)
+    for tag in deep:
+        scale = float(res["0"][tag].abs().max())
+        assert float((deep[tag] - res["0"][tag]).abs().max()) <= 5e-5 * max(scale, 1.0), tag
+    assert not torch.equal(deep["a"], res["5"]["a"])
 
 
 # ------------------------------------------------------------------------------------------- TrainStep after AdamW.load_state_dict

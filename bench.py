@@ -346,8 +346,8 @@ def main():
                          "all-gather of the uint8 mask strips before the connected-component pass (strong scaling; the default for "
                          "--gpus N > 1: north_star's '>= 6x at 8 GPUs' is about one WSI) or one slide per rank (weak scaling, no "
                          "collective); the other partition is reported as a secondary object")
-    ap.add_argument("--strip-batch", type=int, default=64, help="engine batch of the strips leg (a rank holds ~1/N of the windows; smaller "
-                                                                "chunks keep both internal streams busy)")
+    ap.add_argument("--strip-batch", type=int, default=0, help="engine batch of the strips leg; 0 = the engine's own choice (a rank's windows in "
+                                                               "equal chunks, one per internal stream: 124 windows at 8 ranks -> 2 x 62)")
     ap.add_argument("--train-batch", type=int, default=32, help="tiles per GPU of the training step (BASELINE configs[1]/[3]: 32)")
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--cc-stream", type=int, default=1, help="1: the connected-component pass of slide k runs on its own stream beside "
@@ -482,7 +482,7 @@ def main():
             stream beside its next slide ("gather the mask to rank 0 and label there"); its label map is the job's output."""
             image = imgs[it[0] % 2]
             it[0] += 1
-            st, _, _, mask = ca.swi_infer_strip(model, image, roi, args.overlap, rank, world, engine_batch=args.strip_batch,
+            st, _, _, mask = ca.swi_infer_strip(model, image, roi, args.overlap, rank, world, engine_batch=args.strip_batch or None,
                                                 streams=args.streams, exchange=seam_exchange)
             full = parallel.gather_row_strips(mask[st.row_begin:st.row_end], args.size, rows=strip_rows_all)
             return labelled(full) if rank == 0 else (no_labels, no_num)
@@ -502,7 +502,7 @@ def main():
                         win[j - me.halo_begin, :, r0:].copy_(win[me.win_row_end - 1 - me.halo_begin, :, r0:].contiguous().clone())
                     elif src == rr:
                         win[j - me.halo_begin, :, r0:].contiguous().clone()
-            ca.swi_infer_strip(model, image, roi, args.overlap, r, w, engine_batch=args.strip_batch, streams=args.streams,
+            ca.swi_infer_strip(model, image, roi, args.overlap, r, w, engine_batch=args.strip_batch or None, streams=args.streams,
                                exchange=fake_exchange)
             gathered = full_mask.clone()         # a device-local copy of the gathered mask's size in place of the all-gather
             return labelled(gathered) if r == 0 else (no_labels, no_num)
@@ -919,7 +919,7 @@ def main():
     strips_info = {"seam_transport": seam_transport, "strips_error": strips_error,
                    "window_rows_per_rank": [st.win_row_end - st.win_row_begin for st in strip_parts],
                    "windows_per_rank": [(st.win_row_end - st.win_row_begin) * plan.n_w for st in strip_parts],
-                   "output_rows_per_rank": [st.row_end - st.row_begin for st in strip_parts], "strip_batch": args.strip_batch,
+                   "output_rows_per_rank": [st.row_end - st.row_begin for st in strip_parts], "strip_batch": args.strip_batch or "auto",
                    "equal_to_single_gpu_labels": strips_equal}
     if other_part:
         out["strips" if not head_strips else "slides"] = dict(

@@ -30,7 +30,7 @@ def balanced_batch(n_windows: int, streams: int = 2, max_batch: int = MAX_AUTO_B
     where that fits ``max_batch`` (961 windows, 2 streams -> 2 x 481 instead of 256 + 256 + 256 + 193 dealt 2 + 2: the streams finish
     together and every launch is twice as large - measured 35.2 -> 34.5 ms on the 4096^2 slide).  Results do not depend on the batch."""
     n, s = max(1, int(n_windows)), max(1, int(streams))
-    if n <= 128:
+    if n < 16 * s:                                             # a handful of windows: one launch
         return n
     rounds = -(-n // (s * max_batch))
     return -(-n // (s * rounds))
@@ -119,7 +119,7 @@ def _capped_batch(model: UNet, eng, plan: SwiPlan, engine_batch: int, dev, size_
 
 
 def swi_infer_strip(model: UNet, image: torch.Tensor, roi_size, overlap: float, rank: int, world: int, *,
-                    engine_batch: int = DEFAULT_ENGINE_BATCH, streams: int = DEFAULT_STREAMS, exchange=None,
+                    engine_batch: Optional[int] = None, streams: int = DEFAULT_STREAMS, exchange=None,
                     want_logits: bool = False, want_prob: bool = False, want_mask: bool = True):
     """ONE image split over `world` ranks by WINDOW rows (multi-GPU tiled inference; the reference is single-device,
     baseline/predict.py:109).  This rank evaluates its own window rows (``cs_swi_windows``), obtains the lower part of the earlier
@@ -146,6 +146,8 @@ def swi_infer_strip(model: UNet, image: torch.Tensor, roi_size, overlap: float, 
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()   # noqa: E731
     with torch.cuda.device(dev):
         check(lib.cs_unet_set_streams(eng.handle, int(streams)), "cs_unet_set_streams")
+        if not engine_batch:                                   # this rank's own windows in equal chunks (the halo rows, evaluated locally without
+            engine_batch = balanced_batch((st.win_row_end - st.win_row_begin) * plan.n_w, streams)     # an exchange, run at the same batch)
         engine_batch, nbytes = _capped_batch(model, eng, plan, engine_batch, dev, lib.cs_swi_windows_workspace_bytes)
         ws = model.workspace(("swistrip", h, w, plan.roi_h, plan.roi_w, plan.n_h, plan.n_w, engine_batch, int(streams)), nbytes, dev)
         n_rows = st.win_row_end - st.halo_begin

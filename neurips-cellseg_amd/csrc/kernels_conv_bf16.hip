@@ -654,7 +654,204 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
     }
 }
 
-static int g_bf16_rows = [] { const char* e = getenv("CS_BF16_ROWS"); return e ? atoi(e) : 1; }();
+// ------------------------------------------------------------------------------------------------
+// The same streaming shape for 64 -> 64 channels (the 32-base net's 64 x 64 level, the widest tensors of the 64-base net of configs[4]).
+// 9 taps x 2 K chunks x 4 channel tiles of weight fragments are 288 registers, so a strip belongs to a PAIR of waves (one 128-thread
+// block): wave ct computes output channels 32 ct ... 32 ct + 31 (144 weight registers) and stages the 32-channel plane ct of every input
+// row into the window the pair shares - half the staging arithmetic each, ONE block barrier per row, placed where the row staged in a step
+// is first needed a step later (so neither wave waits long for the other).  Rows are two planes of 18 pixels x 80 bytes (conflict-free
+// 16-byte reads at stride 1 as well).
+// ------------------------------------------------------------------------------------------------
+constexpr int R6_PITCH = 80;
+constexpr int R6_PLANE = 18 * R6_PITCH;                     // one 32-channel plane of a row
+constexpr int R6_ROW = 2 * R6_PLANE;
+constexpr int R6_HROW = 2 * 2 * R6_PITCH;                   // halo pixels of a row: 2 planes x 2 pixels
+constexpr int R6_HALO = 16 * R6_HROW;
+constexpr int R6_BLOCK_BYTES = RW_SLOTS * R6_ROW + R6_HALO + 2 * 16 * RW_EPS * 4;
+
+template <bool LAZY>
+__global__ __launch_bounds__(128, 2) void conv_bf16_rows64_kernel(ConvBParams p, int strips, int segs) {
+    __shared__ __attribute__((aligned(16))) char smem[R6_BLOCK_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave's half of the output channels = the plane it stages
+    const int pl = lane & 15, g = lane >> 4;
+    char* const ring = smem;
+    char* const halo = ring + RW_SLOTS * R6_ROW;
+    float* const ep = reinterpret_cast<float*>(halo + R6_HALO) + ct * 16 * RW_EPS;
+    int bid = blockIdx.x;
+    const int strip = bid % strips;
+    bid /= strips;
+    const int seg = bid % segs;
+    const int img = bid / segs;
+    const int ox0 = strip * 16;
+    const int oy_begin = seg * RW_RS, oy_end = oy_begin + RW_RS < p.hout ? oy_begin + RW_RS : p.hout;
+
+    // weights: fragment (K chunk, tap, channel tile 2 ct + t), plane 0 of packed[chunk][tap][ntile_total = 4][3][64][8]
+    bf16x8 b[2][9][2];
+    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + lane;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[kc][tap][t] = wbase[(size_t)((kc * 9 + tap) * 4 + 2 * ct + t) * 3 * 64];
+    float bias[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bias[t] = p.bias ? p.bias[(2 * ct + t) * 16 + pl] : 0.f;
+    float slope = *((LAZY && p.a.slope) ? p.a.slope : p.dummy);
+    if (!(LAZY && p.a.slope)) slope = 0.f;
+    const bool slope01 = slope >= 0.f && slope <= 1.f;
+    // staging items of plane ct (pixel, channel octet c8 = lane & 3): the main pass takes pixels 0 ... 15 of one row (lane >> 2), the halo
+    // pass pixels 16, 17 of eight rows (row lane >> 3, pixel (lane >> 2) & 1)
+    const int c8 = lane & 3;
+    const int px_a = lane >> 2;
+    const int gx_a = ox0 - 1 + px_a, gx_h = ox0 + 15 + ((lane >> 2) & 1);
+    const bool ok_a = gx_a >= 0 && gx_a < p.win, ok_h = gx_h < p.win;
+    const int hrow = lane >> 3;
+    const unsigned short* const src = reinterpret_cast<const unsigned short*>(p.a.ptr) + (size_t)img * p.hin * p.win * p.a.pitch + 32 * ct + 8 * c8;
+    const unsigned off_a = (unsigned)(ok_a ? gx_a : 0) * p.a.pitch, off_h = (unsigned)(ok_h ? gx_h : 0) * p.a.pitch;
+    auto clamp_row = [&](int gy) { return gy < 0 ? 0 : (gy >= p.hin ? p.hin - 1 : gy); };
+    auto load_row = [&](int gy, u32x4& ra) { ra = *reinterpret_cast<const u32x4*>(src + (size_t)clamp_row(gy) * p.win * p.a.pitch + off_a); };
+    auto load_halo = [&](int gy0, u32x4& rh) { rh = *reinterpret_cast<const u32x4*>(src + (size_t)clamp_row(gy0 + hrow) * p.win * p.a.pitch + off_h); };
+    f32x4 tb[4];                                                   // this lane's octet of plane ct: 4 x (scale, shift, scale, shift)
+    {
+        const f32x4* t = LAZY ? reinterpret_cast<const f32x4*>(p.a.tab + (size_t)img * p.a.tab_c + p.a.tab_off + 32 * ct + 8 * c8)
+                              : reinterpret_cast<const f32x4*>(p.dummy);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tb[k] = t[k];
+    }
+    auto activate = [&](u32x4 r, bool ok) -> u32x4 {               // 8 bf16 -> norm + act -> 8 bf16
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float lo = __builtin_bit_cast(float, r[k] << 16), hi = __builtin_bit_cast(float, r[k] & 0xffff0000u);
+            if constexpr (LAZY) {
+                const f32x4 t = tb[k];
+                lo = __builtin_fmaf(lo, t.x, t.y);
+                hi = __builtin_fmaf(hi, t.z, t.w);
+                if (slope01) {
+                    lo = __builtin_fmaxf(lo, lo * slope);
+                    hi = __builtin_fmaxf(hi, hi * slope);
+                } else {
+                    lo = prelu_h(lo, slope);
+                    hi = prelu_h(hi, slope);
+                }
+            }
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const bf16x2 h{(__bf16)lo, (__bf16)hi};
+            o[k] = ok ? __builtin_bit_cast(unsigned, h) : 0u;
+        }
+        return o;
+    };
+    const int r0 = oy_begin - 1;
+    char* const my_halo = halo + ct * 2 * R6_PITCH + c8 * 16;     // + slot * R6_HROW + pixel * R6_PITCH
+    auto stage_halo = [&](int gy0, u32x4 rh) {                     // plane ct of input rows gy0 ... gy0 + 7 -> halo slots (gy - r0) & 15
+        const int gy = gy0 + hrow;
+        *reinterpret_cast<u32x4*>(my_halo + ((gy - r0) & 15) * R6_HROW + ((lane >> 2) & 1) * R6_PITCH) = activate(rh, gy >= 0 && gy < p.hin && ok_h);
+    };
+    auto stage = [&](int gy, u32x4 ra) {                           // plane ct of input row gy -> ring slot (gy + 1) & 3
+        char* const slot = ring + ((gy + 1) & 3) * R6_ROW + ct * R6_PLANE + c8 * 16;
+        u32x4 hv;
+        if (lane < 8) hv = *reinterpret_cast<const u32x4*>(my_halo + ((gy - r0) & 15) * R6_HROW + (lane >> 2) * R6_PITCH);
+        *reinterpret_cast<u32x4*>(slot + px_a * R6_PITCH) = activate(ra, gy >= 0 && gy < p.hin && ok_a);
+        if (lane < 8) *reinterpret_cast<u32x4*>(slot + (16 + (lane >> 2)) * R6_PITCH) = hv;
+    };
+
+    constexpr int UNR = 3;
+    u32x4 aq[UNR], hn;
+    {
+        u32x4 h0, a0, a1, a2;
+        load_halo(r0, h0);
+        load_row(r0, a0);
+        load_row(r0 + 1, a1);
+        load_row(r0 + 2, a2);
+        load_halo(r0 + 8, hn);
+        stage_halo(r0, h0);
+        __builtin_amdgcn_wave_barrier();
+        stage(r0, a0);
+        stage(r0 + 1, a1);
+        stage(r0 + 2, a2);
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) load_row(oy_begin + 2 + j, aq[j]);
+    const size_t out_row = ((size_t)img * p.hout) * p.wout + ox0;
+    unsigned short* const out = reinterpret_cast<unsigned short*>(p.out) + 32 * ct;
+    const int opix = lane >> 2;
+    const bool ostore = ox0 + opix < p.wout;
+    const bool full = ox0 + 16 <= p.wout;
+    float sums[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                  // a lane's <= 128 values per channel of the segment in fp32 (its outputs are rounded to bf16 anyway)
+    auto store_row = [&](int oy) {
+        if (ostore) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8 + 4]);
+            const bf16x8 h{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w, (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+            *reinterpret_cast<bf16x8*>(out + (out_row + (size_t)oy * p.wout + opix) * p.pitch_out + c8 * 8) = h;
+        }
+    };
+    // output row oy reads window rows oy - 1 ... oy + 1 (both planes) and stages plane ct of input row oy + 2 into the slot row oy - 2 left
+    auto row_step = [&](int oy, u32x4& areg) {
+        if (oy > oy_begin) store_row(oy - 1);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // 18 steps (K chunk, tap row, tap column) in conv_bf16s_kernel's order of the products; the A fragment of step i + DEPTH is requested
+        // before the MFMAs of step i (pinned: left alone the compiler keeps one fragment in flight and every MFMA pair waits ~100 cycles for LDS)
+        constexpr int DEPTH = 3;
+        auto a_ptr = [&](int i) {
+            const int kc = i / 9, ky = (i % 9) / 3, kx = i % 3;
+            return ring + ((oy + ky) & 3) * R6_ROW + kc * R6_PLANE + (pl + kx) * R6_PITCH + g * 16;
+        };
+        bf16x8 af[DEPTH + 1];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_ptr(i));      // rows oy - 1, oy: complete since the previous step's barrier
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            // the pair's ONE barrier per row sits in front of the first REQUEST for the newest row (oy + 1, staged during the previous step): the
+            // slower wave of the pair has the first steps of the matrix phase to finish its share of the staging.  Past it both waves have left
+            // step oy - 1 for good: the slot of row oy - 2, written below, is free.
+            if (i + DEPTH == 6) __syncthreads();
+            if (i + DEPTH < 18) af[(i + DEPTH) % (DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(a_ptr(i + DEPTH));
+            __builtin_amdgcn_sched_barrier(0);
+            const int kc = i / 9, tap = i % 9;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % (DEPTH + 1)], b[kc][tap][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage(oy + 2, areg);
+        load_row(oy + 2 + UNR, areg);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[t][r] + bias[t];
+                ep[(g * 4 + r) * RW_EPS + t * 16 + pl] = v;
+                const float vm = full ? v : (ox0 + g * 4 + r < p.wout ? v : 0.f);
+                sums[t][0] += vm;
+                sums[t][1] = fmaf(vm, v, sums[t][1]);
+            }
+    };
+    __syncthreads();                                               // rows r0 ... r0 + 2 of both planes
+#pragma unroll 1
+    for (int oy = oy_begin; oy < oy_end; oy += UNR) {
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            if (oy + j >= oy_end) break;
+            const int rel = oy + j - oy_begin;
+            if (((rel + 3) & 7) == 0) {
+                stage_halo(oy + j + 2, hn);
+                load_halo(oy + j + 10, hn);
+            }
+            row_step(oy + j, aq[j]);
+        }
+    }
+    store_row(oy_end - 1);
+    if (p.stats) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            stats_commit_b((double)sums[t][0], (double)sums[t][1], p.stats + ((size_t)img * p.cout + (2 * ct + t) * 16 + pl) * 2, lane);
+    }
+}
+
+// CS_BF16_ROWS: 0 = block kernels, 1 = the 32 -> 32 layers streamed by waves, 2 (default) = the 64 -> 64 layers too
+static int g_bf16_rows = [] { const char* e = getenv("CS_BF16_ROWS"); return e ? atoi(e) : 2; }();
 
 int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
                       const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
@@ -696,6 +893,14 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     const double bytes = esz * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
     // the 32 -> 32 stride-1 layers of the bf16 datapath: a wave streams a 16-column strip (conv_bf16_rows32_kernel)
+    if (g_bf16_rows >= 2 && act16 && planes == 1 && ksize == 3 && stride == 1 && a.c == 64 && b.c == 0 && cout == 64 && !ex && !in_amax &&
+        a.pitch % 8 == 0 && pitch_out % 8 == 0 && hin >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31) && (!a.tab || (a.tab_c ? a.tab_c : a.c) >= 64)) {
+        const int strips = ceil_div(p.wout, 16), segs = ceil_div(p.hout, RW_RS);
+        if (a.tab) hipLaunchKernelGGL(conv_bf16_rows64_kernel<true>, dim3((unsigned)(strips * segs * n)), dim3(128), 0, s, p, strips, segs);
+        else hipLaunchKernelGGL(conv_bf16_rows64_kernel<false>, dim3((unsigned)(strips * segs * n)), dim3(128), 0, s, p, strips, segs);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     if (g_bf16_rows && act16 && planes == 1 && ksize == 3 && stride == 1 && a.c == 32 && b.c == 0 && cout == 32 && !ex && !in_amax &&
         a.pitch % 8 == 0 && pitch_out % 8 == 0 && hin >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31)) {
         const int strips = ceil_div(p.wout, 16), strip_groups = ceil_div(strips, 4), segs = ceil_div(p.hout, RW_RS);

@@ -415,26 +415,29 @@ torch.save(outs, sys.argv[1])
 
 def test_bf16_32_channel_layers_streamed_by_waves_agree_with_the_block_kernel(tmp_path):
     """bf16 datapath: the 3x3 stride-1 32 -> 32 layers run on conv_bf16_rows32_kernel (a wave streams a 16-column strip row by row with a
-    rolling window of input rows in wave-private LDS and its weights in registers) instead of the one-chunk blocks of conv_bf16s_kernel
-    (CS_BF16_ROWS=0).  The convolution itself is the same products in the same order (bit-identical); the InstanceNorm statistics are
-    summed in another order, and a last-bit change of a norm scale can move a bf16 rounding downstream: logits within 2 % of the range at
-    the worst pixel and 0.2 % on average, on strips / row segments that do not divide the image, several images, and a BatchNorm net
-    (whose table does not depend on the statistics: equal logits)."""
+    rolling window of input rows in wave-private LDS and its weights in registers) and the 64 -> 64 layers on conv_bf16_rows64_kernel (a
+    pair of waves per strip: each stages one 32-channel plane of the shared window and computes half of the output channels) instead of the
+    blocks of conv_bf16s_kernel (CS_BF16_ROWS=0; =1: only the 32-channel form).  The convolution itself is the same products in the same
+    order (bit-identical); the InstanceNorm statistics are summed in another order, and a last-bit change of a norm scale can move a bf16
+    rounding downstream: logits within 2 % of the range at the worst pixel and 0.2 % on average, on strips / row segments that do not
+    divide the image (68 x 52, 25 x 19 and 8 x 12 pixels at the 64-channel levels), several images, and a BatchNorm net (whose table does
+    not depend on the statistics: equal logits)."""
     res = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         path = str(tmp_path / f"rows{mode}.pt")
         env = dict(os.environ, CS_BF16_ROWS=mode, PYTHONPATH=os.pathsep.join([PKG, ROOT]))
         subprocess.run([sys.executable, "-c", _ROWS_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
         res[mode] = torch.load(path)
-    for tag, want in res["0"].items():
-        got = res["1"][tag]
-        scale = max(float(want.abs().max()), 1.0)
-        assert torch.isfinite(got).all(), tag
-        err, mean = float((got - want).abs().max()), float((got - want).abs().mean())
-        if tag == "c":
-            assert err == 0.0, (tag, err)
-        else:
-            assert err <= 0.02 * scale and mean <= 0.002 * scale, (tag, err, mean, scale)
+    for mode in ("1", "2"):
+        for tag, want in res["0"].items():
+            got = res[mode][tag]
+            scale = max(float(want.abs().max()), 1.0)
+            assert torch.isfinite(got).all(), (mode, tag)
+            err, mean = float((got - want).abs().max()), float((got - want).abs().mean())
+            if tag == "c":
+                assert err == 0.0, (mode, tag, err)
+            else:
+                assert err <= 0.02 * scale and mean <= 0.002 * scale, (mode, tag, err, mean, scale)
 
 
 # ------------------------------------------------------------------------------------------- fp8 mode: the all-e4m3 setting of rounds 2-3

@@ -448,7 +448,7 @@ static int launch_b(hipStream_t s, ConvBParams p) {
 //     group x pixel x channel octet) into a side area of 16 row slots; a row step copies its two pixels from there into the window
 //     (8 lanes, LDS to LDS) - a per-row halo pass of 8 active lanes cost as many instructions as the 64-lane main pass;
 //   * 18 MFMAs per row, A fragments as 16-byte reads of the window (conflict-free at 96 bytes per pixel);
-//   * bias, statistics (fp32 per lane over 8 rows, fp64 beyond), and the row leaves through a wave-private slab as one 16-byte store
+//   * bias, statistics (fp32 per lane over the segment's <= 32 rows, fp64 from the lane groups on), and the row leaves through a wave-private slab as one 16-byte store
 //     per lane (64 lanes = 16 pixels x 64 bytes);
 //   * no block barrier until the statistics of the block's four strips meet at the end.
 // Same products in the same order as conv_bf16s_kernel (tap-major, one K = 32 step per tap): the conv results are bit-identical, the
@@ -483,8 +483,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
     const int ox0 = strip * 16;
     const int oy_begin = seg * RW_RS, oy_end = oy_begin + RW_RS < p.hout ? oy_begin + RW_RS : p.hout;
 
-    float sums[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    double dsum[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    float sums[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                  // a lane's <= 128 values per channel of the segment in fp32 (its outputs are rounded to bf16 anyway)
     if (active) {
         // weights: fragment (tap, channel tile) of chunk 0, plane 0 of packed[chunk][tap][ntile_total = 2][3][64][8]
         bf16x8 b[9][2];
@@ -594,15 +593,19 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
             __builtin_amdgcn_wave_barrier();
             if (oy > oy_begin) store_row(oy - 1);
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            // the A fragment of tap i + DEPTH is requested before the MFMAs of tap i (pinned: left alone the compiler keeps one in flight)
+            constexpr int DEPTH = 2;
+            auto a_ptr = [&](int i) { return ring + ((oy + i / 3) & 3) * RW_ROW + (pl + i % 3) * RW_PITCH + g * 16; };      // input row oy - 1 + ky
+            bf16x8 af[DEPTH + 1];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const char* const arow = ring + ((oy + ky) & 3) * RW_ROW + pl * RW_PITCH + g * 16;        // input row oy - 1 + ky
+            for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_ptr(i));
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + kx * RW_PITCH);
+            for (int i = 0; i < 9; ++i) {
+                if (i + DEPTH < 9) af[(i + DEPTH) % (DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(a_ptr(i + DEPTH));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[ky * 3 + kx][t], acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % (DEPTH + 1)], b[i][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             stage(oy + 2, areg);
             load_row(oy + 2 + UNR, areg);
@@ -628,27 +631,14 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_rows32_kernel(ConvBParams p,
                     load_halo(oy + j + 10, hn);
                 }
                 row_step(oy + j, aq[j]);
-                if ((rel & 7) == 7) {                              // a lane's <= 32 values per channel in fp32, fp64 beyond (stats_commit_b's rule)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            dsum[t][k] += (double)sums[t][k];
-                            sums[t][k] = 0.f;
-                        }
-                }
             }
         }
         __builtin_amdgcn_wave_barrier();
         store_row(oy_end - 1);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) dsum[t][k] += (double)sums[t][k];
     }
     if (p.stats) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) stats_stash_b(dsum[t][0], dsum[t][1], red + ((wave * 2 + t) * 16 + pl) * 2, lane);
+        for (int t = 0; t < 2; ++t) stats_stash_b((double)sums[t][0], (double)sums[t][1], red + ((wave * 2 + t) * 16 + pl) * 2, lane);
         __syncthreads();
         stats_flush_b<4, 32>(red, p.stats + (size_t)img * p.cout * 2, tid);
     }

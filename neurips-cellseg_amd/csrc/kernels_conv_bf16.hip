@@ -303,6 +303,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
         load_input(more ? ch + 1 : ch);
         __builtin_amdgcn_sched_barrier(0);
         const char* in_s = smem + (DB ? (ch & 1) * IN_BYTES : 0);
+        constexpr int MG = (MTW % 2 == 0) ? 2 : 1;               // pixel rows per group: MG x NTW independent MFMA chains
+        constexpr int NGRP = MTW / MG;
+        // single-plane modes: the A fragments of group n + 1 (of this tap, or the first group of the next tap) are requested BEFORE the MFMAs of
+        // group n and pinned there.  Left to the compiler every group's reads sat right in front of its own MFMAs - rr [wait] MM [wait] MM -
+        // and each 64 cycles of matrix work waited for a fresh LDS round trip (matrix pipe 40 % busy at two waves per SIMD).
+        constexpr bool PRE = NPL == 1;
+        auto a_read = [&](int ky, int kx, int m0, bf16x8 (&dst)[MG][NPL]) {
+#pragma unroll
+            for (int mm = 0; mm < MG; ++mm)
+#pragma unroll
+                for (int pn = 0; pn < NPL; ++pn)
+                    dst[mm][pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES + (((wm * MTW + m0 + mm) * S + ky) * IW + pl * S + kx) * PITCH + g * 16);
+        };
+        bf16x8 apre[2][MG][NPL];
+        if constexpr (PRE) a_read(0, 0, 0, apre[0]);
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
             const int row_next = ch * KS + ky + 1 < last_row ? ch * KS + ky + 1 : last_row;
@@ -317,16 +332,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
                 // refill this ring slot one tap row ahead (first row of the next chunk after the last row)
                 load_b(ch_n, ky_n, kx);
                 __builtin_amdgcn_sched_barrier(0);
-                constexpr int MG = (MTW % 2 == 0) ? 2 : 1;           // pixel rows per group: MG x NTW independent MFMA chains
 #pragma unroll
                 for (int m0 = 0; m0 < MTW; m0 += MG) {
+                    const int step = (ky * KS + kx) * NGRP + m0 / MG;
                     bf16x8 a[MG][NPL];
+                    if constexpr (PRE) {
+                        if (step + 1 < TAPS * NGRP) {
+                            const int nstep = step + 1, ntap = nstep / NGRP;
+                            a_read(ntap / KS, ntap % KS, (nstep % NGRP) * MG, apre[nstep & 1]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int mm = 0; mm < MG; ++mm)
-#pragma unroll
-                        for (int pn = 0; pn < NPL; ++pn)
-                            a[mm][pn] = *reinterpret_cast<const bf16x8*>(in_s + pn * PLANE_BYTES +
-                                                                         (((wm * MTW + m0 + mm) * S + ky) * IW + pl * S + kx) * PITCH + g * 16);
+                        for (int mm = 0; mm < MG; ++mm) a[mm][0] = apre[step & 1][mm][0];
+                    } else {
+                        a_read(ky, kx, m0, a);
+                    }
                     // smallest terms first, the dominant a0*b0 last; rows and channel tiles alternate inside a term so that
                     // consecutive MFMAs never depend on each other (a dependent 4-pass MFMA cannot issue back to back)
 #pragma unroll
@@ -345,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(ConvBParams p) {
 #pragma unroll
                             for (int t = 0; t < NTW; ++t) asm volatile("" : "+v"(acc[0][m0 + mm][t]));
                     }
+                    if constexpr (PRE) __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

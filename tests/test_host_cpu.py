@@ -80,6 +80,23 @@ def test_plan_window_counts_of_the_configs():
     assert (lambda p: p.n_h * p.n_w)(ca.make_plan(8192, 8192, (512, 512), 0.5)) == 961
 
 
+def test_balanced_batch_deals_equal_chunks_to_the_streams():
+    """engine_batch=None: the window list is cut into EQUAL chunks, one round per internal stream where that fits 512 windows (the slide's
+    961 windows -> 2 x 481, a rank's 124 of the 8-rank strips leg -> 2 x 62), a handful of windows stays one launch, and no chunk exceeds
+    the cap; every window is covered."""
+    import cellseg_amd as ca
+    assert ca.balanced_batch(961, 2) == 481 and ca.balanced_batch(124, 2) == 62 and ca.balanced_batch(480, 2) == 240
+    assert ca.balanced_batch(20, 2) == 20 and ca.balanced_batch(1, 2) == 1 and ca.balanced_batch(961, 1) == 481
+    for n in (1, 31, 32, 33, 441, 961, 1024, 1025, 3969, 10000):
+        for s in (1, 2, 3, 4):
+            b = ca.balanced_batch(n, s)
+            chunks = -(-n // b)
+            assert 1 <= b <= 512 or n < 16 * s
+            assert chunks * b >= n and (chunks - 1) * b < n
+            if n >= 16 * s:
+                assert chunks % s == 0 or chunks * b - n < b, (n, s, b)          # whole rounds over the streams (the last chunk may be short)
+
+
 def test_state_dict_is_monai_compatible_both_ways():
     import cellseg_amd as ca
     from oracle.unet_ref import UNetRef

@@ -1481,7 +1481,8 @@ size_t cs_unet_workspace_bytes(const cs_unet* net, int n, int h, int w) {
     Bump b(nullptr, 0);
     WindowSrc src;
     if (unet_forward_impl(net, src, n, h, w, nullptr, b, nullptr) != CS_OK) return 0;
-    return b.off + 256;
+    const size_t records = ((size_t)n * h * w * 16 + 255) / 256 * 256;      // the batch as pixel records (inference: cs_unet_forward)
+    return b.off + records + 256;
 }
 
 int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n, int h, int w,
@@ -1495,6 +1496,16 @@ int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_
     src.image = x; src.sn = sn; src.sc = sc; src.sh = sh; src.sw = sw;
     src.origins = nullptr; src.img_h = h; src.img_w = w; src.roi_h = h; src.roi_w = w;
     Bump b(workspace, workspace_bytes);
+    // inference: the batch once more as (r, g, b, 0) pixel records - the first layer then runs on the record kernels of kernels_first.hip and
+    // the first unit's shortcut is recomputed by its sum launch (as in the window pass, swi_run_windows)
+    if (!net->training && cs::first_rec_enabled() && net->in_ch == 3 && (int64_t)n * h * w < ((int64_t)1 << 31)) {
+        const bool rec16 = net->planes == 1 || net->planes == 5;                 // unet_forward_impl's bf16 datapath
+        void* rec = b.take<char>((size_t)n * h * w * 16);
+        if (!b.ok()) { set_error("unet_forward: workspace too small"); return CS_ERR_WORKSPACE; }
+        if (int rc0 = cs::launch_image_records((hipStream_t)stream, x, sn, sc, sh, sw, n, h, w, rec, rec16)) return rc0;
+        src.rec = rec;
+        src.rec16 = rec16;
+    }
     // the activation tape is recorded for cs_unet_backward only in training mode (cs_unet_set_training)
     net->tape.valid = false;
     return unet_forward_impl(net, src, n, h, w, logits_nhwc, b, (hipStream_t)stream, net->training ? &net->tape : nullptr);

@@ -330,7 +330,7 @@ def test_first_unit_residual_recomputed_in_the_sum_launch_agrees_with_the_materi
     res = {}
     for mode in ("0", "1"):
         path = str(tmp_path / f"ff{mode}.pt")
-        env = dict(os.environ, CS_FUSE_FIRST=mode, PYTHONPATH=os.pathsep.join([PKG, ROOT]))
+        env = dict(os.environ, CS_FUSE_FIRST=mode, CS_FIRST_REC="0", PYTHONPATH=os.pathsep.join([PKG, ROOT]))      # (the planar-gather kernels: the record kernels have their own test)
         subprocess.run([sys.executable, "-c", _FIRST_EVAL.format(root=ROOT, pkg=PKG), path], check=True, env=env, timeout=600)
         res[mode] = torch.load(path)
     for tag in ("a", "b", "c"):
@@ -360,6 +360,9 @@ for precision in ("fp32", "bf16"):
         x = torch.rand(1, *shape, generator=torch.Generator().manual_seed(4)).to(dev)
         with torch.no_grad():
             outs[precision + "/" + tag] = ca.sliding_window_inference(x, roi, 4, m, overlap=overlap).cpu()
+            if tag in ("a", "d"):                                  # the plain batched forward takes the records too (n images, no window origins)
+                t = torch.rand(3, 3, *(144, 112) if tag == "a" else (100, 76), generator=torch.Generator().manual_seed(5)).to(dev)
+                outs[precision + "/" + tag + "_tiles"] = m(t).cpu()
 torch.save(outs, sys.argv[1])
 """
 

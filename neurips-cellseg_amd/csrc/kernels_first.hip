@@ -492,8 +492,7 @@ int launch_conv_first_rec(hipStream_t s, const WindowSrc& src, const float* wpac
     p.tiles_x = ceil_div(p.wout, 16);
     p.tiles_y = ceil_div(p.hout, 8);
     // tiles a wave walks: 8 (128 output columns = one block per row group) unless the launch would not cover the chip twice
-    static const int tpb_env = getenv("CS_FIRST_TPB") ? atoi(getenv("CS_FIRST_TPB")) : 8;
-    p.tiles_per_block = tpb_env;
+    p.tiles_per_block = 8;                                 // (4 measured 104 / 116 us against 90 / 110 us for the bf16 pair at 256 windows)
     while (p.tiles_per_block > 1 && (int64_t)ceil_div(p.tiles_x, p.tiles_per_block) * p.tiles_y * n < 2 * SMALL_GRID_BLOCKS) p.tiles_per_block /= 2;
     p.xsplit = ceil_div(p.tiles_x, p.tiles_per_block);
     p.nt_pack = cout_pack / 16;

@@ -714,7 +714,8 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     // the two tensors itself (a SUM source) and the norm_act_add pass - two reads and one write of the tensor - is not launched.
     // Training keeps the sums (the tape needs them).  CS_FUSE_SUM=0 materialises them as before.
     static const int fuse_env = getenv("CS_FUSE_SUM") ? atoi(getenv("CS_FUSE_SUM")) : 1;
-    const bool fuse_sum = fuse_env && !tape && !q8 && (a16 ? net->planes == 1 : net->planes == 0);   // fp32 path and bf16 datapath
+    // fp32 path, bf16 datapath and - for the levels whose consumer runs on a bf16 kernel - the mixed fp8 mode
+    const bool fuse_sum = fuse_env && !tape && (a16 ? (net->planes == 1 || net->planes == 5) : net->planes == 0);
     ConvSrc sub;                                                 // "sub" input of the next transposed conv
     // ---- bottom ----
     float* S = nullptr;   // "sub" input of the next up layer
@@ -806,7 +807,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 // (consumers with 64-channel blocks are left alone: the second tensor costs that kernel variant a third of its occupancy -
                 // measured on the 32-base slide: level 2 fused -0.47 ms, level 3 fused -0.06 ms, CS_FUSE_SUM=2 fuses every level)
                 const int c_up = net->up[d - 1].cout;
-                const bool fused_mid = fuse_sum && d >= 2 && c_up % 16 == 0 && rt_upt[d].tab && rt_upu[d].tab &&
+                const bool fused_mid = fuse_sum && d >= 2 && c_up % 16 == 0 && rt_upt[d].tab && rt_upu[d].tab && !(q8 && net->up[d - 1].convt.f8) &&
                                        (a16 ? (c % 32 == 0 && net->up[d - 1].convt.wb != nullptr) : (c_up % 64 != 0 || fuse_env == 2));
                 // ... and the 3-channel top layer (fp32 path): its GEMM + gather kernel stages act(norm(V)) + act(norm(U)) itself for the
                 // 32 channels that come from below - measured -0.9 ms of norm_act_add for +0.3 ms in that kernel per slide

@@ -208,6 +208,78 @@ def cpu_baseline_tiles_and_train(seed):
     return {"tiles": dict(tiles, cores=threads, kind="port", note=note), "train_step": dict(train, cores=threads, kind="port", note=note)}
 
 
+def eager_rocm(dev, size, roi, overlap, width, seed, engine_ms):
+    """BASELINE.json configs[1]'s comparator, "HIP conv/BN kernels vs PyTorch-ROCm eager": what the reference's own code executes on this
+    GPU - the restated network (oracle/unet_ref.py, torch.nn modules -> MIOpen / rocBLAS through PyTorch-ROCm eager) moved to the device,
+    in fp32 and under torch.autocast(bfloat16): the forward over 32 x 3 x 256 x 256 tiles (model_training_3class.py:255), one training
+    step at batch 32 (:250-262: zero_grad, forward, DiceCE, backward, AdamW) and the sliding-window pass with sw_batch_size 4
+    (predict.py:109-111, up to the class-1 probability map on the host; the reference then post-processes on the host cores, which is
+    cpu_baseline's skimage chain).  Runs after every timed region of the engine, like cpu_baseline; `engine_ms` are this run's figures."""
+    from oracle.sliding_window_ref import sliding_window_inference_ref
+    from oracle.train_ref import dice_ce_ref, one_hot_ref
+    from oracle.unet_ref import make_reference_unet
+
+    def timed(fn, reps, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    out = {"torch": torch.__version__, "network": "oracle/unet_ref.py (MONAI UNet restated as torch.nn modules) on cuda:0, eager",
+           "note": "ratio = eager ms / engine ms of this same run (engine: cellseg_amd through the C-ABI); bf16 = torch.autocast(bfloat16) "
+                   "against the engine's bf16 datapath"}
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(32, 3, 256, 256, generator=g).to(dev)
+    y = torch.randint(0, 3, (32, 1, 256, 256), generator=g).to(dev)
+    net = make_reference_unet(seed, channels=WIDTHS[width]).to(dev).eval()
+    modes = (("fp32", None), ("bf16", torch.bfloat16))
+
+    def ctx(dt):
+        import contextlib
+        return torch.autocast("cuda", dtype=dt) if dt is not None else contextlib.nullcontext()
+
+    def pair(key, eager):
+        eng = engine_ms.get(key)
+        return {"eager_ms": round(eager, 3), "engine_ms": round(eng, 3) if eng else None, "ratio": round(eager / eng, 2) if eng else None}
+
+    tiles, train, slide = {}, {}, {}
+    with torch.no_grad():
+        for name, dt in modes:
+            with ctx(dt):
+                tiles[name] = pair(f"tiles_{name}", timed(lambda: net(x), 10))
+    # the slide as predict.py runs it: windows in groups of 4, logits accumulated on the device, softmax, class-1 map to the host
+    img = torch.from_numpy(synthetic_wsi(size, seed)).to(dev)[None]
+
+    def slide_once():
+        logits = sliding_window_inference_ref(img, (roi, roi), 4, net, overlap)
+        return torch.softmax(logits, 1)[0, 1].cpu()
+
+    with torch.no_grad():
+        for name, dt in modes:
+            with ctx(dt):
+                ms = timed(slide_once, 2, warm=1)
+            slide[name] = dict(pair(f"slide_{name}", ms), eager_mpixels_s=round(size * size / 1e3 / ms, 2))
+    slide["scope"] = ("eager: predict.py:109-111 (sliding_window_inference sw_batch_size 4 -> softmax -> class-1 probabilities on the host), WITHOUT the "
+                      "host post-process that follows in the reference; engine: the whole headline step incl. connected components and the label copy")
+    net.train()
+    opt = torch.optim.AdamW(net.parameters(), 6e-4)
+    onehot = one_hot_ref(y, 3)
+    for name, dt in modes:
+        def step():
+            opt.zero_grad()
+            with ctx(dt):
+                loss = dice_ce_ref(net(x).float(), onehot)
+            loss.backward()
+            opt.step()
+        train[name] = pair(f"train_{name}", timed(step, 10))
+    out.update(tiles_forward_n32=tiles, train_step_batch32=train, slide=slide)
+    return out
+
+
 def lowprec_accuracy(dev, steps=150, n_images=8, size=1024, precisions=("fp16x3", "bf16x6", "bf16", "fp8"), seed=7):
     """Accuracy of the low-precision datapaths where it means something: on a TRAINED net (random-init logits sit at the 0.5
     threshold).  A 32-base U-Net is trained for `steps` AdamW steps on seeded synthetic cells (fp32 engine, ca.TrainStep), then
@@ -322,6 +394,66 @@ def launch_ranks(n: int, script: str = None, argv=None) -> int:
               file=sys.stderr)
         return 1
     return 0
+
+
+class StripsGuard:
+    """Watcher thread of the multi-GPU strips leg (armed on construction).  `fail(msg)` posts msg in the process group's store and leaves
+    through `_bail`; the watcher polls the store (and the deadline) twice a second and leaves the same way when any rank has failed or
+    the leg hangs: rank 0 prints `line_fn(msg)` - the slides-leg line with `strips_error` - and every rank exits with code 0 at once,
+    without entering another collective.  Covers asymmetric failures (one rank raises, its peers sit in a collective)."""
+    KEY = "bench_strips_failed"
+
+    def __init__(self, dist, rank, line_fn, deadline_s):
+        import threading
+        self.rank, self.line_fn, self.deadline_s = rank, line_fn, deadline_s
+        self.lock, self.done = threading.Lock(), False
+        try:
+            self.store = dist.distributed_c10d._get_default_store()
+        except Exception:                                           # noqa: BLE001  (no store: the deadline alone guards the leg)
+            self.store = None
+        self.t_end = time.time() + deadline_s
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(0.5)
+            msg = None
+            try:
+                if self.store is not None and self.store.check([self.KEY]):
+                    msg = self.store.get(self.KEY).decode(errors="replace")
+            except Exception:                                       # noqa: BLE001  (rank 0 hosts the store: it has left already)
+                msg = "the strips leg failed on another rank"
+            if msg is None and time.time() > self.t_end:
+                msg = f"the strips leg did not finish within {self.deadline_s:.0f} s (BENCH_STRIPS_DEADLINE_S)"
+            if msg is not None:
+                self._bail(msg)
+
+    def fail(self, msg):
+        try:
+            if self.store is not None:
+                self.store.set(self.KEY, f"rank {self.rank}: {msg}")
+        except Exception:                                           # noqa: BLE001
+            pass
+        self._bail(f"rank {self.rank}: {msg}")
+        time.sleep(3600)                                            # the watcher is already leaving for this process
+
+    def _bail(self, msg):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0:
+                sys.stdout.write(json.dumps(self.line_fn(msg)) + "\n")
+            else:
+                time.sleep(1.0)                                     # rank 0 hosts the store: let the other watchers read the key first
+            sys.stdout.flush()
+            sys.stderr.write(f"bench.py: rank {self.rank} leaves the strips leg: {msg}\n")
+            sys.stderr.flush()
+            os._exit(0)
+
+    def disarm(self):
+        with self.lock:
+            self.done = True
 
 
 def main():
@@ -443,12 +575,20 @@ def main():
 
     # before the strips leg: a 1 KB ring of batched send/recv; when the library's point-to-point path fails the seam halves go
     # through one all-gather instead (reported as seam_transport) - the job does not end there
-    seam_transport = None
-    if dist is not None:
-        seam_transport = os.environ.get("BENCH_SEAM_TRANSPORT") or ("p2p" if parallel.p2p_selfcheck(dev) else "allgather")
+    # (the check runs right before the first strips leg, inside the guarded region - StripsGuard below)
+    seam = {"transport": None}
+    fail_rank = os.environ.get("BENCH_STRIPS_FAIL_RANK")        # test hook: this rank raises inside its seam exchange (an ASYMMETRIC failure)
+
+    def ensure_seam_transport():
+        if dist is not None and seam["transport"] is None:
+            seam["transport"] = os.environ.get("BENCH_SEAM_TRANSPORT") or ("p2p" if parallel.p2p_selfcheck(dev) else "allgather")
 
     def seam_exchange(win, pl, r, w):
-        return parallel.exchange_seam(win, pl, r, w, transport=seam_transport or "p2p")
+        if fail_rank is not None and int(fail_rank) == rank:
+            raise RuntimeError(f"provoked failure on rank {rank} (BENCH_STRIPS_FAIL_RANK)")
+        if os.environ.get("BENCH_STRIPS_HANG_RANK") == str(rank):     # test hook: this rank never leaves its exchange
+            time.sleep(3600)
+        return parallel.exchange_seam(win, pl, r, w, transport=seam["transport"] or "p2p")
 
     def make_step(model, strips, d2h, cc_overlap=True, sim=None):
         imgs = slide_pair(strips)
@@ -654,9 +794,9 @@ def main():
             line = json.loads(cp.stdout.strip().splitlines()[-1])
         except (subprocess.SubprocessError, ValueError, IndexError, OSError) as e:
             return {"error": f"{type(e).__name__}: {e}"[:300]}
-        return {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "value_device", "roofline") if k in line} | {
+        return {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "value_device", "roofline", "roofline_by_dtype") if k in line} | {
             "workload": line["config"]["workload"], "windows": line["config"]["windows"],
-            "kernels": dict(list(line["kernels"].items())[:8]),
+            "kernels": dict(list(line["kernels"].items())[:12]),
             "note": "python bench.py --precision fp8 --width deep64 --roi 512 --size 8192 --steps 3 --warmup 1 as a child process on the same GPU"}
 
     def infer_summary(res, strips):
@@ -755,9 +895,105 @@ def main():
                        "the body through autograd as the reference writes it; FLOPs = 3 x forward conv FLOPs (SURVEY 8(d))"}
         return out
 
+    def roofline(res, precision=None, only=None):
+        prof = res.get("prof")
+        if not prof:
+            return None
+        precision = precision or args.precision
+        total_ms = sum(v["ms"] for v in prof.values())
+        if only is not None:
+            prof = {n: v for n, v in prof.items() if only(n) and v["flops"] > 0}
+            if not prof:
+                return None
+        name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        mfma = k["flops"] > 0 and ("mfma" in name or "wino" in name or name.endswith("_fp8"))
+        sec = k["ms"] / 1e3
+        if mfma:
+            achieved = k["flops"] / sec / 1e12
+            # the peak of the instruction the launches of this group really issue: the fp32 Winograd / direct kernels run on the fp32 matrix
+            # instruction whatever the mode of the other layers; in fp8 mode the e4m3 launches are their own groups (*_fp8) and every other
+            # matrix kernel is a bf16 one
+            peak_of = "fp32" if ("wino" in name or precision == "fp32") else ("fp8" if name.endswith("_fp8") else ("bf16" if precision == "fp8" else precision))
+            peak = round(MFMA_PEAK[peak_of], 1)
+            rl = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                  "frac": round(achieved / peak, 4), "traffic": None, "peak_of": peak_of}
+        else:
+            achieved = k["bytes"] / sec / 1e9
+            rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                  "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
+        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # gfx950 correction applied; tools/pmc_summary.py).  bench.py cannot read PMCs itself, so it quotes the summary.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name, {})
+            if res.get("primary") and args.engine_batch == 0 and args.size == 4096 and args.width == "baseline32" and args.precision == "fp32":
+                rl["traffic"] = pmc.get("hbm_bytes_per_launch")
+                rl["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 PMC passes of the default command)"
+                rl["algorithmic_bytes_per_launch"] = round(k["bytes"] / k["launches"])
+        except (OSError, ValueError, KeyError):
+            pass
+        if "wino" in name:
+            # Winograd: `achieved` counts the multiplies the algorithm really issues on the matrix pipe (F(2x2,3x3): 16 per 2x2 output
+            # tile and channel pair; F(4x4,3x3): 36 per 4x4 tile); the same launches expressed in direct-convolution FLOPs (9 per
+            # output pixel: SURVEY 8(d)'s figure)
+            f4 = name.endswith("wino4")
+            factor = 144 / 36 if f4 else 36 / 16
+            rl["algorithm"] = ("Winograd F(4x4,3x3), fp32: 36 instead of 144 multiplies per 4x4 output tile and channel pair (every stride-1 3x3 "
+                               "layer with >= 32 input channels)" if f4 else
+                               "Winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per output tile and channel pair")
+            rl["direct_conv_equivalent"] = round(rl["achieved"] * factor, 3)
+            rl["frac_direct_conv_equivalent"] = round(rl["achieved"] * factor / rl["peak"], 4)
+        rl.update({"kernel": name, "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 5),
+                   "algorithmic_per_launch": (k["flops"] if mfma else k["bytes"]) / k["launches"],
+                   "share_of_gpu_time": round(k["ms"] / total_ms, 4)})
+        return rl
+
+    def kernel_table(res):
+        tot = sum(v["ms"] for v in res["prof"].values())
+        return {n: {"ms_per_step": round(v["ms"] / args.steps, 4), "share": round(v["ms"] / tot, 4),
+                    "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] else None,
+                    "gbs": round(v["bytes"] / v["ms"] / 1e6, 1)} for n, v in sorted(res["prof"].items(), key=lambda kv: -kv[1]["ms"])}
+
+    def base_line(main_res, head_strips):
+        """The contract keys of the JSON line for one measured inference leg (slides or strips)."""
+        main_res["primary"] = True
+        rccl_ranks = dist.get_world_size() if dist else 1
+        slides = 1 if head_strips else world               # slides segmented per step by the whole job
+        ms_step = main_res["dt"] / args.steps * 1e3
+        out = {
+            "metric": f"Mpixels/s sliding-window inference ({args.size}^2 WSI) incl. GPU connected components, label map on host; pipelined steady state "
+                      f"(the label copy and connected components of slide k overlap the windows of slide k + 1; per-image figure: latency_ms)",
+            "value": round(slides * mpix * args.steps / main_res["dt"], 3),
+            "unit": "Mpixels/s",
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "collective_backend": backend if dist else None,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "strong" if head_strips else "weak", "vs_baseline": None,
+            "dtype": DTYPE[args.precision], "data": "synthetic",
+            "config": {"workload": f"sliding-window inference on 3x{args.size}x{args.size} synthetic WSI, {args.roi} window / "
+                                   f"{plan.interval_h} stride ({n_windows} windows), 3-class residual U-Net channels={list(WIDTHS[args.width])} "
+                                   f"num_res_units=2 InstanceNorm+PReLU random-init, softmax + >0.5 + remove_small_holes(64) + "
+                                   f"remove_small_objects(16) + 8-conn label on GPU, int32 labels copied to pinned host memory; "
+                                   + ("one slide cut into row strips" if head_strips else "one slide per GPU"),
+                       "windows": n_windows, "engine_batch": args.engine_batch or ca.balanced_batch(n_windows, args.streams), "engine_batch_auto": not args.engine_batch,
+                       "streams": args.streams, "precision": args.precision,
+                       "parallelism": (f"1 slide split by window rows over {world} ranks + seam send/recv + mask all-gather" if head_strips
+                                       else f"slides x{world}"),
+                       "instances_found": main_res["n_instances"], "foreground_fraction": round(main_res["fg_frac"], 4)},
+            "value_device": round(slides * mpix * args.steps / main_res["dt_dev"], 3),
+            "value_device_note": "same loop ending when the int32 label map is complete in HBM (no copy to the host)",
+            "value_with_events": round(slides * mpix * args.steps / main_res["dt_prof"], 3),
+            "roofline": roofline(main_res),
+            "kernels": kernel_table(main_res),
+        }
+        if args.precision == "fp8":
+            # mixed mode: the e4m3 launches against the fp8 peak, the bf16 launches of the narrow layers against the bf16 peak - one record per group
+            out["roofline_by_dtype"] = {"fp8": roofline(main_res, only=lambda n: n.endswith("_fp8")),
+                                        "bf16": roofline(main_res, only=lambda n: not n.endswith("_fp8") and "wino" not in n and "mfma" in n)}
+        return out
+
     # ------------------------------------------------------------------------------------------------------------------
     head_strips = args.shard == "strips" and dist is not None
-    main_res = sec_res = None
+    main_res = sec_res = slides_res = None
     modes, other_part, train_res = {}, None, None
     strips_equal = None
     train_ref = None
@@ -767,25 +1003,34 @@ def main():
             # the strips leg is the only one with data-path collectives (seam send/recv, mask all-gather).  The collective-free slides
             # leg runs FIRST and is kept: should the strips leg fail on this node (it has never run on real multi-GPU hardware here), the
             # job still reports the slides figure - marked as such - instead of exiting without a line
-            slides_res = measure_infer(args.width, args.precision, False, True)
+            slides_res = measure_infer(args.width, args.precision, False, True, extras=not args.no_secondary and rank == 0)
+
+            def fallback_line(msg):
+                line = base_line(slides_res, False)
+                line["strips_error"] = msg
+                line["config"]["note"] = "the strong-scaling strips leg failed on this node (strips_error); the headline is the collective-free slides leg"
+                return line
+
+            # A failure inside the strips leg need not be symmetric: a rank that raises leaves its peers inside the seam send/recv or the
+            # mask all-gather, and any later collective then mismatches until the process-group timeout aborts the job without a line.  So
+            # from here to the end of the leg every rank runs a watcher thread: a rank that fails posts the reason in the process group's
+            # store, every watcher sees it within half a second (or the leg's deadline passes), rank 0 prints the slides line with
+            # `strips_error` set and every rank leaves at once - no collective is entered after a failure.
+            guard = StripsGuard(dist, rank, fallback_line, float(os.environ.get("BENCH_STRIPS_DEADLINE_S", "150")))
             try:
-                main_res = measure_infer(args.width, args.precision, True, True)
+                ensure_seam_transport()
+                main_res = measure_infer(args.width, args.precision, True, True)      # ends with a collective: every rank got this far
             except Exception as e:                                  # noqa: BLE001
-                strips_error = f"{type(e).__name__}: {e}"[:500]
-            try:                                                    # every rank takes part in the vote, also the one that caught the error
-                failed = max_over_ranks([1.0 if strips_error else 0.0])[0] > 0
-            except Exception as e:                                  # noqa: BLE001  (the process group itself is gone)
-                failed, strips_error = True, strips_error or f"{type(e).__name__}: {e}"[:500]
-            if failed:                                              # one failing rank switches every rank
-                strips_error = strips_error or "the strips leg failed on another rank"
-                main_res, head_strips = slides_res, False
-            elif not args.no_secondary:
+                guard.fail(f"{type(e).__name__}: {e}"[:500])        # does not return
+            guard.disarm()
+            if not args.no_secondary:
                 other_part = infer_summary(slides_res, False)
                 strips_equal = bool(torch.equal(slides_res["labels"], main_res["labels"])) if rank == 0 else None
         else:
             main_res = measure_infer(args.width, args.precision, False, True, extras=not args.no_secondary and rank == 0)
         if not args.no_secondary:
             if dist is not None and not head_strips and strips_error is None:
+                ensure_seam_transport()
                 other = measure_infer(args.width, args.precision, True, False)
                 other_part = infer_summary(other, True)
                 # rank 0's slides-leg slide pair is the strips leg's pair: the two partitions must produce the same label map
@@ -820,56 +1065,6 @@ def main():
             dist.destroy_process_group()
         return
 
-    def roofline(res, precision=None):
-        prof = res.get("prof")
-        if not prof:
-            return None
-        precision = precision or args.precision
-        name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        mfma = k["flops"] > 0 and ("mfma" in name or "wino" in name)
-        sec = k["ms"] / 1e3
-        if mfma:
-            achieved = k["flops"] / sec / 1e12
-            # the fp32 Winograd / direct kernels run on the fp32 matrix instruction whatever the mode of the other layers
-            peak = round(MFMA_PEAK["fp32" if ("wino" in name or precision == "fp32") else precision], 1)
-            rl = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                  "frac": round(achieved / peak, 4), "traffic": None}
-        else:
-            achieved = k["bytes"] / sec / 1e9
-            rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                  "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
-        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # gfx950 correction applied; tools/pmc_summary.py).  bench.py cannot read PMCs itself, so it quotes the summary.
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name, {})
-            if res is main_res and args.engine_batch == 0 and args.size == 4096 and args.width == "baseline32" and args.precision == "fp32":
-                rl["traffic"] = pmc.get("hbm_bytes_per_launch")
-                rl["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 PMC passes of the default command)"
-                rl["algorithmic_bytes_per_launch"] = round(k["bytes"] / k["launches"])
-        except (OSError, ValueError, KeyError):
-            pass
-        if "wino" in name:
-            # Winograd: `achieved` counts the multiplies the algorithm really issues on the matrix pipe (F(2x2,3x3): 16 per 2x2 output
-            # tile and channel pair; F(4x4,3x3): 36 per 4x4 tile); the same launches expressed in direct-convolution FLOPs (9 per
-            # output pixel: SURVEY 8(d)'s figure)
-            f4 = name.endswith("wino4")
-            factor = 144 / 36 if f4 else 36 / 16
-            rl["algorithm"] = ("Winograd F(4x4,3x3), fp32: 36 instead of 144 multiplies per 4x4 output tile and channel pair (every stride-1 3x3 "
-                               "layer with >= 32 input channels)" if f4 else
-                               "Winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per output tile and channel pair")
-            rl["direct_conv_equivalent"] = round(rl["achieved"] * factor, 3)
-            rl["frac_direct_conv_equivalent"] = round(rl["achieved"] * factor / rl["peak"], 4)
-        rl.update({"kernel": name, "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 5),
-                   "algorithmic_per_launch": (k["flops"] if mfma else k["bytes"]) / k["launches"],
-                   "share_of_gpu_time": round(k["ms"] / sum(v["ms"] for v in prof.values()), 4)})
-        return rl
-
-    def kernel_table(res):
-        tot = sum(v["ms"] for v in res["prof"].values())
-        return {n: {"ms_per_step": round(v["ms"] / args.steps, 4), "share": round(v["ms"] / tot, 4),
-                    "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] else None,
-                    "gbs": round(v["bytes"] / v["ms"] / 1e6, 1)} for n, v in sorted(res["prof"].items(), key=lambda kv: -kv[1]["ms"])}
-
     rccl_ranks = dist.get_world_size() if dist else 1
     if args.mode == "train":
         out = {
@@ -889,34 +1084,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    slides = 1 if head_strips else world               # slides segmented per step by the whole job
-    ms_step = main_res["dt"] / args.steps * 1e3
-    out = {
-        "metric": "Mpixels/s sliding-window inference (4096^2 WSI) incl. GPU connected components, label map on host",
-        "value": round(slides * mpix * args.steps / main_res["dt"], 3),
-        "unit": "Mpixels/s",
-        "n_gpus": world, "rccl_ranks": rccl_ranks, "collective_backend": backend if dist else None,
-        "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 3),
-        "higher_is_better": True, "scaling": "strong" if head_strips else "weak", "vs_baseline": None,
-        "dtype": DTYPE[args.precision], "data": "synthetic",
-        "config": {"workload": f"sliding-window inference on 3x{args.size}x{args.size} synthetic WSI, {args.roi} window / "
-                               f"{plan.interval_h} stride ({n_windows} windows), 3-class residual U-Net channels={list(WIDTHS[args.width])} "
-                               f"num_res_units=2 InstanceNorm+PReLU random-init, softmax + >0.5 + remove_small_holes(64) + "
-                               f"remove_small_objects(16) + 8-conn label on GPU, int32 labels copied to pinned host memory; "
-                               + ("one slide cut into row strips" if head_strips else "one slide per GPU"),
-                   "windows": n_windows, "engine_batch": args.engine_batch or ca.balanced_batch(n_windows, args.streams), "engine_batch_auto": not args.engine_batch,
-                   "streams": args.streams, "precision": args.precision,
-                   "parallelism": (f"1 slide split by window rows over {world} ranks + seam send/recv + mask all-gather" if head_strips
-                                   else f"slides x{world}"),
-                   "instances_found": main_res["n_instances"], "foreground_fraction": round(main_res["fg_frac"], 4)},
-        "value_device": round(slides * mpix * args.steps / main_res["dt_dev"], 3),
-        "value_device_note": "same loop ending when the int32 label map is complete in HBM (no copy to the host)",
-        "value_with_events": round(slides * mpix * args.steps / main_res["dt_prof"], 3),
-        "roofline": roofline(main_res),
-        "kernels": kernel_table(main_res),
-    }
-    strips_info = {"seam_transport": seam_transport, "strips_error": strips_error,
+    out = base_line(main_res, head_strips)
+    strips_info = {"seam_transport": seam["transport"], "strips_error": strips_error,
                    "window_rows_per_rank": [st.win_row_end - st.win_row_begin for st in strip_parts],
                    "windows_per_rank": [(st.win_row_end - st.win_row_begin) * plan.n_w for st in strip_parts],
                    "output_rows_per_rank": [st.row_end - st.row_begin for st in strip_parts], "strip_batch": args.strip_batch or "auto",
@@ -935,14 +1104,15 @@ def main():
     if strips_error:
         out["strips_error"] = strips_error
         out["config"]["note"] = "the strong-scaling strips leg failed on this node (strips_error); the headline is the collective-free slides leg"
-    if main_res.get("latency"):
-        out.update(latency_ms=main_res["latency"]["latency_ms"], latency=dict(
-            main_res["latency"], note="one slide at a time: image tensor resident in HBM -> int32 labels in pinned host memory, synchronised "
+    extras_res = slides_res if head_strips else main_res          # latency / reference scope are per-image figures of the slides leg
+    if extras_res.get("latency"):
+        out.update(latency_ms=extras_res["latency"]["latency_ms"], latency=dict(
+            extras_res["latency"], note="one slide at a time: image tensor resident in HBM -> int32 labels in pinned host memory, synchronised "
                                       "on both sides, no overlap with a neighbour slide (SURVEY 8(d) per-image latency)"))
-    if main_res.get("incl_tiff"):
-        out.update(value_incl_tiff=main_res["incl_tiff"]["value_incl_tiff"], reference_timer_scope=main_res["incl_tiff"])
-    if main_res.get("strips_sim"):
-        out["strips_sim"] = main_res["strips_sim"]
+    if extras_res.get("incl_tiff"):
+        out.update(value_incl_tiff=extras_res["incl_tiff"]["value_incl_tiff"], reference_timer_scope=extras_res["incl_tiff"])
+    if extras_res.get("strips_sim"):
+        out["strips_sim"] = extras_res["strips_sim"]
     if sec_res:
         out["reference_width"] = dict(infer_summary(sec_res, False), channels=list(WIDTHS["reference16"]), roofline=roofline(sec_res))
     if modes:
@@ -967,6 +1137,14 @@ def main():
                                 "pixels / time; roofline = the dominant kernel of that forward (HIP events on the launch stream)")
         if args.precision == "fp32" and args.size == 4096:
             out["configs4_fp8"] = measure_configs4()
+    if world == 1 and dist is None and not args.no_secondary and args.precision == "fp32" and "tiles" in out and train_res and modes:
+        try:
+            engine_ms = {"tiles_fp32": out["tiles"]["fp32"]["n32"]["ms_per_forward"], "tiles_bf16": out["tiles"]["bf16"]["n32"]["ms_per_forward"],
+                         "train_fp32": train_res["ms_per_step"], "train_bf16": train_res.get("bf16", {}).get("ms_per_step"),
+                         "slide_fp32": out["ms_per_step"], "slide_bf16": modes["bf16"]["ms_per_step"]}
+            out["eager_rocm"] = eager_rocm(dev, args.size, args.roi, args.overlap, args.width, seed, engine_ms)
+        except Exception as e:                                      # noqa: BLE001  (a comparator must not cost the line)
+            out["eager_rocm"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.overlap, WIDTHS[args.width], seed)
         if not args.no_secondary:

@@ -90,6 +90,17 @@ int cs_unet_read_param(cs_unet* net, const char* key_host, float* dst, int64_t n
  * caller's stream with events), so the HBM-bound kernels of one chunk overlap the MFMA-bound ones of another.  The side
  * streams and events are created here, never on the launch path.  cs_swi_workspace_bytes scales with n. */
 int cs_unet_set_streams(cs_unet* net, int n);
+/* Introspection for the per-layer parity tests (tests/test_gpu_layers.py; no counterpart in the reference, whose layers are
+ * torch.nn modules one can hook - baseline/predict.py:45-52).  With tracing on, cs_unet_forward records where every activation
+ * tensor and lazy-norm table of the forward lives inside the CALLER's workspace; afterwards
+ *   cs_unet_trace_count  number of recorded tensors
+ *   cs_unet_trace_entry  name (64 chars, e.g. "down1.E", "bottom.tab0", "up2.U") and info[8] = {byte offset in the workspace, n, h, w,
+ *                        channels, pixel pitch in elements, kind (0 fp32, 1 bf16, 2 e4m3 activations NHWC; 3 float2 (scale, shift)
+ *                        table [n][channels] of act(norm(x)) = prelu(x * scale + shift)), 0}.
+ * The tests read the tensors out of the workspace, recompute one layer at a time on the CPU from the layer's own inputs and compare. */
+int cs_unet_trace(cs_unet* net, int on);
+int cs_unet_trace_count(const cs_unet* net);
+int cs_unet_trace_entry(const cs_unet* net, int index, char* name_out_host, int64_t* info_out_host);
 
 /* State-dict surface (replaces model.load_state_dict / model.state_dict, predict.py:80-81,
  * model_training_3class.py:269-274).  Keys are MONAI's: "model.0.conv.unit0.conv.weight", ... */
@@ -354,7 +365,7 @@ int cs_remove_boundary_cells(const int32_t* labels, int h, int w, int border, in
  * returns per-kernel-id totals.  Disabled (default) costs nothing.  The state is kept per device: the calls act on the
  * device that is current when they are made.
  * ---------------------------------------------------------------------------------------------- */
-enum { CS_PROF_MAX_KERNELS = 32 };
+enum { CS_PROF_MAX_KERNELS = 48 };
 int cs_prof_enable(int on);
 int cs_prof_is_enabled(void);
 int cs_prof_reset(void);

@@ -52,6 +52,9 @@ def _load() -> C.CDLL:
         "cs_unet_load_begin": (i32, [vp]),
         "cs_unet_load_end": (i32, [vp, vp]),
         "cs_unet_set_streams": (i32, [vp, i32]),
+        "cs_unet_trace": (i32, [vp, i32]),
+        "cs_unet_trace_count": (i32, [vp]),
+        "cs_unet_trace_entry": (i32, [vp, i32, C.c_char_p, C.POINTER(i64)]),
         "cs_unet_num_params": (i32, [vp]),
         "cs_unet_param_info": (i32, [vp, i32, C.c_char_p, C.POINTER(i64)]),
         "cs_unet_load_param": (i32, [vp, C.c_char_p, vp, i64, vp]),
@@ -112,7 +115,7 @@ def _load() -> C.CDLL:
 
 
 lib = _load()
-EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_destroy cs_unet_set_precision cs_unet_set_training cs_unet_set_batch_stats cs_unet_read_param cs_unet_set_streams cs_unet_num_params "
+EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_destroy cs_unet_set_precision cs_unet_set_training cs_unet_set_batch_stats cs_unet_read_param cs_unet_set_streams cs_unet_trace cs_unet_trace_count cs_unet_trace_entry cs_unet_num_params "
             "cs_unet_param_info cs_unet_load_param cs_unet_load_begin cs_unet_load_end cs_unet_workspace_bytes cs_unet_forward cs_unet_grad_numel "
             "cs_unet_grad_offset cs_unet_backward_workspace_bytes cs_unet_backward cs_swi_make_plan "
             "cs_swi_window_start cs_swi_workspace_bytes cs_swi_windows_workspace_bytes cs_swi_windows cs_swi_partition cs_swi_infer cs_swi_finalize cs_normalize_workspace_bytes "
@@ -145,7 +148,7 @@ def stream_ptr():
 
 def prof_collect():
     """-> {kernel_name: dict(ms, launches, flops, bytes)} accumulated since the last cs_prof_reset."""
-    n = 32
+    n = 48          # CS_PROF_MAX_KERNELS (include/cellseg_hip.h)
     names = C.create_string_buffer(48 * n)
     ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
     la = (C.c_int64 * n)()

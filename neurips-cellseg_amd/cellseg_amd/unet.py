@@ -341,6 +341,32 @@ class UNet(nn.Module):
                 self._pull_running_stats(eng)
         return out.permute(0, 3, 1, 2), ws        # NCHW view of the NHWC result, like a channels_last tensor
 
+    def traced_forward(self, x: torch.Tensor):
+        """Inference forward that also returns every intermediate tensor of the engine (``cs_unet_trace``): -> (logits [N,3,H,W],
+        {name: tensor}) with activations as NHWC views of the workspace in their stored element type (float32 / bfloat16 /
+        float8_e4m3fn, channel padding cut off) and lazy-norm tables as float32 [N, C, 2] = (scale, shift).  For the per-layer parity
+        tests (the reference's layers are torch.nn modules one would hook: baseline/predict.py:45-52); not a fast path."""
+        _lib.require_gpu(x)
+        eng = self.engine(False)
+        check(lib.cs_unet_trace(eng.handle, 1), "cs_unet_trace")
+        try:
+            with torch.no_grad():
+                out, ws = self._forward_engine(x.float(), tag="trace")
+            taps = {}
+            name, info = C.create_string_buffer(64), (C.c_int64 * 8)()
+            for i in range(check(lib.cs_unet_trace_count(eng.handle), "cs_unet_trace_count")):
+                check(lib.cs_unet_trace_entry(eng.handle, i, name, info), "cs_unet_trace_entry")
+                off, n, h, w, c, pitch, kind = (int(v) for v in info[:7])
+                if kind == 3:
+                    taps[name.value.decode()] = ws[off:off + n * c * 8].view(torch.float32).view(n, c, 2)
+                    continue
+                dt = (torch.float32, torch.bfloat16, torch.float8_e4m3fn)[kind]
+                nbytes = n * h * w * pitch * dt.itemsize
+                taps[name.value.decode()] = ws[off:off + nbytes].view(dt).view(n, h, w, pitch)[..., :c]
+        finally:
+            check(lib.cs_unet_trace(eng.handle, 0), "cs_unet_trace")
+        return out, taps
+
     def _pull_running_stats(self, eng) -> None:
         """Train-mode BatchNorm: the engine has just updated its running_mean / running_var; mirror them into the module's buffers
         (what state_dict() saves) with one batched copy kernel, and count the batch like nn.BatchNorm2d does."""

@@ -33,7 +33,9 @@ enum KernelId {
     K_CONV3_S1 = 0, K_CONV3_S2, K_CONV1, K_CONV_FIRST, K_CONVT, K_CONVT_TOP, K_CONV_LAST,
     K_NORM_FINALIZE, K_NORM_ACT_ADD, K_SWI_FINALIZE, K_PACK, K_CCL_INIT, K_CCL_MERGE, K_CCL_COMPRESS,
     K_CCL_SIZES, K_CCL_FILTER, K_CCL_COUNT, K_CCL_SCAN, K_CCL_RANK, K_CCL_RELABEL, K_MEMSET, K_NORM_BWD, K_COLSUM,
-    K_WGRAD, K_TOP_BWD, K_PRE, K_METRIC, K_UNPACK, K_CONV3_WINO, K_LOSS, K_CONV3_WINO4, K_LABEL_DEFLATE, K_NUM_IDS
+    K_WGRAD, K_TOP_BWD, K_PRE, K_METRIC, K_UNPACK, K_CONV3_WINO, K_LOSS, K_CONV3_WINO4, K_LABEL_DEFLATE,
+    K_CONV3_S1_FP8, K_CONV3_S2_FP8, K_CONV1_FP8, K_CONVT_FP8,      // the e4m3 launches of the fp8 mode (their own matrix peak)
+    K_NUM_IDS
 };
 const char* kernel_name(int id);
 struct ProfScope {   // records start event on construction and stop event on destruction when profiling is on

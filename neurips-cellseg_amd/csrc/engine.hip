@@ -34,7 +34,8 @@ static const char* kNames[K_NUM_IDS] = {
     "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
     "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset", "norm_bwd",
     "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric", "wgrad_unpack", "conv3x3_s1_wino", "dice_ce_loss", "conv3x3_s1_wino4",
-    "label_deflate"};
+    "label_deflate", "conv3x3_s1_fp8", "conv3x3_s2_fp8", "conv1x1_fp8", "convT3x3s2_fp8"};
+static_assert(K_NUM_IDS <= CS_PROF_MAX_KERNELS, "cs_prof_collect: the caller's arrays hold CS_PROF_MAX_KERNELS entries");
 const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
 
 struct ProfRecord {
@@ -203,6 +204,14 @@ struct NormRt {   // run-time state of one norm site for the current forward
     float2* xtab = nullptr;   // BatchNorm with batch statistics: (rstd, -mean*rstd) for the backward pass
 };
 
+// cs_unet_trace: one tensor of the forward inside the caller's workspace (kind: 0 fp32, 1 bf16, 2 e4m3 activations [n, h, w, pitch];
+// 3 float2 norm table [n, c] = (scale, shift) of act(norm(x)) = prelu(x * scale + shift))
+struct TraceEntry {
+    std::string name;
+    int64_t off = 0;
+    int n = 0, h = 0, w = 0, c = 0, pitch = 0, kind = 0;
+};
+
 // Pointers into the forward workspace recorded by the last forward; the backward pass replays them.
 struct Tape {
     bool valid = false;
@@ -244,6 +253,12 @@ struct cs_unet {
     int n_streams = 1;
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    // stagger of the window streams (swi_run_windows): the first chunk's stream records ev_stagger after encoder level `stagger_level`
+    // of its forward (unet_forward_impl, when stagger_armed), the second chunk's stream starts behind that event - the two streams then
+    // run DIFFERENT layers at any time, HBM-bound launches of one beside matrix-bound launches of the other
+    hipEvent_t ev_stagger = nullptr;
+    int stagger_level = -1;
+    mutable bool stagger_armed = false;
     Tape tape;
     // backward: the weight-gradient launches (off the critical chain dy -> data gradient -> norm backward -> dy) run on a side
     // stream, forked from the caller's stream by an event once their dy is complete
@@ -257,6 +272,9 @@ struct cs_unet {
     cs::PackCtx* pack_readback = nullptr;
     int bound_planes = -1;
     bool bound_training = false;
+    // cs_unet_trace: where every tensor of the last cs_unet_forward lives inside the caller's workspace (per-layer parity tests)
+    bool trace = false;
+    mutable std::vector<cs::TraceEntry> trace_log;
 };
 
 struct cs_graph {
@@ -586,6 +604,15 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     auto take_act = [&](size_t count) -> float* {
         return a16 ? reinterpret_cast<float*>(ws.take<unsigned short>(count)) : ws.take<float>(count);
     };
+    const bool tracing = net->trace && !dry;
+    if (tracing) net->trace_log.clear();
+    auto tap = [&](const std::string& name, const void* ptr, int hh, int ww, int c, int pitch, int kind) {
+        if (!tracing || !ptr) return;
+        TraceEntry e;
+        e.name = name; e.off = (const char*)ptr - ws.base; e.n = n; e.h = hh; e.w = ww; e.c = c; e.pitch = pitch; e.kind = kind;
+        net->trace_log.push_back(e);
+    };
+    const int k16 = a16 ? 1 : 0;
     if (tape) {
         tape->valid = false;
         tape->E.assign(nl, nullptr); tape->Y.assign(nl, {}); tape->U.assign(nl, nullptr); tape->V.assign(nl, nullptr);
@@ -704,6 +731,19 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             CS_TRY(launch_norm_act_add(s, lazy_src(cur, c, cur_pitch, rt_down[d][last], u.norms[last], cur_tabc, a16),
                                        raw_src(act_off(E, c, a16), c, c0, a16), X[d], c, (int64_t)oh * ow, n, a16, Xq[d], c));
         }
+        if (tracing) {
+            const std::string pfx = "down" + std::to_string(d) + ".";
+            tap(pfx + "E", E, oh, ow, ec, ec, k16);
+            for (int su = 1; su < u.subunits; ++su) tap(pfx + "Y" + std::to_string(su), Y[su], oh, ow, c, c, k16);
+            tap(pfx + "X", X[d], oh, ow, c, c, k16);
+            tap(pfx + "Xq", Xq[d], oh, ow, c, c, 2);
+            tap(pfx + "Aq", Aq, oh, ow, c, c, 2);
+            for (int su = 0; su < u.subunits; ++su) tap(pfx + "tab" + std::to_string(su), rt_down[d][su].tab, 1, 1, su == 0 ? c0 : c, su == 0 ? c0 : c, 3);
+        }
+        if (!dry && net->stagger_armed && d == net->stagger_level) {
+            CS_HIP(hipEventRecord(net->ev_stagger, s));
+            net->stagger_armed = false;
+        }
         prev = X[d];
         prevq = Xq[d];
         ph = oh; pw = ow; pc = c;
@@ -755,6 +795,16 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             CS_TRY(launch_norm_act_add(s, ly, u.res_conv ? raw_src(R, c, c, a16) : raw_src(prev, c, pc, a16), S, c, (int64_t)ph * pw, n,
                                        a16, Sq, c));
             sub = raw_src(S, c, c, a16);
+        }
+        if (tracing) {
+            for (int su = 0; su < u.subunits; ++su) {
+                tap("bottom.Y" + std::to_string(su), Y[su], ph, pw, c, c, k16);
+                tap("bottom.tab" + std::to_string(su), rt_bottom[su].tab, 1, 1, c, c, 3);
+            }
+            tap("bottom.R", R, ph, pw, c, c, k16);
+            tap("bottom.S", S, ph, pw, c, c, k16);
+            tap("bottom.Sq", Sq, ph, pw, c, c, 2);
+            tap("bottom.Aq", Aq, ph, pw, c, c, 2);
         }
         if (tape) { tape->Yb = Y; tape->Rb = R; tape->Sb = S; }
     }
@@ -818,11 +868,23 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 if (fused) {
                     sub = lv;
                     sub.ptr2 = U; sub.tab2 = rt_upt[d].tab; sub.slope2 = u.norm_t.slope;
+                    D = nullptr;                                 // never written: the consumer reads V and U itself
+                    Dq = nullptr;
                 } else {
                     CS_TRY(launch_norm_act_add(s, lv, lu, D, c, (int64_t)oh * ow, n, a16, Dq, c));
                     sub = raw_src(D, c, c, a16);
                 }
             }
+        }
+        if (tracing) {
+            const std::string pfx = "up" + std::to_string(d) + ".";
+            tap(pfx + "U", U, oh, ow, c, c, u16 ? 1 : 0);
+            tap(pfx + "tabt", rt_upt[d].tab, 1, 1, c, c, 3);
+            tap(pfx + "V", V, oh, ow, c, c, k16);
+            tap(pfx + "Uq", Uq, oh, ow, c, c, 2);
+            tap(pfx + "tabu", rt_upu[d].tab, 1, 1, c, c, 3);
+            tap(pfx + "D", D, oh, ow, c, c, k16);
+            tap(pfx + "Dq", Dq, oh, ow, c, c, 2);
         }
         S = D;
         Sq = Dq;
@@ -1307,6 +1369,25 @@ int cs_unet_read_param(cs_unet* net, const char* key_host, float* dst, int64_t n
     return CS_ERR_UNKNOWN_KEY;
 }
 
+int cs_unet_trace(cs_unet* net, int on) {
+    CS_REQUIRE(net, "unet_trace: null handle");
+    net->trace = on != 0;
+    net->trace_log.clear();
+    return CS_OK;
+}
+
+int cs_unet_trace_count(const cs_unet* net) { return net ? (int)net->trace_log.size() : CS_ERR_INVALID; }
+
+int cs_unet_trace_entry(const cs_unet* net, int index, char* name_out_host, int64_t* info_out_host) {
+    CS_REQUIRE(net && name_out_host && info_out_host && index >= 0 && index < (int)net->trace_log.size(), "unet_trace_entry: bad argument");
+    const cs::TraceEntry& e = net->trace_log[index];
+    strncpy(name_out_host, e.name.c_str(), 63);
+    name_out_host[63] = 0;
+    const int64_t info[8] = {e.off, e.n, e.h, e.w, e.c, e.pitch, e.kind, 0};
+    for (int i = 0; i < 8; ++i) info_out_host[i] = info[i];
+    return CS_OK;
+}
+
 int cs_unet_set_streams(cs_unet* net, int n) {
     CS_REQUIRE(net && n >= 1 && n <= 4, "set_streams: n must be 1..4");
     for (int i = 0; i < n && n > 1; ++i) {          // created here, never on the launch path
@@ -1314,6 +1395,11 @@ int cs_unet_set_streams(cs_unet* net, int n) {
         if (!net->ev_join[i]) CS_HIP(hipEventCreateWithFlags(&net->ev_join[i], hipEventDisableTiming));
     }
     if (n > 1 && !net->ev_fork) CS_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+    if (n > 1 && !net->ev_stagger) CS_HIP(hipEventCreateWithFlags(&net->ev_stagger, hipEventDisableTiming));
+    {   // experiment switch (round 5): CS_SWI_STAGGER=<encoder level> delays the second window stream behind that level of the first
+        static const int lvl = [] { const char* e = getenv("CS_SWI_STAGGER"); return e ? atoi(e) : -1; }();
+        net->stagger_level = lvl;
+    }
     net->n_streams = n;
     return CS_OK;
 }
@@ -1325,6 +1411,7 @@ int cs_unet_destroy(cs_unet* net) {
         if (net->ev_join[i]) (void)hipEventDestroy(net->ev_join[i]);
     }
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    if (net->ev_stagger) (void)hipEventDestroy(net->ev_stagger);
     for (auto& st : net->bwd_side)
         if (st) {
             (void)hipStreamSynchronize(st);
@@ -1499,7 +1586,7 @@ int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_
     Bump b(workspace, workspace_bytes);
     // inference: the batch once more as (r, g, b, 0) pixel records - the first layer then runs on the record kernels of kernels_first.hip and
     // the first unit's shortcut is recomputed by its sum launch (as in the window pass, swi_run_windows)
-    if (!net->training && cs::first_rec_enabled() && net->in_ch == 3 && (int64_t)n * h * w < ((int64_t)1 << 31)) {
+    if (!net->training && cs::first_rec_enabled() && net->in_ch == 3 && (int64_t)n * h * w < ((int64_t)1 << 31) && h < 65536 && n < 65536) {   // grid y / z limits of the record kernel
         const bool rec16 = net->planes == 1 || net->planes == 5;                 // unet_forward_impl's bf16 datapath
         void* rec = b.take<char>((size_t)n * h * w * 16);
         if (!b.ok()) { set_error("unet_forward: workspace too small"); return CS_ERR_WORKSPACE; }
@@ -1679,7 +1766,7 @@ static int swi_run_windows(cs_unet* net, const cs_swi_plan* pl, const float* ima
     src.image = image; src.sn = 0; src.sc = sc; src.sh = sh; src.sw = sw;
     src.img_h = pl->img_h; src.img_w = pl->img_w; src.roi_h = pl->roi_h; src.roi_w = pl->roi_w;
     // the image once more as (r, g, b, 0) pixel records: every window's first layer gathers its patches from these (kernels_first.hip)
-    if (cs::first_rec_enabled() && net->in_ch == 3 && (int64_t)pl->img_h * pl->img_w < ((int64_t)1 << 31)) {
+    if (cs::first_rec_enabled() && net->in_ch == 3 && (int64_t)pl->img_h * pl->img_w < ((int64_t)1 << 31) && pl->img_h < 65536) {   // taller images keep the planar path
         const bool rec16 = (net->planes == 1 || net->planes == 5) && !net->training;       // unet_forward_impl's bf16 datapath
         void* rec = b.take<char>((size_t)pl->img_h * pl->img_w * 16);
         if (!b.ok()) { cs::set_error("swi: workspace too small"); return CS_ERR_WORKSPACE; }
@@ -1711,7 +1798,11 @@ static int swi_run_windows(cs_unet* net, const cs_swi_plan* pl, const float* ima
         src.origins = origins + k0;
         if (ns > 1) {
             cs::Bump bs(b.base + mark + (size_t)(chunk % ns) * slice, slice);
+            const bool stagger = net->stagger_level >= 0 && net->stagger_level < net->nl && net->ev_stagger && ns == 2;
+            if (stagger && chunk == 0) net->stagger_armed = true;
+            if (stagger && chunk == 1) CS_HIP(hipStreamWaitEvent(net->side[1], net->ev_stagger, 0));
             rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, bs, net->side[chunk % ns]);
+            net->stagger_armed = false;
         } else {
             b.off = mark;   // every chunk reuses the same activation workspace (stream order serialises them)
             rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, b, s);

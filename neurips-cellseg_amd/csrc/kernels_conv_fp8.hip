@@ -331,7 +331,7 @@ int launch_conv_fp8(hipStream_t s, int ksize, int stride, const ConvSrc& a, cons
     // FLOPs are the ALGORITHMIC ones (2 * cin * ...), not the zero-padded K the matrix pipe executes
     const double flops = 2.0 * n * p.hout * p.wout * (double)cout * (a.c + b.c) * ksize * ksize;
     const double bytes = n * (1.0 * hin * win * (a.c + b.c) + 2.0 * p.hout * p.wout * cout);
-    ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
+    ProfScope prof(ksize == 1 ? K_CONV1_FP8 : (stride == 1 ? K_CONV3_S1_FP8 : K_CONV3_S2_FP8), s, flops, bytes);
     const bool tall = stride == 1 && p.hout >= 16;
 #define CS_8(S_, KS_)                                                               \
     switch (wn) {                                                                   \
@@ -551,7 +551,7 @@ int launch_convt_fp8(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const un
     const int wn = (cout % 64 == 0) ? 4 : (cout % 32 == 0) ? 2 : 1;
     const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
     const double bytes = n * (1.0 * hin * win * (a.c + b.c) + 2.0 * 4.0 * hin * win * cout);
-    ProfScope prof(K_CONVT, s, flops, bytes);
+    ProfScope prof(K_CONVT_FP8, s, flops, bytes);
     switch (wn) {
         case 4: return launch_t8<2, 2>(s, p);
         case 2: return launch_t8<2, 1>(s, p);

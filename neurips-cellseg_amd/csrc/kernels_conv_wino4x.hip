@@ -932,6 +932,7 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
     CS_REQUIRE((a.pitch % 4) == 0 && (pitch_out % 4) == 0, "conv(winograd 4x4, 32x32): pixel pitch must be a multiple of 4 floats");
     CS_REQUIRE(!a.h16 && !a.q8 && !a.ptr2, "conv(winograd 4x4, 32x32): plain fp32 activations only");
     CS_REQUIRE((size_t)h * w * a.pitch * 4 < ((size_t)1 << 32), "conv(winograd 4x4, 32x32): one image's activation tensor must stay below 4 GB");
+    CS_REQUIRE((size_t)h * w * pitch_out * 4 < ((size_t)1 << 32), "conv(winograd 4x4, 32x32): one image's output tensor must stay below 4 GB");
     ConvParams p{};
     p.a = SrcDev{a.ptr, a.tab, a.slope, a.c, a.pitch, a.tab_c ? a.tab_c : a.c, a.tab_off};
     p.wpack = wpack_wino4x;

@@ -14,9 +14,10 @@ host", so `value` includes that copy; `value_device` is the same loop stopping w
 GPU) and forwards rank 0's JSON line.
 
 Multi-GPU legs:
-  slides  (headline, weak scaling)   every rank segments its own slide, no data-path collective
-  strips  (`strips` object, strong)  ONE slide split by WINDOW rows (no window evaluated twice), seam halves sent to the neighbour
-                                     below (RCCL send/recv), all-gather (RCCL) of the uint8 mask strips, CC on rank 0 (own stream)
+  slides  (weak scaling)             every rank segments its own slide, no data-path collective
+  strips  (headline for N > 1,       ONE slide split by its WINDOW LIST (shares differ by one window at most; no window evaluated twice),
+           strong scaling)           window parts sent to the later neighbour (RCCL send/recv), all-gather (RCCL) of the finalised uint8
+                                     rectangles, CC + label copy on rank (slide index mod N) on its own stream
   train   (`train_step` object; `--mode train` makes it the headline) data-parallel training step, batch 32x3x256x256 per
           GPU (BASELINE.json configs[1]/[3]): forward + DiceCE + backward + ONE flat-bucket RCCL all-reduce + AdamW
 Prints ONE JSON line on rank 0 (contract in the task description), including `roofline` (dominant kernel, HIP
@@ -280,7 +281,7 @@ def eager_rocm(dev, size, roi, overlap, width, seed, engine_ms):
     return out
 
 
-def lowprec_accuracy(dev, steps=150, n_images=8, size=1024, precisions=("fp16x3", "bf16x6", "bf16", "fp8"), seed=7):
+def lowprec_accuracy(dev, steps=150, n_images=8, size=1024, precisions=("fp16x3", "bf16x6", "bf16", "fp8"), seed=7, width="baseline32", roi=256):
     """Accuracy of the low-precision datapaths where it means something: on a TRAINED net (random-init logits sit at the 0.5
     threshold).  A 32-base U-Net is trained for `steps` AdamW steps on seeded synthetic cells (fp32 engine, ca.TrainStep), then
     `n_images` held-out synthetic images of size^2 are segmented in fp32 and in every mode: instance F1@0.5 against the fp32
@@ -289,7 +290,7 @@ def lowprec_accuracy(dev, steps=150, n_images=8, size=1024, precisions=("fp16x3"
     import cellseg_amd as ca
     from cellseg_amd import data, metrics
     torch.manual_seed(seed)
-    model = ca.UNet(channels=WIDTHS["baseline32"], strides=(2, 2, 2, 2), num_res_units=2).to(dev).train()
+    model = ca.UNet(channels=WIDTHS[width], strides=(2, 2, 2, 2), num_res_units=2).to(dev).train()
     ds = data.SyntheticCells(64, 256, 2022)
     batches = [(torch.stack([ds[i]["img"] for i in range(b, b + 8)]).to(dev),
                 ca.one_hot(torch.stack([ds[i]["label"] for i in range(b, b + 8)]).to(dev), 3)) for b in range(0, 64, 8)]
@@ -312,7 +313,7 @@ def lowprec_accuracy(dev, steps=150, n_images=8, size=1024, precisions=("fp16x3"
             res = {}
             for prec in ("fp32",) + tuple(precisions):
                 model.precision = prec
-                _, _, mask = ca.swi_infer_image(model, img, (256, 256), 0.5, want_logits=False, want_mask=True)
+                _, _, mask = ca.swi_infer_image(model, img, (roi, roi), 0.5, want_logits=False, want_mask=True)
                 res[prec] = (mask.clone(), ca.mask_to_instances(mask))
             cells += int(res["fp32"][1].max())
             f1_truth_fp32 += metrics.f1_score(truth, res["fp32"][1])[5]
@@ -321,7 +322,7 @@ def lowprec_accuracy(dev, steps=150, n_images=8, size=1024, precisions=("fp16x3"
                 sums[prec]["pixel_agreement"] += float((res["fp32"][0] == res[prec][0]).float().mean())
                 sums[prec]["f1_vs_truth"] += metrics.f1_score(truth, res[prec][1])[5]
     model.precision = "fp32"
-    out = {"trained_net": {"channels": list(WIDTHS["baseline32"]), "steps": steps, "loss_first": round(first, 4), "loss_last": round(last, 4),
+    out = {"trained_net": {"channels": list(WIDTHS[width]), "window": roi, "steps": steps, "loss_first": round(first, 4), "loss_last": round(last, 4),
                            "held_out_images": n_images, "image_size": size, "cells_found_fp32": cells,
                            "f1_vs_truth_fp32": round(f1_truth_fp32 / n_images, 5)}}
     for prec in precisions:
@@ -474,7 +475,7 @@ def main():
     ap.add_argument("--precision", choices=sorted(MFMA_PEAK), default="fp32",
                     help="matrix-core arithmetic of the convolutions")
     ap.add_argument("--shard", choices=["slides", "strips"], default=None,
-                    help="headline multi-GPU partition: ONE slide split by window rows over the ranks with the seam exchange and the "
+                    help="headline multi-GPU partition: ONE slide split by its window list over the ranks with the seam exchange and the "
                          "all-gather of the uint8 mask strips before the connected-component pass (strong scaling; the default for "
                          "--gpus N > 1: north_star's '>= 6x at 8 GPUs' is about one WSI) or one slide per rank (weak scaling, no "
                          "collective); the other partition is reported as a secondary object")
@@ -568,8 +569,7 @@ def main():
                 images[key] = torch.from_numpy(synthetic_wsi(args.size, key)).to(dev)      # resident in HBM before timing
         return [images[k] for k in keys]
 
-    strip_parts = [ca.strip_partition(plan, r, world) for r in range(world)]
-    strip_rows_all = [(st.row_begin, st.row_end) for st in strip_parts]
+    share_parts = [ca.share_partition(plan, r, world) for r in range(world)]
 
     no_labels, no_num = torch.zeros((1, 1), dtype=torch.int32, device=dev), torch.zeros((), dtype=torch.int32, device=dev)
 
@@ -588,11 +588,12 @@ def main():
             raise RuntimeError(f"provoked failure on rank {rank} (BENCH_STRIPS_FAIL_RANK)")
         if os.environ.get("BENCH_STRIPS_HANG_RANK") == str(rank):     # test hook: this rank never leaves its exchange
             time.sleep(3600)
-        return parallel.exchange_seam(win, pl, r, w, transport=seam["transport"] or "p2p")
+        return parallel.exchange_share(win, pl, r, w, transport=seam["transport"] or "p2p")
 
     def make_step(model, strips, d2h, cc_overlap=True, sim=None):
         imgs = slide_pair(strips)
         it = [0]
+        force_label = [None]                       # strips leg: None = the ranks take turns; True / False = this rank labels / does not
         pipelined = bool(args.cc_stream) and cc_overlap
 
         def labelled(mask):
@@ -616,38 +617,47 @@ def main():
             return labelled(mask)
 
         def step_strips():
-            """One slide across ranks, split by WINDOW rows (31 rows over 8 ranks = 3,4,4,4,4,4,4,4; no window evaluated twice): every
-            rank runs its windows, the seam halves go to the neighbour below (RCCL send/recv), every rank finalises its rows, the uint8
-            mask strips are all-gathered (RCCL) and RANK 0 - which holds the smaller share of windows - labels the full mask on its CC
-            stream beside its next slide ("gather the mask to rank 0 and label there"); its label map is the job's output."""
-            image = imgs[it[0] % 2]
+            """One slide across ranks, split by the window LIST (961 windows over 8 ranks = 120 / 121 each; no window evaluated twice):
+            every rank runs its windows, the parts later ranks finalise under go to them (RCCL send/recv), every rank finalises its
+            rectangles, the uint8 rectangles are all-gathered (RCCL) and ONE rank - slide k: rank k mod N, so that the connected-component
+            pass and the label copy cost every rank 1/N of a slide instead of rank 0 all of it - labels the full mask on its CC stream
+            beside its next slide; its label map (copied to its pinned host buffer) is the job's output for that slide."""
+            k = it[0]
+            image = imgs[k % 2]
             it[0] += 1
-            st, _, _, mask = ca.swi_infer_strip(model, image, roi, args.overlap, rank, world, engine_batch=args.strip_batch or None,
-                                                streams=args.streams, exchange=seam_exchange)
-            full = parallel.gather_row_strips(mask[st.row_begin:st.row_end], args.size, rows=strip_rows_all)
-            return labelled(full) if rank == 0 else (no_labels, no_num)
+            mine = force_label[0] if force_label[0] is not None else (k % world == rank)
+            _, _, _, mask = ca.swi_infer_share(model, image, roi, args.overlap, rank, world, engine_batch=args.strip_batch or None,
+                                               streams=args.streams, exchange=seam_exchange)
+            full = parallel.gather_shares(mask, plan, world, assemble=mine)
+            return labelled(full) if mine else (no_labels, no_num)
 
         def step_sim():
             """ONE GPU doing the work of rank sim[0] of sim[1] of the strips leg: its windows, the local pack / unpack copies of the
-            seam exchange (the link transfer itself, 12 MB over one xGMI link, is not simulated), the finalize of its rows, and - for
-            rank 0 - the connected-component pass over a FULL mask (sim[2], from the single-GPU leg) on the CC stream."""
-            image = imgs[it[0] % 2]
+            exchange (the link transfer itself, 12 MB over one xGMI link, is not simulated), the finalize of its rectangles, a device-local
+            copy of the gathered mask's size in place of the all-gather, and - on its turn, every sim[1]-th slide - the connected-component
+            pass over a FULL mask (sim[2], from the single-GPU leg) on the CC stream."""
+            k = it[0]
+            image = imgs[k % 2]
             it[0] += 1
             r, w, full_mask = sim
 
             def fake_exchange(win, pl, rr, ww):
-                me = ca.strip_partition(pl, rr, ww)
-                for src, dst, j, r0 in parallel.seam_transfers(pl, ww):
-                    if dst == rr:                # pack (sender's side, stood in for locally), a device-local copy in place of the link, unpack
-                        win[j - me.halo_begin, :, r0:].copy_(win[me.win_row_end - 1 - me.halo_begin, :, r0:].contiguous().clone())
-                    elif src == rr:
-                        win[j - me.halo_begin, :, r0:].contiguous().clone()
-            ca.swi_infer_strip(model, image, roi, args.overlap, r, w, engine_batch=args.strip_batch or None, streams=args.streams,
+                base = ca.share_partition(pl, rr, ww).slot_row_begin * pl.n_w
+                for (src, dst), groups in parallel._share_groups(pl, ww).items():
+                    for (lo, hi), ks in groups:
+                        if dst == rr:            # pack (stood in for locally: the rank's own last windows), a device-local copy in place of the link, unpack
+                            own = torch.as_tensor([sh_me.win_end - 1 - base - (i % 8) for i in range(len(ks))], dtype=torch.long, device=win.device)
+                            win[torch.as_tensor([kk - base for kk in ks], dtype=torch.long, device=win.device), lo:hi] = win[own, lo:hi].clone()
+                        elif src == rr:
+                            win[torch.as_tensor([kk - base for kk in ks], dtype=torch.long, device=win.device), lo:hi].clone()
+            sh_me = ca.share_partition(plan, r, w)
+            ca.swi_infer_share(model, image, roi, args.overlap, r, w, engine_batch=args.strip_batch or None, streams=args.streams,
                                exchange=fake_exchange)
             gathered = full_mask.clone()         # a device-local copy of the gathered mask's size in place of the all-gather
-            return labelled(gathered) if r == 0 else (no_labels, no_num)
+            return labelled(gathered) if k % w == r else (no_labels, no_num)
 
         inner = step_sim if sim else (step_strips if (strips and dist is not None) else step_slide)
+        inner.it, inner.force_label = it, force_label
         if not d2h:
             return inner
 
@@ -664,6 +674,7 @@ def main():
                 host.copy_(lab, non_blocking=True)
             lab.record_stream(copy_stream)
             return lab, num
+        step_d2h.it, step_d2h.force_label = it, force_label
         return step_d2h
 
     def measure_infer(width, precision, strips, with_prof, extras=False):
@@ -677,8 +688,12 @@ def main():
         with torch.no_grad():
             for _ in range(args.warmup):
                 step_host()
-            dt, (labels, num) = time_steps(step_host, args.steps, barrier)
+            dt, _ = time_steps(step_host, args.steps, barrier)
             dt_dev, _ = time_steps(step_dev, args.steps, barrier)
+            # one more step, untimed, on the FIRST slide of the pair with rank 0 labelling it: the label map the legs are compared by
+            step_dev.it[0], step_dev.force_label[0] = 0, rank == 0
+            labels, num = step_dev()
+            step_dev.force_label[0] = None
             dt_prof = 0.0
             if with_prof:
                 # same K steps again with HIP events around every kernel launch (on the launch stream) for the roofline
@@ -741,28 +756,31 @@ def main():
                          "threshold, post-process -> int32 deflate TIFF on disk (label map deflated on the device, compressed strips to the host), one image at a time"}
 
     def measure_strips_sim(model, full_s, sim_world=8):
-        """How long ONE rank of the 8-GPU strips leg works per slide, measured on this GPU (see step_sim): rank 0 (smaller share of the
-        windows + the connected-component pass) and an interior rank (larger share, no labelling); the job runs at the slower of them."""
+        """How long ONE rank of the 8-GPU strips leg works per slide, measured on this GPU (see step_sim): rank 0 (sends only), an
+        interior rank (receives and sends) and the last rank (the share with one window more); every rank labels every 8th slide.  The
+        job runs at the slowest of them."""
         _, _, full_mask = ca.swi_infer_image(model, slide_pair(True)[0], roi, args.overlap, engine_batch=args.engine_batch or None,
                                              want_logits=False, want_mask=True, streams=args.streams)
-        parts = [ca.strip_partition(plan, r, sim_world) for r in range(sim_world)]
+        parts = [ca.share_partition(plan, r, sim_world) for r in range(sim_world)]
+        n_sim = -(-args.steps // sim_world) * sim_world              # whole rounds of the labelling turn
         ranks = {}
-        for sim_rank in sorted({0, min(3, sim_world - 1)}):
+        for sim_rank in sorted({0, min(3, sim_world - 1), sim_world - 1}):
             step = make_step(model, True, False, sim=(sim_rank, sim_world, full_mask))
             for _ in range(2):
                 step()
-            dt_sim, _ = time_steps(step, args.steps, barrier)
-            st = parts[sim_rank]
-            ranks[str(sim_rank)] = {"windows": (st.win_row_end - st.win_row_begin) * plan.n_w, "labels_the_mask": sim_rank == 0,
-                                    "ms_per_slide": round(dt_sim / args.steps * 1e3, 3)}
+            step.it[0] = 0
+            dt_sim, _ = time_steps(step, n_sim, barrier)
+            ranks[str(sim_rank)] = {"windows": parts[sim_rank].win_end - parts[sim_rank].win_begin, "labels_every": sim_world,
+                                    "ms_per_slide": round(dt_sim / n_sim * 1e3, 3)}
         worst = max(v["ms_per_slide"] for v in ranks.values())
-        return {"of": sim_world, "ranks": ranks, "window_rows_per_rank": [p.win_row_end - p.win_row_begin for p in parts],
-                "max_windows_per_rank": max(p.win_row_end - p.win_row_begin for p in parts) * plan.n_w,
+        return {"of": sim_world, "ranks": ranks, "windows_per_rank": [p.win_end - p.win_begin for p in parts],
+                "max_windows_per_rank": max(p.win_end - p.win_begin for p in parts), "steps": n_sim,
                 "ms_per_slide": worst, "full_slide_ms": round(full_s * 1e3, 3), "ratio": round(full_s * 1e3 / worst, 3),
-                "note": "one GPU doing one rank's share of the 8-rank strips leg (its windows, the seam pack / unpack copies, its finalize; "
-                        "rank 0 also the CC pass over a full mask on the CC stream); ms_per_slide = the slower of the simulated ranks; the seam "
-                        "transfer (12 MB over one xGMI link) and the mask all-gather (16 MB gathered) are stood in for by device-local copies of "
-                        "the same sizes, so `ratio` is an UPPER bound of the 8-GPU speed-up: link latency, RCCL launch cost and rank skew are not in it"}
+                "note": "one GPU doing one rank's share of the 8-rank strips leg (window-list partition: its 120 / 121 windows, the exchange's pack / "
+                        "unpack copies, the finalize of its rectangles, and on its turn - every 8th slide - the CC pass over a full mask on the CC "
+                        "stream); ms_per_slide = the slowest of the simulated ranks; the seam transfer (12 MB over one xGMI link) and the mask "
+                        "all-gather (16 MB gathered) are stood in for by device-local copies of the same sizes, so `ratio` is an UPPER bound of "
+                        "the 8-GPU speed-up: link latency, RCCL launch cost and rank skew are not in it"}
 
     def measure_tiles(width, precision, n, k=20):
         """SURVEY.md 8(d) 'tile throughput': forward-only U-Net on N x 3 x 256 x 256 synthetic tiles (the predictor call of
@@ -976,7 +994,7 @@ def main():
                                    + ("one slide cut into row strips" if head_strips else "one slide per GPU"),
                        "windows": n_windows, "engine_batch": args.engine_batch or ca.balanced_batch(n_windows, args.streams), "engine_batch_auto": not args.engine_batch,
                        "streams": args.streams, "precision": args.precision,
-                       "parallelism": (f"1 slide split by window rows over {world} ranks + seam send/recv + mask all-gather" if head_strips
+                       "parallelism": (f"1 slide split by its window list over {world} ranks + seam send/recv + mask all-gather, labelling rank round-robin" if head_strips
                                        else f"slides x{world}"),
                        "instances_found": main_res["n_instances"], "foreground_fraction": round(main_res["fg_frac"], 4)},
             "value_device": round(slides * mpix * args.steps / main_res["dt_dev"], 3),
@@ -1086,15 +1104,16 @@ def main():
 
     out = base_line(main_res, head_strips)
     strips_info = {"seam_transport": seam["transport"], "strips_error": strips_error,
-                   "window_rows_per_rank": [st.win_row_end - st.win_row_begin for st in strip_parts],
-                   "windows_per_rank": [(st.win_row_end - st.win_row_begin) * plan.n_w for st in strip_parts],
-                   "output_rows_per_rank": [st.row_end - st.row_begin for st in strip_parts], "strip_batch": args.strip_batch or "auto",
+                   "partition": "window list (cs_swi_partition_windows): contiguous shares that differ by at most one window",
+                   "windows_per_rank": [sh.win_end - sh.win_begin for sh in share_parts],
+                   "output_pixels_per_rank": [sum((r1 - r0) * (c1 - c0) for r0, r1, c0, c1 in sh.rects()) for sh in share_parts],
+                   "labelling": "round-robin over the ranks", "strip_batch": args.strip_batch or "auto",
                    "equal_to_single_gpu_labels": strips_equal}
     if other_part:
         out["strips" if not head_strips else "slides"] = dict(
             other_part, scaling="strong" if not head_strips else "weak",
-            note=("ONE slide split by window rows across the ranks (no window evaluated twice), seam halves sent to the neighbour below, "
-                  "uint8 mask strips all-gathered, CC on rank 0 (smaller window share) on its CC stream: value = one slide's pixels / time"
+            note=("ONE slide split by its window list across the ranks (shares differ by one window at most; no window evaluated twice), window parts sent to the later neighbour, "
+                  "finalised uint8 rectangles all-gathered, CC + label copy on rank (slide index mod N) on its CC stream: value = one slide's pixels / time"
                   if not head_strips else "one slide per rank, no collective: value = N slides' pixels / time"))
         out["strips" if not head_strips else "slides"].update(strips_info if not head_strips else {})
         out["value_slides"] = out["value"] if not head_strips else other_part["value"]
@@ -1137,6 +1156,11 @@ def main():
                                 "pixels / time; roofline = the dominant kernel of that forward (HIP events on the launch stream)")
         if args.precision == "fp32" and args.size == 4096:
             out["configs4_fp8"] = measure_configs4()
+            try:          # ... and its accuracy claim at its OWN width and window: the 64...1024 net trained on synthetic cells, 512^2 windows
+                acc4 = lowprec_accuracy(dev, n_images=4, size=2048, precisions=("bf16", "fp8"), width="deep64", roi=512)
+                out["configs4_fp8"]["accuracy_on_trained_net"] = acc4
+            except Exception as e:                                  # noqa: BLE001
+                out["configs4_fp8"]["accuracy_on_trained_net"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if world == 1 and dist is None and not args.no_secondary and args.precision == "fp32" and "tiles" in out and train_res and modes:
         try:
             engine_ms = {"tiles_fp32": out["tiles"]["fp32"]["n32"]["ms_per_forward"], "tiles_bf16": out["tiles"]["bf16"]["n32"]["ms_per_forward"],

@@ -204,10 +204,35 @@ typedef struct cs_swi_strip {
 } cs_swi_strip;
 int cs_swi_partition(const cs_swi_plan* plan_host, int rank, int world, cs_swi_strip* out_host);
 
+/* Window-LIST partition (round 5): the row-major window list cut into `world` contiguous shares that differ by at most ONE window
+ * (961 windows over 8 ranks = 120 or 121 each; whole window rows give 3,4,...,4 rows = 93...124).  A pixel is finalised by the rank that
+ * evaluates the LAST window (highest index) covering it, so every window a rank still needs has a lower index and comes from an earlier
+ * rank - the same one-directional seam as the row partition, and the sums keep the reference's window-index order (bit-identical result).
+ *   [win_begin, win_end)            window indices rank `rank` evaluates (cs_swi_windows_range)
+ *   [slot_row_begin, slot_row_end)  window rows its window buffer holds: its own rows and the earlier rows that still cover its first
+ *                                   image row; window k lives in slot k - slot_row_begin * n_w
+ *   rect[n_rects][4]                the image rectangles (row_begin, row_end, col_begin, col_end) it finalises (cs_swi_finalize_rect):
+ *                                   the rest of its first window row's band, whole bands, the beginning of its last band */
+typedef struct cs_swi_share {
+    int win_begin, win_end;
+    int slot_row_begin, slot_row_end;
+    int n_rects;
+    int rect[3][4];
+} cs_swi_share;
+int cs_swi_partition_windows(const cs_swi_plan* plan_host, int rank, int world, cs_swi_share* out_host);
+/* cs_swi_windows for a range of window INDICES: logits of window k go to win_logits[k - win_begin]. */
+int cs_swi_windows_range(cs_unet* net, const cs_swi_plan* plan_host, const float* image, int64_t sc, int64_t sh, int64_t sw,
+                         int engine_batch, int win_begin, int win_end, float* win_logits,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* Finalize step alone (average overlapping windows in window-index order, softmax, threshold) for window
  * predictions produced by any predictor: win_logits [(#window rows from ih_base) * n_w][roi_h][roi_w][classes]. */
 int cs_swi_finalize(const cs_swi_plan* plan_host, const float* win_logits, int classes, int ih_base,
                     int row_begin, int row_end, float* logits_nchw, float* prob1, uint8_t* mask, void* stream);
+/* ... restricted to the image rectangle [row_begin, row_end) x [col_begin, col_end). */
+int cs_swi_finalize_rect(const cs_swi_plan* plan_host, const float* win_logits, int classes, int ih_base,
+                         int row_begin, int row_end, int col_begin, int col_end,
+                         float* logits_nchw, float* prob1, uint8_t* mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Input normalisation  -  replaces normalize_channel + the channel fix-up + `/ np.max`

@@ -26,6 +26,15 @@ class SwiStrip(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("win_row_begin", "win_row_end", "halo_begin", "row_begin", "row_end")]
 
 
+class SwiShare(C.Structure):
+    """Mirror of ``cs_swi_share`` (window-list partition of one image over ranks)."""
+    _fields_ = [("win_begin", C.c_int), ("win_end", C.c_int), ("slot_row_begin", C.c_int), ("slot_row_end", C.c_int), ("n_rects", C.c_int),
+                ("rect", (C.c_int * 4) * 3)]
+
+    def rects(self):
+        return [tuple(self.rect[i]) for i in range(self.n_rects)]
+
+
 class SwiPlan(C.Structure):
     """Mirror of ``cs_swi_plan``."""
     _fields_ = [(n, C.c_int) for n in ("img_h", "img_w", "roi_h", "roi_w", "pad_top", "pad_left", "pad_h", "pad_w",
@@ -70,6 +79,9 @@ def _load() -> C.CDLL:
         "cs_swi_windows_workspace_bytes": (sz, [vp, C.POINTER(SwiPlan), i32]),
         "cs_swi_windows": (i32, [vp, C.POINTER(SwiPlan), vp, i64, i64, i64, i32, i32, i32, vp, vp, sz, vp]),
         "cs_swi_partition": (i32, [C.POINTER(SwiPlan), i32, i32, C.POINTER(SwiStrip)]),
+        "cs_swi_partition_windows": (i32, [C.POINTER(SwiPlan), i32, i32, C.POINTER(SwiShare)]),
+        "cs_swi_windows_range": (i32, [vp, C.POINTER(SwiPlan), vp, i64, i64, i64, i32, i32, i32, vp, vp, sz, vp]),
+        "cs_swi_finalize_rect": (i32, [C.POINTER(SwiPlan), vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
         "cs_swi_infer": (i32, [vp, C.POINTER(SwiPlan), vp, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
         "cs_swi_finalize": (i32, [C.POINTER(SwiPlan), vp, i32, i32, i32, i32, vp, vp, vp, vp]),
         "cs_normalize_workspace_bytes": (sz, [i32, i32]),
@@ -118,7 +130,7 @@ lib = _load()
 EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_destroy cs_unet_set_precision cs_unet_set_training cs_unet_set_batch_stats cs_unet_read_param cs_unet_set_streams cs_unet_trace cs_unet_trace_count cs_unet_trace_entry cs_unet_num_params "
             "cs_unet_param_info cs_unet_load_param cs_unet_load_begin cs_unet_load_end cs_unet_workspace_bytes cs_unet_forward cs_unet_grad_numel "
             "cs_unet_grad_offset cs_unet_backward_workspace_bytes cs_unet_backward cs_swi_make_plan "
-            "cs_swi_window_start cs_swi_workspace_bytes cs_swi_windows_workspace_bytes cs_swi_windows cs_swi_partition cs_swi_infer cs_swi_finalize cs_normalize_workspace_bytes "
+            "cs_swi_window_start cs_swi_workspace_bytes cs_swi_windows_workspace_bytes cs_swi_windows cs_swi_partition cs_swi_partition_windows cs_swi_windows_range cs_swi_infer cs_swi_finalize cs_swi_finalize_rect cs_normalize_workspace_bytes "
             "cs_normalize_image cs_label_max cs_label_overlap cs_remove_boundary_workspace_bytes cs_remove_boundary_cells "
             "cs_augment_workspace_bytes cs_augment_batch cs_label_deflate_workspace_bytes cs_label_deflate_bound cs_label_deflate cs_ccl_workspace_bytes "
             "cs_ccl_postprocess cs_ccl_label cs_interior_map cs_dice_ce_workspace_bytes cs_dice_ce_forward cs_dice_ce_backward cs_adamw_step "

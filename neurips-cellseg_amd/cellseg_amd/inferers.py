@@ -18,7 +18,7 @@ from typing import Callable, Optional, Sequence, Tuple, Union
 import torch
 
 from . import _lib
-from ._lib import SwiPlan, SwiStrip, check, lib
+from ._lib import SwiPlan, SwiShare, SwiStrip, check, lib
 from .unet import UNet
 
 DEFAULT_ENGINE_BATCH = 256   # windows per engine call when the caller fixes the batch (strips leg, tests)
@@ -64,6 +64,15 @@ def strip_partition(plan: SwiPlan, rank: int, world: int) -> SwiStrip:
     st = SwiStrip()
     check(lib.cs_swi_partition(C.byref(plan), int(rank), int(world), C.byref(st)), "cs_swi_partition")
     return st
+
+
+def share_partition(plan: SwiPlan, rank: int, world: int) -> SwiShare:
+    """Window-LIST partition of one image (``cs_swi_partition_windows``): the row-major window list cut into contiguous shares that
+    differ by at most one window (961 windows over 8 ranks = 120 / 121; whole window rows give 93...124), the image rectangles the
+    rank finalises (the pixels whose LAST covering window is one of its own) and the window rows its buffer has to hold."""
+    sh = SwiShare()
+    check(lib.cs_swi_partition_windows(C.byref(plan), int(rank), int(world), C.byref(sh)), "cs_swi_partition_windows")
+    return sh
 
 
 WORKSPACE_BUDGET = 64 << 30     # bytes of HBM the tiler may take for window activations (of 288 GB)
@@ -169,6 +178,60 @@ def swi_infer_strip(model: UNet, image: torch.Tensor, roi_size, overlap: float, 
         check(lib.cs_swi_finalize(C.byref(plan), ptr(win), model.out_channels, st.halo_begin, st.row_begin, st.row_end,
                                   ptr(logits), ptr(prob), ptr(mask), _lib.stream_ptr()), "cs_swi_finalize")
     return st, logits, prob, mask
+
+
+def swi_infer_share(model: UNet, image: torch.Tensor, roi_size, overlap: float, rank: int, world: int, *,
+                    engine_batch: Optional[int] = None, streams: int = DEFAULT_STREAMS, exchange=None,
+                    want_logits: bool = False, want_prob: bool = False, want_mask: bool = True):
+    """ONE image split over `world` ranks by the window LIST (``share_partition``; multi-GPU tiled inference; the
+    reference is single-device, baseline/predict.py:109).  This rank evaluates its own windows (``cs_swi_windows_range``), obtains the
+    parts of earlier ranks' windows that cover its rectangles through ``exchange(win, plan, rank, world)`` - ``parallel.exchange_share``
+    under torch.distributed; ``None`` evaluates them locally (single process) - and finalises its rectangles (``cs_swi_finalize_rect``).
+    Every window a rank lacks has a LOWER index than its own, and the reference adds window predictions in window-index order, so the
+    received parts are exactly the prefix of each pixel's sum: bit-identical to the single-GPU result.
+    -> (share, logits | None, prob1 | None, mask | None); only the share's rectangles of the outputs are written."""
+    _lib.require_gpu(image)
+    if image.dim() != 3:
+        raise ValueError("image must be [C,H,W]")
+    if image.dtype != torch.float32:
+        image = image.float()
+    _, h, w = image.shape
+    plan = make_plan(h, w, roi_size, overlap)
+    sh = share_partition(plan, rank, world)
+    eng = model.engine()
+    dev = image.device
+    logits = torch.empty((model.out_channels, h, w), dtype=torch.float32, device=dev) if want_logits else None
+    prob = torch.empty((h, w), dtype=torch.float32, device=dev) if want_prob else None
+    mask = torch.empty((h, w), dtype=torch.uint8, device=dev) if want_mask else None
+    if sh.win_end == sh.win_begin:
+        return sh, logits, prob, mask
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()   # noqa: E731
+    with torch.cuda.device(dev):
+        check(lib.cs_unet_set_streams(eng.handle, int(streams)), "cs_unet_set_streams")
+        if not engine_batch:
+            engine_batch = balanced_batch(sh.win_end - sh.win_begin, streams)
+        engine_batch, nbytes = _capped_batch(model, eng, plan, engine_batch, dev, lib.cs_swi_windows_workspace_bytes)
+        ws = model.workspace(("swistrip", h, w, plan.roi_h, plan.roi_w, plan.n_h, plan.n_w, engine_batch, int(streams)), nbytes, dev)
+        base = sh.slot_row_begin * plan.n_w
+        n_slots = (sh.slot_row_end - sh.slot_row_begin) * plan.n_w
+        win_bytes = n_slots * plan.roi_h * plan.roi_w * model.out_channels * 4
+        win = model.workspace(("swiwin", n_slots, plan.roi_h, plan.roi_w), win_bytes, dev)[:win_bytes]
+        win = win.view(torch.float32).view(n_slots, plan.roi_h, plan.roi_w, model.out_channels)
+        sc, sh_, sw = image.stride()
+
+        def run(k_lo, k_hi):
+            check(lib.cs_swi_windows_range(eng.handle, C.byref(plan), ptr(image), sc, sh_, sw, engine_batch, int(k_lo), int(k_hi),
+                                           ptr(win[k_lo - base]), ptr(ws), ws.numel(), _lib.stream_ptr()), "cs_swi_windows_range")
+
+        run(sh.win_begin, sh.win_end)
+        if exchange is not None:
+            exchange(win, plan, rank, world)
+        elif sh.win_begin > base:
+            run(base, sh.win_begin)                              # single process: the earlier windows of the held rows, evaluated here
+        for r0, r1, c0, c1 in sh.rects():
+            check(lib.cs_swi_finalize_rect(C.byref(plan), ptr(win), model.out_channels, sh.slot_row_begin, r0, r1, c0, c1,
+                                           ptr(logits), ptr(prob), ptr(mask), _lib.stream_ptr()), "cs_swi_finalize_rect")
+    return sh, logits, prob, mask
 
 
 def sliding_window_inference(inputs: torch.Tensor, roi_size: Union[Sequence[int], int], sw_batch_size: int,

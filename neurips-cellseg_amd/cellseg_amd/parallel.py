@@ -176,6 +176,140 @@ def exchange_seam(win: torch.Tensor, plan, rank: int, world: int, group=None, tr
     return len(ops)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# window-LIST partition (inferers.share_partition): shares of 120 / 121 windows instead of 3 / 4 window rows
+# ----------------------------------------------------------------------------------------------------------------------
+def share_transfers(plan, world: int) -> List[Tuple[int, int, int, int, int]]:
+    """Every (src_rank, dst_rank, window, row_lo, row_hi) the window-list partition needs: window `window`, evaluated by src_rank,
+    intersects a rectangle dst_rank finalises - its window-local rows [row_lo, row_hi) (all columns: one contiguous block) are what
+    dst_rank reads.  src_rank < dst_rank always (a pixel belongs to the rank of its LAST covering window).  Deterministic and
+    identical on every rank."""
+    from .inferers import share_partition, window_starts
+    shares = [share_partition(plan, r, world) for r in range(world)]
+    hs, ws = window_starts(plan)                                    # padded coordinates
+    out = []
+    for dst, sh in enumerate(shares):
+        rects = [(r0 + plan.pad_top, r1 + plan.pad_top, c0 + plan.pad_left, c1 + plan.pad_left) for r0, r1, c0, c1 in sh.rects()]
+        for k in range(sh.slot_row_begin * plan.n_w, sh.win_begin):
+            i, j = divmod(k, plan.n_w)
+            lo, hi = None, None
+            for r0, r1, c0, c1 in rects:
+                a, b = max(r0, hs[i]), min(r1, hs[i] + plan.roi_h)
+                if a < b and max(c0, ws[j]) < min(c1, ws[j] + plan.roi_w):
+                    lo = a if lo is None else min(lo, a)
+                    hi = b if hi is None else max(hi, b)
+            if lo is not None:
+                src = next(r for r, s in enumerate(shares) if s.win_begin <= k < s.win_end)
+                out.append((src, dst, k, lo - hs[i], hi - hs[i]))
+    return out
+
+
+def _share_groups(plan, world: int):
+    """share_transfers grouped for the wire: {(src, dst): [((row_lo, row_hi), [windows...]), ...]} - the windows of one pair that want the
+    same rows travel as ONE tensor [n, rows, roi_w, C] (three groups per pair at most: lower halves, the left neighbour's upper part)."""
+    groups = {}
+    for src, dst, k, lo, hi in share_transfers(plan, world):
+        groups.setdefault((src, dst), {}).setdefault((lo, hi), []).append(k)
+    return {pair: sorted(g.items()) for pair, g in groups.items()}
+
+
+def exchange_share(win: torch.Tensor, plan, rank: int, world: int, group=None, transport: str = "p2p") -> int:
+    """Seam exchange of the window-LIST partition.  win: this rank's window slots [n_slots, roi_h, roi_w, C] (``inferers.swi_infer_share``:
+    slot of window k = k - slot_row_begin * n_w).  Sends the parts of its windows that later ranks finalise under and receives the parts
+    of earlier ranks' windows that cover its own rectangles; transports as ``exchange_seam`` (batched RCCL send/recv, or ONE all-gather
+    of equally sized slots for a library whose point-to-point path fails).  Returns the number of tensors this rank sent or received."""
+    import torch.distributed as dist
+    from .inferers import share_partition
+    if transport not in ("p2p", "allgather"):
+        raise ValueError(f"exchange_share: unknown transport {transport!r}")
+    groups = _share_groups(plan, world)
+    if not groups or not _collectives_on(group):
+        return 0
+    base = share_partition(plan, rank, world).slot_row_begin * plan.n_w
+    idx = lambda ks: torch.as_tensor([k - base for k in ks], dtype=torch.long, device=win.device)      # noqa: E731
+    bounce = _host_bounce(win, group)
+    wire = torch.device("cpu") if bounce else win.device
+    n = 0
+    if transport == "allgather":
+        offs, fill = {}, [0] * world
+        for (src, dst), gs in sorted(groups.items()):
+            for (lo, hi), ks in gs:
+                offs[(src, dst, lo, hi)] = fill[src]
+                fill[src] += len(ks) * (hi - lo) * plan.roi_w * win.shape[-1]
+        slot = max(fill)
+        mine = torch.zeros(slot, dtype=win.dtype, device=wire)
+        for (src, dst), gs in sorted(groups.items()):
+            if src == rank:
+                for (lo, hi), ks in gs:
+                    part = win[idx(ks), lo:hi].reshape(-1)
+                    o = offs[(src, dst, lo, hi)]
+                    mine[o:o + part.numel()].copy_(part)
+                    n += 1
+        out = mine.new_empty(world * slot)
+        dist.all_gather_into_tensor(out, mine, group=group)
+        for (src, dst), gs in sorted(groups.items()):
+            if dst == rank:
+                for (lo, hi), ks in gs:
+                    o = src * slot + offs[(src, dst, lo, hi)]
+                    numel = len(ks) * (hi - lo) * plan.roi_w * win.shape[-1]
+                    win[idx(ks), lo:hi] = out[o:o + numel].view(len(ks), hi - lo, plan.roi_w, win.shape[-1]).to(win.device)
+                    n += 1
+        return n
+    ops, landing = [], []
+    for (src, dst), gs in sorted(groups.items()):
+        if rank not in (src, dst):
+            continue
+        for (lo, hi), ks in gs:
+            if rank == src:
+                buf = win[idx(ks), lo:hi]                           # advanced indexing: a packed copy [n, rows, roi_w, C]
+                ops.append(dist.P2POp(dist.isend, buf.to(wire), dst, group))
+            else:
+                buf = torch.empty((len(ks), hi - lo, plan.roi_w, win.shape[-1]), dtype=win.dtype, device=wire)
+                ops.append(dist.P2POp(dist.irecv, buf, src, group))
+                landing.append((ks, lo, hi, buf))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for ks, lo, hi, buf in landing:
+        win[idx(ks), lo:hi] = buf.to(win.device)
+    return len(ops)
+
+
+def gather_shares(mask: torch.Tensor, plan, world: int, group=None, assemble: bool = True) -> Optional[torch.Tensor]:
+    """all-gather of the rectangles every rank finalised (``inferers.share_partition``) into the full [img_h, img_w] tensor: ONE
+    collective over equally sized flat slots (RCCL on device tensors).  mask: this rank's full-size tensor with its rectangles filled in.
+    Every rank takes part; ``assemble=False`` skips the unpacking on ranks that do not need the full tensor (only the rank that labels
+    this slide does) and returns None."""
+    import torch.distributed as dist
+    from .inferers import share_partition
+    if not _collectives_on(group):
+        return mask
+    shares = [share_partition(plan, r, world) for r in range(world)]
+    sizes = [sum((r1 - r0) * (c1 - c0) for r0, r1, c0, c1 in s.rects()) for s in shares]
+    slot = max(max(sizes), 1)
+    rank = dist.get_rank(group)
+    bounce = _host_bounce(mask, group)
+    wire = torch.device("cpu") if bounce else mask.device
+    mine = torch.zeros(slot, dtype=mask.dtype, device=wire)
+    o = 0
+    for r0, r1, c0, c1 in shares[rank].rects():
+        part = mask[r0:r1, c0:c1].reshape(-1)
+        mine[o:o + part.numel()].copy_(part)
+        o += part.numel()
+    out = mine.new_empty(world * slot)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    if not assemble:
+        return None
+    full = torch.empty_like(mask)
+    for r, s in enumerate(shares):
+        o = r * slot
+        for r0, r1, c0, c1 in s.rects():
+            n = (r1 - r0) * (c1 - c0)
+            full[r0:r1, c0:c1] = out[o:o + n].view(r1 - r0, c1 - c0).to(mask.device)
+            o += n
+    return full
+
+
 def sync_gradients(model, group=None, reduce: bool = True, rebind: bool = True) -> None:
     """Data-parallel gradient exchange: ONE RCCL all-reduce over the engine's flat fp32
     gradient bucket (6.5 MB at the reference width), then the mean.  `loss.backward()` leaves every parameter

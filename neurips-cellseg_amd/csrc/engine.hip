@@ -253,12 +253,6 @@ struct cs_unet {
     int n_streams = 1;
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
-    // stagger of the window streams (swi_run_windows): the first chunk's stream records ev_stagger after encoder level `stagger_level`
-    // of its forward (unet_forward_impl, when stagger_armed), the second chunk's stream starts behind that event - the two streams then
-    // run DIFFERENT layers at any time, HBM-bound launches of one beside matrix-bound launches of the other
-    hipEvent_t ev_stagger = nullptr;
-    int stagger_level = -1;
-    mutable bool stagger_armed = false;
     Tape tape;
     // backward: the weight-gradient launches (off the critical chain dy -> data gradient -> norm backward -> dy) run on a side
     // stream, forked from the caller's stream by an event once their dy is complete
@@ -740,10 +734,6 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
             tap(pfx + "Aq", Aq, oh, ow, c, c, 2);
             for (int su = 0; su < u.subunits; ++su) tap(pfx + "tab" + std::to_string(su), rt_down[d][su].tab, 1, 1, su == 0 ? c0 : c, su == 0 ? c0 : c, 3);
         }
-        if (!dry && net->stagger_armed && d == net->stagger_level) {
-            CS_HIP(hipEventRecord(net->ev_stagger, s));
-            net->stagger_armed = false;
-        }
         prev = X[d];
         prevq = Xq[d];
         ph = oh; pw = ow; pc = c;
@@ -859,11 +849,12 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                 const int c_up = net->up[d - 1].cout;
                 const bool fused_mid = fuse_sum && d >= 2 && c_up % 16 == 0 && rt_upt[d].tab && rt_upu[d].tab && !(q8 && net->up[d - 1].convt.f8) &&
                                        (a16 ? (c % 32 == 0 && net->up[d - 1].convt.wb != nullptr) : (c_up % 64 != 0 || fuse_env == 2));
-                // ... and the 3-channel top layer (fp32 path): its GEMM + gather kernel stages act(norm(V)) + act(norm(U)) itself for the
-                // 32 channels that come from below - measured -0.9 ms of norm_act_add for +0.3 ms in that kernel per slide
+                // ... and the 3-channel top layer: its GEMM + gather kernel stages act(norm(V)) + act(norm(U)) itself for the 32 channels
+                // that come from below - fp32 path: measured -0.9 ms of norm_act_add for +0.3 ms in that kernel per slide; bf16 datapath /
+                // mixed fp8 mode (round 5): the sum is rounded to bf16 once while it is staged, bitwise what norm_act_add16x8 would have stored
                 const int cin_top = net->up[0].cin_skip + c;
-                const bool fused_top = fuse_sum && d == 1 && !a16 && net->up[0].top && rt_upt[d].tab && rt_upu[d].tab && c % 4 == 0 &&
-                                       net->up[0].cin_skip == c && (cin_top == 64 || cin_top == 128);
+                const bool fused_top = fuse_sum && d == 1 && (!a16 || c % 16 == 0) && net->up[0].top && rt_upt[d].tab && rt_upu[d].tab &&
+                                       c % 4 == 0 && net->up[0].cin_skip == c && (cin_top == 64 || cin_top == 128);
                 const bool fused = fused_mid || fused_top;
                 if (fused) {
                     sub = lv;
@@ -1245,10 +1236,10 @@ static int check_loaded(const cs_unet* net, bool for_backward = false) {
     return CS_OK;
 }
 
-__global__ void swi_origins_kernel(cs_swi_plan pl, int ih_lo, int count, int2* out) {
+__global__ void swi_origins_kernel(cs_swi_plan pl, int k_lo, int count, int2* out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
-    const int ih = ih_lo + k / pl.n_w, iw = k % pl.n_w;
+    const int ih = (k_lo + k) / pl.n_w, iw = (k_lo + k) % pl.n_w;
     int hs = ih * pl.interval_h, wsx = iw * pl.interval_w;
     hs = hs < pl.pad_h - pl.roi_h ? hs : pl.pad_h - pl.roi_h;
     wsx = wsx < pl.pad_w - pl.roi_w ? wsx : pl.pad_w - pl.roi_w;
@@ -1395,11 +1386,6 @@ int cs_unet_set_streams(cs_unet* net, int n) {
         if (!net->ev_join[i]) CS_HIP(hipEventCreateWithFlags(&net->ev_join[i], hipEventDisableTiming));
     }
     if (n > 1 && !net->ev_fork) CS_HIP(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
-    if (n > 1 && !net->ev_stagger) CS_HIP(hipEventCreateWithFlags(&net->ev_stagger, hipEventDisableTiming));
-    {   // experiment switch (round 5): CS_SWI_STAGGER=<encoder level> delays the second window stream behind that level of the first
-        static const int lvl = [] { const char* e = getenv("CS_SWI_STAGGER"); return e ? atoi(e) : -1; }();
-        net->stagger_level = lvl;
-    }
     net->n_streams = n;
     return CS_OK;
 }
@@ -1411,7 +1397,6 @@ int cs_unet_destroy(cs_unet* net) {
         if (net->ev_join[i]) (void)hipEventDestroy(net->ev_join[i]);
     }
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
-    if (net->ev_stagger) (void)hipEventDestroy(net->ev_stagger);
     for (auto& st : net->bwd_side)
         if (st) {
             (void)hipStreamSynchronize(st);
@@ -1646,15 +1631,14 @@ int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspac
     CS_HIP(hipMemsetAsync(workspace, 0, acc_bytes, s));
     CS_HIP(hipMemsetAsync(flat_grad, 0, (size_t)net->grad_floats * sizeof(float), s));
     Bump acc(workspace, acc_bytes), buf((char*)workspace + acc_bytes, workspace_bytes - acc_bytes);
-    static const bool side_env = !(getenv("CS_BWD_SIDE") && atoi(getenv("CS_BWD_SIDE")) == 0);     // A/B: CS_BWD_SIDE=0 = one stream
-    static const int n_side_env = getenv("CS_BWD_SIDE") ? atoi(getenv("CS_BWD_SIDE")) : 1;   // measured: 7.38 ms (0) / 6.90 (1) / 7.04 (2 alternating)
+    static const bool side_env = !(getenv("CS_BWD_SIDE") && atoi(getenv("CS_BWD_SIDE")) == 0);     // A/B: CS_BWD_SIDE=0 = one stream (7.38 vs 6.90 ms per step)
     if (side_env && !prof_enabled() && !net->bwd_side[0]) {      // (per-kernel HIP-event profiling keeps everything on one stream)
         for (auto& st : net->bwd_side) CS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (auto& ev : net->bwd_ev) CS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     const bool use_side = side_env && !prof_enabled() && net->bwd_side[0];
     net->tape.valid = false;      // the gradient buffers reuse nothing of the tape, but one backward per forward (also when it fails)
-    rc = unet_backward_impl(net, grad_logits_nhwc, acc, buf, flat_grad, s, net->bwd_side, use_side ? (n_side_env >= 2 ? 2 : 1) : 0, net->bwd_ev, 48);
+    rc = unet_backward_impl(net, grad_logits_nhwc, acc, buf, flat_grad, s, net->bwd_side, use_side ? 1 : 0, net->bwd_ev, 48);
     if (rc != CS_OK && use_side) {
         // an early return skipped the join at the end of the pass: side-stream weight gradients may still be reading / writing the
         // caller's buffers, which the caller is about to free - drain them before reporting the error
@@ -1753,14 +1737,14 @@ size_t cs_swi_workspace_bytes(const cs_unet* net, const cs_swi_plan* pl, int eng
     return win + (nwin * pl->roi_h * pl->roi_w * net->out_ch * 4 + 255) / 256 * 256;
 }
 
-// Window pass over window rows [ih_lo, ih_hi): logits of window (ih, iw) go to win_logits[(ih - ih_lo) * n_w + iw].
+// Window pass over the windows [k_lo, k_hi) of the row-major window list: logits of window k go to win_logits[k - k_lo].
 static int swi_run_windows(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_t sc, int64_t sh, int64_t sw, int engine_batch,
-                           int ih_lo, int ih_hi, float* win_logits, cs::Bump& b, hipStream_t s) {
-    const int nwin = (ih_hi - ih_lo) * pl->n_w;
+                           int k_lo, int k_hi, float* win_logits, cs::Bump& b, hipStream_t s) {
+    const int nwin = k_hi - k_lo;
     const size_t win_floats = (size_t)pl->roi_h * pl->roi_w * net->out_ch;
     int2* origins = b.take<int2>((size_t)nwin);
     if (!b.ok()) { cs::set_error("swi: workspace too small"); return CS_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(cs::swi_origins_kernel, dim3((unsigned)cs::ceil_div(nwin, 256)), dim3(256), 0, s, *pl, ih_lo, nwin, origins);
+    hipLaunchKernelGGL(cs::swi_origins_kernel, dim3((unsigned)cs::ceil_div(nwin, 256)), dim3(256), 0, s, *pl, k_lo, nwin, origins);
     CS_HIP(hipGetLastError());
     WindowSrc src;
     src.image = image; src.sn = 0; src.sc = sc; src.sh = sh; src.sw = sw;
@@ -1798,11 +1782,7 @@ static int swi_run_windows(cs_unet* net, const cs_swi_plan* pl, const float* ima
         src.origins = origins + k0;
         if (ns > 1) {
             cs::Bump bs(b.base + mark + (size_t)(chunk % ns) * slice, slice);
-            const bool stagger = net->stagger_level >= 0 && net->stagger_level < net->nl && net->ev_stagger && ns == 2;
-            if (stagger && chunk == 0) net->stagger_armed = true;
-            if (stagger && chunk == 1) CS_HIP(hipStreamWaitEvent(net->side[1], net->ev_stagger, 0));
             rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, bs, net->side[chunk % ns]);
-            net->stagger_armed = false;
         } else {
             b.off = mark;   // every chunk reuses the same activation workspace (stream order serialises them)
             rc = unet_forward_impl(net, src, nb, pl->roi_h, pl->roi_w, win_logits + (size_t)k0 * win_floats, b, s);
@@ -1827,7 +1807,20 @@ int cs_swi_windows(cs_unet* net, const cs_swi_plan* pl, const float* image, int6
     if (int rc = check_loaded(net)) return rc;
     if (win_row_begin == win_row_end) return CS_OK;
     cs::Bump b(workspace, workspace_bytes);
-    return swi_run_windows(net, pl, image, sc, sh, sw, engine_batch, win_row_begin, win_row_end, win_logits, b, (hipStream_t)stream);
+    return swi_run_windows(net, pl, image, sc, sh, sw, engine_batch, win_row_begin * pl->n_w, win_row_end * pl->n_w, win_logits, b, (hipStream_t)stream);
+}
+
+int cs_swi_windows_range(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_t sc, int64_t sh, int64_t sw, int engine_batch,
+                         int win_begin, int win_end, float* win_logits, void* workspace, size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(net && pl && image && workspace && win_logits, "swi_windows_range: null argument");
+    CS_REQUIRE(engine_batch > 0, "swi_windows_range: engine_batch %d", engine_batch);
+    CS_REQUIRE(win_begin >= 0 && win_end <= pl->n_h * pl->n_w && win_begin <= win_end, "swi_windows_range: bad window range [%d, %d) of %d", win_begin,
+               win_end, pl->n_h * pl->n_w);
+    if (int rcd = check_device(net)) return rcd;
+    if (int rc = check_loaded(net)) return rc;
+    if (win_begin == win_end) return CS_OK;
+    cs::Bump b(workspace, workspace_bytes);
+    return swi_run_windows(net, pl, image, sc, sh, sw, engine_batch, win_begin, win_end, win_logits, b, (hipStream_t)stream);
 }
 
 int cs_swi_partition(const cs_swi_plan* pl, int rank, int world, cs_swi_strip* out) {
@@ -1878,7 +1871,7 @@ int cs_swi_infer(cs_unet* net, const cs_swi_plan* pl, const float* image, int64_
     const size_t win_floats = (size_t)pl->roi_h * pl->roi_w * net->out_ch;
     float* win_logits = b.take<float>((size_t)nwin * win_floats);
     if (!b.ok()) { cs::set_error("swi_infer: workspace too small"); return CS_ERR_WORKSPACE; }
-    rc = swi_run_windows(net, pl, image, sc, sh, sw, engine_batch, ih_lo, ih_hi + 1, win_logits, b, s);
+    rc = swi_run_windows(net, pl, image, sc, sh, sw, engine_batch, ih_lo * pl->n_w, (ih_hi + 1) * pl->n_w, win_logits, b, s);
     if (rc) return rc;
     SwiFinalizeArgs fa{};
     fa.win_logits = win_logits;
@@ -1907,6 +1900,72 @@ int cs_swi_finalize(const cs_swi_plan* pl, const float* win_logits, int classes,
     fa.prob1 = prob1;
     fa.mask = mask;
     return launch_swi_finalize((hipStream_t)stream, fa);
+}
+
+int cs_swi_finalize_rect(const cs_swi_plan* pl, const float* win_logits, int classes, int ih_base, int row_begin, int row_end, int col_begin,
+                         int col_end, float* logits_nchw, float* prob1, uint8_t* mask, void* stream) {
+    CS_REQUIRE(pl && win_logits, "swi_finalize_rect: null argument");
+    if (col_end <= col_begin || row_end <= row_begin) return CS_OK;
+    SwiFinalizeArgs fa{};
+    fa.win_logits = win_logits;
+    fa.plan = *pl;
+    fa.c = classes;
+    fa.ih_base = ih_base;
+    fa.row_begin = row_begin;
+    fa.row_end = row_end;
+    fa.col_begin = col_begin;
+    fa.col_end = col_end;
+    fa.logits_nchw = logits_nchw;
+    fa.prob1 = prob1;
+    fa.mask = mask;
+    return launch_swi_finalize((hipStream_t)stream, fa);
+}
+
+int cs_swi_partition_windows(const cs_swi_plan* pl, int rank, int world, cs_swi_share* out) {
+    CS_REQUIRE(pl && out && world >= 1 && rank >= 0 && rank < world, "swi_partition_windows: bad argument (rank %d of %d)", rank, world);
+    const int nwin = pl->n_h * pl->n_w;
+    auto first_win = [&](int r) { return (int)(((long long)r * nwin) / world); };            // shares differ by at most one window
+    // image row / column at which the band of window row / column i begins (the pixels whose LAST covering window row / column is i)
+    auto band = [&](int i, int n, int interval, int pad_size, int roi, int pad_before, int img) {
+        if (i <= 0) return 0;
+        if (i >= n) return img;
+        int v = cs_swi_window_start(i, interval, pad_size, roi) - pad_before;
+        v = v < 0 ? 0 : v;
+        return v > img ? img : v;
+    };
+    auto row_of = [&](int i) { return band(i, pl->n_h, pl->interval_h, pl->pad_h, pl->roi_h, pl->pad_top, pl->img_h); };
+    auto col_of = [&](int j) { return band(j, pl->n_w, pl->interval_w, pl->pad_w, pl->roi_w, pl->pad_left, pl->img_w); };
+    memset(out, 0, sizeof(*out));
+    const int a = first_win(rank), b = first_win(rank + 1);
+    out->win_begin = a;
+    out->win_end = b;
+    if (a == b) {                                       // a rank without windows owns nothing
+        out->slot_row_begin = out->slot_row_end = a / (pl->n_w > 0 ? pl->n_w : 1);
+        return CS_OK;
+    }
+    const int j0 = a / pl->n_w, c0 = a % pl->n_w, j1 = (b - 1) / pl->n_w, c1 = (b - 1) % pl->n_w;
+    int n = 0;
+    auto add = [&](int r0, int r1, int x0, int x1) {
+        if (r1 > r0 && x1 > x0) {
+            out->rect[n][0] = r0; out->rect[n][1] = r1; out->rect[n][2] = x0; out->rect[n][3] = x1;
+            ++n;
+        }
+    };
+    if (j0 == j1) {
+        add(row_of(j0), row_of(j0 + 1), col_of(c0), col_of(c1 + 1));
+    } else {
+        add(row_of(j0), row_of(j0 + 1), col_of(c0), pl->img_w);
+        add(row_of(j0 + 1), row_of(j1), 0, pl->img_w);
+        add(row_of(j1), row_of(j1 + 1), 0, col_of(c1 + 1));
+    }
+    out->n_rects = n;
+    // earlier window rows that still cover the first owned image row
+    int halo = j0;
+    const int p0 = row_of(j0) + pl->pad_top;
+    while (halo > 0 && cs_swi_window_start(halo - 1, pl->interval_h, pl->pad_h, pl->roi_h) + pl->roi_h > p0) --halo;
+    out->slot_row_begin = halo;
+    out->slot_row_end = j1 + 1;
+    return CS_OK;
 }
 
 size_t cs_normalize_workspace_bytes(int h, int w) { return cs::normalize_workspace_bytes(h, w); }

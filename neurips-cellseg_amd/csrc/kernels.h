@@ -68,7 +68,7 @@ size_t packed_wino4_floats(int cout_total, int cin_total);
 int pack_wino4_weights(PackCtx* pc, hipStream_t s, const float* w, int cout, int cin, float* packed, bool dgrad = false);   // dgrad: (cout, cin) of the
                                                                                           // DATA-GRADIENT convolution (= the layer's cin, cout)
 bool wino4_fits(int cin, int cout, int h, int w);
-// layers with cout % 64 == 0 (CS_WINO >= 3) or cout % 32 == 0 (CS_WINO >= 4) take the 32x32x2-MFMA form (kernels_conv_wino4x.hip): its weight
+// layers with cin % 32 == 0 and cout % 32 == 0 take the 32x32x2-MFMA form (kernels_conv_wino4x.hip): its weight
 // fragments are packed[cin/16][36 positions][cout/32][2][64 lanes][4] (same size, other order) - pack and launch ask this predicate
 bool wino4_layout32(int cin, int cout);
 int wino4_form(int cin, int cout);     // 0: kernels_conv_wino4.hip; 1 / 2 / 3: the 64-channel, 32-channel and register-epilogue kernels of kernels_conv_wino4x.hip
@@ -109,12 +109,10 @@ int launch_conv_mfma(hipStream_t s, int ksize, int stride, const ConvSrc& a, con
 // 3x3 stride-1 pad-1 convolution as Winograd F(2x2, 3x3) on the fp32 matrix pipe (kernels_conv_wino.hip): 16 instead of 36
 // multiplies per 2x2 output tile; fp32 throughout, same outputs / statistics contract as launch_conv_mfma.  cout % 32 == 0.
 bool wino_enabled();           // CS_WINO=0 disables it (A/B against the direct kernels)
-int wino_level();              // CS_WINO: 0 direct kernels, 1 F(2x2,3x3) everywhere, 2 F(4x4,3x3) on 16x16x4 MFMAs, 3 F(4x4,3x3) on 32x32x2
-                               // MFMAs where the layer has >= 64 output channels, 4 (default) also its 32-channel form
+int wino_level();              // CS_WINO: 0 direct kernels, 1 F(2x2,3x3) everywhere, 2 (default) F(4x4,3x3) where the layer has a kernel for it
 // the kernel addresses one image's input tensor with 32-bit byte offsets; larger tensors (a plain forward over a > 4 GB image
 // level) take the direct kernels
 static inline bool wino_fits(int h, int w, int pitch) { return (size_t)h * w * pitch * 4 < ((size_t)1 << 32); }
-void wino_set_stamp_buffer(long long* dev);   // diagnostics: in-kernel cycle stamps of block 0 (null = off)
 int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, const float* bias, float* out, int pitch_out, int cout,
                      double* stats, int n, int h, int w, const ConvOutExtra* ex = nullptr);   // ex: addend only
 
@@ -298,6 +296,7 @@ struct SwiFinalizeArgs {
     int c;                      // classes (<= 4)
     int ih_base;                // window-row index of win_logits[0] (a rank holds only the window rows it ran)
     int row_begin, row_end;     // image rows finalised by this call
+    int col_begin, col_end;     // ... and columns (col_end == 0: the whole width)
     float* logits_nchw;         // [c][img_h][img_w] or null
     float* prob1;               // [img_h][img_w] or null
     uint8_t* mask;              // [img_h][img_w] or null

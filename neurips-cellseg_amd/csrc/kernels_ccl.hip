@@ -19,6 +19,7 @@
 //   filter   flip pixels of small components.
 //   rank     roots are counted per 1024-pixel chunk, chunk counts are scanned, every root gets
 //            1 + (number of roots before it) - exactly scipy's numbering - and pixels read their root's rank.
+#include <atomic>
 #include "kernels.h"
 
 namespace cs {
@@ -329,17 +330,17 @@ int forest(hipStream_t s, const uint8_t* m, int want, int h, int w, int conn, co
         while (rows < 16 && 2 * rows * w <= CCL_STRIP_PIXELS && 2 * rows <= h) rows *= 2;
         if (rows > 1) {
             // the > 64 KB dynamic-LDS opt-in is an attribute of the function ON THE CURRENT DEVICE: remembered per device
-            static unsigned long long lds_set = 0ull;
+            static std::atomic<unsigned long long> lds_set{0ull};
             int dev = 0;
             CS_HIP(hipGetDevice(&dev));
             CS_REQUIRE(dev >= 0 && dev < 64, "ccl: device index %d out of range", dev);
-            if (!((lds_set >> dev) & 1ull)) {
+            if (!((lds_set.load(std::memory_order_relaxed) >> dev) & 1ull)) {
                 const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl_merge_local_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     CCL_STRIP_PIXELS * 4) == hipSuccess &&
                                 hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl_merge_local_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     CCL_STRIP_PIXELS * 4) == hipSuccess;
                 CS_REQUIRE(ok, "ccl: the strip kernel could not reserve %d bytes of LDS on device %d", CCL_STRIP_PIXELS * 4, dev);
-                lds_set |= 1ull << dev;
+                lds_set.fetch_or(1ull << dev, std::memory_order_relaxed);
             }
             const dim3 gl((unsigned)ceil_div(h, rows));
             const size_t lds = (size_t)rows * w * sizeof(int);

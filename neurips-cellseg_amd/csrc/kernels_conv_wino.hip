@@ -35,7 +35,7 @@ constexpr int V_FLOATS = 16 * 4 * 32 * 4;          // 8192
 }  // namespace
 
 template <int NTW, int OCC, bool LAZY>
-__global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long long* stamps) {
+__global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p) {
     constexpr int IN_ITERS = (WIH * WIW + 63) / 64;            // 3
     constexpr int RS = 16 * NTW + 4;                           // floats per (xi, j, tile) record of the epilogue exchange
     constexpr int R_FLOATS = 4 * 2 * 32 * RS;
@@ -49,18 +49,6 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything indexed by the wave id stays on the SALU
     const int pl = lane & 15, g = lane >> 4;
-    // in-kernel stamps (diagnostics; null in production): cycles per phase of block 0, wave 0
-    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    auto stamp = [&](int k) {
-        if (stamps) {
-            __builtin_amdgcn_sched_barrier(0);
-            const long long t = (long long)__builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_sched_barrier(0);
-            tsum[k] += t - tlast;
-            tlast = t;
-        }
-    };
     const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NTW);
     if (!wk.valid) return;
     int bid = wk.spatial;
@@ -167,7 +155,6 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
     __syncthreads();
     transform();
     __syncthreads();
-    stamp(0);                                  // [0] prologue
     const float* const a_src = vs + ((wave * 4 * 4 + g) * 32 + pl) * 4;   // + nu * 512 + m * 64
     for (int ch = 0; ch < chunks; ++ch) {
         const bool more = ch + 1 < chunks;
@@ -193,16 +180,11 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
         }
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) asm volatile("" ::"v"(rin[it]));   // keeps the loads above the MFMA section
-        stamp(1);                              // [1] loads issued + MFMA phase
         if (more) store_raw();
-        stamp(2);                              // [2] norm + patch stores
         __syncthreads();
-        stamp(3);                              // [3] barrier
         if (more) {
             transform();
-            stamp(4);                          // [4] transform
             __syncthreads();
-            stamp(5);                          // [5] barrier
         }
     }
 
@@ -301,9 +283,6 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
             atomicAdd(p.stats + ((size_t)img * p.cout + nt0 * 16 + c) * 2 + k, v);
         }
     }
-    stamp(6);                                  // [6] epilogue
-    if (stamps && blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 8; ++k) stamps[wave * 8 + k] = tsum[k];
 }
 
 
@@ -334,7 +313,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_kernel(ConvParams p, long 
 // LDS: 2 x (14 KB + 32 KB) in the loop; the epilogue exchange R [4][2][32][132] (132 KB) + statistics reuse it: one block per CU.
 // ------------------------------------------------------------------------------------------------
 template <bool LAZY>
-__global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long long* stamps) {
+__global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p) {
     constexpr int NTW = 8;
     constexpr int IN_ITERS = (WIH * WIW + 63) / 64;            // 3
     constexpr int RS = 16 * NTW + 4;
@@ -349,17 +328,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long l
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
-    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    auto stamp = [&](int k) {
-        if (stamps) {
-            __builtin_amdgcn_sched_barrier(0);
-            const long long t = (long long)__builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_sched_barrier(0);
-            tsum[k] += t - tlast;
-            tlast = t;
-        }
-    };
     const WorkId wk = decode_work(p.tiles_x * p.tiles_y * p.n, p.ntile_total / NTW);
     if (!wk.valid) return;
     int bid = wk.spatial;
@@ -467,7 +435,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long l
     park(raw0 + RAW_FLOATS);
     load_in(2);
     __syncthreads();
-    stamp(0);                                  // [0] prologue
     const int a_off = ((wave * 16 + g) * 32 + pl) * 4;            // + nu * 512 + m * 64
     for (int ch = 0; ch < chunks; ++ch) {
         const int b = ch & 1;
@@ -507,22 +474,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long l
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            stamp(1);                          // [1] MFMA steps (+ the reads issued in front of them)
             if (nu == 0 && more1) {            // piece 2: transform arithmetic + V stores of chunk c + 1
                 transform_write(vs0 + (b ^ 1) * V_FLOATS);
                 __builtin_amdgcn_sched_barrier(0);
-                stamp(4);                      // [4] transform arithmetic + V stores
             }
             if (nu == 1) {                     // piece 3: park chunk c + 2 (its loads were issued an iteration ago), request chunk c + 3
                 if (more2) park(raw0 + b * RAW_FLOATS);
                 load_in(ch + 3);
                 __builtin_amdgcn_sched_barrier(0);
-                stamp(5);                      // [5] park + loads
             }
         }
-        stamp(6);                              // [6] weight loads of the last step, loop overhead
         __syncthreads();
-        stamp(2);                              // [2] barrier
     }
 
     // ---- epilogue: nu half of A^T M A in registers, xi half after the exchange through LDS ----
@@ -606,32 +568,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino1_kernel(ConvParams p, long l
             atomicAdd(p.stats + ((size_t)img * p.cout + nt0 * 16 + c) * 2 + k, v);
         }
     }
-    stamp(3);                                  // [3] epilogue
-    if (stamps && blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 8; ++k) stamps[wave * 8 + k] = tsum[k];
 }
 
-long long* g_wino_stamps = nullptr;    // diagnostics: device buffer of 8 x 8 counters (tests/diagnostics/wino_layer_bench.hip)
-void wino_set_stamp_buffer(long long* dev) { g_wino_stamps = dev; }
-
-int g_wino = 5;   // A/B switch (CS_WINO): 0 = direct kernels, 1 = Winograd F(2x2,3x3) everywhere, 2 = F(4x4,3x3) on 16x16x4 MFMAs,
-                  // 3 = F(4x4,3x3) on 32x32x2 MFMAs for the layers with >= 64 output channels (kernels_conv_wino4x.hip),
-                  // 4 = ... and its 32-channel form for the 32-channel layers, 5 (default) = ... and the register-epilogue form for cin <= 128
+int g_wino = 2;   // the one A/B switch of the fp32 3x3 stride-1 layers (CS_WINO): 0 = direct kernels, 1 = Winograd F(2x2,3x3) everywhere (what a
+                  // training forward runs), 2 (default) = F(4x4,3x3) where the layer has a kernel for it (inference), F(2x2) elsewhere
 static const int g_wino_init = [] {
     if (const char* e = getenv("CS_WINO")) g_wino = atoi(e);
     return 0;
 }();
 bool wino_enabled() { return g_wino != 0; }
 int wino_level() { return g_wino; }
-// the register-epilogue form takes the layers up to 128 input channels (measured per layer, DESIGN 3.1a''); beyond, its half-size blocks are 4-6 % faster
-// per launch too, but the slide loses what the window pass's two streams overlap (35.3 vs 34.4 ms)
-static const int g_wino4y_max_cin = [] { const char* e = getenv("CS_WINO4Y_MAX_CIN"); return e ? atoi(e) : 128; }();      // (A/B switch)
-// which F(4x4) kernel a layer takes: 0 = kernels_conv_wino4.hip (16x16x4, a wave owns positions), 1 / 2 = the 32x32x2 forms of
-// kernels_conv_wino4x.hip (64- / 32-channel blocks), 3 = its 16x16x4 form with the output transform in registers (short K loops)
+// which F(4x4) kernel a layer takes: 0 = kernels_conv_wino4.hip (16x16x4 MFMAs, a wave owns positions: the general form, channel counts that are
+// not multiples of 32), 1 / 2 = the 32x32x2 forms of kernels_conv_wino4x.hip (64- / 32-channel blocks), 3 = its 16x16x4 form with the output
+// transform in registers for the short K loops (cin <= 128: measured per layer, DESIGN 3.1a''; beyond, its half-size blocks are 4-6 % faster per
+// launch too, but the slide loses what the window pass's two streams overlap: 35.3 vs 34.4 ms)
 int wino4_form(int cin, int cout) {
-    if (g_wino < 3 || cin % 32 != 0) return 0;
-    if (cout % 64 == 0) return (g_wino >= 5 && cin <= g_wino4y_max_cin) ? 3 : 1;
-    return (g_wino >= 4 && cout % 32 == 0) ? 2 : 0;
+    if (cin % 32 != 0) return 0;
+    if (cout % 64 == 0) return cin <= 128 ? 3 : 1;
+    return cout % 32 == 0 ? 2 : 0;
 }
 bool wino4_layout32(int cin, int cout) { const int f = wino4_form(cin, cout); return f == 1 || f == 2; }
 
@@ -669,14 +623,14 @@ int launch_conv_wino(hipStream_t s, const ConvSrc& a, const float* wpack_wino, c
     CS_REQUIRE((size_t)h * w * a.pitch * 4 < ((size_t)1 << 32), "conv(winograd): one image's activation tensor must stay below 4 GB");
     const bool lazy = a.tab != nullptr;
 #define CS_WINO_LAUNCH(NTW_, OCC_, LAZY_)                                                                                       \
-    hipLaunchKernelGGL((conv_wino_kernel<NTW_, OCC_, LAZY_>), dim3(xcd_grid(nsp, p.ntile_total / NTW_)), dim3(256), 0, s, p, g_wino_stamps)
+    hipLaunchKernelGGL((conv_wino_kernel<NTW_, OCC_, LAZY_>), dim3(xcd_grid(nsp, p.ntile_total / NTW_)), dim3(256), 0, s, p)
     // 128-channel blocks at one wave per SIMD (conv_wino1_kernel) where the grid still fills the chip twice over: measured 2-8 %
     // faster than the 64-channel kernel on the 128...512-channel layers of the slide; small (training-sized) launches keep the
     // 64-channel kernel and its twice as many blocks.
     if (cout % 128 == 0 && (long long)xcd_grid(nsp, p.ntile_total / 8) >= 512) {
         const dim3 grid1(xcd_grid(nsp, p.ntile_total / 8));
-        if (lazy) hipLaunchKernelGGL((conv_wino1_kernel<true>), grid1, dim3(256), 0, s, p, g_wino_stamps);
-        else hipLaunchKernelGGL((conv_wino1_kernel<false>), grid1, dim3(256), 0, s, p, g_wino_stamps);
+        if (lazy) hipLaunchKernelGGL((conv_wino1_kernel<true>), grid1, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_wino1_kernel<false>), grid1, dim3(256), 0, s, p);
     } else if (cout % 64 == 0 && (long long)xcd_grid(nsp, p.ntile_total / 4) >= SMALL_GRID_BLOCKS) {     // (else: 32-channel blocks, twice the grid)
         if (lazy) CS_WINO_LAUNCH(4, 2, true);
         else CS_WINO_LAUNCH(4, 2, false);

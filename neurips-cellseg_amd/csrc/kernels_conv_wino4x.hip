@@ -20,6 +20,7 @@
 //     position ahead), 72 MFMAs of 64 cycles, 144 accumulator registers;
 //   * epilogue: one sub-tile at a time through LDS [36][16 tiles][64] (registers 0..7 / 8..15 of every 32x32 accumulator); thread (row
 //     pair, tile, channel quad) applies A^T M A, bias, fp64 statistics of the sub-tile's image, 16-byte stores.
+#include <atomic>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -62,17 +63,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __
 }  // namespace
 
 template <bool LAZY>
-__global__ __launch_bounds__(512, 2) void conv_wino4x_kernel(ConvParams p, long long* stamps) {
-    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const long long treal0 = stamps ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-    long long tlast = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    auto stamp = [&](int k) {
-        if (stamps) {
-            const long long t = (long long)__builtin_amdgcn_s_memtime();
-            tsum[k] += t - tlast;
-            tlast = t;
-        }
-    };
+__global__ __launch_bounds__(512, 2) void conv_wino4x_kernel(ConvParams p) {
     constexpr int IN_ITERS = 6;                                  // (pixel, channel quad) items per thread; the sixth only for 16 threads of a half
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const vs = smem + X_RAW;
@@ -210,7 +201,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4x_kernel(ConvParams p, long 
     __syncthreads();
     transform();
     __syncthreads();
-    stamp(0);
     const int a_i = lane & 31, a_h = lane >> 5;
     // + position * 512; the second read (sh = 1) sits 128 floats further with its own tile permutation
     const float* const a_src0 = vs + (pg * 9) * 512 + ((a_h * 2 + 0) * 32 + (a_i ^ (2 * (2 * a_h + 0)))) * 4;
@@ -251,14 +241,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4x_kernel(ConvParams p, long 
             for (int e = 0; e < 4; ++e) acc[ps] = mfma32(av[ps & 1][1][e], wc[ps % 3][1][e], acc[ps]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        stamp(1);
         __syncthreads();
-        stamp(3);
         if (more) {
             transform();
-            stamp(4);
             __syncthreads();
-            stamp(5);
         }
     }
 
@@ -353,11 +339,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4x_kernel(ConvParams p, long 
     };
     pass(std::integral_constant<int, 0>());
     pass(std::integral_constant<int, 1>());
-    stamp(6);
-    if (stamps) tsum[7] = (long long)__builtin_amdgcn_s_memrealtime() - treal0;       // 100 MHz ticks of the block's life
-    // block 0 -> slots 0..63; one block of the LAST round (grid - 1) -> slots 64..127
-    if (stamps && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0)
-        for (int k = 0; k < 8; ++k) stamps[(blockIdx.x ? 64 : 0) + wave * 8 + k] = tsum[k];
 }
 
 
@@ -374,19 +355,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4x_kernel(ConvParams p, long 
 // NSUB = 1: a 256-thread block of ONE sub-tile with the same per-wave work (raw 26 KB + V 37 KB: TWO independent blocks per CU, whose
 // prologues, barriers and epilogues fall into each other's matrix phases instead of onto the same cycles).
 template <bool LAZY, int NSUB>
-__global__ __launch_bounds__(256 * NSUB, 2) void conv_wino4y_kernel(ConvParams p, long long* stamps) {
+__global__ __launch_bounds__(256 * NSUB, 2) void conv_wino4y_kernel(ConvParams p) {
     constexpr int TPP = 16 * NSUB;                               // tiles per position plane of V
     constexpr int VPOS = TPP * 16;                               // floats per position
-    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const long long treal0 = stamps ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-    long long tlast = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    auto stamp = [&](int k) {
-        if (stamps) {
-            const long long t = (long long)__builtin_amdgcn_s_memtime();
-            tsum[k] += t - tlast;
-            tlast = t;
-        }
-    };
     constexpr int IN_ITERS = 6;                                  // (pixel, channel quad) items per thread; the sixth only for 16 threads of a half
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const vs = smem + NSUB * X_RAW1;
@@ -520,7 +491,6 @@ __global__ __launch_bounds__(256 * NSUB, 2) void conv_wino4y_kernel(ConvParams p
     __syncthreads();
     transform();
     __syncthreads();
-    stamp(0);
     const float* const a_src = vs + (g * TPP + th * 16 + (pl ^ (2 * g))) * 4;              // + position * VPOS
 #pragma unroll 1
     for (int ch = 0; ch < chunks; ++ch) {
@@ -558,14 +528,10 @@ __global__ __launch_bounds__(256 * NSUB, 2) void conv_wino4y_kernel(ConvParams p
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        stamp(1);
         __syncthreads();
-        stamp(3);
         if (more) {
             transform();
-            stamp(4);
             __syncthreads();
-            stamp(5);
         }
     }
 
@@ -644,10 +610,6 @@ __global__ __launch_bounds__(256 * NSUB, 2) void conv_wino4y_kernel(ConvParams p
             }
         }
     }
-    stamp(6);
-    if (stamps) tsum[7] = (long long)__builtin_amdgcn_s_memrealtime() - treal0;
-    if (stamps && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0)
-        for (int k = 0; k < 8; ++k) stamps[(blockIdx.x ? 64 : 0) + wave * 8 + k] = tsum[k];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -924,8 +886,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4z_kernel(ConvParams p) {
     pass(std::integral_constant<int, 1>());
 }
 
-extern long long* g_wino_stamps;       // diagnostics (tests/diagnostics/wino_layer_bench.hip); null in production
-
 int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4x, const float* bias, float* out, int pitch_out, int cout,
                        double* stats, int n, int h, int w, const ConvOutExtra* ex) {
     CS_REQUIRE(a.c % 32 == 0 && a.c > 0 && cout % 32 == 0, "conv(winograd 4x4, 32x32): channels (%d -> %d) unsupported", a.c, cout);
@@ -957,7 +917,7 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
     const double bytes = 4.0 * n * (double)h * w * (a.c + cout);
     ProfScope prof(K_CONV3_WINO4, s, flops, bytes);
     // opt-in to > 64 KB of dynamic LDS: an attribute of the function ON THE CURRENT DEVICE, so it is remembered per (kernel, device)
-    static unsigned long long lds_set[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    static std::atomic<unsigned long long> lds_set[6];        // (launches may come from several host threads: fetch_or, not a read-modify-write)
     int dev = 0;
     CS_HIP(hipGetDevice(&dev));
     CS_REQUIRE(dev >= 0 && dev < 64, "conv(winograd 4x4, 32x32): device index %d out of range", dev);
@@ -967,39 +927,32 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
     const size_t lds = wide ? X_LDS_BYTES : Z_LDS_BYTES;
     const dim3 grid(wide ? xcd_grid((n_spatial + 1) / 2, p.ntile_total / 4) : xcd_grid((n_spatial + 1) / 2, p.ntile_total / 2));
     auto ensure = [&](const void* kern, int which) -> int {
-        if (!((lds_set[which] >> dev) & 1ull)) {
+        if (!((lds_set[which].load(std::memory_order_relaxed) >> dev) & 1ull)) {
             CS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set[which] |= 1ull << dev;
+            lds_set[which].fetch_or(1ull << dev, std::memory_order_relaxed);
         }
         return CS_OK;
     };
     if (form == 3) {                           // 16x16x4 MFMAs, a wave = channel tile x sub-tile x all positions, output transform in registers
-        static const int y_half = [] { const char* e = getenv("CS_WINO_YHALF"); return e ? atoi(e) : 1; }();
-        static unsigned long long lds_set_y[4] = {0ull, 0ull, 0ull, 0ull};
-        const int nsub = y_half ? 1 : 2;
-        const size_t lds_y = (size_t)(nsub * X_RAW1 + 36 * 16 * nsub * 16) * 4;
-        const dim3 grid_y(xcd_grid(nsub == 2 ? (n_spatial + 1) / 2 : n_spatial, p.ntile_total / 4));
-        const int which = (nsub == 2 ? 2 : 0) + (a.tab ? 1 : 0);
-        const void* kern = nsub == 2 ? (a.tab ? reinterpret_cast<const void*>(&conv_wino4y_kernel<true, 2>) : reinterpret_cast<const void*>(&conv_wino4y_kernel<false, 2>))
-                                     : (a.tab ? reinterpret_cast<const void*>(&conv_wino4y_kernel<true, 1>) : reinterpret_cast<const void*>(&conv_wino4y_kernel<false, 1>));
-        if (!((lds_set_y[which] >> dev) & 1ull)) {
+        // 256-thread blocks of ONE sub-tile (the 512-thread block of two sub-tiles measured 346 vs 323 us on the 64 -> 64 layer: DESIGN 3.1a'')
+        static std::atomic<unsigned long long> lds_set_y[2];
+        const size_t lds_y = (size_t)(X_RAW1 + 36 * 16 * 16) * 4;
+        const dim3 grid_y(xcd_grid(n_spatial, p.ntile_total / 4));
+        const int which = a.tab ? 1 : 0;
+        const void* kern = a.tab ? reinterpret_cast<const void*>(&conv_wino4y_kernel<true, 1>) : reinterpret_cast<const void*>(&conv_wino4y_kernel<false, 1>);
+        if (!((lds_set_y[which].load(std::memory_order_relaxed) >> dev) & 1ull)) {
             CS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_y));
-            lds_set_y[which] |= 1ull << dev;
+            lds_set_y[which].fetch_or(1ull << dev, std::memory_order_relaxed);
         }
-        if (nsub == 2) {
-            if (a.tab) hipLaunchKernelGGL((conv_wino4y_kernel<true, 2>), grid_y, dim3(512), lds_y, s, p, g_wino_stamps);
-            else hipLaunchKernelGGL((conv_wino4y_kernel<false, 2>), grid_y, dim3(512), lds_y, s, p, g_wino_stamps);
-        } else {
-            if (a.tab) hipLaunchKernelGGL((conv_wino4y_kernel<true, 1>), grid_y, dim3(256), lds_y, s, p, g_wino_stamps);
-            else hipLaunchKernelGGL((conv_wino4y_kernel<false, 1>), grid_y, dim3(256), lds_y, s, p, g_wino_stamps);
-        }
+        if (a.tab) hipLaunchKernelGGL((conv_wino4y_kernel<true, 1>), grid_y, dim3(256), lds_y, s, p);
+        else hipLaunchKernelGGL((conv_wino4y_kernel<false, 1>), grid_y, dim3(256), lds_y, s, p);
     } else if (wide) {
         if (a.tab) {
             if (int rc = ensure(reinterpret_cast<const void*>(&conv_wino4x_kernel<true>), 1)) return rc;
-            hipLaunchKernelGGL(conv_wino4x_kernel<true>, grid, dim3(512), lds, s, p, g_wino_stamps);
+            hipLaunchKernelGGL(conv_wino4x_kernel<true>, grid, dim3(512), lds, s, p);
         } else {
             if (int rc = ensure(reinterpret_cast<const void*>(&conv_wino4x_kernel<false>), 0)) return rc;
-            hipLaunchKernelGGL(conv_wino4x_kernel<false>, grid, dim3(512), lds, s, p, g_wino_stamps);
+            hipLaunchKernelGGL(conv_wino4x_kernel<false>, grid, dim3(512), lds, s, p);
         }
     } else {
         if (a.tab) {

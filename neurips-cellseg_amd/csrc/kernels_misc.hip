@@ -608,11 +608,17 @@ __global__ __launch_bounds__(256) void convt_top_gemm_kernel(SmallSrc a, SmallSr
 // GEMM runs on v_mfma_f32_16x16x32_bf16 (CIN / 32 instructions per tile instead of CIN / 4 fp32 ones); weights are converted to
 // bf16 fragments once per (persistent) block.  Gather, bias, statistics and the fp32 3-channel output as above.
 // ------------------------------------------------------------------------------------------------
+// SUM2 (bf16 datapath, round 5): the `b` source is the residual sum D = act(norm(V)) + act(norm(U)) of the level below, read as its two raw
+// bf16 tensors with their lazy tables: the staging computes the sum in fp32 and rounds it to bf16 once - the very value norm_act_add16x8
+// would have written - so the pass that materialised D (two reads and one write of a 32-channel 128 x 128 tensor per window) is not
+// launched and the results are bitwise those of the unfused sequence.  Items are dealt so that a wave instruction covers ONE tensor: every
+// wave takes the skip tensor's 16-byte items first and the sum's after them (which items pay for the second load and the two activations
+// is known at compile time; the four waves carry equal shares).
 typedef __bf16 bf16x8m __attribute__((ext_vector_type(8)));
-template <int CIN>
+template <int CIN, bool SUM2 = false>
 __global__ __launch_bounds__(256) void convt_top_gemm16_kernel(SmallSrc a, SmallSrc b, const float* __restrict__ w, const float* bias,
                                                                float* out, double* stats, int hin, int win, int tiles_x, int tiles_y,
-                                                               int n_tiles) {
+                                                               int n_tiles, SumExtra sx) {
     constexpr int TH = 8, TW = 16, IH = TH + 1, IW = TW + 1, NPIX = IH * IW, MPAD = 160;
     constexpr int PP = 33;                                   // P pitch in floats
     constexpr int XP = CIN + 8;                              // x pitch in bf16 elements: 16-byte A-fragment reads are conflict-free
@@ -635,25 +641,52 @@ __global__ __launch_bounds__(256) void convt_top_gemm16_kernel(SmallSrc a, Small
         const int k = c32 * 32 + 8 * (ln >> 4) + j, col = nn * 16 + (ln & 15);
         w_s[i] = (unsigned short)f32_to_bf16_bits(col < 27 ? w[(size_t)k * 27 + col] : 0.f);
     }
-    constexpr int c8n = CIN / 8, ITERS = (MPAD * c8n + 255) / 256;   // 16-byte items
+    static_assert(!SUM2 || CIN == 64 || CIN == 128, "sum sources: 64 / 128 input channels (half of them summed)");
+    constexpr int c8n = CIN / 8;                             // 16-byte items per pixel
+    // SUM2: G item columns per tensor, PXW pixels per wave instruction, KS items per wave and tensor (pixels >= MPAD are dropped)
+    constexpr int G = c8n / 2, PXW = 64 / G, KS = (MPAD + 4 * PXW - 1) / (4 * PXW);
+    constexpr int ITERS = SUM2 ? 2 * KS : (MPAD * c8n + 255) / 256;
     typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
     u32x4t rx[ITERS];
+    u32x4t rx2[SUM2 ? KS : 1];
     const unsigned short* sptr[ITERS];
     int rel[ITERS], spitch[ITERS], liy[ITERS], lix[ITERS];
+    auto item_of = [&](int it, int& pix, int& c8, bool& live) {
+        if constexpr (SUM2) {
+            const int sec = it >= KS ? 1 : 0, k = it - sec * KS;
+            c8 = sec * G + (lane % G);
+            pix = lane / G + PXW * (wave + 4 * k);
+            live = pix < MPAD;
+        } else {
+            const int i = tid + 256 * it;
+            pix = i / c8n;
+            c8 = i - pix * c8n;
+            live = i < MPAD * c8n;
+        }
+    };
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int i = tid + 256 * it;
-        const int pix = i / c8n, c8 = i - pix * c8n;
+        int pix, c8;
+        bool live;
+        item_of(it, pix, c8, live);
         const int iy = pix / IW, ix = pix - iy * IW;
         const int c = 8 * c8;
         const bool in_a = c < a.c;
         sptr[it] = reinterpret_cast<const unsigned short*>(in_a ? a.ptr : b.ptr) + (in_a ? c : c - a.c);
         spitch[it] = in_a ? a.pitch : b.pitch;
         rel[it] = (iy * win + ix) * spitch[it];
-        liy[it] = (pix < NPIX && i < MPAD * c8n) ? iy : (1 << 20);
+        liy[it] = (pix < NPIX && live) ? iy : (1 << 20);
         lix[it] = ix;
     }
     unsigned okmask = 0;
+    const int cb = SUM2 ? 8 * (lane % G) : 0;                // channel of this lane's sum-source items inside b
+    const ptrdiff_t delta2 = SUM2 ? reinterpret_cast<const unsigned short*>(sx.ptr2) - reinterpret_cast<const unsigned short*>(b.ptr) : 0;
+    f32x4m tA[4], tB[4];                                     // (scale, shift) x 8 channels of V's and of U's table
+    float slA = 0.f, slB = 0.f;
+    if constexpr (SUM2) {
+        slA = sx.slope ? *sx.slope : 0.f;
+        slB = sx.slope2 ? *sx.slope2 : 0.f;
+    }
     auto prefetch = [&](int img, int iy0, int ix0) {
         okmask = 0;
         const int base_px = (img * hin + iy0) * win + ix0;
@@ -662,8 +695,32 @@ __global__ __launch_bounds__(256) void convt_top_gemm16_kernel(SmallSrc a, Small
             const bool ok = iy0 + liy[it] < hin && ix0 + lix[it] < win;
             const int off = ok ? base_px * spitch[it] + rel[it] : 0;
             rx[it] = *reinterpret_cast<const u32x4t*>(sptr[it] + off);
+            if constexpr (SUM2)
+                if (it >= KS) rx2[it - KS] = *reinterpret_cast<const u32x4t*>(sptr[it] + delta2 + off);
             okmask |= ok ? (1u << it) : 0u;
         }
+        if constexpr (SUM2) {
+            const f32x4m* ta = reinterpret_cast<const f32x4m*>(sx.tab + (size_t)img * sx.tab_c + sx.tab_off + cb);
+            const f32x4m* tb = reinterpret_cast<const f32x4m*>(sx.tab2 + (size_t)img * sx.tab_c + sx.tab_off + cb);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tA[k] = ta[k];
+                tB[k] = tb[k];
+            }
+        }
+    };
+    // act(norm(V)) + act(norm(U)) on 8 channels, the operations and their order as in norm_act_add16x8_kernel (load_lazy8), one bf16 rounding
+    auto sum8 = [&](const u32x4t& v, const u32x4t& u) {
+        u32x4t o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v0 = __builtin_bit_cast(float, v[k] << 16), v1 = __builtin_bit_cast(float, v[k] & 0xffff0000u);
+            const float u0 = __builtin_bit_cast(float, u[k] << 16), u1 = __builtin_bit_cast(float, u[k] & 0xffff0000u);
+            const float s0 = prelu1(v0 * tA[k].x + tA[k].y, slA) + prelu1(u0 * tB[k].x + tB[k].y, slB);
+            const float s1 = prelu1(v1 * tA[k].z + tA[k].w, slA) + prelu1(u1 * tB[k].z + tB[k].w, slB);
+            o[k] = f32_to_bf16_bits(s0) | (f32_to_bf16_bits(s1) << 16);
+        }
+        return o;
     };
     int xo[5], wo[5];
 #pragma unroll
@@ -722,10 +779,13 @@ __global__ __launch_bounds__(256) void convt_top_gemm16_kernel(SmallSrc a, Small
         const int iy0 = ty * TH, ix0 = tx * TW, cur_img = img;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int i = tid + 256 * it;
-            const int pix = i / c8n, c8 = i - pix * c8n;
-            if (ITERS * 256 == MPAD * c8n || i < MPAD * c8n)
-                *reinterpret_cast<u32x4t*>(&x_s[pix * XP + 8 * c8]) = ((okmask >> it) & 1u) ? rx[it] : u32x4t{0u, 0u, 0u, 0u};
+            int pix, c8;
+            bool live;
+            item_of(it, pix, c8, live);
+            u32x4t xv = rx[it];
+            if constexpr (SUM2)
+                if (it >= KS) xv = sum8(rx[it], rx2[it - KS]);
+            if (live) *reinterpret_cast<u32x4t*>(&x_s[pix * XP + 8 * c8]) = ((okmask >> it) & 1u) ? xv : u32x4t{0u, 0u, 0u, 0u};
         }
         __syncthreads();
         const bool more = tile + 1 < t_end;
@@ -791,8 +851,8 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
     CS_REQUIRE(cout == 3, "convT(small): cout %d unsupported (3-class contract)", cout);
     const bool sum2 = b.ptr2 != nullptr;
     CS_REQUIRE(a.tab == nullptr && (b.tab == nullptr || sum2), "convT(small): lazy inputs only as a sum source (second operand)");
-    CS_REQUIRE(!sum2 || (b.tab && b.tab2 && !a.h16 && !b.h16 && a.c == b.c && (a.c + b.c == 64 || a.c + b.c == 128)),
-               "convT(small): a sum source needs both lazy tables, fp32 activations, 64 / 128 input channels and as many skip channels as summed ones");
+    CS_REQUIRE(!sum2 || (b.tab && b.tab2 && a.h16 == b.h16 && a.c == b.c && (a.c + b.c == 64 || a.c + b.c == 128)),
+               "convT(small): a sum source needs both lazy tables, 64 / 128 input channels and as many skip channels as summed ones");
     CS_REQUIRE(a.c % 4 == 0 && b.c % 4 == 0, "convT(small): channels must be multiples of 4");
     CS_REQUIRE(a.h16 == b.h16 || b.c == 0, "convT(small): mixed activation element types");
     const int cin = a.c + b.c;
@@ -810,18 +870,20 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
         const SumExtra sx{b.ptr2, b.tab, b.tab2, b.slope, b.slope2, b.tab_c ? b.tab_c : b.c, b.tab_off};
 #define CS_TOP(CIN_, H_) hipLaunchKernelGGL((convt_top_gemm_kernel<CIN_, H_>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles, sx)
 #define CS_TOPS(CIN_) hipLaunchKernelGGL((convt_top_gemm_kernel<CIN_, false, true>), grid, dim3(256), sm, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles, sx)
-        if (sum2) {
+        if (sum2 && !a.h16) {
             if (cin == 64) CS_TOPS(64); else CS_TOPS(128);
             CS_HIP(hipGetLastError());
             return CS_OK;
         }
+        CS_REQUIRE(!sum2 || (a.c % 16 == 0 && a.pitch % 8 == 0 && b.pitch % 8 == 0 && sx.tab_off % 8 == 0), "convT(small): bf16 sum source: channels / pitches in multiples of 8");
         if (a.h16 && a.c % 8 == 0 && b.c % 8 == 0) {           // bf16 inputs: bf16 matrix pipe, plain-copy staging
             const size_t xb = (size_t)160 * (cin + 8) * 2, pb = (size_t)160 * 33 * 4;
             const size_t sm16 = (xb > pb ? xb : pb) + (size_t)cin * 32 * 2;
             const int resident16 = 256 * (int)((160 * 1024) / (sm16 + 64));
             const dim3 grid16((unsigned)(n_tiles < resident16 ? n_tiles : resident16));
-#define CS_TOP16(CIN_) hipLaunchKernelGGL((convt_top_gemm16_kernel<CIN_>), grid16, dim3(256), sm16, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles)
-            if (cin == 32) CS_TOP16(32); else if (cin == 64) CS_TOP16(64); else CS_TOP16(128);
+#define CS_TOP16(CIN_, S_) hipLaunchKernelGGL((convt_top_gemm16_kernel<CIN_, S_>), grid16, dim3(256), sm16, s, sa, sb, w_torch, bias, out, stats, hin, win, tiles_x, tiles_y, n_tiles, sx)
+            if (sum2) { if (cin == 64) CS_TOP16(64, true); else CS_TOP16(128, true); }
+            else if (cin == 32) CS_TOP16(32, false); else if (cin == 64) CS_TOP16(64, false); else CS_TOP16(128, false);
 #undef CS_TOP16
         } else if (a.h16) {
             if (cin == 32) CS_TOP(32, true); else if (cin == 64) CS_TOP(64, true); else CS_TOP(128, true);
@@ -849,19 +911,20 @@ int launch_convt_small(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const 
 // last layer: logits = conv3x3(T(u)) + bias + T(u)   (ResidualUnit(3->3, subunits=1, last_conv_only) with an
 // identity residual).  T = InstanceNorm + PReLU of the top transposed conv, applied lazily.  One thread per pixel.
 // ------------------------------------------------------------------------------------------------
+// Round 5: the patch is staged with 16-byte loads and read back with 16-byte LDS reads, the 81 weights sit in scalar registers and the
+// 12 output floats of a thread leave as three 16-byte stores (the first form moved every element as a dword - 14 loads, 14 LDS stores and
+// 135 LDS reads per thread - and ran at 44 % of the HBM rate).  Window widths are multiples of 16, so every row of u / out starts on a
+// 16-byte boundary; the LDS row mirrors global floats [3 x0 - 4, 3 x0 + 200) of the image row, i.e. patch pixel x0 - 1 starts at float 1.
 template <int C>
-__global__ __launch_bounds__(256) void conv_last_kernel(const float* u, const float2* tab, const float* slope_p, const float* w,
-                                                        const float* bias, float* out, int h, int wd, int tiles_x, int tiles_y) {
-    // Tile of 16 x 64 output pixels per block, 4 consecutive pixels per thread.  The (18 x 66)-pixel patch of T(u) is staged
-    // through LDS once (row segments are contiguous in HBM: coalesced dword loads, 3.5 per output pixel instead of 27), with
-    // the lazy InstanceNorm + PReLU applied on the way in and zeros outside the image (padding follows the activation).
-    constexpr int TH = 16, TW = 64, PH = TH + 2, PW = TW + 2, ROWF = PW * C, PITCH = ROWF + 3;   // +3: rows start on different banks
-    __shared__ float p_s[PH * PITCH];
-    __shared__ float w_s[C * C * 9];
-    __shared__ float b_s[C];
+__global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict__ u, const float2* __restrict__ tab, const float* __restrict__ slope_p,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
+                                                        int h, int wd, int tiles_x, int tiles_y) {
+    static_assert(C == 3, "3-class contract");
+    constexpr int TH = 16, TW = 64, PH = TH + 2;
+    constexpr int ROW4 = (TW * C + 8 + 3) / 4 + 1;           // 51 float4 per patch row: floats [-4, 200) around the tile's first pixel
+    constexpr int PITCH4 = ROW4 + 2;                         // 53 float4: rows start 16 banks apart (the 16 threads of a row read 48-byte strides)
+    __shared__ f32x4m p_s[PH * PITCH4];
     const int tid = threadIdx.x;
-    for (int i = tid; i < C * C * 9; i += 256) w_s[i] = w[i];
-    if (tid < C) b_s[tid] = bias ? bias[tid] : 0.f;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
     bid /= tiles_x;
@@ -876,62 +939,85 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const float* u, const fl
         sc[c] = t.x;
         sh[c] = t.y;
     }
-    const float* base = u + (size_t)img * h * wd * C;
-    constexpr int N_EL = PH * ROWF, ITERS = (N_EL + 255) / 256;
-    float rv[ITERS];
+    float wr[C * C * 9], br[C];                              // uniform addresses: scalar loads, the FMAs below take them as SGPR operands
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {                     // unconditional, clamped loads: all in flight together
+    for (int i = 0; i < C * C * 9; ++i) wr[i] = w[i];
+#pragma unroll
+    for (int c = 0; c < C; ++c) br[c] = bias ? bias[c] : 0.f;
+    const float* base = u + (size_t)img * h * wd * C;
+    const int row_floats = wd * C;
+    constexpr int N4 = PH * ROW4, ITERS = (N4 + 255) / 256;
+    f32x4m rv[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {                     // unconditional, clamped 16-byte loads: all in flight together
         const int i = tid + 256 * it;
-        const int r = i / ROWF, e = i - r * ROWF;
-        const int yy = y0 - 1 + r, xx = x0 - 1 + e / C;
-        const bool ok = i < N_EL && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)wd;
-        rv[it] = base[ok ? ((size_t)yy * wd + x0 - 1) * C + e : 0];
+        const int r = i / ROW4, q4 = i - r * ROW4;
+        const int yy = y0 - 1 + r, f0 = x0 * C - 4 + 4 * q4;  // first float of the quad inside the image row
+        const bool ok = i < N4 && (unsigned)yy < (unsigned)h && f0 >= 0 && f0 + 3 < row_floats;
+        rv[it] = *reinterpret_cast<const f32x4m*>(base + (ok ? (size_t)yy * row_floats + f0 : 0));
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = tid + 256 * it;
-        const int r = i / ROWF, e = i - r * ROWF;
-        const int c = e % C;
-        const int yy = y0 - 1 + r, xx = x0 - 1 + e / C;
-        const bool ok = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)wd;
-        float v = rv[it];
-        if (tab) v = prelu1(v * (c == 0 ? sc[0] : c == 1 ? sc[1] : sc[C - 1]) + (c == 0 ? sh[0] : c == 1 ? sh[1] : sh[C - 1]), slope);
-        if (i < N_EL) p_s[r * PITCH + e] = ok ? v : 0.f;
+        const int r = i / ROW4, q4 = i - r * ROW4;
+        const int yy = y0 - 1 + r, f0 = x0 * C - 4 + 4 * q4;
+        const bool ok = (unsigned)yy < (unsigned)h && f0 >= 0 && f0 + 3 < row_floats;      // quads never straddle the image edge (wd % 4 == 0)
+        f32x4m v = rv[it];
+        if (tab) {
+            // channel of float f0 + k: (f0 + k) % 3 with f0 = 3 x0 - 4 + 4 q4, x0 % 4 == 0  ->  (2 + q4 + k) % 3
+            const int c0 = (2 + q4) % 3;
+            const float s0 = c0 == 0 ? sc[0] : c0 == 1 ? sc[1] : sc[2], s1 = c0 == 0 ? sc[1] : c0 == 1 ? sc[2] : sc[0], s2 = c0 == 0 ? sc[2] : c0 == 1 ? sc[0] : sc[1];
+            const float h0 = c0 == 0 ? sh[0] : c0 == 1 ? sh[1] : sh[2], h1 = c0 == 0 ? sh[1] : c0 == 1 ? sh[2] : sh[0], h2 = c0 == 0 ? sh[2] : c0 == 1 ? sh[0] : sh[1];
+            v.x = prelu1(v.x * s0 + h0, slope);
+            v.y = prelu1(v.y * s1 + h1, slope);
+            v.z = prelu1(v.z * s2 + h2, slope);
+            v.w = prelu1(v.w * s0 + h0, slope);
+        }
+        if (i < N4) p_s[r * PITCH4 + q4] = ok ? v : f32x4m{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     const int ly = tid >> 4, lx = (tid & 15) * 4;            // 16 rows x 16 groups of 4 pixels
-    float nb[3][6 * C];                                      // 3 rows x 6 columns x C channels around the 4 pixels
+    // the thread's 6 x 3 floats of a row start at float 1 + 3 lx = 1 + 12 m of the LDS row: five 16-byte reads [12 m, 12 m + 20)
+    float nb[3][20];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int e = 0; e < 6 * C; ++e) nb[r][e] = p_s[(ly + r) * PITCH + lx * C + e];
+        for (int k = 0; k < 5; ++k) {
+            const f32x4m q = p_s[(ly + r) * PITCH4 + (lx * C) / 4 + k];
+            nb[r][4 * k] = q.x; nb[r][4 * k + 1] = q.y; nb[r][4 * k + 2] = q.z; nb[r][4 * k + 3] = q.w;
+        }
     const int y = y0 + ly;
-    if (y >= h) return;
+    if (y >= h || x0 + lx >= wd) return;                     // (wd % 4 == 0: a thread's four pixels are inside or outside together)
+    float o[4 * C];
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
-        const int x = x0 + lx + px;
-        if (x >= wd) break;
         float acc[C];
 #pragma unroll
-        for (int co = 0; co < C; ++co) acc[co] = b_s[co];
+        for (int co = 0; co < C; ++co) acc[co] = br[co];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int ci = 0; ci < C; ++ci) {
-                    const float v = nb[ky][(px + kx) * C + ci];
+                    const float v = nb[ky][1 + (px + kx) * C + ci];
 #pragma unroll
-                    for (int co = 0; co < C; ++co) acc[co] += v * w_s[(co * C + ci) * 9 + ky * 3 + kx];
+                    for (int co = 0; co < C; ++co) acc[co] += v * wr[(co * C + ci) * 9 + ky * 3 + kx];
                 }
-        const float* ctr = &nb[1][(px + 1) * C];               // identity residual T(u), added after the conv as the reference does
-        *reinterpret_cast<Px3*>(out + (((size_t)img * h + y) * wd + x) * C) = Px3{acc[0] + ctr[0], acc[1] + ctr[1], acc[C - 1] + ctr[C - 1]};
+        // identity residual T(u), added after the conv as the reference does
+#pragma unroll
+        for (int co = 0; co < C; ++co) o[px * C + co] = acc[co] + nb[1][1 + (px + 1) * C + co];
     }
+    f32x4m* dst = reinterpret_cast<f32x4m*>(out + (((size_t)img * h + y) * wd + x0 + lx) * C);
+    dst[0] = f32x4m{o[0], o[1], o[2], o[3]};
+    dst[1] = f32x4m{o[4], o[5], o[6], o[7]};
+    dst[2] = f32x4m{o[8], o[9], o[10], o[11]};
 }
 
 int launch_conv_last(hipStream_t s, const ConvSrc& u, const float* w_torch, const float* bias, float* out, int c, int n, int h,
                      int w) {
     CS_REQUIRE(c == 3 && u.pitch == 3, "conv(last): %d channels unsupported (3-class contract)", c);
+    CS_REQUIRE(w % 4 == 0, "conv(last): the width %d must be a multiple of 4 (windows are multiples of 16)", w);
     const double flops = 2.0 * n * h * w * 81.0;
     const double bytes = 4.0 * n * (double)h * w * 6;
     ProfScope prof(K_CONV_LAST, s, flops, bytes);
@@ -955,9 +1041,9 @@ __device__ __forceinline__ int win_start(int i, int interval, int size, int roi)
 template <int C>
 __global__ __launch_bounds__(256) void swi_finalize_kernel(SwiFinalizeArgs a) {
     const cs_swi_plan& pl = a.plan;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = a.col_begin + blockIdx.x * blockDim.x + threadIdx.x;
     const int y = a.row_begin + blockIdx.y;
-    if (x >= pl.img_w || y >= a.row_end) return;
+    if (x >= a.col_end || y >= a.row_end) return;
     const int py = y + pl.pad_top, px = x + pl.pad_left;   // padded coordinates
     float sum[C];
 #pragma unroll
@@ -1006,13 +1092,16 @@ __global__ __launch_bounds__(256) void swi_finalize_kernel(SwiFinalizeArgs a) {
     }
 }
 
-int launch_swi_finalize(hipStream_t s, const SwiFinalizeArgs& a) {
+int launch_swi_finalize(hipStream_t s, const SwiFinalizeArgs& a0) {
+    SwiFinalizeArgs a = a0;
+    if (a.col_end == 0 && a.col_begin == 0) a.col_end = a.plan.img_w;     // callers that finalise whole rows
     CS_REQUIRE(a.c == 3, "swi finalize: %d classes unsupported (3-class contract)", a.c);
     CS_REQUIRE(a.row_begin >= 0 && a.row_end <= a.plan.img_h && a.row_begin <= a.row_end, "swi finalize: bad row range");
-    if (a.row_end == a.row_begin) return CS_OK;
-    const double px = (double)(a.row_end - a.row_begin) * a.plan.img_w;
+    CS_REQUIRE(a.col_begin >= 0 && a.col_end <= a.plan.img_w && a.col_begin <= a.col_end, "swi finalize: bad column range");
+    if (a.row_end == a.row_begin || a.col_end == a.col_begin) return CS_OK;
+    const double px = (double)(a.row_end - a.row_begin) * (a.col_end - a.col_begin);
     ProfScope prof(K_SWI_FINALIZE, s, 0, px * (12.0 * 4 + 17.0));
-    dim3 grid((unsigned)ceil_div(a.plan.img_w, 256), (unsigned)(a.row_end - a.row_begin));
+    dim3 grid((unsigned)ceil_div(a.col_end - a.col_begin, 256), (unsigned)(a.row_end - a.row_begin));
     hipLaunchKernelGGL((swi_finalize_kernel<3>), grid, dim3(256), 0, s, a);
     CS_HIP(hipGetLastError());
     return CS_OK;

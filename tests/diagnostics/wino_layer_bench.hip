@@ -152,54 +152,7 @@ int main(int argc, char** argv) {
             printf("      F(4x4): %7.1f us (%5.1f TF issued = %4.1f%% of 157.3; %5.1f TF direct-equivalent)   max|dy| %.2e (at img %zu y %zu x %zu ch %zu), stats rel %.1e\n",
                    us_4, f4_gf / us_4 * 1e3, f4_gf / us_4 * 1e3 / 157.3 * 100, direct_gf / us_4 * 1e3, err4, wpix / ((size_t)L.hw * L.hw),
                    (wpix / L.hw) % L.hw, wpix % L.hw, worst % L.cout, serr4);
-            if (getenv("WINO_STAMPS4")) {     // one more launch with in-kernel stamps (kernels_conv_wino4x.hip): cycles per phase, first and last block
-                long long* sb;
-                CK(hipMalloc(&sb, 128 * 8));
-                CK(hipMemset(sb, 0, 128 * 8));
-                cs::wino_set_stamp_buffer(sb);
-                run_4();
-                CK(hipStreamSynchronize(s));
-                cs::wino_set_stamp_buffer(nullptr);
-                long long hs[128];
-                CK(hipMemcpy(hs, sb, 128 * 8, hipMemcpyDeviceToHost));
-                const char* nm[8] = {"prologue", "loads+mfma", "norm+store", "barrier", "transform", "barrier", "epilogue", "-"};
-                for (int blk = 0; blk < 2; ++blk)
-                    for (int wv : {0, 5}) {
-                        const long long* h = hs + blk * 64 + wv * 8;
-                        long long tot = 0;
-                        for (int k = 0; k < 7; ++k) tot += h[k];
-                        if (!tot) continue;
-                        printf("      x %s block wave %d: %lld cyc in %.1f us = %.2f GHz:", blk ? "last " : "first", wv, tot, h[7] / 100.0, tot / (h[7] * 10.0));
-                        for (int k = 0; k < 7; ++k) printf("  %s %lld", nm[k], h[k]);
-                        printf("\n");
-                    }
-                (void)hipFree(sb);
-            }
             (void)hipFree(w4);
-        }
-        if (getenv("WINO_STAMPS")) {       // one more launch with in-kernel stamps: cycles per phase, block 0, per wave
-            long long* sb;
-            CK(hipMalloc(&sb, 64 * 8));
-            CK(hipMemset(sb, 0, 64 * 8));
-            cs::wino_set_stamp_buffer(sb);
-            run_w();
-            CK(hipStreamSynchronize(s));
-            cs::wino_set_stamp_buffer(nullptr);
-            long long hs[64];
-            CK(hipMemcpy(hs, sb, 64 * 8, hipMemcpyDeviceToHost));
-            const char* names_m[8] = {"barrier", "mfma", "handover", "-", "-", "-", "-", "-"};
-            const char* names_s[8] = {"barrier", "wait+norm+store", "issue loads", "transform", "combine", "-", "-", "-"};
-            const char* names_1[8] = {"prologue", "loads+mfma", "norm+store", "barrier", "transform", "barrier", "epilogue", "-"};
-            const bool v1 = getenv("CS_WINO") && atoi(getenv("CS_WINO")) == 1;
-            for (int wv : {0, 4}) {
-                if (v1 && wv) break;
-                long long tot = 0;
-                for (int k = 0; k < 8; ++k) tot += hs[wv * 8 + k];
-                printf("      wave %d: total %lld cyc:", wv, tot);
-                for (int k = 0; k < 7; ++k) printf("  %s %.1f%%", v1 ? names_1[k] : wv < 4 ? names_m[k] : names_s[k], 100.0 * hs[wv * 8 + k] / (tot ? tot : 1));
-                printf("\n");
-            }
-            (void)hipFree(sb);
         }
         if (tab) { (void)hipFree(tab); (void)hipFree(slope); }
         for (void* ptr : {(void*)x, (void*)w, (void*)b, (void*)ww, (void*)wd, (void*)y1, (void*)y2, (void*)st1, (void*)st2}) (void)hipFree(ptr);

@@ -289,7 +289,7 @@ def test_low_precision_modes_against_the_fp32_path_and_the_ground_truth():
     """north_star: "F1 within 1e-3 of reference on held-out tuning set".  On the synthetic-trained 32-base net (bench.lowprec_accuracy:
     150 AdamW steps, EIGHT held-out 1024^2 synthetic images with known ground truth, ~3 600 cells: one cell is < 3e-4 of F1) the
     fp32-grade modes must reproduce the fp32 instances and stay within 1e-3 of the fp32 path's F1 against the ground truth; the bf16
-    datapath within 1e-3 and the fp8 mode - layers below 128 channels on the bf16 kernels, "mixed fp8 weights / bf16" - within 2e-3
+    datapath and the fp8 mode - layers below 128 channels on the bf16 kernels, "mixed fp8 weights / bf16" - within the same 1e-3
     (measured +2.7e-4 / +2.2e-4 and F1 0.9988 / 0.9986 against the fp32 instances, profiles/fp8_mix_accuracy_r04.json; with EVERY
     layer in e4m3, as in rounds 2-3, the same images give -4.3e-4 and 0.9934)."""
     sys.path[:0] = [ROOT, PKG]
@@ -301,7 +301,22 @@ def test_low_precision_modes_against_the_fp32_path_and_the_ground_truth():
     assert res["bf16"]["f1_vs_fp32"] >= 0.995 and res["bf16"]["pixel_agreement"] >= 0.998, res["bf16"]
     assert res["fp8"]["f1_vs_fp32"] >= 0.995 and res["fp8"]["pixel_agreement"] >= 0.998, res["fp8"]
     assert abs(res["bf16"]["delta_f1_vs_truth"]) <= 1e-3, res["bf16"]
-    assert abs(res["fp8"]["delta_f1_vs_truth"]) <= 2e-3, res["fp8"]
+    assert abs(res["fp8"]["delta_f1_vs_truth"]) <= 1e-3, res["fp8"]
+
+
+def test_configs4_accuracy_at_its_own_width_and_window():
+    """BASELINE.json configs[4] names a 64-base U-Net on 512 x 512 windows with fp8 weights: the accuracy claim is made THERE - the
+    64...1024 net trained on synthetic cells (150 AdamW steps, fp32 engine), four held-out 2048^2 images segmented with 512^2 windows in
+    fp32, on the bf16 datapath and in the mixed fp8 mode; instance F1@0.5 against the ground truth (compute_metric.py:107-122 semantics)
+    within 1e-3 of the fp32 path's, north_star's bound."""
+    sys.path[:0] = [ROOT, PKG]
+    from bench import lowprec_accuracy
+    res = lowprec_accuracy(_dev(), n_images=4, size=2048, precisions=("bf16", "fp8"), width="deep64", roi=512)
+    assert res["trained_net"]["channels"] == [64, 128, 256, 512, 1024] and res["trained_net"]["window"] == 512
+    assert res["trained_net"]["cells_found_fp32"] > 3000 and res["trained_net"]["f1_vs_truth_fp32"] > 0.6, res["trained_net"]
+    for prec in ("bf16", "fp8"):
+        assert res[prec]["f1_vs_fp32"] >= 0.995 and res[prec]["pixel_agreement"] >= 0.998, (prec, res[prec])
+        assert abs(res[prec]["delta_f1_vs_truth"]) <= 1e-3, (prec, res[prec])
 
 
 def test_predict_cli_accepts_fp8(tmp_path):

@@ -217,3 +217,111 @@ def test_bench_launcher_stops_all_ranks_when_one_dies(tmp_path):
     finally:
         os.environ.pop("BENCH_DEVICE")
     assert rc == 1 and took < 30
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# window-LIST partition of ONE image (cs_swi_partition_windows / parallel.share_transfers / exchange_share / gather_shares)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 8, 40])
+@pytest.mark.parametrize("h,w,overlap", [(4096, 520, 0.5), (1000, 700, 0.25), (700, 520, 0.5), (200, 300, 0.25), (257, 513, 0.5), (8192, 1100, 0.5),
+                                         (300, 260, 0.75)])
+def test_window_list_partition_covers_every_pixel_once_and_names_every_needed_window(world, h, w, overlap):
+    import cellseg_amd as ca
+    from cellseg_amd import parallel
+    roi = 512 if h == 8192 else 256
+    plan = ca.make_plan(h, w, (roi, roi), overlap)
+    hs, ws = ca.window_starts(plan)
+    nwin = plan.n_h * plan.n_w
+    shares = [ca.share_partition(plan, r, world) for r in range(world)]
+    # windows: contiguous, disjoint, complete, shares differ by at most ONE window
+    assert shares[0].win_begin == 0 and shares[-1].win_end == nwin
+    sizes = [s.win_end - s.win_begin for s in shares]
+    assert all(a.win_end == b.win_begin for a, b in zip(shares, shares[1:])) and max(sizes) - min(sizes) <= 1
+    # rectangles: every pixel exactly once
+    cover = np.zeros((h, w), np.int32)
+    owner = np.full((h, w), -1, np.int32)
+    for r, s in enumerate(shares):
+        assert (s.n_rects == 0) == (s.win_end == s.win_begin) or s.n_rects > 0
+        for r0, r1, c0, c1 in s.rects():
+            assert 0 <= r0 < r1 <= h and 0 <= c0 < c1 <= w
+            cover[r0:r1, c0:c1] += 1
+            owner[r0:r1, c0:c1] = r
+    assert (cover == 1).all()
+    # a pixel belongs to the rank of its LAST covering window; every other covering window is its own or named by share_transfers
+    transfers = parallel.share_transfers(plan, world)
+    have = {}
+    for src, dst, k, lo, hi in transfers:
+        assert src < dst and shares[src].win_begin <= k < shares[src].win_end and 0 <= lo < hi <= roi
+        assert shares[dst].slot_row_begin * plan.n_w <= k < shares[dst].win_begin
+        have[(dst, k)] = (lo, hi)
+    rng = np.random.default_rng(0)
+    ys = np.unique(np.concatenate([rng.integers(0, h, 24), [0, h - 1], np.clip(np.array(hs) - plan.pad_top, 0, h - 1)]))
+    xs = np.unique(np.concatenate([rng.integers(0, w, 24), [0, w - 1], np.clip(np.array(ws) - plan.pad_left, 0, w - 1)]))
+    for y in ys:
+        rows = [i for i, s0 in enumerate(hs) if s0 <= y + plan.pad_top < s0 + roi]
+        for x in xs:
+            cols = [j for j, s0 in enumerate(ws) if s0 <= x + plan.pad_left < s0 + roi]
+            r = int(owner[y, x])
+            s = shares[r]
+            last = rows[-1] * plan.n_w + cols[-1]
+            assert s.win_begin <= last < s.win_end, (y, x, r, last)
+            for i in rows:
+                assert s.slot_row_begin <= i < s.slot_row_end
+                for j in cols:
+                    k = i * plan.n_w + j
+                    if not (s.win_begin <= k < s.win_end):
+                        lo, hi = have[(r, k)]
+                        assert lo <= y + plan.pad_top - hs[i] < hi, (y, x, r, k, lo, hi)
+    if (h, overlap, world) == (4096, 0.5, 8):
+        plan2 = ca.make_plan(4096, 4096, (256, 256), 0.5)
+        sizes2 = [s.win_end - s.win_begin for s in (ca.share_partition(plan2, r, 8) for r in range(8))]
+        assert sorted(sizes2) == [120] * 7 + [121] and sum(sizes2) == 961
+
+
+def _share_worker(rank, world, port, h, w, overlap, q, transport):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cellseg_amd as ca
+        from cellseg_amd import parallel
+        roi = 32
+        plan = ca.make_plan(h, w, (roi, roi), overlap)
+        g = torch.Generator().manual_seed(5)
+        every = torch.rand(plan.n_h * plan.n_w, roi, roi, 3, generator=g)       # what all windows of the image predict
+        me = ca.share_partition(plan, rank, world)
+        base = me.slot_row_begin * plan.n_w
+        n_slots = (me.slot_row_end - me.slot_row_begin) * plan.n_w
+        win = torch.full((max(n_slots, 1), roi, roi, 3), float("nan"))
+        win[me.win_begin - base:me.win_end - base] = every[me.win_begin:me.win_end]
+        n = parallel.exchange_share(win, plan, rank, world, transport=transport)
+        ok = True
+        for src, dst, k, lo, hi in parallel.share_transfers(plan, world):
+            if dst == rank:
+                ok &= bool(torch.equal(win[k - base, lo:hi], every[k, lo:hi]))
+        # the rectangles re-assemble into the full mask on every rank (and assemble=False returns nothing)
+        full = (torch.rand(h, w, generator=torch.Generator().manual_seed(6)) > 0.5).to(torch.uint8)
+        mine = torch.full((h, w), 7, dtype=torch.uint8)
+        for r0, r1, c0, c1 in me.rects():
+            mine[r0:r1, c0:c1] = full[r0:r1, c0:c1]
+        out = parallel.gather_shares(mine, plan, world)
+        none = parallel.gather_shares(mine, plan, world, assemble=False)
+        q.put((rank, ok, bool(torch.equal(out, full)) and none is None, n))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["p2p", "allgather"])
+@pytest.mark.parametrize("world,h,w,overlap", [(2, 200, 70, 0.5), (3, 200, 130, 0.5), (3, 171, 90, 0.25), (4, 97, 97, 0.5), (1, 120, 70, 0.5), (5, 64, 200, 0.75)])
+def test_share_exchange_and_rectangle_gather(world, h, w, overlap, transport):
+    """Both transports of the window-list seam exchange deliver exactly the window parts the partition asks for, and the all-gather of
+    the finalised rectangles re-assembles the image."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_share_worker, args=(r, world, port, h, w, overlap, q, transport)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok and ok2 for _, ok, ok2, _ in res), res

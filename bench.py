@@ -642,14 +642,14 @@ def main():
             r, w, full_mask = sim
 
             def fake_exchange(win, pl, rr, ww):
-                base = ca.share_partition(pl, rr, ww).slot_row_begin * pl.n_w
-                for (src, dst), groups in parallel._share_groups(pl, ww).items():
-                    for (lo, hi), ks in groups:
-                        if dst == rr:            # pack (stood in for locally: the rank's own last windows), a device-local copy in place of the link, unpack
-                            own = torch.as_tensor([sh_me.win_end - 1 - base - (i % 8) for i in range(len(ks))], dtype=torch.long, device=win.device)
-                            win[torch.as_tensor([kk - base for kk in ks], dtype=torch.long, device=win.device), lo:hi] = win[own, lo:hi].clone()
+                base = sh_me.slot_row_begin * pl.n_w
+                own0 = sh_me.win_begin - base                      # stand-in source on this GPU: the rank's own first windows
+                for (src, dst), runs in parallel._share_runs(pl, ww).items():
+                    for lo, hi, k0, cnt in runs:
+                        if dst == rr:            # pack (stood in for locally), a device-local copy in place of the link, unpack
+                            win[k0 - base:k0 - base + cnt, lo:hi].copy_(win[own0:own0 + cnt, lo:hi].contiguous().clone())
                         elif src == rr:
-                            win[torch.as_tensor([kk - base for kk in ks], dtype=torch.long, device=win.device), lo:hi].clone()
+                            win[k0 - base:k0 - base + cnt, lo:hi].contiguous().clone()
             sh_me = ca.share_partition(plan, r, w)
             ca.swi_infer_share(model, image, roi, args.overlap, r, w, engine_batch=args.strip_batch or None, streams=args.streams,
                                exchange=fake_exchange)

@@ -204,13 +204,26 @@ def share_transfers(plan, world: int) -> List[Tuple[int, int, int, int, int]]:
     return out
 
 
-def _share_groups(plan, world: int):
-    """share_transfers grouped for the wire: {(src, dst): [((row_lo, row_hi), [windows...]), ...]} - the windows of one pair that want the
-    same rows travel as ONE tensor [n, rows, roi_w, C] (three groups per pair at most: lower halves, the left neighbour's upper part)."""
-    groups = {}
-    for src, dst, k, lo, hi in share_transfers(plan, world):
-        groups.setdefault((src, dst), {}).setdefault((lo, hi), []).append(k)
-    return {pair: sorted(g.items()) for pair, g in groups.items()}
+_SHARE_RUNS = {}
+
+
+def _share_runs(plan, world: int):
+    """share_transfers grouped for the wire: {(src, dst): [(row_lo, row_hi, first_window, count), ...]} - consecutive windows of one pair
+    that want the same rows travel as ONE tensor [count, rows, roi_w, C], a plain slice of the window slots on both sides (two runs per
+    pair at overlap 0.5: the lower halves of the n_w windows above the cut and the left neighbour of the first own window).  Cached per
+    plan: the partition is fixed for a slide size."""
+    key = (tuple(getattr(plan, f) for f, _ in plan._fields_), world)
+    runs = _SHARE_RUNS.get(key)
+    if runs is None:
+        runs = {}
+        for src, dst, k, lo, hi in share_transfers(plan, world):
+            lst = runs.setdefault((src, dst), [])
+            if lst and lst[-1][0] == lo and lst[-1][1] == hi and lst[-1][2] + lst[-1][3] == k:
+                lst[-1] = (lo, hi, lst[-1][2], lst[-1][3] + 1)
+            else:
+                lst.append((lo, hi, k, 1))
+        _SHARE_RUNS[key] = runs
+    return runs
 
 
 def exchange_share(win: torch.Tensor, plan, rank: int, world: int, group=None, transport: str = "p2p") -> int:
@@ -222,56 +235,55 @@ def exchange_share(win: torch.Tensor, plan, rank: int, world: int, group=None, t
     from .inferers import share_partition
     if transport not in ("p2p", "allgather"):
         raise ValueError(f"exchange_share: unknown transport {transport!r}")
-    groups = _share_groups(plan, world)
-    if not groups or not _collectives_on(group):
+    runs = _share_runs(plan, world)
+    if not runs or not _collectives_on(group):
         return 0
     base = share_partition(plan, rank, world).slot_row_begin * plan.n_w
-    idx = lambda ks: torch.as_tensor([k - base for k in ks], dtype=torch.long, device=win.device)      # noqa: E731
     bounce = _host_bounce(win, group)
     wire = torch.device("cpu") if bounce else win.device
+    row_floats = plan.roi_w * win.shape[-1]
     n = 0
     if transport == "allgather":
         offs, fill = {}, [0] * world
-        for (src, dst), gs in sorted(groups.items()):
-            for (lo, hi), ks in gs:
-                offs[(src, dst, lo, hi)] = fill[src]
-                fill[src] += len(ks) * (hi - lo) * plan.roi_w * win.shape[-1]
+        for (src, dst), rs in sorted(runs.items()):
+            for lo, hi, k0, cnt in rs:
+                offs[(src, dst, k0)] = fill[src]
+                fill[src] += cnt * (hi - lo) * row_floats
         slot = max(fill)
         mine = torch.zeros(slot, dtype=win.dtype, device=wire)
-        for (src, dst), gs in sorted(groups.items()):
+        for (src, dst), rs in sorted(runs.items()):
             if src == rank:
-                for (lo, hi), ks in gs:
-                    part = win[idx(ks), lo:hi].reshape(-1)
-                    o = offs[(src, dst, lo, hi)]
-                    mine[o:o + part.numel()].copy_(part)
+                for lo, hi, k0, cnt in rs:
+                    o, numel = offs[(src, dst, k0)], cnt * (hi - lo) * row_floats
+                    mine[o:o + numel].view(cnt, hi - lo, plan.roi_w, win.shape[-1]).copy_(win[k0 - base:k0 - base + cnt, lo:hi])
                     n += 1
         out = mine.new_empty(world * slot)
         dist.all_gather_into_tensor(out, mine, group=group)
-        for (src, dst), gs in sorted(groups.items()):
+        for (src, dst), rs in sorted(runs.items()):
             if dst == rank:
-                for (lo, hi), ks in gs:
-                    o = src * slot + offs[(src, dst, lo, hi)]
-                    numel = len(ks) * (hi - lo) * plan.roi_w * win.shape[-1]
-                    win[idx(ks), lo:hi] = out[o:o + numel].view(len(ks), hi - lo, plan.roi_w, win.shape[-1]).to(win.device)
+                for lo, hi, k0, cnt in rs:
+                    o, numel = src * slot + offs[(src, dst, k0)], cnt * (hi - lo) * row_floats
+                    win[k0 - base:k0 - base + cnt, lo:hi].copy_(out[o:o + numel].view(cnt, hi - lo, plan.roi_w, win.shape[-1]), non_blocking=True)
                     n += 1
         return n
     ops, landing = [], []
-    for (src, dst), gs in sorted(groups.items()):
+    for (src, dst), rs in sorted(runs.items()):
         if rank not in (src, dst):
             continue
-        for (lo, hi), ks in gs:
+        for lo, hi, k0, cnt in rs:
+            view = win[k0 - base:k0 - base + cnt, lo:hi]             # [cnt, rows, roi_w, C]: contiguous per window
             if rank == src:
-                buf = win[idx(ks), lo:hi]                           # advanced indexing: a packed copy [n, rows, roi_w, C]
-                ops.append(dist.P2POp(dist.isend, buf.to(wire), dst, group))
+                buf = view.contiguous()
+                ops.append(dist.P2POp(dist.isend, buf.cpu() if bounce else buf, dst, group))
             else:
-                buf = torch.empty((len(ks), hi - lo, plan.roi_w, win.shape[-1]), dtype=win.dtype, device=wire)
+                buf = torch.empty(view.shape, dtype=win.dtype, device=wire)
                 ops.append(dist.P2POp(dist.irecv, buf, src, group))
-                landing.append((ks, lo, hi, buf))
+                landing.append((view, buf))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    for ks, lo, hi, buf in landing:
-        win[idx(ks), lo:hi] = buf.to(win.device)
+    for view, buf in landing:
+        view.copy_(buf, non_blocking=True)
     return len(ops)
 
 

@@ -66,13 +66,15 @@ def test_window_row_strips_are_bitwise_the_single_gpu_result(shape, overlap, wor
 
 
 def test_seam_exchange_between_two_ranks_sharing_the_gpu():
-    """bench.py --gpus 2 --shard strips over gloo on one GPU: the seam halves really travel between two processes, the mask strips
-    are gathered, and the labels equal those of the one-slide-per-rank leg on the same slide."""
+    """bench.py --gpus 2 --shard strips over gloo on one GPU: the window parts of the window-list partition really travel between two
+    processes, the finalised rectangles are gathered, the rank whose turn it is labels the mask, and the labels equal those of the
+    one-slide-per-rank leg on the same slide."""
     line = _bench("--gpus", "2", "--shard", "strips", "--size", "1024", "--steps", "2", "--warmup", "1", "--train-batch", "2",
                   "--train-steps", "2", "--strip-batch", "8", BENCH_DEVICE=0, BENCH_BACKEND="gloo")
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
-    assert line["config"]["window_rows_per_rank"] == [3, 4] and line["config"]["equal_to_single_gpu_labels"] is True
+    assert line["config"]["windows_per_rank"] == [24, 25] and line["config"]["equal_to_single_gpu_labels"] is True
     assert line["value_strips"] == line["value"] and line["value_slides"] == line["slides"]["value"]
+    assert line["config"]["labelling"] == "round-robin over the ranks"
 
 
 # ------------------------------------------------------------------------------------------- RCCL, executed
@@ -131,7 +133,8 @@ def test_bench_line_has_latency_reference_scope_and_strips_simulation():
     assert line["latency_ms"] > 0 and line["latency"]["min_ms"] <= line["latency_ms"] <= line["latency"]["max_ms"]
     assert 0 < line["value_incl_tiff"] < line["value"] * 1.5
     sim = line["strips_sim"]
-    assert sim["of"] == 8 and sim["max_windows_per_rank"] == -(-7 // 8) * 7 and sim["ratio"] > 1 and sim["ranks"]["0"]["labels_the_mask"]
+    assert sim["of"] == 8 and sim["max_windows_per_rank"] == 7 and sorted(sim["windows_per_rank"]) == [6] * 7 + [7]      # 49 windows: 6 or 7 each
+    assert sim["ratio"] > 1 and sim["ranks"]["0"]["labels_every"] == 8
 
 
 # ------------------------------------------------------------------------------------------- BatchNorm under the tiler

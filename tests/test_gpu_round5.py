@@ -68,17 +68,3 @@ def test_window_list_shares_are_bitwise_the_single_gpu_result(shape, overlap, wo
                 assert torch.equal(lg[:, r0:r1, c0:c1], logits[:, r0:r1, c0:c1]), (r, r0, r1, c0, c1)
                 assert torch.equal(pr[r0:r1, c0:c1], prob[r0:r1, c0:c1]) and torch.equal(mk[r0:r1, c0:c1], mask[r0:r1, c0:c1])
     assert bool((seen == 1).all())
-
-
-def test_share_exchange_between_two_ranks_sharing_the_gpu():
-    """bench.py --gpus 2 --shard strips over gloo on one GPU: the window parts really travel between two processes, the finalised
-    rectangles are gathered, the rank whose turn it is labels the mask, and the labels equal those of the one-slide-per-rank leg."""
-    from conftest import cli_env
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "strips", "--size", "1024", "--steps", "2",
-                          "--warmup", "1", "--train-batch", "2", "--train-steps", "2", "--strip-batch", "8"], capture_output=True, text=True,
-                         timeout=900, env=cli_env(BENCH_DEVICE=0, BENCH_BACKEND="gloo"))
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
-    assert line["config"]["windows_per_rank"] == [24, 25] and line["config"]["equal_to_single_gpu_labels"] is True
-    assert line["config"]["labelling"] == "round-robin over the ranks"

@@ -30,6 +30,7 @@ namespace cs {
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 
 constexpr int X_IH = 18, X_IW = 18;
 constexpr int X_PS = 20;                               // floats per staged raw pixel (16 + 4: see kernels_conv_wino4.hip)
@@ -60,6 +61,18 @@ __device__ __forceinline__ void xat6(const f32x4 (&m)[6], f32x4 (&o)[4]) {
     o[3] = (d1 + 8.f * d2) + m[5];
 }
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// rows 2 g, 2 g + 1 of A^T m for a WAVE-UNIFORM g (the output threads of a wave all own the same row pair): the branch is a scalar one,
+// so a thread computes the two rows it needs instead of all four followed by eight selects
+__device__ __forceinline__ void xat6_rows(const f32x4 (&m)[6], int g, f32x4& oa, f32x4& ob) {
+    const f32x4 s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
+    if (g == 0) {
+        oa = (m[0] + s1) + s2;
+        ob = d1 + 2.f * d2;
+    } else {
+        oa = s1 + 4.f * s2;
+        ob = (d1 + 8.f * d2) + m[5];
+    }
+}
 }  // namespace
 
 template <bool LAZY>
@@ -800,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4z_kernel(ConvParams p) {
     // ---- epilogue: one sub-tile (16 tiles x 32 channels) at a time through LDS; registers 0..7 / 8..15 of every accumulator ----
     float* const ms = smem;                                     // [36 positions][16 tiles][32 channels]
     double* const st_s = reinterpret_cast<double*>(smem + Z_BODY);           // [4 waves][32 channels][2]
-    const int e_grp = tid >> 7;                                 // output rows 2 e_grp, 2 e_grp + 1 of the tile
+    const int e_grp = __builtin_amdgcn_readfirstlane(tid >> 7);  // output rows 2 e_grp, 2 e_grp + 1 of the tile (wave-uniform)
     const int e_lt = (tid >> 3) & 15, e_q = tid & 7;
     const int e_ty = e_lt >> 2, e_tx = e_lt & 3;
     const int co = nt0 * 16 + 4 * e_q;
@@ -828,23 +841,30 @@ __global__ __launch_bounds__(256, 2) void conv_wino4z_kernel(ConvParams p) {
                 f32x4 m[6];
 #pragma unroll
                 for (int xi = 0; xi < 6; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(src + (xi * 6 + nu) * 512);
-                f32x4 o[4];
-                xat6(m, o);
-                tm[0][nu] = e_grp ? o[2] : o[0];
-                tm[1][nu] = e_grp ? o[3] : o[1];
+                xat6_rows(m, e_grp, tm[0][nu], tm[1][nu]);
             }
+            // outputs leave as buffer stores: descriptor of the sub-tile's image + the (row, pixel) offset in SGPRs, ONE per-lane offset
+            // (a 64-bit address per store cost six integer instructions, and on this path every VALU instruction is taken from the matrix pipe)
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)e_img * p.hout * p.wout * p.pitch_out, 0,
+                                                                                   (int)((size_t)p.hout * p.wout * p.pitch_out * 4), 0x00020000);
+            const int oy_t = e_oy0 + 4 * e_ty + 2 * e_grp;
+            const unsigned ovoff = ((unsigned)(oy_t * p.wout + ox) * (unsigned)p.pitch_out + (unsigned)co) * 4u;
+            const unsigned prow = (unsigned)p.wout * (unsigned)p.pitch_out * 4u, ppix = (unsigned)p.pitch_out * 4u;
+            const bool inside = e_valid && e_oy0 + 16 <= p.hout && e_ox0 + 16 <= p.wout;      // block-uniform: no per-store bounds checks
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 f32x4 y[4];
                 xat6(tm[ii], y);
-                const int oy = e_oy0 + 4 * e_ty + 2 * e_grp + ii;
+                const int oy = oy_t + ii;
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) {
                     f32x4 v = y[jx] + bias4;
-                    if (e_valid && oy < p.hout && ox + jx < p.wout) {
-                        const size_t gp = ((size_t)e_img * p.hout + oy) * p.wout + ox + jx;
-                        if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + gp * p.pitch_add + co);
-                        *reinterpret_cast<f32x4*>(p.out + gp * p.pitch_out + co) = v;
+                    if (inside || (e_valid && oy < p.hout && ox + jx < p.wout)) {
+                        if (p.addend) {
+                            const size_t gp = ((size_t)e_img * p.hout + oy) * p.wout + ox + jx;
+                            v += *reinterpret_cast<const f32x4*>(p.addend + gp * p.pitch_add + co);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, v), orsrc, ovoff, (unsigned)ii * prow + (unsigned)jx * ppix, 0);
                         if (p.stats) {
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {

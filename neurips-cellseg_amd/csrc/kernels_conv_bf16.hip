@@ -862,7 +862,174 @@ __global__ __launch_bounds__(128, 2) void conv_bf16_rows64_kernel(ConvBParams p,
     }
 }
 
-// CS_BF16_ROWS: 0 = block kernels, 1 = the 32 -> 32 layers streamed by waves, 2 (default) = the 64 -> 64 layers too
+// ------------------------------------------------------------------------------------------------
+// The streaming shape for the fused stride-2 pair [unit0 || residual] of the first encoder level below the image (round 5): 3x3 stride 2, 32 input
+// channels (KC = cin / 32 = 1; KC = 2 compiles, but at 256 registers and 94 KB of LDS it ran slower than the block kernel), output channels in groups of 128.  conv_bf16s_kernel<2, 3, 4, 2, 1> runs the 32 -> 128 layer as blocks of ONE K
+// chunk - gather 9 x 33 pixels, barrier, 72 MFMAs per wave, epilogue: 21 % matrix busy, 410 us for a launch whose traffic is worth 200.
+// Here the FOUR waves of a block walk the same strip of 16 output columns down RS2 rows, wave w computing output channels 32 w ... 32 w + 31
+// of the block's 128 (18 KC weight fragments in registers for the whole strip); each keeps its own rolling window of four input rows (33
+// pixels x KC planes) in wave-private LDS - the inputs of these layers are materialised sums, so staging is a plain copy and the three
+// re-reads of a row by the other waves are L2 hits; two new input rows per output row, requested two steps ahead; NO block barrier at all
+// (every wave owns its channels' statistics).  Same products in the same order as the block kernel (tap-major, KC k-steps per tap).
+// ------------------------------------------------------------------------------------------------
+constexpr int S2_RS = 32;                                    // output rows of a block's strip segment
+constexpr int S2_PITCH = 80;                                 // bytes per staged pixel and plane: 32 bf16 + pad (stride-2 A reads)
+constexpr int S2_NPX = 33;                                   // input columns 2 ox0 - 1 ... 2 ox0 + 31
+template <int KC>
+struct S2Cfg {
+    static constexpr int PLANE = S2_NPX * S2_PITCH;
+    static constexpr int ROW = KC * PLANE;
+    static constexpr int WAVE_BYTES = 4 * ROW + 16 * RW_EPS * 4;
+};
+
+template <int KC>
+__global__ __launch_bounds__(256, 2) void conv_bf16_rows_s2_kernel(ConvBParams p, int strips, int segs, int cgroups) {
+    typedef S2Cfg<KC> C;
+    __shared__ __attribute__((aligned(16))) char smem[4 * C::WAVE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+    char* const ring = smem + wave * C::WAVE_BYTES;
+    float* const ep = reinterpret_cast<float*>(ring + 4 * C::ROW);
+    int bid = blockIdx.x;
+    const int cg = bid % cgroups;
+    bid /= cgroups;
+    const int strip = bid % strips;
+    bid /= strips;
+    const int seg = bid % segs;
+    const int img = bid / segs;
+    const int ox0 = strip * 16;
+    const int oy_begin = seg * S2_RS, oy_end = oy_begin + S2_RS < p.hout ? oy_begin + S2_RS : p.hout;
+    const int nt0 = cg * 8 + wave * 2;                          // this wave's first 16-channel tile
+
+    // weights: fragment (K chunk, tap, channel tile nt0 + t), plane 0 of packed[chunk][tap][ntile_total][3][64][8]
+    bf16x8 b[KC][9][2];
+    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + lane;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[kc][tap][t] = wbase[(size_t)((kc * 9 + tap) * p.ntile_total + nt0 + t) * 3 * 64];
+    float bias[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bias[t] = p.bias ? p.bias[(nt0 + t) * 16 + pl] : 0.f;
+
+    // staging items (pixel, channel octet c8 = lane & 3) of a plane: passes 0 / 1 take pixels 0 ... 15 / 16 ... 31 (lane >> 2), pass 2 pixel 32 (4 lanes)
+    const int c8 = lane & 3;
+    const int gx0 = 2 * ox0 - 1;                                // image column of staged pixel 0
+    int offx[3];
+    bool okx[3];
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+        const int px = ps < 2 ? 16 * ps + (lane >> 2) : 32;
+        const int gx = gx0 + px;
+        okx[ps] = gx >= 0 && gx < p.win && (ps < 2 || lane < 4);
+        offx[ps] = (okx[ps] ? gx : 0) * p.a.pitch;
+    }
+    const unsigned short* const src = reinterpret_cast<const unsigned short*>(p.a.ptr) + (size_t)img * p.hin * p.win * p.a.pitch + 8 * c8;
+    auto clamp_row = [&](int gy) { return gy < 0 ? 0 : (gy >= p.hin ? p.hin - 1 : gy); };
+    struct RowRegs { u32x4 v[KC][3]; };
+    auto load_row = [&](int gy, RowRegs& r) {                   // unconditional, clamped loads
+        const unsigned short* rowp = src + (size_t)clamp_row(gy) * p.win * p.a.pitch;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int ps = 0; ps < 3; ++ps) r.v[kc][ps] = *reinterpret_cast<const u32x4*>(rowp + offx[ps] + 32 * kc);
+    };
+    auto stage = [&](int gy, const RowRegs& r) {                // input row gy -> ring slot (gy + 1) & 3; rows / columns outside the image are zeros
+        char* const slot = ring + ((gy + 1) & 3) * C::ROW;
+        const bool oky = gy >= 0 && gy < p.hin;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps)
+                *reinterpret_cast<u32x4*>(slot + kc * C::PLANE + (16 * ps + (lane >> 2)) * S2_PITCH + c8 * 16) =
+                    (oky && okx[ps]) ? r.v[kc][ps] : u32x4{0u, 0u, 0u, 0u};
+            if (lane < 4)
+                *reinterpret_cast<u32x4*>(slot + kc * C::PLANE + 32 * S2_PITCH + c8 * 16) = (oky && okx[2]) ? r.v[kc][2] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+
+    float sums[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                 // a lane's <= 128 values per channel of the segment in fp32 (the outputs are rounded to bf16 anyway)
+    RowRegs q0, q1;                                             // the two input rows the NEXT step needs (2 oy + 2, 2 oy + 3)
+    {
+        RowRegs a0, a1, a2;
+        load_row(2 * oy_begin - 1, a0);
+        load_row(2 * oy_begin, a1);
+        load_row(2 * oy_begin + 1, a2);
+        load_row(2 * oy_begin + 2, q0);
+        load_row(2 * oy_begin + 3, q1);
+        stage(2 * oy_begin - 1, a0);
+        stage(2 * oy_begin, a1);
+        stage(2 * oy_begin + 1, a2);
+    }
+    const size_t out_row = ((size_t)img * p.hout) * p.wout + ox0;
+    unsigned short* const out = reinterpret_cast<unsigned short*>(p.out) + nt0 * 16;
+    const int opix = lane >> 2;                                 // the pixel (and channel octet c8) this lane stores
+    const bool ostore = ox0 + opix < p.wout;
+    const bool full = ox0 + 16 <= p.wout;
+    // a row leaves through a wave-private slab as ONE 16-byte store per lane, one step late (its slab is read while the next row's MFMAs run).
+    // (Measured against it: the MFMA operands swapped - weights as A, pixels as B - so that a lane holds four consecutive channels of one pixel
+    // and stores 8 bytes straight from the accumulators, no slab: 1.75 vs 1.57 ms for the stride-2 group per slide - the 8-byte stores lose
+    // more than the slab costs.)
+    auto store_row = [&](int oy) {
+        if (ostore) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8 * 8 + 4]);
+            const bf16x8 h{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w, (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+            *reinterpret_cast<bf16x8*>(out + (out_row + (size_t)oy * p.wout + opix) * p.pitch_out + c8 * 8) = h;
+        }
+    };
+#pragma unroll 1
+    for (int oy = oy_begin; oy < oy_end; ++oy) {
+        __builtin_amdgcn_wave_barrier();
+        if (oy > oy_begin) store_row(oy - 1);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // input row 2 oy - 1 + ky sits in slot (2 oy + ky) & 3; output pixel pl reads staged pixel 2 pl + kx
+        constexpr int NA = 9 * KC, DEPTH = 2;
+        auto a_ptr = [&](int i) {
+            const int kc = i / 9, tap = i - kc * 9, ky = tap / 3, kx = tap - ky * 3;
+            return ring + ((2 * oy + ky) & 3) * C::ROW + kc * C::PLANE + (2 * pl + kx) * S2_PITCH + g * 16;
+        };
+        bf16x8 af[DEPTH + 1];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_ptr(i));
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i + DEPTH < NA) af[(i + DEPTH) % (DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(a_ptr(i + DEPTH));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % (DEPTH + 1)], b[i / 9][i % 9][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the two rows of the next step: into the slots rows 2 oy - 2 and 2 oy - 1 leave (LDS operations of a wave complete in order: the
+        // reads of row 2 oy - 1 above are done before these writes)
+        stage(2 * oy + 2, q0);
+        stage(2 * oy + 3, q1);
+        load_row(2 * oy + 4, q0);
+        load_row(2 * oy + 5, q1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[t][r] + bias[t];
+                ep[(g * 4 + r) * RW_EPS + t * 16 + pl] = v;
+                const float vm = full ? v : (ox0 + g * 4 + r < p.wout ? v : 0.f);
+                sums[t][0] += vm;
+                sums[t][1] = fmaf(vm, v, sums[t][1]);
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+    store_row(oy_end - 1);
+    if (p.stats) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            stats_commit_b((double)sums[t][0], (double)sums[t][1], p.stats + ((size_t)img * p.cout + (nt0 + t) * 16 + pl) * 2, lane);
+    }
+}
+
+// CS_BF16_ROWS: 0 = block kernels, 1 = the 32 -> 32 layers streamed by waves, 2 (default) = the 64 -> 64 layers and the 32-channel stride-2 pair too
 static int g_bf16_rows = [] { const char* e = getenv("CS_BF16_ROWS"); return e ? atoi(e) : 2; }();
 
 int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
@@ -904,6 +1071,16 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     const double esz = act16 ? 2.0 : 4.0;
     const double bytes = esz * n * ((double)hin * win * (a.c + b.c) + (double)p.hout * p.wout * cout);
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
+    // the fused stride-2 pairs of the shallow encoder levels (raw 32- / 64-channel inputs, output channels in groups of 128): four waves stream a strip
+    if (g_bf16_rows >= 2 && act16 && planes == 1 && ksize == 3 && stride == 2 && !a.tab && b.c == 0 && a.c == 32 && cout % 128 == 0 &&
+        !ex && !in_amax && a.pitch % 8 == 0 && pitch_out % 8 == 0 && p.hout >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31)) {
+        const int strips = ceil_div(p.wout, 16), segs = ceil_div(p.hout, S2_RS), cgroups = cout / 128;
+        const dim3 grid((unsigned)(cgroups * strips * segs * n));
+        hipLaunchKernelGGL(conv_bf16_rows_s2_kernel<1>, grid, dim3(256), 0, s, p, strips, segs, cgroups);      // (KC = 2, 64 input channels: 256 registers, one
+                                                                                                              //  block per CU - measured slower than the block kernel)
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
     // the 32 -> 32 stride-1 layers of the bf16 datapath: a wave streams a 16-column strip (conv_bf16_rows32_kernel)
     if (g_bf16_rows >= 2 && act16 && planes == 1 && ksize == 3 && stride == 1 && a.c == 64 && b.c == 0 && cout == 64 && !ex && !in_amax &&
         a.pitch % 8 == 0 && pitch_out % 8 == 0 && hin >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31) && (!a.tab || (a.tab_c ? a.tab_c : a.c) >= 64)) {

@@ -325,3 +325,51 @@ def test_share_exchange_and_rectangle_gather(world, h, w, overlap, transport):
     for p in procs:
         p.join(timeout=60)
     assert all(ok and ok2 for _, ok, ok2, _ in res), res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bench.StripsGuard: an ASYMMETRIC failure inside the strips leg (one rank raises, its peer sits in a collective)
+# ----------------------------------------------------------------------------------------------------------------------
+_GUARD_SCRIPT = r"""
+import json, os, sys, time, importlib.util
+import torch, torch.distributed as dist
+spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join({root!r}, "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+guard = bench.StripsGuard(dist, rank, lambda msg: {{"value": 1.0, "scaling": "weak", "strips_error": msg}}, float(os.environ.get("DEADLINE", "60")))
+mode = os.environ["MODE"]
+if mode == "raise" and rank == 1:
+    time.sleep(0.3)
+    guard.fail("RuntimeError: provoked")                 # does not return
+if mode == "hang" and rank == 1:
+    time.sleep(3600)
+t = torch.zeros(4)
+dist.all_reduce(t)                                       # rank 0 waits here for a peer that never comes
+print(json.dumps({{"unexpected": "the collective completed"}}))
+"""
+
+
+@pytest.mark.parametrize("mode", ["raise", "hang"])
+def test_strips_guard_releases_both_ranks_with_one_line(tmp_path, mode):
+    """One rank fails (or hangs) inside the guarded leg while the other is blocked in a collective: rank 0 prints the fallback line with
+    strips_error, both processes exit with code 0 within seconds - nobody waits for the process-group timeout."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "guard.py"
+    script.write_text(_GUARD_SCRIPT.format(root=root))
+    port = _free_port()
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MODE=mode,
+                                       DEADLINE="6" if mode == "hang" else "60")) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], [o[1][-800:] for o in outs]
+    lines = [ln for ln in outs[0][0].strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]      # (gloo announces its peers on stdout)
+    import json
+    line = json.loads(lines[0])
+    assert line["scaling"] == "weak" and ("provoked" in line["strips_error"] if mode == "raise" else "did not finish within" in line["strips_error"])
+    assert time.time() - t0 < 60

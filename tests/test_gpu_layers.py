@@ -265,18 +265,21 @@ def check_net(model, x, mode, rep):
 
 
 CASES = [
-    # (mode, channels, n, size): 32-base = BASELINE configs[1]/[2] (rows32 / rows64 / block kernels, record first layer);
-    # 64-base = configs[4] (64-channel first layer, fp8 from level 1 on)
-    ("bf16", (32, 64, 128, 256, 512), 3, 64),
-    ("bf16", (64, 128, 256, 512, 1024), 2, 64),
-    ("bf16", (16, 32, 64, 128, 256), 2, 96),
-    ("fp8", (32, 64, 128, 256, 512), 3, 64),
-    ("fp8", (64, 128, 256, 512, 1024), 2, 64),
+    # (mode, channels, n, size, sparse): 32-base = BASELINE configs[1]/[2] (rows32 / rows64 / stride-2 streaming / block kernels, record first
+    # layer); 64-base = configs[4] (64-channel first layer, fp8 from level 1 on); sparse = a 22 x 13 image in a zero window (round-5 sweep: the
+    # whole-net fp8 logits of such a window were 0.53 from the fp32 oracle - the layers below show that this is e4m3 on near-constant maps, not a kernel)
+    ("bf16", (32, 64, 128, 256, 512), 3, 64, False),
+    ("bf16", (64, 128, 256, 512, 1024), 2, 64, False),
+    ("bf16", (16, 32, 64, 128, 256), 2, 96, False),
+    ("fp8", (32, 64, 128, 256, 512), 3, 64, False),
+    ("fp8", (64, 128, 256, 512, 1024), 2, 64, False),
+    ("bf16", (32, 64, 128, 256), 2, 128, True),
+    ("fp8", (32, 64, 128, 256), 2, 128, True),
 ]
 
 
-@pytest.mark.parametrize("mode,channels,n,size", CASES)
-def test_every_layer_matches_its_own_cpu_recomputation(mode, channels, n, size):
+@pytest.mark.parametrize("mode,channels,n,size,sparse", CASES)
+def test_every_layer_matches_its_own_cpu_recomputation(mode, channels, n, size, sparse):
     import cellseg_amd as ca
     dev = _dev()
     torch.manual_seed(11)
@@ -288,8 +291,12 @@ def test_every_layer_matches_its_own_cpu_recomputation(mode, channels, n, size):
             elif k.endswith("bias"):
                 p.uniform_(-0.2, 0.2)
     x = torch.rand(n, 3, size, size, generator=torch.Generator().manual_seed(5)).to(dev)
+    if sparse:                                 # a small image inside a zero-padded window (the tiler's padding of images below the window size): most
+        keep = torch.zeros_like(x)            # of every map is constant, InstanceNorm variances are tiny and every rounding is amplified downstream -
+        keep[:, :, 20:42, 30:43] = x[:, :, 20:42, 30:43]     # the layers themselves must still be one rounding step from their recomputation
+        x = keep
     rep = check_net(model, x, mode, Report())
-    rep.dump(f"{mode}-{channels[0]}-{size}")
+    rep.dump(f"{mode}-{channels[0]}-{size}" + ("-sparse" if sparse else ""))
     bad = rep.failures()
     assert not bad, json.dumps(bad, indent=1)
     assert len(rep.rows) >= 30

@@ -1386,6 +1386,200 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The streaming shape for the decoder's widest transposed conv (round 5): 64 skip + 64 deeper channels -> 32 channels, 64 x 64 -> 128 x 128
+// per window (up1 of the 32-base net), bf16 datapath.  convt_bf16s_kernel<2, 1, 1> runs it as 30 720 blocks of 4 x 16 input pixels with four
+// chunk barriers each: 556 us per 481-window launch for 1.26 GB of traffic (250 us at the HBM rate), matrix pipe 11 % busy - latency, not work.
+// Here a PAIR of waves (one 128-thread block) walks a strip of 16 input columns down CT_RS input rows; wave ct computes output channels
+// 16 ct ... 16 ct + 15 of all four output phases (36 weight fragments = 144 registers for the whole strip) and stages planes ct and ct + 2
+// of every input row - one 32-channel plane of the skip tensor (a plain copy) and one of the deeper source, which is either a materialised
+// tensor or (SUM2) the residual sum act(norm(V)) + act(norm(U)) computed in fp32 and rounded to bf16 once, exactly what norm_act_add16x8
+// stores - into the window the pair shares; ONE block barrier per input row.  Per row and K step the nine taps read only FOUR distinct A
+// fragments (input pixel offsets (0,0), (0,1), (1,0), (1,1)).  The two output rows of an input row leave through a wave-private slab as one
+// 16-byte store per lane and row.  Same products in the same order as the block kernel (chunk-major, tap-major).
+// ------------------------------------------------------------------------------------------------
+constexpr int CT_RS = 32;                                    // input rows of a pair's strip segment
+constexpr int CT_PITCH = 80;                                 // bytes per staged pixel and plane
+constexpr int CT_NPX = 17;                                   // input columns ix0 ... ix0 + 16 (one halo column on the right)
+constexpr int CT_PLANE = CT_NPX * CT_PITCH;
+constexpr int CT_ROW = 4 * CT_PLANE;                         // planes: skip 0..31, skip 32..63, deeper 0..31, deeper 32..63
+constexpr int CT_EPS = 20;                                   // floats per slab pixel: 16 channels + pad
+constexpr int CT_SLAB = 2 * 32 * CT_EPS * 4;                 // two output rows of 32 pixels
+constexpr int CT_BLOCK_BYTES = 4 * CT_ROW + 2 * CT_SLAB;
+
+template <bool SUM2>
+__global__ __launch_bounds__(128, 2) void convt_bf16_rows_kernel(ConvBParams p, int strips, int segs) {
+    __shared__ __attribute__((aligned(16))) char smem[CT_BLOCK_BYTES];
+    __shared__ f32x4 tab_s[2][2][16];                           // SUM2: [V | U][wave][octet c8 x 4] (scale, shift) pairs - 32 registers per lane otherwise
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);    // this wave's channel tile = the pair of planes it stages
+    const int pl = lane & 15, g = lane >> 4;
+    char* const ring = smem;
+    float* const ep = reinterpret_cast<float*>(smem + 4 * CT_ROW + ct * CT_SLAB);
+    int bid = blockIdx.x;
+    const int strip = bid % strips;
+    bid /= strips;
+    const int seg = bid % segs;
+    const int img = bid / segs;
+    const int ix0 = strip * 16;
+    const int iy_begin = seg * CT_RS, iy_end = iy_begin + CT_RS < p.hin ? iy_begin + CT_RS : p.hin;
+
+    // weights: fragment (K chunk kc, tap, channel tile ct), plane 0 of packed[chunk][tap][ntile_total = 2][3][64][8]; chunks 0, 1 = skip, 2, 3 = deeper
+    bf16x8 b[4][9];
+    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + lane;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) b[kc][tap] = wbase[(size_t)((kc * 9 + tap) * 2 + ct) * 3 * 64];
+    const float bias = p.bias ? p.bias[ct * 16 + pl] : 0.f;
+
+    // staging items (pixel, channel octet c8 = lane & 3) of a plane: the main pass takes pixels 0 ... 15 (lane >> 2), the halo pass pixel 16 (4 lanes)
+    const int c8 = lane & 3;
+    int offx[2];
+    bool okx[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int gx = ix0 + (ps == 0 ? (lane >> 2) : 16);
+        okx[ps] = gx < p.win && (ps == 0 || lane < 4);
+        offx[ps] = okx[ps] ? gx : 0;
+    }
+    const size_t img_px = (size_t)img * p.hin * p.win;
+    const unsigned short* const src_a = reinterpret_cast<const unsigned short*>(p.a.ptr) + img_px * p.a.pitch + 32 * ct + 8 * c8;
+    const unsigned short* const src_b = reinterpret_cast<const unsigned short*>(p.b.ptr) + img_px * p.b.pitch + 32 * ct + 8 * c8;
+    const unsigned short* const src_b2 = SUM2 ? reinterpret_cast<const unsigned short*>(p.b.ptr2) + img_px * p.b.pitch + 32 * ct + 8 * c8 : src_b;
+    float slope_v = 0.f, slope_u = 0.f;
+    if constexpr (SUM2) {                                        // the tables of this wave's 32 channels: 16 x 16 bytes per tensor, read back per item
+        if (lane < 32) {
+            const float2* t = (lane < 16 ? p.b.tab : p.b.tab2) + (size_t)img * p.b.tab_c + p.b.tab_off + 32 * ct;
+            tab_s[lane >> 4][ct][lane & 15] = reinterpret_cast<const f32x4*>(t)[lane & 15];
+        }
+        slope_v = p.b.slope ? *p.b.slope : 0.f;
+        slope_u = p.b.slope2 ? *p.b.slope2 : 0.f;
+    }
+    auto clamp_row = [&](int gy) { return gy >= p.hin ? p.hin - 1 : gy; };
+    struct RowRegs { u32x4 a[2], v[2], u[2]; };
+    auto load_row = [&](int gy, RowRegs& r) {                   // unconditional, clamped loads
+        const size_t row = (size_t)clamp_row(gy) * p.win;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            r.a[ps] = *reinterpret_cast<const u32x4*>(src_a + (row + offx[ps]) * p.a.pitch);
+            r.v[ps] = *reinterpret_cast<const u32x4*>(src_b + (row + offx[ps]) * p.b.pitch);
+            if constexpr (SUM2) r.u[ps] = *reinterpret_cast<const u32x4*>(src_b2 + (row + offx[ps]) * p.b.pitch);
+        }
+    };
+    // act(norm(V)) + act(norm(U)) on 8 channels: the operations and their order as in norm_act_add16x8_kernel (load_lazy8), one bf16 rounding
+    auto sum8 = [&](const u32x4& v, const u32x4& u) {
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 tvk = tab_s[0][ct][4 * c8 + k], tuk = tab_s[1][ct][4 * c8 + k];
+            const float v0 = __builtin_bit_cast(float, v[k] << 16), v1 = __builtin_bit_cast(float, v[k] & 0xffff0000u);
+            const float u0 = __builtin_bit_cast(float, u[k] << 16), u1 = __builtin_bit_cast(float, u[k] & 0xffff0000u);
+            const float s0 = prelu_h(v0 * tvk.x + tvk.y, slope_v) + prelu_h(u0 * tuk.x + tuk.y, slope_u);
+            const float s1 = prelu_h(v1 * tvk.z + tvk.w, slope_v) + prelu_h(u1 * tuk.z + tuk.w, slope_u);
+            o[k] = f32_to_bf16_bits(s0) | (f32_to_bf16_bits(s1) << 16);
+        }
+        return o;
+    };
+    auto stage = [&](int gy, const RowRegs& r) {                // input row gy -> ring slot gy & 3, planes ct and ct + 2; outside the image: zeros
+        char* const slot = ring + (gy & 3) * CT_ROW;
+        const bool oky = gy < p.hin;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            if (ps == 1 && lane >= 4) break;
+            const int px = ps == 0 ? (lane >> 2) : 16;
+            const bool ok = oky && okx[ps];
+            const u32x4 zero{0u, 0u, 0u, 0u};
+            u32x4 d = r.v[ps];
+            if constexpr (SUM2) d = sum8(r.v[ps], r.u[ps]);
+            *reinterpret_cast<u32x4*>(slot + ct * CT_PLANE + px * CT_PITCH + c8 * 16) = ok ? r.a[ps] : zero;
+            *reinterpret_cast<u32x4*>(slot + (2 + ct) * CT_PLANE + px * CT_PITCH + c8 * 16) = ok ? d : zero;
+        }
+    };
+
+    float sum = 0.f, sq = 0.f;                                   // this lane's channel: <= 32 rows x 16 values in fp32 (the outputs are rounded to bf16 anyway)
+    // Rows are requested ONE step before they are staged (a second register set spilled: 144 weight registers); the HBM round trip is taken
+    // earlier by TOUCHING the main-pass lines of the row three steps ahead with one 4-byte load per tensor, so that the real loads are L2 hits
+    auto touch_row = [&](int gy) {
+        const size_t row = (size_t)clamp_row(gy) * p.win;
+        unsigned ta = *reinterpret_cast<const unsigned*>(src_a + (row + offx[0]) * p.a.pitch);
+        unsigned tv2 = *reinterpret_cast<const unsigned*>(src_b + (row + offx[0]) * p.b.pitch);
+        asm volatile("" ::"v"(ta), "v"(tv2));
+        if constexpr (SUM2) {
+            unsigned tu2 = *reinterpret_cast<const unsigned*>(src_b2 + (row + offx[0]) * p.b.pitch);
+            asm volatile("" ::"v"(tu2));
+        }
+    };
+    RowRegs q;
+    {
+        RowRegs a1;
+        load_row(iy_begin, q);
+        load_row(iy_begin + 1, a1);
+        touch_row(iy_begin + 3);
+        touch_row(iy_begin + 4);
+        __syncthreads();                                         // (the tables are in LDS)
+        stage(iy_begin, q);
+        load_row(iy_begin + 2, q);
+        stage(iy_begin + 1, a1);
+    }
+    unsigned short* const out = reinterpret_cast<unsigned short*>(p.out) + ((size_t)img * p.hout * p.wout + 2 * ix0) * p.pitch_out + 16 * ct;
+    const int opix = lane >> 1, oh = lane & 1;                   // the output pixel (of 32) and channel octet this lane stores
+    const bool ostore = 2 * ix0 + opix < p.wout;
+    auto store_rows = [&](int iy) {                              // the two output rows of input row iy, one step late
+        if (ostore) {
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ep[(pa * 32 + opix) * CT_EPS + oh * 8]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ep[(pa * 32 + opix) * CT_EPS + oh * 8 + 4]);
+                const bf16x8 h{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w, (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+                *reinterpret_cast<bf16x8*>(out + ((size_t)(2 * iy + pa) * p.wout + opix) * p.pitch_out + oh * 8) = h;
+            }
+        }
+    };
+#pragma unroll 1
+    for (int iy = iy_begin; iy < iy_end; ++iy) {
+        __syncthreads();                                         // rows iy and iy + 1 are complete in the window (both waves' planes)
+        if (iy > iy_begin) store_rows(iy - 1);
+        f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            bf16x8 a[2][2];
+#pragma unroll
+            for (int di = 0; di < 2; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj)
+                    a[di][dj] = *reinterpret_cast<const bf16x8*>(ring + ((iy + di) & 3) * CT_ROW + kc * CT_PLANE + (pl + dj) * CT_PITCH + g * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int pa = (ky == 1) ? 0 : 1, di = (ky == 0) ? 1 : 0;
+                const int pb = (kx == 1) ? 0 : 1, dj = (kx == 0) ? 1 : 0;
+                acc[pa * 2 + pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[di][dj], b[kc][tap], acc[pa * 2 + pb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // row iy + 2 into the slot row iy - 2 left (both waves finished reading it before this step's barrier), then the load of row iy + 3
+        stage(iy + 2, q);
+        load_row(iy + 3, q);
+        touch_row(iy + 5);
+        const bool row_ok = true;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[ph][r] + bias;
+                ep[((ph >> 1) * 32 + 2 * (g * 4 + r) + (ph & 1)) * CT_EPS + pl] = v;
+                const float vm = (row_ok && ix0 + g * 4 + r < p.win) ? v : 0.f;
+                sum += vm;
+                sq = fmaf(vm, v, sq);
+            }
+    }
+    __syncthreads();
+    store_rows(iy_end - 1);
+    if (p.stats) stats_commit_b((double)sum, (double)sq, p.stats + ((size_t)img * p.cout + ct * 16 + pl) * 2, lane);
+}
+
 template <int WN, int NTW, int NP, bool A16 = false>
 static int launch_tb(hipStream_t s, ConvBParams p) {
     dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
@@ -1423,6 +1617,16 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
     const double flops = 2.0 * n * hin * win * (double)cout * (a.c + b.c) * 9;
     const double bytes = (act16 ? 2.0 : 4.0) * n * ((double)hin * win * (a.c + (b.ptr2 ? 2 : 1) * b.c) + 4.0 * hin * win * cout);
     ProfScope prof(K_CONVT, s, flops, bytes);
+    // the widest decoder level of the 32-base net (64 + 64 -> 32 channels): a pair of waves streams a strip (convt_bf16_rows_kernel)
+    if (g_bf16_rows >= 2 && act16 && planes == 1 && a.c == 64 && b.c == 64 && cout == 32 && !a.tab && (b.ptr2 ? (b.tab && b.tab2) : !b.tab) && !ex &&
+        a.pitch % 8 == 0 && b.pitch % 8 == 0 && pitch_out % 8 == 0 && b.tab_off % 8 == 0 && hin >= 4 && (size_t)hin * win * (a.pitch > b.pitch ? a.pitch : b.pitch) < ((size_t)1 << 31)) {
+        const int strips = ceil_div(win, 16), segs = ceil_div(hin, CT_RS);
+        const dim3 grid((unsigned)(strips * segs * n));
+        if (b.ptr2) hipLaunchKernelGGL(convt_bf16_rows_kernel<true>, grid, dim3(128), 0, s, p, strips, segs);
+        else hipLaunchKernelGGL(convt_bf16_rows_kernel<false>, grid, dim3(128), 0, s, p, strips, segs);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
 #define CS_TB(NP_, A16_)                                             \
     switch (wn) {                                                    \
         case 4: return launch_tb<2, 2, NP_, A16_>(s, p);             \

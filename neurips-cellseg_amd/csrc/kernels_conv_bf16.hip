@@ -1029,6 +1029,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rows_s2_kernel(ConvBParams p
     }
 }
 
+constexpr long long STREAM_MIN_BLOCKS = 1024;   // the round-5 streaming kernels (stride-2 pair, transposed conv) below this many blocks: the block kernels
+                                                // (32 tiles of 256 x 256 give them 256 blocks for 256 CUs: forward 0.758 vs 0.735 ms)
 // CS_BF16_ROWS: 0 = block kernels, 1 = the 32 -> 32 layers streamed by waves, 2 (default) = the 64 -> 64 layers and the 32-channel stride-2 pair too
 static int g_bf16_rows = [] { const char* e = getenv("CS_BF16_ROWS"); return e ? atoi(e) : 2; }();
 
@@ -1073,7 +1075,8 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     ProfScope prof(ksize == 1 ? K_CONV1 : (stride == 1 ? K_CONV3_S1 : K_CONV3_S2), s, flops, bytes);
     // the fused stride-2 pairs of the shallow encoder levels (raw 32- / 64-channel inputs, output channels in groups of 128): four waves stream a strip
     if (g_bf16_rows >= 2 && act16 && planes == 1 && ksize == 3 && stride == 2 && !a.tab && b.c == 0 && a.c == 32 && cout % 128 == 0 &&
-        !ex && !in_amax && a.pitch % 8 == 0 && pitch_out % 8 == 0 && p.hout >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31)) {
+        !ex && !in_amax && a.pitch % 8 == 0 && pitch_out % 8 == 0 && p.hout >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31) &&
+        (long long)(cout / 128) * ceil_div(p.wout, 16) * ceil_div(p.hout, S2_RS) * n >= STREAM_MIN_BLOCKS) {      // (small launches: too few strips to fill the chip)
         const int strips = ceil_div(p.wout, 16), segs = ceil_div(p.hout, S2_RS), cgroups = cout / 128;
         const dim3 grid((unsigned)(cgroups * strips * segs * n));
         hipLaunchKernelGGL(conv_bf16_rows_s2_kernel<1>, grid, dim3(256), 0, s, p, strips, segs, cgroups);      // (KC = 2, 64 input channels: 256 registers, one
@@ -1619,7 +1622,8 @@ int launch_convt_bf16s(hipStream_t s, int planes, const ConvSrc& a, const ConvSr
     ProfScope prof(K_CONVT, s, flops, bytes);
     // the widest decoder level of the 32-base net (64 + 64 -> 32 channels): a pair of waves streams a strip (convt_bf16_rows_kernel)
     if (g_bf16_rows >= 2 && act16 && planes == 1 && a.c == 64 && b.c == 64 && cout == 32 && !a.tab && (b.ptr2 ? (b.tab && b.tab2) : !b.tab) && !ex &&
-        a.pitch % 8 == 0 && b.pitch % 8 == 0 && pitch_out % 8 == 0 && b.tab_off % 8 == 0 && hin >= 4 && (size_t)hin * win * (a.pitch > b.pitch ? a.pitch : b.pitch) < ((size_t)1 << 31)) {
+        a.pitch % 8 == 0 && b.pitch % 8 == 0 && pitch_out % 8 == 0 && b.tab_off % 8 == 0 && hin >= 4 && (size_t)hin * win * (a.pitch > b.pitch ? a.pitch : b.pitch) < ((size_t)1 << 31) &&
+        (long long)ceil_div(win, 16) * ceil_div(hin, CT_RS) * n >= STREAM_MIN_BLOCKS) {
         const int strips = ceil_div(win, 16), segs = ceil_div(hin, CT_RS);
         const dim3 grid((unsigned)(strips * segs * n));
         if (b.ptr2) hipLaunchKernelGGL(convt_bf16_rows_kernel<true>, grid, dim3(128), 0, s, p, strips, segs);

@@ -123,6 +123,24 @@ class Report:
                           "frac_over_half_tol": 0.0})
         return worst
 
+    def compare_table(self, name, tab, acc, eps=1e-5):
+        """The lazy-norm table (scale, shift) = (rstd, -mean * rstd) against the statistics of the unrounded accumulators acc [n,h,w,c].
+        The 16-bit datapaths sum a lane's <= 32 values in fp32 before going to fp64 (relative error <= 2e-6 of sum x^2), and
+        var = E[x^2] - mean^2 turns that into d(rstd) <= 1e-6 * E[x^2] * rstd^3 - invisible on real maps, dominant on 2 x 2 maps of
+        near-constant channels (rstd in the hundreds).  There the fp32 accumulation of the convolution itself shows too: an absolute
+        perturbation delta of the outputs (K <= 9 216 products of O(1) operands summed in fp32: a few 1e-6) moves rstd by rstd^2 * delta.
+        Tolerance: 2e-4 of the value + four times the first bound + the second with delta = 8e-6 (on maps of >= 64 pixels the tables sit below a tenth of this tolerance)."""
+        tab, acc = tab.double().cpu(), acc.double()
+        mean, ex2 = acc.mean(dim=(1, 2)), acc.pow(2).mean(dim=(1, 2))
+        rstd = 1.0 / torch.sqrt(ex2 - mean * mean + eps)
+        d_rstd = 4e-6 * ex2 * rstd ** 3 + 8e-6 * rstd ** 2
+        tol_scale = 2e-4 * rstd + d_rstd
+        tol_shift = 2e-4 * (1.0 + (mean * rstd).abs()) + mean.abs() * d_rstd + 4e-6 * ex2.sqrt() * rstd
+        worst = max(float(((tab[..., 0] - rstd).abs() / tol_scale).max()), float(((tab[..., 1] + mean * rstd).abs() / tol_shift).max()))
+        self.rows.append({"layer": name, "what": "norm table", "worst_over_tol": round(worst, 3), "max_abs": float((tab[..., 0] - rstd).abs().max()),
+                          "rms": float(rstd.max()), "frac_over_half_tol": 0.0})
+        return worst
+
     def failures(self):
         return [r for r in self.rows if not (r["worst_over_tol"] <= 1.0)]
 
@@ -151,7 +169,6 @@ def check_net(model, x, mode, rep):
     nl, ch = net.nl, net.ch
     img = x.cpu()
     a_in = lambda v: bf16r(v)                     # noqa: E731  every 16-bit kernel stages bf16 activations
-    tab_tol = 2e-4
 
     def conv_layer(name, inp_act, w, b, stride, out, tab, f8=False, transposed=False, out_ulp=BF16_ULP, wq=True):
         """inp_act: fp32 activated input (or the stored e4m3 tensor when f8); out: stored output; tab: stored table or None."""
@@ -164,8 +181,7 @@ def check_net(model, x, mode, rep):
             acc = convt(a_in(inp_act), ww, b) if transposed else conv(a_in(inp_act), ww, b, stride)
         rep.compare(name, out, acc, out_ulp)
         if tab is not None:
-            c = acc.shape[-1]
-            rep.compare_abs(name, tab[:, :c], table_of(acc), tab_tol, "norm table")
+            rep.compare_table(name, tab[:, :acc.shape[-1]], acc)
         return acc
 
     # ---- encoder ----
@@ -185,7 +201,7 @@ def check_net(model, x, mode, rep):
         else:
             src = t[f"down{d - 1}.Xq"] if f8_0 else prev
             acc = conv_layer(pfx + "unit0||res", src, torch.cat([w0, wr]), torch.cat([b0, br]), 2, E, None, f8=f8_0)
-            rep.compare_abs(pfx + "unit0||res", t[pfx + "tab0"][:, :c], table_of(acc[..., :c]), tab_tol, "norm table")
+            rep.compare_table(pfx + "unit0||res", t[pfx + "tab0"][:, :c], acc[..., :c])
         f8_1 = mode == "fp8" and c >= 128
         a0 = activated(E[..., :c], t[pfx + "tab0"][:, :c], net.slope(ru + ".conv.unit0"))
         if f8_1:
@@ -275,6 +291,9 @@ CASES = [
     ("fp8", (64, 128, 256, 512, 1024), 2, 64, False),
     ("bf16", (32, 64, 128, 256), 2, 128, True),
     ("fp8", (32, 64, 128, 256), 2, 128, True),
+    # 1 040 windows of 32 x 32: launches of >= 1 024 blocks, where the round-5 streaming kernels (stride-2 pair, 64 + 64 -> 32 transposed conv) take over
+    ("bf16", (32, 64, 128, 256, 512), 1040, 32, False),
+    ("fp8", (32, 64, 128, 256, 512), 1040, 32, False),
 ]
 
 

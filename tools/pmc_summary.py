@@ -14,9 +14,9 @@ import json
 import re
 import sys
 
-GROUPS = [(r"conv_wino4[xyz]?_kernel", "conv3x3_s1_wino4"), (r"conv_wino1?_kernel", "conv3x3_s1_wino"), (r"conv_(mfma|wreg|bf16s|fp8)_kernel<1, 3,|conv_bf16_rows32_kernel", "conv3x3_s1_mfma"), (r"conv_(mfma|wreg|bf16s|fp8)_kernel<2, 3,", "conv3x3_s2_mfma"),
+GROUPS = [(r"conv_wino4[xyz]?_kernel", "conv3x3_s1_wino4"), (r"conv_wino1?_kernel", "conv3x3_s1_wino"), (r"conv_(mfma|wreg|bf16s|fp8)_kernel<1, 3,|conv_bf16_rows(32|64)_kernel", "conv3x3_s1_mfma"), (r"conv_(mfma|wreg|bf16s|fp8)_kernel<2, 3,|conv_bf16_rows_s2_kernel", "conv3x3_s2_mfma"),
           (r"conv_(mfma|bf16s|fp8)_kernel<1, 1,", "conv1x1_mfma"), (r"conv_first(16)?(_rec)?_kernel|image_records_kernel", "conv_first_mfma"),
-          (r"convt_(mfma|bf16s|fp8|wino)_kernel", "convT3x3s2_mfma"), (r"convt_small_kernel|convt_top_gemm(16)?_kernel", "convT_top_mfma"),
+          (r"convt_(mfma|bf16s|fp8|wino|bf16_rows)_kernel", "convT3x3s2_mfma"), (r"convt_small_kernel|convt_top_gemm(16)?_kernel", "convT_top_mfma"),
           (r"conv_last_kernel", "conv_last_valu"), (r"norm_finalize_kernel", "norm_finalize"),
           (r"norm_act_add\w*_kernel|act_quant_kernel", "norm_act_add"), (r"swi_finalize_kernel", "swi_finalize"),
           (r"ccl_(\w+)_kernel", None)]

@@ -1029,6 +1029,155 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rows_s2_kernel(ConvBParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The stride-2 pair with 64 input channels (64 -> 2 x 128 at the 32-base net's second level, 64 -> 2 x 128 of the 64-base net's first: the
+// widest stride-2 launch of configs[4]).  Two K steps per tap are 36 weight fragments = 144 registers for a wave's 32 output channels, so the
+// four waves of a block cannot each keep a private copy of the rows as conv_bf16_rows_s2_kernel<1> does (94 KB of LDS, measured slower than
+// the block kernel): here they SHARE one window of six row slots (two 32-channel planes of 33 pixels each) that they stage together - two
+// new input rows per output row are 528 sixteen-byte items for 256 lanes - with ONE block barrier per output row.  Six slots because the
+// rows staged in a step (2 oy + 2, 2 oy + 3) must not land on a row another wave may still be reading (2 oy - 1 ... 2 oy + 1).
+// ------------------------------------------------------------------------------------------------
+constexpr int S2X_PLANE = S2_NPX * S2_PITCH;
+constexpr int S2X_ROW = 2 * S2X_PLANE;
+constexpr int S2X_SLOTS = 6;
+constexpr int S2X_ITEMS = 2 * S2_NPX * 4;                    // 16-byte items of one input row: plane x pixel x channel octet
+constexpr int S2X_BLOCK_BYTES = S2X_SLOTS * S2X_ROW + 4 * 16 * RW_EPS * 4;
+
+__global__ __launch_bounds__(256, 2) void conv_bf16_rows_s2x_kernel(ConvBParams p, int strips, int segs, int cgroups) {
+    __shared__ __attribute__((aligned(16))) char smem[S2X_BLOCK_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+    char* const ring = smem;
+    float* const ep = reinterpret_cast<float*>(smem + S2X_SLOTS * S2X_ROW) + wave * 16 * RW_EPS;
+    int bid = blockIdx.x;
+    const int cg = bid % cgroups;
+    bid /= cgroups;
+    const int strip = bid % strips;
+    bid /= strips;
+    const int seg = bid % segs;
+    const int img = bid / segs;
+    const int ox0 = strip * 16;
+    const int oy_begin = seg * S2_RS, oy_end = oy_begin + S2_RS < p.hout ? oy_begin + S2_RS : p.hout;
+    const int nt0 = cg * 8 + wave * 2;
+
+    bf16x8 b[2][9][2];
+    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(p.wpack) + lane;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[kc][tap][t] = wbase[(size_t)((kc * 9 + tap) * p.ntile_total + nt0 + t) * 3 * 64];
+    float bias[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bias[t] = p.bias ? p.bias[(nt0 + t) * 16 + pl] : 0.f;
+
+    // staging: the two input rows of a step are 2 x S2X_ITEMS = 528 items (row, plane, pixel, octet) dealt to the block's 256 lanes in three passes
+    const int gx0 = 2 * ox0 - 1;
+    int it_row[3], it_lds[3], it_goff[3];
+    bool it_ok[3];
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+        const int it = tid + 256 * ps;
+        const bool live = it < 2 * S2X_ITEMS;
+        const int r = it / S2X_ITEMS, rem = it - r * S2X_ITEMS;
+        const int plane = rem / (S2_NPX * 4), px = (rem - plane * S2_NPX * 4) >> 2, c8 = rem & 3;
+        const int gx = gx0 + px;
+        it_row[ps] = r;
+        it_lds[ps] = plane * S2X_PLANE + px * S2_PITCH + c8 * 16;
+        it_ok[ps] = live && gx >= 0 && gx < p.win;
+        it_goff[ps] = (it_ok[ps] ? gx : 0) * p.a.pitch + 32 * plane + 8 * c8;
+        if (!live) it_row[ps] = -1;
+    }
+    const unsigned short* const src = reinterpret_cast<const unsigned short*>(p.a.ptr) + (size_t)img * p.hin * p.win * p.a.pitch;
+    auto clamp_row = [&](int gy) { return gy < 0 ? 0 : (gy >= p.hin ? p.hin - 1 : gy); };
+    struct PairRegs { u32x4 v[3]; };
+    auto load_pair = [&](int gy0, PairRegs& r) {                // input rows gy0, gy0 + 1 (unconditional, clamped loads)
+#pragma unroll
+        for (int ps = 0; ps < 3; ++ps) {
+            const int gy = gy0 + (it_row[ps] > 0 ? 1 : 0);
+            r.v[ps] = *reinterpret_cast<const u32x4*>(src + (size_t)clamp_row(gy) * p.win * p.a.pitch + it_goff[ps]);
+        }
+    };
+    auto slot_of = [&](int gy) { return ((gy + 7) % S2X_SLOTS) * S2X_ROW; };      // gy >= -1
+    auto stage_pair = [&](int gy0, const PairRegs& r) {
+#pragma unroll
+        for (int ps = 0; ps < 3; ++ps) {
+            if (it_row[ps] < 0) continue;
+            const int gy = gy0 + it_row[ps];
+            const bool ok = it_ok[ps] && gy >= 0 && gy < p.hin;
+            *reinterpret_cast<u32x4*>(ring + slot_of(gy) + it_lds[ps]) = ok ? r.v[ps] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+
+    float sums[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    PairRegs q;
+    {
+        PairRegs a0, a1;
+        load_pair(2 * oy_begin - 2, a0);                         // rows 2 oy - 2 (unused, staged into a free slot) and 2 oy - 1
+        load_pair(2 * oy_begin, a1);
+        load_pair(2 * oy_begin + 2, q);
+        stage_pair(2 * oy_begin - 2, a0);                        // (rows above the image are staged as zeros)
+        stage_pair(2 * oy_begin, a1);
+    }
+    const size_t out_row = ((size_t)img * p.hout) * p.wout + ox0;
+    unsigned short* const out = reinterpret_cast<unsigned short*>(p.out) + nt0 * 16;
+    const int opix = lane >> 2, c8o = lane & 3;
+    const bool ostore = ox0 + opix < p.wout;
+    const bool full = ox0 + 16 <= p.wout;
+    auto store_row = [&](int oy) {
+        if (ostore) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8o * 8]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&ep[opix * RW_EPS + c8o * 8 + 4]);
+            const bf16x8 h{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w, (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+            *reinterpret_cast<bf16x8*>(out + (out_row + (size_t)oy * p.wout + opix) * p.pitch_out + c8o * 8) = h;
+        }
+    };
+#pragma unroll 1
+    for (int oy = oy_begin; oy < oy_end; ++oy) {
+        __syncthreads();                                         // rows 2 oy - 1 ... 2 oy + 1 are complete in the shared window
+        if (oy > oy_begin) store_row(oy - 1);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        constexpr int NA = 18, DEPTH = 2;
+        const int so[3] = {slot_of(2 * oy - 1), slot_of(2 * oy), slot_of(2 * oy + 1)};
+        auto a_ptr = [&](int i) {
+            const int kc = i / 9, tap = i - kc * 9, ky = tap / 3, kx = tap - ky * 3;
+            return ring + so[ky] + kc * S2X_PLANE + (2 * pl + kx) * S2_PITCH + g * 16;
+        };
+        bf16x8 af[DEPTH + 1];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_ptr(i));
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i + DEPTH < NA) af[(i + DEPTH) % (DEPTH + 1)] = *reinterpret_cast<const bf16x8*>(a_ptr(i + DEPTH));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % (DEPTH + 1)], b[i / 9][i % 9][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage_pair(2 * oy + 2, q);                               // into the slots of rows 2 oy - 4, 2 oy - 3: nobody reads those any more
+        load_pair(2 * oy + 4, q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[t][r] + bias[t];
+                ep[(g * 4 + r) * RW_EPS + t * 16 + pl] = v;
+                const float vm = full ? v : (ox0 + g * 4 + r < p.wout ? v : 0.f);
+                sums[t][0] += vm;
+                sums[t][1] = fmaf(vm, v, sums[t][1]);
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+    store_row(oy_end - 1);
+    if (p.stats) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            stats_commit_b((double)sums[t][0], (double)sums[t][1], p.stats + ((size_t)img * p.cout + (nt0 + t) * 16 + pl) * 2, lane);
+    }
+}
+
 constexpr long long STREAM_MIN_BLOCKS = 1024;   // the round-5 streaming kernels (stride-2 pair, transposed conv) below this many blocks: the block kernels
                                                 // (32 tiles of 256 x 256 give them 256 blocks for 256 CUs: forward 0.758 vs 0.735 ms)
 // CS_BF16_ROWS: 0 = block kernels, 1 = the 32 -> 32 layers streamed by waves, 2 (default) = the 64 -> 64 layers and the 32-channel stride-2 pair too
@@ -1081,6 +1230,15 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
         const dim3 grid((unsigned)(cgroups * strips * segs * n));
         hipLaunchKernelGGL(conv_bf16_rows_s2_kernel<1>, grid, dim3(256), 0, s, p, strips, segs, cgroups);      // (KC = 2, 64 input channels: 256 registers, one
                                                                                                               //  block per CU - measured slower than the block kernel)
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
+    // ... and the one with 64 input channels: four waves, a shared window (conv_bf16_rows_s2x_kernel)
+    if (g_bf16_rows >= 2 && act16 && planes == 1 && ksize == 3 && stride == 2 && !a.tab && b.c == 0 && a.c == 64 && cout % 128 == 0 &&
+        !ex && !in_amax && a.pitch % 8 == 0 && pitch_out % 8 == 0 && p.hout >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31) &&
+        (long long)(cout / 128) * ceil_div(p.wout, 16) * ceil_div(p.hout, S2_RS) * n >= STREAM_MIN_BLOCKS) {
+        const int strips = ceil_div(p.wout, 16), segs = ceil_div(p.hout, S2_RS), cgroups = cout / 128;
+        hipLaunchKernelGGL(conv_bf16_rows_s2x_kernel, dim3((unsigned)(cgroups * strips * segs * n)), dim3(256), 0, s, p, strips, segs, cgroups);
         CS_HIP(hipGetLastError());
         return CS_OK;
     }

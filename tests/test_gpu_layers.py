@@ -294,6 +294,8 @@ CASES = [
     # 1 040 windows of 32 x 32: launches of >= 1 024 blocks, where the round-5 streaming kernels (stride-2 pair, 64 + 64 -> 32 transposed conv) take over
     ("bf16", (32, 64, 128, 256, 512), 1040, 32, False),
     ("fp8", (32, 64, 128, 256, 512), 1040, 32, False),
+    # 520 windows of 64 x 64: the 64-channel stride-2 pair (shared-window streaming kernel) reaches 1 040 blocks
+    ("bf16", (32, 64, 128, 256, 512), 520, 64, False),
 ]
 
 

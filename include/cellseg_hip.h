@@ -307,6 +307,31 @@ int cs_ccl_postprocess(const uint8_t* mask, int h, int w, int hole_area, int min
 int cs_ccl_label(const uint8_t* mask, int h, int w, int connectivity,
                  int32_t* labels, int32_t* n_labels, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same post-process with the slide cut into strips of rows, one rank (GPU) per strip - SURVEY.md 8(e) third row, "strip-local
+ * union-find + one seam-merge pass"; replaces the single-device call of baseline/predict.py:113 when one slide is spread over GPUs.
+ * Labels are bit-identical to cs_ccl_postprocess on the whole mask.  Per rank, with two all-gathers by the caller in between:
+ *   cs_ccl_strip_local    mask_rows: uint8 [ext_h][w] = the strip's rows plus cs_ccl_strip_halo(hole_area, min_size) rows above and
+ *                         below it (fewer only at the image's own first / last row); the strip is rows [strip_row0, strip_row0 + strip_h)
+ *                         of those.  Filters the rows, labels the strip locally, writes the edge record (cs_ccl_strip_edge_ints(w) int32:
+ *                         per pixel of the strip's first and last row, which local component it belongs to).
+ *   -- all-gather the records: all_records int32 [world][cs_ccl_strip_edge_ints(w)] --
+ *   cs_ccl_strip_resolve  the seam union-find (identical on every rank), final numbering of this strip; edge_ids: int32 [2][w] out (ids
+ *                         of the strip's first / last row), n_labels: device int, components of the whole slide (may be NULL).
+ *   -- all-gather the edge ids: all_edge_ids int32 [world][2][w] --
+ *   cs_ccl_strip_finish   labels: int32 [strip_h][w] out.
+ * workspace: cs_ccl_workspace_bytes(ext_h, w), the SAME buffer for the three calls (it carries the strip's forest between them);
+ * seam_workspace: cs_ccl_seam_workspace_bytes(world, w).  strip_h = 0 (more ranks than rows) is allowed. */
+int cs_ccl_strip_halo(int hole_area, int min_size);
+int cs_ccl_strip_edge_ints(int w);
+size_t cs_ccl_seam_workspace_bytes(int world, int w);
+int cs_ccl_strip_local(const uint8_t* mask_rows, int ext_h, int w, int strip_row0, int strip_h, int hole_area, int min_size,
+                       int32_t* edge_record, void* workspace, size_t workspace_bytes, void* stream);
+int cs_ccl_strip_resolve(const int32_t* all_records, int world, int rank, int ext_h, int w, int strip_h, int32_t* edge_ids,
+                         int32_t* n_labels, void* workspace, size_t workspace_bytes, void* seam_workspace, size_t seam_workspace_bytes,
+                         void* stream);
+int cs_ccl_strip_finish(const int32_t* all_edge_ids, int world, int rank, int ext_h, int w, int strip_h, int32_t* labels,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Instance map -> the 3-class training label (0 background, 1 interior, 2 boundary).
  * Replaces create_interior_map (/root/reference/data/pre_process_3class.py:31-56):
  *   boundary = binary_dilation(find_boundaries(inst, mode='inner'), disk(1));

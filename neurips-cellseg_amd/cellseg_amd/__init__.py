@@ -13,11 +13,11 @@ from ._lib import CellSegHipError, LIB_PATH, lib  # noqa: F401
 from .unet import UNet  # noqa: F401
 from .inferers import (balanced_batch, make_plan, rank_rows, sliding_window_inference, share_partition, strip_partition, swi_infer_image, swi_infer_share, swi_infer_strip,  # noqa: F401
                        window_starts)
-from .postprocess import create_interior_map, label, mask_to_instances, prob_to_instances  # noqa: F401
+from .postprocess import StripLabeller, create_interior_map, label, mask_to_instances, mask_to_instances_strips, prob_to_instances  # noqa: F401
 from .losses import DiceCELoss, one_hot  # noqa: F401
 from .optim import AdamW  # noqa: F401
 from .trainer import TrainStep  # noqa: F401
 from . import metrics, parallel  # noqa: F401
 
 __all__ = ["UNet", "sliding_window_inference", "swi_infer_image", "make_plan", "window_starts", "rank_rows", "strip_partition", "swi_infer_strip", "share_partition", "swi_infer_share",
-           "label", "mask_to_instances", "prob_to_instances", "create_interior_map", "DiceCELoss", "one_hot", "AdamW", "TrainStep", "CellSegHipError", "lib", "LIB_PATH"]
+           "label", "mask_to_instances", "mask_to_instances_strips", "StripLabeller", "prob_to_instances", "create_interior_map", "DiceCELoss", "one_hot", "AdamW", "TrainStep", "CellSegHipError", "lib", "LIB_PATH"]

@@ -98,6 +98,12 @@ def _load() -> C.CDLL:
         "cs_ccl_workspace_bytes": (sz, [i32, i32]),
         "cs_ccl_postprocess": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
         "cs_ccl_label": (i32, [vp, i32, i32, i32, vp, vp, vp, sz, vp]),
+        "cs_ccl_strip_halo": (i32, [i32, i32]),
+        "cs_ccl_strip_edge_ints": (i32, [i32]),
+        "cs_ccl_seam_workspace_bytes": (sz, [i32, i32]),
+        "cs_ccl_strip_local": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+        "cs_ccl_strip_resolve": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, sz, vp]),
+        "cs_ccl_strip_finish": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
         "cs_interior_map": (i32, [vp, i32, i32, i32, vp, vp, sz, vp]),
         "cs_dice_ce_workspace_bytes": (sz, [i32, i32]),
         "cs_dice_ce_forward": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), i32, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -133,7 +139,7 @@ EXPORTED = ("cs_last_error cs_version cs_device_count cs_unet_create cs_unet_des
             "cs_swi_window_start cs_swi_workspace_bytes cs_swi_windows_workspace_bytes cs_swi_windows cs_swi_partition cs_swi_partition_windows cs_swi_windows_range cs_swi_infer cs_swi_finalize cs_swi_finalize_rect cs_normalize_workspace_bytes "
             "cs_normalize_image cs_label_max cs_label_overlap cs_remove_boundary_workspace_bytes cs_remove_boundary_cells "
             "cs_augment_workspace_bytes cs_augment_batch cs_label_deflate_workspace_bytes cs_label_deflate_bound cs_label_deflate cs_ccl_workspace_bytes "
-            "cs_ccl_postprocess cs_ccl_label cs_interior_map cs_dice_ce_workspace_bytes cs_dice_ce_forward cs_dice_ce_backward cs_adamw_step "
+            "cs_ccl_postprocess cs_ccl_label cs_ccl_strip_halo cs_ccl_strip_edge_ints cs_ccl_seam_workspace_bytes cs_ccl_strip_local cs_ccl_strip_resolve cs_ccl_strip_finish cs_interior_map cs_dice_ce_workspace_bytes cs_dice_ce_forward cs_dice_ce_backward cs_adamw_step "
             "cs_unet_bind_params cs_unet_repack cs_unet_readback cs_adamw_step_dev cs_graph_begin cs_graph_end cs_graph_abort cs_graph_launch "
             "cs_graph_num_nodes cs_graph_destroy cs_prof_is_enabled cs_prof_enable cs_prof_reset cs_prof_collect").split()
 

@@ -322,6 +322,66 @@ def gather_shares(mask: torch.Tensor, plan, world: int, group=None, assemble: bo
     return full
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# strip-local connected components with a seam merge (SURVEY.md 8(e), third row, first option)
+# ----------------------------------------------------------------------------------------------------------------------
+def _all_gather_flat(t: torch.Tensor, group=None) -> torch.Tensor:
+    """[n] -> [world, n] on every rank (ONE collective; through the host under gloo)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    bounce = _host_bounce(t, group)
+    src = (t.cpu() if bounce else t).contiguous().view(-1)
+    out = src.new_empty(world * src.numel())                        # flat on both sides: gloo accepts nothing else
+    dist.all_gather_into_tensor(out, src, group=group)
+    out = out.view((world,) + tuple(t.shape))
+    return out.to(t.device) if bounce else out
+
+
+def label_strips(mask: torch.Tensor, group=None, hole_area: int = 64, min_size: int = 16, labeller=None):
+    """``measure.label(remove_small_objects(remove_small_holes(mask), 16))`` (predict.py:113) of ONE slide over the ranks of `group`:
+    rank r filters and labels its ``rank_rows`` strip of the thresholded mask (+ an 80-row halo) on its own GPU, the strips' first / last
+    rows are exchanged in two small all-gathers (32 KB + 16 KB per rank at 4096 columns) around the seam union-find, and every rank ends
+    with the FINAL int32 labels of its rows - bit-identical to the single-GPU pass, numbering included.  mask: the full [H, W] mask
+    (every rank has it after ``gather_shares``) - only the strip's rows and halo are read.
+    -> (labels [rows, W] int32, (row_begin, row_end), n_labels device int32 scalar = components of the whole slide).
+    Without a process group: one strip = the whole slide."""
+    import torch.distributed as dist
+    from .postprocess import StripLabeller
+    on = _collectives_on(group)
+    world, rank = (dist.get_world_size(group), dist.get_rank(group)) if on else (1, 0)
+    if labeller is None:
+        labeller = StripLabeller(mask.shape[0], mask.shape[1], rank, world, mask.device, hole_area, min_size)
+    rec = labeller.local(mask)
+    recs = _all_gather_flat(rec, group) if on else rec[None]
+    ids = labeller.resolve(recs)
+    all_ids = _all_gather_flat(ids, group) if on else ids[None]
+    labels = labeller.finish(all_ids)
+    return labels, (labeller.row_begin, labeller.row_end), labeller.n_labels
+
+
+def gather_label_strips(strip: torch.Tensor, img_h: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """The ranks' label strips ([rows_r, W] int32, ``rank_rows`` strips) -> the full [img_h, W] map on rank `dst` (one gather: 8 MB per
+    rank at 4096^2, straight onto dst's links); None on the other ranks."""
+    import torch.distributed as dist
+    if not _collectives_on(group):
+        return strip
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rows = [rank_rows(img_h, r, world) for r in range(world)]
+    max_rows = max(hi - lo for lo, hi in rows)
+    bounce = _host_bounce(strip, group)
+    src = strip.cpu() if bounce else strip
+    if src.shape[0] != max_rows:
+        padded = src.new_zeros((max_rows,) + tuple(src.shape[1:]))
+        padded[: src.shape[0]] = src
+        src = padded
+    parts = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
+    dist.gather(src.contiguous(), parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    full = torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(rows)], 0)
+    return full.to(strip.device) if bounce else full
+
+
 def sync_gradients(model, group=None, reduce: bool = True, rebind: bool = True) -> None:
     """Data-parallel gradient exchange: ONE RCCL all-reduce over the engine's flat fp32
     gradient bucket (6.5 MB at the reference width), then the mean.  `loss.backward()` leaves every parameter

@@ -35,6 +35,7 @@ enum KernelId {
     K_CCL_SIZES, K_CCL_FILTER, K_CCL_COUNT, K_CCL_SCAN, K_CCL_RANK, K_CCL_RELABEL, K_MEMSET, K_NORM_BWD, K_COLSUM,
     K_WGRAD, K_TOP_BWD, K_PRE, K_METRIC, K_UNPACK, K_CONV3_WINO, K_LOSS, K_CONV3_WINO4, K_LABEL_DEFLATE,
     K_CONV3_S1_FP8, K_CONV3_S2_FP8, K_CONV1_FP8, K_CONVT_FP8,      // the e4m3 launches of the fp8 mode (their own matrix peak)
+    K_CCL_SEAM,                                                    // edge records + seam union-find of the strip-local labelling
     K_NUM_IDS
 };
 const char* kernel_name(int id);

@@ -34,7 +34,7 @@ static const char* kNames[K_NUM_IDS] = {
     "conv_last_valu", "norm_finalize", "norm_act_add", "swi_finalize", "pack_weights", "ccl_init", "ccl_merge",
     "ccl_compress", "ccl_sizes", "ccl_filter", "ccl_count", "ccl_scan", "ccl_rank", "ccl_relabel", "memset", "norm_bwd",
     "colsum", "wgrad_mfma", "top_bwd_valu", "normalize_input", "f1_metric", "wgrad_unpack", "conv3x3_s1_wino", "dice_ce_loss", "conv3x3_s1_wino4",
-    "label_deflate", "conv3x3_s1_fp8", "conv3x3_s2_fp8", "conv1x1_fp8", "convT3x3s2_fp8"};
+    "label_deflate", "conv3x3_s1_fp8", "conv3x3_s2_fp8", "conv1x1_fp8", "convT3x3s2_fp8", "ccl_seam"};
 static_assert(K_NUM_IDS <= CS_PROF_MAX_KERNELS, "cs_prof_collect: the caller's arrays hold CS_PROF_MAX_KERNELS entries");
 const char* kernel_name(int id) { return (id >= 0 && id < K_NUM_IDS) ? kNames[id] : "?"; }
 
@@ -2033,6 +2033,30 @@ int cs_ccl_label(const uint8_t* mask, int h, int w, int connectivity, int32_t* l
                  size_t workspace_bytes, void* stream) {
     CS_REQUIRE(mask && labels && workspace, "ccl_label: null argument");
     return cs::ccl_label((hipStream_t)stream, mask, h, w, connectivity, labels, n_labels, workspace, workspace_bytes);
+}
+
+int cs_ccl_strip_halo(int hole_area, int min_size) { return cs::ccl_strip_halo(hole_area, min_size); }
+int cs_ccl_strip_edge_ints(int w) { return cs::ccl_strip_edge_ints(w); }
+size_t cs_ccl_seam_workspace_bytes(int world, int w) { return cs::ccl_seam_workspace_bytes(world, w); }
+
+int cs_ccl_strip_local(const uint8_t* mask_rows, int ext_h, int w, int strip_row0, int strip_h, int hole_area, int min_size,
+                       int32_t* edge_record, void* workspace, size_t workspace_bytes, void* stream) {
+    CS_REQUIRE(w == 0 || (edge_record && workspace && (mask_rows || ext_h == 0)), "ccl_strip_local: null argument");
+    return cs::ccl_strip_local((hipStream_t)stream, mask_rows, ext_h, w, strip_row0, strip_h, hole_area, min_size, edge_record, workspace,
+                               workspace_bytes);
+}
+
+int cs_ccl_strip_resolve(const int32_t* all_records, int world, int rank, int ext_h, int w, int strip_h, int32_t* edge_ids, int32_t* n_labels,
+                         void* workspace, size_t workspace_bytes, void* seam_workspace, size_t seam_workspace_bytes, void* stream) {
+    CS_REQUIRE((all_records && edge_ids && workspace && seam_workspace) || w == 0, "ccl_strip_resolve: null argument");
+    return cs::ccl_strip_resolve((hipStream_t)stream, all_records, world, rank, ext_h, w, strip_h, edge_ids, n_labels, workspace,
+                                 workspace_bytes, seam_workspace, seam_workspace_bytes);
+}
+
+int cs_ccl_strip_finish(const int32_t* all_edge_ids, int world, int rank, int ext_h, int w, int strip_h, int32_t* labels, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    CS_REQUIRE((all_edge_ids && labels && workspace) || w == 0 || strip_h == 0, "ccl_strip_finish: null argument");
+    return cs::ccl_strip_finish((hipStream_t)stream, all_edge_ids, world, rank, ext_h, w, strip_h, labels, workspace, workspace_bytes);
 }
 
 int cs_prof_enable(int on) {

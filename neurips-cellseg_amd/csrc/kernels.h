@@ -347,5 +347,15 @@ int ccl_postprocess(hipStream_t s, const uint8_t* mask, int h, int w, int hole_a
 int interior_map(hipStream_t s, const int32_t* inst, int h, int w, int min_size, uint8_t* out, void* ws, size_t ws_bytes);
 int ccl_label(hipStream_t s, const uint8_t* mask, int h, int w, int conn, int32_t* labels, int32_t* n_labels, void* ws,
               size_t ws_bytes);
+// strip-local labelling with a seam merge (one rank per strip of rows; kernels_ccl.hip)
+int ccl_strip_halo(int hole_area, int min_size);
+int ccl_strip_edge_ints(int w);
+size_t ccl_seam_workspace_bytes(int world, int w);
+int ccl_strip_local(hipStream_t s, const uint8_t* mask_ext, int ext_h, int w, int strip_row0, int strip_h, int hole_area, int min_size,
+                    int32_t* edge_rec, void* ws, size_t ws_bytes);
+int ccl_strip_resolve(hipStream_t s, const int32_t* all_recs, int world, int rank, int ext_h, int w, int strip_h, int32_t* edge_ids,
+                      int32_t* n_labels, void* ws, size_t ws_bytes, void* seam_ws, size_t seam_bytes);
+int ccl_strip_finish(hipStream_t s, const int32_t* all_edge_ids, int world, int rank, int ext_h, int w, int strip_h, int32_t* labels,
+                     void* ws, size_t ws_bytes);
 
 }  // namespace cs

@@ -214,13 +214,15 @@ __device__ __forceinline__ int block_sum_256(int v, int* smem) {
     return smem[0] + smem[1] + smem[2] + smem[3];
 }
 
-__global__ __launch_bounds__(256) void ccl_count_kernel(int64_t n, const int* L, int* chunk_count) {
+// `alive` (strip-local labelling, below): a root whose alive[] entry is <= 0 has been merged into a component that starts in an
+// earlier strip and is not counted; nullptr = every root counts
+__global__ __launch_bounds__(256) void ccl_count_kernel(int64_t n, const int* L, const int* alive, int* chunk_count) {
     __shared__ int smem[4];
     const int64_t base = (int64_t)blockIdx.x * CHUNK;
     int c = 0;
     for (int k = 0; k < CHUNK / 256; ++k) {
         const int64_t i = base + k * 256 + threadIdx.x;
-        if (i < n && L[i] == (int)i) ++c;
+        if (i < n && L[i] == (int)i && (!alive || alive[i] > 0)) ++c;
     }
     const int total = block_sum_256(c, smem);
     if (threadIdx.x == 0) chunk_count[blockIdx.x] = total;
@@ -254,8 +256,10 @@ __global__ __launch_bounds__(1024) void ccl_scan_kernel(int* chunk_count, int n_
     if (threadIdx.x == 0 && n_labels) *n_labels = carry_s;
 }
 
-// rank[i] = 1 + number of roots before i, written at roots
-__global__ __launch_bounds__(256) void ccl_rank_kernel(int64_t n, const int* L, const int* chunk_off, int* rank) {
+// rank[i] = 1 + number of roots before i (+ *first_id: the components that start in earlier strips), written at roots; `alive` as in
+// ccl_count_kernel (it may alias `rank`: a thread reads the entries of its own four pixels before it writes them)
+__global__ __launch_bounds__(256) void ccl_rank_kernel(int64_t n, const int* L, const int* alive, const int* chunk_off, const int* first_id,
+                                                       int* rank) {
     __shared__ int wave_tot[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t base = (int64_t)blockIdx.x * CHUNK + threadIdx.x * 4;   // 4 consecutive pixels per thread
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void ccl_rank_kernel(int64_t n, const int* L, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int64_t i = base + k;
-        flag[k] = (i < n && L[i] == (int)i) ? 1 : 0;
+        flag[k] = (i < n && L[i] == (int)i && (!alive || alive[i] > 0)) ? 1 : 0;
         mine += flag[k];
     }
     int inc = mine;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256) void ccl_rank_kernel(int64_t n, const int* L, 
     }
     if (lane == 63) wave_tot[wv] = inc;
     __syncthreads();
-    int run = chunk_off[blockIdx.x] + inc - mine;
+    int run = chunk_off[blockIdx.x] + inc - mine + (first_id ? *first_id : 0);
     for (int k = 0; k < wv; ++k) run += wave_tot[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -294,6 +298,7 @@ struct Ws {
     int* chunk;
     uint8_t* m;
     uint8_t* big;
+    int* spare;      // 64 ints behind the arrays (ccl_workspace_bytes reserves 256 bytes)
 };
 
 int carve(void* ws, size_t ws_bytes, int h, int w, Ws* out) {
@@ -313,6 +318,8 @@ int carve(void* ws, size_t ws_bytes, int h, int w, Ws* out) {
     out->m = (uint8_t*)p;
     p += (n + 255) / 256 * 256;
     out->big = (uint8_t*)p;
+    p += (n + 255) / 256 * 256;
+    out->spare = (int*)p;
     return CS_OK;
 }
 
@@ -383,21 +390,32 @@ int flip_small(hipStream_t s, uint8_t* m, int want, int h, int w, int thr, const
     return CS_OK;
 }
 
-int number(hipStream_t s, int h, int w, const Ws& ws, int32_t* labels, int32_t* n_labels) {
+// ranks of the roots of ws.L into ws.size (1-based, raster order); renumber = second pass of the strip-local labelling: roots whose
+// ws.size entry is <= 0 are skipped and the numbering starts behind *first_id
+int rank_roots(hipStream_t s, int h, int w, const Ws& ws, int32_t* n_roots, bool renumber, const int* first_id) {
     const int64_t n = (int64_t)h * w;
     const int n_chunks = (int)((n + CHUNK - 1) / CHUNK);
+    const int* alive = renumber ? ws.size : nullptr;
     {
         ProfScope prof(K_CCL_COUNT, s, 0, 4.0 * n);
-        hipLaunchKernelGGL(ccl_count_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, n, ws.L, ws.chunk);
+        hipLaunchKernelGGL(ccl_count_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, n, ws.L, alive, ws.chunk);
     }
     {
         ProfScope prof(K_CCL_SCAN, s, 0, 8.0 * n_chunks);
-        hipLaunchKernelGGL(ccl_scan_kernel, dim3(1), dim3(1024), 0, s, ws.chunk, n_chunks, n_labels);
+        hipLaunchKernelGGL(ccl_scan_kernel, dim3(1), dim3(1024), 0, s, ws.chunk, n_chunks, n_roots);
     }
     {
         ProfScope prof(K_CCL_RANK, s, 0, 4.0 * n);
-        hipLaunchKernelGGL(ccl_rank_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, n, ws.L, ws.chunk, ws.size);
+        hipLaunchKernelGGL(ccl_rank_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, n, ws.L, alive, ws.chunk, first_id, ws.size);
     }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int number(hipStream_t s, int h, int w, const Ws& ws, int32_t* labels, int32_t* n_labels) {
+    const int64_t n = (int64_t)h * w;
+    int rc = rank_roots(s, h, w, ws, n_labels, false, nullptr);
+    if (rc) return rc;
     {
         ProfScope prof(K_CCL_RELABEL, s, 0, 8.0 * n);
         hipLaunchKernelGGL(ccl_relabel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ws.L, ws.size, labels);
@@ -494,6 +512,294 @@ int ccl_label(hipStream_t s, const uint8_t* mask, int h, int w, int conn, int32_
     if (rc) return rc;
     if ((rc = forest(s, mask, 1, h, w, conn, ws))) return rc;
     return number(s, h, w, ws, labels, n_labels);
+}
+
+
+// =====================================================================================================================
+// Strip-local labelling with a seam merge (third row, first option: "strip-local union-find + one seam-merge pass").
+// One slide, one rank per strip of image rows; every rank holds the thresholded mask of its rows + a halo.
+//
+//   strip_local   the two size filters on the rows [strip - halo, strip + halo) with halo = hole_area + min_size (a component of fewer
+//                 than T pixels spans fewer than T rows, so whatever intersects the strip and is small lies inside the halo, and whatever
+//                 is cut by the halo's outer row has at least halo + 1 pixels: the filtered strip is exactly the filtered slide), the
+//                 8-connected forest of the STRIP rows only, local ranks rho = 1.. of its roots in raster order, and an edge record:
+//                 for the strip's first and last row, per pixel, (rep, rho) - rep = the first edge position (0..w-1 first row, w..2w-1
+//                 last row) at which the pixel's component shows up, -1 for background.              --> all-gather of the records
+//   strip_resolve every rank runs the same seam union-find over the (strip, rep) nodes of all records (8-connectivity across each seam,
+//                 the root of a merged component is the part with the smallest (strip, rho) = its first raster pixel), counts per strip the
+//                 components merged AWAY into an earlier start, and renumbers its own strip: ids start behind the components that begin in
+//                 earlier strips, local roots that were merged away are skipped and remember the edge position of their root's
+//                 representative instead.                                                            --> all-gather of the edge ids
+//   strip_finish  merged-away roots read the final id of their root at that position; pixels read their root's id.
+// Ids are those of the single-pass labelling, bit for bit (tests/test_gpu_ccl_strips.py).  All integer, HBM / latency bound.
+namespace {
+
+constexpr int EDGE_HDR = 4;                          // record = [n_local, strip_h, 0, 0][top rep w][top rho w][bottom rep w][bottom rho w]
+
+__device__ __forceinline__ int64_t edge_pixel(int p, int w, int strip_h) { return p < w ? p : (int64_t)(strip_h - 1) * w + (p - w); }
+
+// one block; phases separated by block barriers (global stores of a block are visible to it behind a barrier)
+__global__ __launch_bounds__(1024) void ccl_edge_rep_kernel(const int* L, int* scratch, int w, int strip_h, int* rec) {
+    const int n = 2 * w;
+    for (int p = threadIdx.x; p < n; p += 1024) {
+        const int r = L[edge_pixel(p, w, strip_h)];
+        if (r >= 0) scratch[r] = 0x7fffffff;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += 1024) {
+        const int r = L[edge_pixel(p, w, strip_h)];
+        if (r >= 0) atomicMin(&scratch[r], p);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += 1024) {
+        const int r = L[edge_pixel(p, w, strip_h)];
+        rec[EDGE_HDR + (p < w ? p : 2 * w + (p - w))] = r >= 0 ? scratch[r] : -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void ccl_edge_rank_kernel(const int* L, const int* rank, const int* n_local, int w, int strip_h, int* rec) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p == 0) {
+        rec[0] = *n_local;
+        rec[1] = strip_h;
+        rec[2] = rec[3] = 0;
+    }
+    if (p >= 2 * w) return;
+    const int r = L[edge_pixel(p, w, strip_h)];
+    rec[EDGE_HDR + w + (p < w ? p : 2 * w + (p - w))] = r >= 0 ? rank[r] : 0;
+}
+
+__global__ __launch_bounds__(256) void ccl_edge_empty_kernel(int w, int* rec) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= EDGE_HDR + 4 * w) return;
+    const int j = i - EDGE_HDR;
+    rec[i] = (j >= 0 && ((j / w) & 1) == 0) ? -1 : 0;          // rep rows -1, rho rows and header 0
+}
+
+struct SeamView {
+    const int* recs;
+    int w, rec_ints;
+    __device__ int rep(int k, int p) const { return recs[(int64_t)k * rec_ints + EDGE_HDR + (p < w ? p : 2 * w + (p - w))]; }
+    __device__ int rho(int k, int p) const { return recs[(int64_t)k * rec_ints + EDGE_HDR + w + (p < w ? p : 2 * w + (p - w))]; }
+    __device__ int n_local(int k) const { return recs[(int64_t)k * rec_ints]; }
+    __device__ int strip_h(int k) const { return recs[(int64_t)k * rec_ints + 1]; }
+    // node = k * 2w + rep; "a starts before b" = (strip, local rank) order = raster order of the components' first pixels
+    __device__ bool before(int a, int b) const {
+        const int ka = a / (2 * w), kb = b / (2 * w);
+        if (ka != kb) return ka < kb;
+        return rho(ka, a - ka * 2 * w) < rho(kb, b - kb * 2 * w);
+    }
+};
+
+// parent[] is read and written with device-scope atomics only: the hooks are atomics that execute in L2, and a plain load could keep
+// returning a stale L1 line of the same CU
+__device__ __forceinline__ int seam_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int seam_find(int* parent, int x) {
+    int p = seam_ld(&parent[x]);
+    while (p != x) {
+        const int gp = seam_ld(&parent[p]);
+        // halving: x is not a root and never becomes one again; gp is an ancestor
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+
+// parents always start before their children, so the root of a merged component is its earliest start; a failed hook (a had stopped
+// being a root) continues from a's actual parent, so every retry climbs the real tree
+__device__ __forceinline__ void seam_unite(const SeamView& v, int* parent, int a, int b) {
+    while (true) {
+        a = seam_find(parent, a);
+        b = seam_find(parent, b);
+        if (a == b) return;
+        if (v.before(a, b)) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicCAS(&parent[a], a, b);       // hook the later start under the earlier one
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// ONE block.  seam: parent[world * 2w], n_away[world], first_id[world + 1].  Writes, for strip `rank`: at merged-away local roots
+// size[root] = -(1 + node of the merged component's root); first_id[k] = ids handed out before strip k; *n_total.
+__global__ __launch_bounds__(1024) void ccl_seam_resolve_kernel(SeamView v, int world, int rank, int* parent, int* n_away, int* first_id,
+                                                                const int* L, int* size, int* n_total) {
+    const int w = v.w, n2 = 2 * w;
+    const int tid = threadIdx.x;
+    if (tid < world) __hip_atomic_store(&n_away[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int idx = tid; idx < world * n2; idx += 1024) {
+        const int k = idx / n2, p = idx - k * n2;
+        if (v.strip_h(k) > 0 && v.rep(k, p) == p) __hip_atomic_store(&parent[idx], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // seams: last row of strip k against the first row of the next strip that has rows
+    for (int idx = tid; idx < world * w; idx += 1024) {
+        const int kb = idx / w, c = idx - kb * w;              // kb = the strip BELOW the seam
+        if (v.strip_h(kb) <= 0) continue;
+        int ka = kb - 1;
+        while (ka >= 0 && v.strip_h(ka) <= 0) --ka;
+        if (ka < 0) continue;
+        const int rb = v.rep(kb, c);
+        if (rb < 0) continue;
+        for (int d = -1; d <= 1; ++d) {
+            const int cc = c + d;
+            if (cc < 0 || cc >= w) continue;
+            const int ra = v.rep(ka, w + cc);
+            if (ra >= 0) seam_unite(v, parent, kb * n2 + rb, ka * n2 + ra);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < world * n2; idx += 1024) {
+        const int k = idx / n2, p = idx - k * n2;
+        if (v.strip_h(k) <= 0 || v.rep(k, p) != p) continue;
+        const int root = seam_find(parent, idx);
+        if (root != idx) atomicAdd(&n_away[k], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int k = 0; k < world; ++k) {
+            first_id[k] = run;
+            run += v.n_local(k) - seam_ld(&n_away[k]);
+        }
+        first_id[world] = run;
+        if (n_total) *n_total = run;
+    }
+    const int sh = v.strip_h(rank);
+    if (sh > 0) {
+        for (int p = tid; p < n2; p += 1024) {
+            const int rp = v.rep(rank, p);
+            if (rp < 0) continue;
+            const int root = seam_find(parent, rank * n2 + rp);
+            if (root != rank * n2 + rp) size[L[edge_pixel(p, w, sh)]] = -(1 + root);   // same value from every pixel of the component
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ccl_edge_ids_kernel(const int* L, const int* id, int w, int strip_h, int* edge_ids) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= 2 * w) return;
+    int v = 0;
+    if (strip_h > 0) {
+        const int r = L[edge_pixel(p, w, strip_h)];
+        v = r >= 0 ? id[r] : 0;
+    }
+    edge_ids[p] = v;
+}
+
+// merged-away roots take the final id of their component's root: all_ids[node] (node = strip * 2w + edge position, a live component)
+__global__ __launch_bounds__(256) void ccl_edge_fix_kernel(const int* L, int* id, const int* all_ids, int w, int strip_h) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= 2 * w) return;
+    const int r = L[edge_pixel(p, w, strip_h)];
+    if (r < 0) return;
+    const int v = id[r];
+    if (v < 0) id[r] = all_ids[-v - 1];
+}
+
+size_t seam_ints(int world, int w) { return (size_t)world * 2 * w + 2 * (size_t)world + 8; }
+
+}  // namespace
+
+int ccl_strip_halo(int hole_area, int min_size) { return (hole_area > 0 ? hole_area : 0) + (min_size > 0 ? min_size : 0); }
+int ccl_strip_edge_ints(int w) { return EDGE_HDR + 4 * w; }
+size_t ccl_seam_workspace_bytes(int world, int w) { return (seam_ints(world, w) * 4 + 255) / 256 * 256; }
+
+int ccl_strip_local(hipStream_t s, const uint8_t* mask_ext, int ext_h, int w, int strip_row0, int strip_h, int hole_area, int min_size,
+                    int32_t* edge_rec, void* ws_p, size_t ws_bytes) {
+    CS_REQUIRE(ext_h >= 0 && w >= 0 && (int64_t)ext_h * w < (1ll << 31) - CHUNK, "ccl_strip: rows %d x %d too large", ext_h, w);
+    CS_REQUIRE(strip_row0 >= 0 && strip_h >= 0 && strip_row0 + strip_h <= ext_h, "ccl_strip: strip rows [%d, %d) outside the %d rows given",
+               strip_row0, strip_row0 + strip_h, ext_h);
+    if (w == 0) return CS_OK;
+    if (strip_h == 0) {
+        hipLaunchKernelGGL(ccl_edge_empty_kernel, dim3((unsigned)ceil_div(EDGE_HDR + 4 * w, 256)), dim3(256), 0, s, w, edge_rec);
+        CS_HIP(hipGetLastError());
+        return CS_OK;
+    }
+    Ws ws;
+    int rc = carve(ws_p, ws_bytes, ext_h, w, &ws);
+    if (rc) return rc;
+    const int64_t n = (int64_t)ext_h * w;
+    hipLaunchKernelGGL(ccl_binarize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mask_ext, ws.m, n);
+    if (hole_area > 0 && (rc = flip_small(s, ws.m, 0, ext_h, w, hole_area, ws))) return rc;
+    if (min_size > 0 && (rc = flip_small(s, ws.m, 1, ext_h, w, min_size, ws))) return rc;
+    // the forest of the strip rows alone: indices local to the strip, at the front of ws.L / ws.size
+    if ((rc = forest(s, ws.m + (size_t)strip_row0 * w, 1, strip_h, w, 8, ws))) return rc;
+    {
+        ProfScope prof(K_CCL_SEAM, s, 0, 24.0 * w);
+        hipLaunchKernelGGL(ccl_edge_rep_kernel, dim3(1), dim3(1024), 0, s, ws.L, ws.size, w, strip_h, edge_rec);
+    }
+    // local ranks of the strip's roots -> ws.size[root], their number -> ws.spare[0]
+    if ((rc = rank_roots(s, strip_h, w, ws, ws.spare, false, nullptr))) return rc;
+    {
+        ProfScope prof(K_CCL_SEAM, s, 0, 16.0 * w);
+        hipLaunchKernelGGL(ccl_edge_rank_kernel, dim3((unsigned)ceil_div(2 * w, 256)), dim3(256), 0, s, ws.L, ws.size, ws.spare, w, strip_h,
+                           edge_rec);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int ccl_strip_resolve(hipStream_t s, const int32_t* all_recs, int world, int rank, int ext_h, int w, int strip_h, int32_t* edge_ids,
+                      int32_t* n_labels, void* ws_p, size_t ws_bytes, void* seam_p, size_t seam_bytes) {
+    CS_REQUIRE(world >= 1 && world <= 1024 && rank >= 0 && rank < world, "ccl_strip: rank %d of %d", rank, world);
+    CS_REQUIRE(ext_h >= 0 && w >= 0 && (int64_t)ext_h * w < (1ll << 31) - CHUNK, "ccl_strip: rows %d x %d too large", ext_h, w);
+    CS_REQUIRE((int64_t)world * 2 * w < (1ll << 30), "ccl_strip: %d strips of width %d: too many seam nodes", world, w);
+    CS_REQUIRE(strip_h >= 0 && strip_h <= ext_h, "ccl_strip: strip of %d rows in %d", strip_h, ext_h);
+    if (w == 0) {
+        if (n_labels) CS_HIP(hipMemsetAsync(n_labels, 0, sizeof(int32_t), s));
+        return CS_OK;
+    }
+    if (seam_bytes < ccl_seam_workspace_bytes(world, w)) {
+        set_error("ccl_strip: seam workspace %zu < %zu bytes", seam_bytes, ccl_seam_workspace_bytes(world, w));
+        return CS_ERR_WORKSPACE;
+    }
+    Ws ws;
+    int rc = carve(ws_p, ws_bytes, ext_h, w, &ws);
+    if (rc) return rc;
+    int* parent = (int*)seam_p;
+    int* n_away = parent + (size_t)world * 2 * w;
+    int* first_id = n_away + world;
+    SeamView v{all_recs, w, EDGE_HDR + 4 * w};
+    {
+        ProfScope prof(K_CCL_SEAM, s, 0, 24.0 * world * w);
+        hipLaunchKernelGGL(ccl_seam_resolve_kernel, dim3(1), dim3(1024), 0, s, v, world, rank, parent, n_away, first_id, ws.L, ws.size,
+                           n_labels);
+    }
+    if (strip_h > 0 && (rc = rank_roots(s, strip_h, w, ws, nullptr, true, first_id + rank))) return rc;
+    {
+        ProfScope prof(K_CCL_SEAM, s, 0, 12.0 * w);
+        hipLaunchKernelGGL(ccl_edge_ids_kernel, dim3((unsigned)ceil_div(2 * w, 256)), dim3(256), 0, s, ws.L, ws.size, w, strip_h, edge_ids);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int ccl_strip_finish(hipStream_t s, const int32_t* all_edge_ids, int world, int rank, int ext_h, int w, int strip_h, int32_t* labels,
+                     void* ws_p, size_t ws_bytes) {
+    CS_REQUIRE(world >= 1 && rank >= 0 && rank < world, "ccl_strip: rank %d of %d", rank, world);
+    CS_REQUIRE(ext_h >= 0 && w >= 0 && (int64_t)ext_h * w < (1ll << 31) - CHUNK, "ccl_strip: rows %d x %d too large", ext_h, w);
+    CS_REQUIRE(strip_h >= 0 && strip_h <= ext_h, "ccl_strip: strip of %d rows in %d", strip_h, ext_h);
+    if (w == 0 || strip_h == 0) return CS_OK;
+    Ws ws;
+    int rc = carve(ws_p, ws_bytes, ext_h, w, &ws);
+    if (rc) return rc;
+    const int64_t n = (int64_t)strip_h * w;
+    {
+        ProfScope prof(K_CCL_SEAM, s, 0, 12.0 * w);
+        hipLaunchKernelGGL(ccl_edge_fix_kernel, dim3((unsigned)ceil_div(2 * w, 256)), dim3(256), 0, s, ws.L, ws.size, all_edge_ids, w, strip_h);
+    }
+    {
+        ProfScope prof(K_CCL_RELABEL, s, 0, 8.0 * n);
+        hipLaunchKernelGGL(ccl_relabel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ws.L, ws.size, labels);
+    }
+    CS_HIP(hipGetLastError());
+    return CS_OK;
 }
 
 }  // namespace cs

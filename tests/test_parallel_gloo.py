@@ -373,3 +373,67 @@ def test_strips_guard_releases_both_ranks_with_one_line(tmp_path, mode):
     line = json.loads(lines[0])
     assert line["scaling"] == "weak" and ("provoked" in line["strips_error"] if mode == "raise" else "did not finish within" in line["strips_error"])
     assert time.time() - t0 < 60
+
+
+# ------------------------------------------------------------------------------------------- strip-local labelling: the collectives
+class _StubLabeller:
+    """Stands in for cellseg_amd.StripLabeller (device code, tests/test_gpu_ccl_strips.py) so that the two all-gathers and the gather of
+    parallel.label_strips / gather_label_strips run over gloo on CPU tensors: every step checks what it is handed."""
+
+    def __init__(self, h, w, rank, world):
+        import cellseg_amd as ca
+        self.rank, self.world, self.w = rank, world, w
+        self.row_begin, self.row_end = ca.rank_rows(h, rank, world)
+        self.n_labels = torch.tensor(7, dtype=torch.int32)
+
+    def local(self, mask):
+        return torch.arange(4 * self.w + 4, dtype=torch.int32) + 1000 * self.rank
+
+    def resolve(self, recs):
+        assert recs.shape == (self.world, 4 * self.w + 4)
+        assert all(int(recs[r, 0]) == 1000 * r for r in range(self.world))
+        return torch.arange(2 * self.w, dtype=torch.int32) - 1000 * self.rank
+
+    def finish(self, ids):
+        assert ids.shape == (self.world, 2 * self.w) and all(int(ids[r, 0]) == -1000 * r for r in range(self.world))
+        return torch.full((self.row_end - self.row_begin, self.w), self.rank + 1, dtype=torch.int32)
+
+
+def _label_strips_worker(rank, world, port, h, w, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cellseg_amd as ca
+        from cellseg_amd import parallel
+        lab, rows, n = parallel.label_strips(torch.zeros(h, w, dtype=torch.uint8), labeller=_StubLabeller(h, w, rank, world))
+        ok = rows == ca.rank_rows(h, rank, world) and int(n) == 7
+        dst = world - 1
+        full = parallel.gather_label_strips(lab, h, dst=dst)
+        if rank == dst:
+            want = torch.cat([torch.full((ca.rank_rows(h, r, world)[1] - ca.rank_rows(h, r, world)[0], w), r + 1, dtype=torch.int32)
+                              for r in range(world)])
+            ok = ok and torch.equal(full, want)
+        else:
+            ok = ok and full is None
+        q.put((rank, bool(ok)))
+    except Exception:                                                 # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,hw", [(2, (31, 4)), (3, (100, 17)), (4, (3, 5))])
+def test_label_strips_collectives(world, hw):
+    """Uneven strips (31 rows over 2, 3 rows over 4 ranks: an empty strip) through the record all-gather, the id all-gather and the
+    gather of the label strips to the last rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_label_strips_worker, args=(r, world, port, hw[0], hw[1], q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok is True for _, ok in res), res

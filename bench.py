@@ -485,6 +485,10 @@ def main():
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--cc-stream", type=int, default=1, help="1: the connected-component pass of slide k runs on its own stream beside "
                                                               "the convolutions of slide k + 1 (0: same stream)")
+    ap.add_argument("--cc", choices=["turns", "strips"], default="turns",
+                    help="connected components of the strips leg: turns = slide k's gathered mask is labelled whole by rank k mod N (no label "
+                         "traffic; best throughput); strips = every rank filters and labels its own rows of every slide, two small all-gathers "
+                         "around the seam union-find, label strips gathered to rank k mod N (shortest latency of ONE slide)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (reference width, other precisions, "
                                                                 "the other partition, the training step)")
@@ -572,6 +576,7 @@ def main():
     share_parts = [ca.share_partition(plan, r, world) for r in range(world)]
 
     no_labels, no_num = torch.zeros((1, 1), dtype=torch.int32, device=dev), torch.zeros((), dtype=torch.int32, device=dev)
+    strip_labeller = [None]
 
     # before the strips leg: a 1 KB ring of batched send/recv; when the library's point-to-point path fails the seam halves go
     # through one all-gather instead (reported as seam_transport) - the job does not end there
@@ -609,6 +614,21 @@ def main():
             mask.record_stream(cc_stream)
             return lab, num
 
+        def labelled_strips(full, dst, mine):
+            """--cc strips: this rank's rows of the slide are filtered and labelled here (cs_ccl_strip_*, SURVEY.md 8(e) third row: strip-local
+            union-find + seam merge; two all-gathers of edge rows), the int32 strips are gathered to rank dst, which holds the slide's label map."""
+            if strip_labeller[0] is None:
+                strip_labeller[0] = ca.StripLabeller(args.size, args.size, rank, world, dev)
+            if pipelined:
+                mask_ready.record()
+                cc_stream.wait_event(mask_ready)
+            with torch.cuda.stream(cc_stream if pipelined else torch.cuda.current_stream()):
+                lab, _, num = parallel.label_strips(full, labeller=strip_labeller[0])
+                whole = parallel.gather_label_strips(lab, args.size, dst=dst)
+            if pipelined:
+                full.record_stream(cc_stream)
+            return (whole, num) if mine else (no_labels, no_num)
+
         def step_slide():
             image = imgs[it[0] % 2]
             it[0] += 1
@@ -628,6 +648,9 @@ def main():
             mine = force_label[0] if force_label[0] is not None else (k % world == rank)
             _, _, _, mask = ca.swi_infer_share(model, image, roi, args.overlap, rank, world, engine_batch=args.strip_batch or None,
                                                streams=args.streams, exchange=seam_exchange)
+            if args.cc == "strips":
+                full = parallel.gather_shares(mask, plan, world, assemble=True)
+                return labelled_strips(full, k % world, mine)
             full = parallel.gather_shares(mask, plan, world, assemble=mine)
             return labelled(full) if mine else (no_labels, no_num)
 
@@ -639,7 +662,7 @@ def main():
             k = it[0]
             image = imgs[k % 2]
             it[0] += 1
-            r, w, full_mask = sim
+            r, w, full_mask = sim[:3]
 
             def fake_exchange(win, pl, rr, ww):
                 base = sh_me.slot_row_begin * pl.n_w
@@ -654,6 +677,19 @@ def main():
             ca.swi_infer_share(model, image, roi, args.overlap, r, w, engine_batch=args.strip_batch or None, streams=args.streams,
                                exchange=fake_exchange)
             gathered = full_mask.clone()         # a device-local copy of the gathered mask's size in place of the all-gather
+            if len(sim) > 3:                     # --cc strips: this rank's strip of EVERY slide (records / ids of the other strips precomputed)
+                lab_s, all_recs, all_ids = sim[3]
+                if pipelined:
+                    mask_ready.record()
+                    cc_stream.wait_event(mask_ready)
+                with torch.cuda.stream(cc_stream if pipelined else torch.cuda.current_stream()):
+                    lab_s.local(gathered)
+                    lab_s.resolve(all_recs.clone())      # clones: device-local copies in place of the two all-gathers
+                    lab = lab_s.finish(all_ids.clone())
+                    whole = torch.cat([lab] * w)[:args.size] if k % w == r else None      # in place of the gather: the strips' bytes land here
+                if pipelined:
+                    gathered.record_stream(cc_stream)
+                return (whole, lab_s.n_labels) if k % w == r else (no_labels, no_num)
             return labelled(gathered) if k % w == r else (no_labels, no_num)
 
         inner = step_sim if sim else (step_strips if (strips and dist is not None) else step_slide)
@@ -764,6 +800,9 @@ def main():
         parts = [ca.share_partition(plan, r, sim_world) for r in range(sim_world)]
         n_sim = -(-args.steps // sim_world) * sim_world              # whole rounds of the labelling turn
         ranks = {}
+        labellers = [ca.StripLabeller(args.size, args.size, r, sim_world, dev) for r in range(sim_world)]
+        all_recs = torch.stack([lb.local(full_mask) for lb in labellers])
+        all_ids = torch.stack([lb.resolve(all_recs) for lb in labellers])
         for sim_rank in sorted({0, min(3, sim_world - 1), sim_world - 1}):
             step = make_step(model, True, False, sim=(sim_rank, sim_world, full_mask))
             for _ in range(2):
@@ -772,15 +811,26 @@ def main():
             dt_sim, _ = time_steps(step, n_sim, barrier)
             ranks[str(sim_rank)] = {"windows": parts[sim_rank].win_end - parts[sim_rank].win_begin, "labels_every": sim_world,
                                     "ms_per_slide": round(dt_sim / n_sim * 1e3, 3)}
+            # the same share with --cc strips: the rank labels its 1/8 of the rows (+ halo) of EVERY slide instead of a whole mask every 8th
+            step = make_step(model, True, False, sim=(sim_rank, sim_world, full_mask, (labellers[sim_rank], all_recs, all_ids)))
+            for _ in range(2):
+                step()
+            step.it[0] = 0
+            dt_sim, _ = time_steps(step, n_sim, barrier)
+            ranks[str(sim_rank)]["ms_per_slide_cc_strips"] = round(dt_sim / n_sim * 1e3, 3)
         worst = max(v["ms_per_slide"] for v in ranks.values())
+        worst_cc = max(v["ms_per_slide_cc_strips"] for v in ranks.values())
         return {"of": sim_world, "ranks": ranks, "windows_per_rank": [p.win_end - p.win_begin for p in parts],
                 "max_windows_per_rank": max(p.win_end - p.win_begin for p in parts), "steps": n_sim,
                 "ms_per_slide": worst, "full_slide_ms": round(full_s * 1e3, 3), "ratio": round(full_s * 1e3 / worst, 3),
+                "ms_per_slide_cc_strips": worst_cc, "ratio_cc_strips": round(full_s * 1e3 / worst_cc, 3),
                 "note": "one GPU doing one rank's share of the 8-rank strips leg (window-list partition: its 120 / 121 windows, the exchange's pack / "
                         "unpack copies, the finalize of its rectangles, and on its turn - every 8th slide - the CC pass over a full mask on the CC "
                         "stream); ms_per_slide = the slowest of the simulated ranks; the seam transfer (12 MB over one xGMI link) and the mask "
                         "all-gather (16 MB gathered) are stood in for by device-local copies of the same sizes, so `ratio` is an UPPER bound of "
-                        "the 8-GPU speed-up: link latency, RCCL launch cost and rank skew are not in it"}
+                        "the 8-GPU speed-up: link latency, RCCL launch cost and rank skew are not in it; *_cc_strips = the same with the strip-local "
+                        "connected components (--cc strips: every rank labels its rows + 80-row halo of every slide, seam union-find, device-local "
+                        "copies in place of the two edge all-gathers and the label-strip gather)"}
 
     def measure_tiles(width, precision, n, k=20):
         """SURVEY.md 8(d) 'tile throughput': forward-only U-Net on N x 3 x 256 x 256 synthetic tiles (the predictor call of
@@ -1041,7 +1091,7 @@ def main():
             except Exception as e:                                  # noqa: BLE001
                 guard.fail(f"{type(e).__name__}: {e}"[:500])        # does not return
             guard.disarm()
-            if not args.no_secondary:
+            if not args.no_secondary or os.environ.get("BENCH_COMPARE_LEGS") == "1":
                 other_part = infer_summary(slides_res, False)
                 strips_equal = bool(torch.equal(slides_res["labels"], main_res["labels"])) if rank == 0 else None
         else:
@@ -1107,7 +1157,9 @@ def main():
                    "partition": "window list (cs_swi_partition_windows): contiguous shares that differ by at most one window",
                    "windows_per_rank": [sh.win_end - sh.win_begin for sh in share_parts],
                    "output_pixels_per_rank": [sum((r1 - r0) * (c1 - c0) for r0, r1, c0, c1 in sh.rects()) for sh in share_parts],
-                   "labelling": "round-robin over the ranks", "strip_batch": args.strip_batch or "auto",
+                   "labelling": ("round-robin over the ranks: slide k's gathered mask is labelled whole by rank k mod N" if args.cc == "turns" else
+                                 "strip-local: every rank labels its rows of every slide, seam union-find, label strips gathered to rank k mod N"),
+                   "strip_batch": args.strip_batch or "auto",
                    "equal_to_single_gpu_labels": strips_equal}
     if other_part:
         out["strips" if not head_strips else "slides"] = dict(

@@ -74,7 +74,16 @@ def test_seam_exchange_between_two_ranks_sharing_the_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["windows_per_rank"] == [24, 25] and line["config"]["equal_to_single_gpu_labels"] is True
     assert line["value_strips"] == line["value"] and line["value_slides"] == line["slides"]["value"]
-    assert line["config"]["labelling"] == "round-robin over the ranks"
+    assert line["config"]["labelling"].startswith("round-robin over the ranks")
+
+
+def test_strip_local_labelling_in_the_strips_leg_between_two_ranks_sharing_the_gpu():
+    """The same leg with --cc strips: every rank filters and labels its own rows of every slide (cs_ccl_strip_*), the edge rows travel in
+    two all-gathers, the label strips are gathered to the slide's output rank - and the label map equals the one-slide-per-rank leg's."""
+    line = _bench("--gpus", "2", "--shard", "strips", "--cc", "strips", "--size", "1024", "--steps", "2", "--warmup", "1", "--strip-batch", "8",
+                  "--no-secondary", BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_COMPARE_LEGS=1)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["labelling"].startswith("strip-local") and line["config"]["equal_to_single_gpu_labels"] is True
 
 
 # ------------------------------------------------------------------------------------------- RCCL, executed

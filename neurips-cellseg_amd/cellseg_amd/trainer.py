@@ -43,7 +43,7 @@ class _Shape:
     """Static buffers + captured graphs for one batch shape."""
 
     def __init__(self):
-        self.x = self.t = self.logits = self.dlogits = self.ws_f = self.ws_b = self.ws_l = self.loss = None
+        self.x = self.t = self.logits = self.dlogits = self.ws_f = self.ws_b = self.ws_l = self.loss = self.loss_out = None
         self.graph_a = self.graph_b = None
         self.eager_steps = 0
 
@@ -187,8 +187,11 @@ class TrainStep:
         ls = (C.c_int64 * 4)(*[int(v) for v in lg.stride()])
         ts = (C.c_int64 * 4)(*[int(v) for v in t.stride()])
         cls = model.out_channels
+        # the loss lands in a tensor of its own per step (an allocation out of torch's cache, no launch) - a captured step replays fixed
+        # addresses, so it keeps the static scalar and __call__ clones it (one runtime copy kernel + its dispatch gap per step)
+        sh.loss_out = sh.loss if self.capture else torch.empty((), dtype=torch.float32, device=sh.loss.device)
         check(lib.cs_dice_ce_forward(C.c_void_p(sh.logits.data_ptr()), ls, C.c_void_p(t.data_ptr()), ts, n, cls, hh, ww, lf.smooth_nr,
-                                     lf.smooth_dr, lf.lambda_dice, lf.lambda_ce, C.c_void_p(sh.loss.data_ptr()), C.c_void_p(sh.ws_l.data_ptr()),
+                                     lf.smooth_dr, lf.lambda_dice, lf.lambda_ce, C.c_void_p(sh.loss_out.data_ptr()), C.c_void_p(sh.ws_l.data_ptr()),
                                      sh.ws_l.numel(), s), "cs_dice_ce_forward")
         check(lib.cs_dice_ce_backward(C.c_void_p(sh.logits.data_ptr()), ls, C.c_void_p(t.data_ptr()), ts, n, cls, hh, ww, lf.smooth_nr,
                                       lf.smooth_dr, lf.lambda_dice, lf.lambda_ce, C.c_void_p(), C.c_void_p(sh.ws_l.data_ptr()), sh.ws_l.numel(),
@@ -289,7 +292,7 @@ class TrainStep:
         self._expected_step = int(self.optimizer._step)
         if self._nbt:
             torch._foreach_add_(self._nbt, 1)                   # nn.BatchNorm2d counts its train-mode batches
-        return sh.loss.clone()
+        return sh.loss.clone() if self.capture else sh.loss_out
 
     def _exchange(self) -> None:
         from . import parallel

@@ -636,7 +636,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     if (!dry && inst) {
         if (!ws.ok()) { set_error("unet: workspace too small"); return CS_ERR_WORKSPACE; }
         ProfScope prof(K_MEMSET, s, 0, (double)stats_bytes);
-        CS_HIP(hipMemsetAsync(ws.base + stats_mark, 0, stats_bytes, s));
+        CS_TRY(launch_zero(s, ws.base + stats_mark, stats_bytes));
     }
     auto new_tab = [&](NormRt& rt, int c_total) {
         rt.tab = ws.take<float2>((size_t)n * c_total);
@@ -1628,17 +1628,17 @@ int cs_unet_backward(cs_unet* net, const float* grad_logits_nhwc, void* workspac
         cs::set_error("unet_backward: workspace %zu < %zu bytes", workspace_bytes, acc_bytes + buf_bytes);
         return CS_ERR_WORKSPACE;
     }
-    CS_HIP(hipMemsetAsync(workspace, 0, acc_bytes, s));
-    CS_HIP(hipMemsetAsync(flat_grad, 0, (size_t)net->grad_floats * sizeof(float), s));
+    if (int zrc = launch_zero((hipStream_t)s, workspace, acc_bytes, flat_grad, (size_t)net->grad_floats * sizeof(float))) return zrc;
     Bump acc(workspace, acc_bytes), buf((char*)workspace + acc_bytes, workspace_bytes - acc_bytes);
-    static const bool side_env = !(getenv("CS_BWD_SIDE") && atoi(getenv("CS_BWD_SIDE")) == 0);     // A/B: CS_BWD_SIDE=0 = one stream (7.38 vs 6.90 ms per step)
+    static const int side_n = [] { const char* e = getenv("CS_BWD_SIDE"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : v > 2 ? 2 : v; }();
+    static const bool side_env = side_n != 0;     // A/B: CS_BWD_SIDE=0 = one stream (7.38 vs 6.90 ms per step), 2 = the weight-gradient groups alternate over two side streams
     if (side_env && !prof_enabled() && !net->bwd_side[0]) {      // (per-kernel HIP-event profiling keeps everything on one stream)
         for (auto& st : net->bwd_side) CS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (auto& ev : net->bwd_ev) CS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     const bool use_side = side_env && !prof_enabled() && net->bwd_side[0];
     net->tape.valid = false;      // the gradient buffers reuse nothing of the tape, but one backward per forward (also when it fails)
-    rc = unet_backward_impl(net, grad_logits_nhwc, acc, buf, flat_grad, s, net->bwd_side, use_side ? 1 : 0, net->bwd_ev, 48);
+    rc = unet_backward_impl(net, grad_logits_nhwc, acc, buf, flat_grad, s, net->bwd_side, use_side ? side_n : 0, net->bwd_ev, 48);
     if (rc != CS_OK && use_side) {
         // an early return skipped the join at the end of the pass: side-stream weight gradients may still be reading / writing the
         // caller's buffers, which the caller is about to free - drain them before reporting the error

@@ -289,6 +289,9 @@ int launch_conv_last_bwd(hipStream_t s, const float* dlogits, const ConvSrc& u, 
 int launch_convt_small_bwd_data(hipStream_t s, const float* du, const float* w_torch, int cin_total, int c_begin, int c_count,
                                 float* dst, int dst_pitch, bool accumulate, int n, int hin, int win);
 
+// zero-fill of one or two 16-byte aligned regions as ONE kernel launch (kernels_misc.hip; other alignments fall back to hipMemsetAsync)
+int launch_zero(hipStream_t s, void* a, size_t a_bytes, void* b = nullptr, size_t b_bytes = 0);
+
 // ---- tiler finalize -------------------------------------------------------------------------------
 struct SwiFinalizeArgs {
     const float* win_logits;    // [n_h*n_w][roi_h][roi_w][c] NHWC

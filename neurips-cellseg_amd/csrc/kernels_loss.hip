@@ -169,7 +169,7 @@ int dice_ce_forward(hipStream_t s, const float* logits, const int64_t* ls, const
     if (int rc = fill_args(a, logits, ls, target, ts, n, c, h, w, smooth_nr, smooth_dr, lambda_dice, lambda_ce, ws, ws_bytes)) return rc;
     CS_REQUIRE(loss_out, "dice_ce: null loss pointer");
     ProfScope prof(K_LOSS, s, 0, 8.0 * n * c * (double)h * w);
-    CS_HIP(hipMemsetAsync(ws, 0, dice_ce_workspace_bytes(n, c), s));
+    if (int zrc = launch_zero(s, ws, dice_ce_workspace_bytes(n, c))) return zrc;
     const int bx = ceil_div(h * w, 256) < LOSS_BLOCKS_PER_IMAGE ? ceil_div(h * w, 256) : LOSS_BLOCKS_PER_IMAGE;
     const dim3 grid((unsigned)bx, (unsigned)n);
     switch (c) {

@@ -457,6 +457,57 @@ class StripsGuard:
             self.done = True
 
 
+def live_pmc_traffic(group_name, timeout_s=300):
+    """HBM bytes per launch of one kernel group, MEASURED by this run: two child passes of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    (counter passes on their own, no tracing flags, the program itself behind `--`) around ONE slide of the default command on one stream,
+    corrected as MI355X_MICROARCH.md's HBM section prescribes for gfx950 (FETCH_SIZE / WRITE_SIZE count KiB; FETCH_SIZE reports half the
+    bytes of wide coalesced reads) - tools/pmc_summary.py's arithmetic, grouping the kernel symbols under the engine's profiling ids.
+    Children of this process (never an exec: the GPU is initialised here); -> (bytes_per_launch, detail dict) or (None, {"error": ...})."""
+    import csv
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, {"error": "rocprofv3 not found"}
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, {"error": "this run is itself under a profiler"}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_summary import group
+    finally:
+        sys.path.pop(0)
+    out_dir = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_FORCE_DIST")}
+    env["TMPDIR"] = "/tmp"
+    got, t0 = {}, time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out_dir, counter)
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "1",
+                   "--warmup", "0", "--streams", "1", "--cc-stream", "0", "--no-cpu-baseline", "--no-secondary"]
+            cp = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            files = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+            if cp.returncode != 0 or not files:
+                return None, {"error": f"rocprofv3 --pmc {counter}: rc {cp.returncode}, {len(files)} counter files: {cp.stderr[-200:]}"}
+            tot, cnt = 0.0, 0
+            for path in files:
+                for r in csv.DictReader(open(path)):
+                    if r.get("Counter_Name", counter) == counter and group(r["Kernel_Name"]) == group_name:
+                        tot += float(r["Counter_Value"])
+                        cnt += 1
+            if not cnt:
+                return None, {"error": f"no {group_name} launches in the {counter} pass"}
+            got[counter] = (tot / cnt, cnt)
+    except (subprocess.SubprocessError, OSError, ValueError, KeyError) as e:
+        return None, {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    read_b = 2.0 * got["FETCH_SIZE"][0] * 1024
+    write_b = got["WRITE_SIZE"][0] * 1024
+    return round(read_b + write_b), {"hbm_read_bytes_per_launch": round(read_b), "hbm_write_bytes_per_launch": round(write_b),
+                                     "launches_counted": got["FETCH_SIZE"][1], "seconds": round(time.perf_counter() - t0, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -489,6 +540,8 @@ def main():
                     help="connected components of the strips leg: turns = slide k's gathered mask is labelled whole by rank k mod N (no label "
                          "traffic; best throughput); strips = every rank filters and labels its own rows of every slide, two small all-gathers "
                          "around the seam union-find, label strips gathered to rank k mod N (shortest latency of ONE slide)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic: quote profiles/pmc_traffic.json instead of running the two "
+                                                                   "rocprofv3 --pmc child passes (default command at N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (reference width, other precisions, "
                                                                 "the other partition, the training step)")
@@ -989,16 +1042,26 @@ def main():
             achieved = k["bytes"] / sec / 1e9
             rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                   "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
-        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # gfx950 correction applied; tools/pmc_summary.py).  bench.py cannot read PMCs itself, so it quotes the summary.
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name, {})
-            if res.get("primary") and args.engine_batch == 0 and args.size == 4096 and args.width == "baseline32" and args.precision == "fp32":
-                rl["traffic"] = pmc.get("hbm_bytes_per_launch")
-                rl["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 PMC passes of the default command)"
-                rl["algorithmic_bytes_per_launch"] = round(k["bytes"] / k["launches"])
-        except (OSError, ValueError, KeyError):
-            pass
+        # HBM bytes per launch of this group: measured by THIS run where it can be (the default command on one GPU: two child passes of
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied - live_pmc_traffic), else quoted from the committed passes
+        # of the same command (profiles/pmc_traffic.json, tools/pmc_summary.py) and labelled as a quote
+        if res.get("primary") and args.engine_batch == 0 and args.size == 4096 and args.width == "baseline32" and args.precision == "fp32":
+            rl["algorithmic_bytes_per_launch"] = round(k["bytes"] / k["launches"])
+            live = None
+            if world == 1 and dist is None and not args.no_secondary and not args.no_live_traffic:
+                live, detail = live_pmc_traffic(name)
+                rl["traffic_live"] = detail
+            if live is not None:
+                rl["traffic"] = live
+                rl["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of `bench.py --steps 1 --warmup 0 "
+                                        "--streams 1 --cc-stream 0 --no-cpu-baseline --no-secondary`, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch")
+            else:
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name, {})
+                    rl["traffic"] = pmc.get("hbm_bytes_per_launch")
+                    rl["traffic_source"] = "QUOTED from profiles/pmc_traffic.json (committed rocprofv3 PMC passes of the default command), not measured by this run"
+                except (OSError, ValueError, KeyError):
+                    pass
         if "wino" in name:
             # Winograd: `achieved` counts the multiplies the algorithm really issues on the matrix pipe (F(2x2,3x3): 16 per 2x2 output
             # tile and channel pair; F(4x4,3x3): 36 per 4x4 tile); the same launches expressed in direct-convolution FLOPs (9 per

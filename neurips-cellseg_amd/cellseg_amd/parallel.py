@@ -340,7 +340,7 @@ def _all_gather_flat(t: torch.Tensor, group=None) -> torch.Tensor:
 def label_strips(mask: torch.Tensor, group=None, hole_area: int = 64, min_size: int = 16, labeller=None):
     """``measure.label(remove_small_objects(remove_small_holes(mask), 16))`` (predict.py:113) of ONE slide over the ranks of `group`:
     rank r filters and labels its ``rank_rows`` strip of the thresholded mask (+ an 80-row halo) on its own GPU, the strips' first / last
-    rows are exchanged in two small all-gathers (32 KB + 16 KB per rank at 4096 columns) around the seam union-find, and every rank ends
+    rows are exchanged in two small all-gathers (64 KB + 32 KB per rank at 4096 columns) around the seam union-find, and every rank ends
     with the FINAL int32 labels of its rows - bit-identical to the single-GPU pass, numbering included.  mask: the full [H, W] mask
     (every rank has it after ``gather_shares``) - only the strip's rows and halo are read.
     -> (labels [rows, W] int32, (row_begin, row_end), n_labels device int32 scalar = components of the whole slide).

@@ -3,7 +3,8 @@
 
     python tests/diagnostics/gpu_fuzz.py [--seconds 120] [--seed 0]
 
-* connected-components post-process vs the plain-C oracle on random masks of random shapes / densities / structures;
+* connected-components post-process vs the plain-C oracle on random masks of random shapes / densities / structures - as one pass and as
+  1...12 strips of rows (even and random, also empty, cuts) with the seam merge;
 * tiler (+ net) vs the torch-CPU oracle on random image sizes, roi sizes and overlaps with a small net;
 * create_interior_map, remove_boundary_cells / label_overlap vs their oracles on random instance maps.
 Prints one JSON line with the case counts; exits non-zero on the first mismatch (after printing the failing case)."""
@@ -25,7 +26,7 @@ def run(seconds: float = 120.0, seed: int = 0, channels=(16, 32, 64), precision:
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
     P.build_c()
-    counts = {"ccl": 0, "tiler": 0, "interior": 0, "metric": 0}
+    counts = {"ccl": 0, "ccl_strips": 0, "tiler": 0, "interior": 0, "metric": 0}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 
 
@@ -74,6 +75,19 @@ def run(seconds: float = 120.0, seed: int = 0, channels=(16, 32, 64), precision:
             print("CCL MISMATCH", h, w, hole, mins)
             raise AssertionError("gpu_fuzz mismatch (see the line above)")
         counts["ccl"] += 1
+        # ---- the same chain as strips of rows with a seam merge (cs_ccl_strip_*): random strip counts and random (also empty) cuts
+        world = int(rng.integers(1, 13))
+        rows = None
+        if rng.random() < 0.5:
+            cuts = np.sort(rng.integers(0, h + 1, size=world - 1)).tolist() if world > 1 else []
+            cuts = [0] + cuts + [h]
+            rows = list(zip(cuts[:-1], cuts[1:]))
+        got_s = ca.mask_to_instances_strips(torch.from_numpy(m).to(dev), world, hole_area=hole, min_size=mins, rows=rows).cpu().numpy()
+        if not np.array_equal(want, got_s):
+            np.save(os.path.join(ROOT, "gpurun_out") + "/fuzz_fail_mask.npy", m)
+            print("CCL STRIPS MISMATCH", h, w, hole, mins, world, rows)
+            raise AssertionError("gpu_fuzz mismatch (see the line above)")
+        counts["ccl_strips"] += 1
         # ---- interior map + metric pieces on the labelled result
         if want.max() > 0 and min(h, w) >= 6:
             inst = torch.from_numpy(want).to(dev)

@@ -5,7 +5,10 @@
 Per image: read -> per-channel percentile normalisation (host) -> H2D -> sliding-window U-Net inference, softmax,
 > 0.5, remove_small_holes, remove_small_objects, 8-connected labelling (all on the MI355X) -> D2H -> int32 zlib
 TIFF ``<stem>_label.tiff``.  Only ``--model_name unet`` is accelerated (unetr / swinunetr are out of scope and
-refused).  Under ``torchrun`` the images are dealt to the ranks (one process per GPU, no collective).
+refused).  Under ``torchrun`` the images are dealt to the ranks (one process per GPU, no collective); with ``--split_slides`` every
+image is instead spread over ALL ranks (whole-slide images: its sliding windows are split by the window list, window parts travel to
+the later neighbour, the mask rectangles are all-gathered, every rank labels its own rows - strip-local connected components with a
+seam merge - and rank 0 collects and writes the label map; the file is bit-identical to the single-GPU one).
 """
 from __future__ import annotations
 
@@ -45,6 +48,9 @@ def main(argv=None):
     parser.add_argument("--input_size", default=256, type=int, help="sliding-window size")
     parser.add_argument("--overlap", default=0.25, type=float, help="window overlap (MONAI default 0.25)")
     parser.add_argument("--random_init", action="store_true", help="no checkpoint: random weights (smoke runs)")
+    parser.add_argument("--split_slides", action="store_true",
+                        help="under torchrun: spread EVERY image over all ranks (RCCL seam exchange, mask all-gather, strip-local connected "
+                             "components) instead of dealing whole images to the ranks (engine option; the reference is single-device)")
     parser.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3", "bf16x6", "bf16x3", "bf16", "fp8"],
                         help="matrix-core arithmetic of the convolutions (engine option; fp16x3 / bf16x6 are fp32-grade)")
     args = parser.parse_args(argv)
@@ -61,11 +67,24 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("predict needs an MI355X: there is no CPU path")
+    local = int(os.environ.get("CELLSEG_DEVICE", local))          # (functional checks on a one-GPU box: all ranks on one device, gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    split = bool(args.split_slides) and world > 1
+    transport = "p2p"
+    if split:
+        import datetime
+        import torch.distributed as dist
+        backend = os.environ.get("CELLSEG_BACKEND", "nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get("CELLSEG_PG_TIMEOUT_S", "600"))), **kw)
+        transport = "p2p" if parallel.p2p_selfcheck(device) else "allgather"      # a library whose send/recv fails: one all-gather instead
 
     os.makedirs(args.output_path, exist_ok=True)
     img_names = preprocess.list_images(args.input_path)
+    if args.random_init:
+        torch.manual_seed(0)                                  # smoke runs are repeatable, and every rank of a split slide holds the same net
     model = ca.UNet(spatial_dims=2, in_channels=3, out_channels=args.num_class, channels=(16, 32, 64, 128, 256),
                     strides=(2, 2, 2, 2), num_res_units=2)
     if not args.random_init:
@@ -78,7 +97,8 @@ def main(argv=None):
     # file I/O either side of the GPU path overlaps with it: the next image is decoded by a reader thread while the current one is
     # on the GPU, label maps (and overlays) are written by a writer thread; the order of the printed lines stays the input order
     from concurrent.futures import ThreadPoolExecutor
-    todo = list(parallel.shard_items(len(img_names), rank, world))
+    todo = list(range(len(img_names))) if split else list(parallel.shard_items(len(img_names), rank, world))
+    say = print if (not split or rank == 0) else (lambda *a, **k: None)     # split slides: every rank sees every image, rank 0 reports
     reader, writer = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
     pending_writes = []
 
@@ -112,13 +132,13 @@ def main(argv=None):
             got = nxt.result()
             nxt = reader.submit(read, todo[pos + 1]) if pos + 1 < len(todo) else None
             if isinstance(got, Exception):
-                print(f"Prediction FAILED: {img_name}: {got}")
+                say(f"Prediction FAILED: {img_name}: {got}")
                 failed.append(img_name)
                 continue
             img_data, staged = got
             t0 = time.time()
             if img_data.ndim not in (2, 3) or (img_data.ndim == 3 and img_data.shape[-1] < 3):
-                print(f"Prediction FAILED: {img_name}: unsupported image shape {img_data.shape} ({img_data.dtype})")
+                say(f"Prediction FAILED: {img_name}: unsupported image shape {img_data.shape} ({img_data.dtype})")
                 failed.append(img_name)
                 continue
             if img_data.dtype in (np.uint8, np.uint16):
@@ -129,15 +149,29 @@ def main(argv=None):
                 pre_img_data = preprocess.prepare_image(img_data)
                 x = torch.from_numpy(preprocess.to_unit_float(pre_img_data)).to(device)      # [H,W,3]: NHWC, no copy needed
                 shape = pre_img_data.shape
-            _, _, mask = ca.swi_infer_image(model, x.permute(2, 0, 1), roi_size, args.overlap, want_logits=False, want_mask=True)
-            lab = ca.mask_to_instances(mask)
+            if split:
+                # one slide over all ranks: this rank's share of the window list, the seam exchange, its rectangles of the mask; ONE
+                # all-gather of the uint8 rectangles; its rows filtered and labelled here (two small all-gathers around the seam
+                # union-find); the int32 strips gathered on rank 0, which deflates and writes like the single-GPU path
+                image = x.permute(2, 0, 1)
+                plan = ca.make_plan(image.shape[1], image.shape[2], roi_size, args.overlap)
+                _, _, _, part = ca.swi_infer_share(model, image, roi_size, args.overlap, rank, world,
+                                                   exchange=lambda win, pl, r, w: parallel.exchange_share(win, pl, r, w, transport=transport))
+                mask = parallel.gather_shares(part, plan, world)
+                strip, _, _ = parallel.label_strips(mask)
+                lab = parallel.gather_label_strips(strip, mask.shape[0], dst=0)
+                if rank != 0:
+                    continue
+            else:
+                _, _, mask = ca.swi_infer_image(model, x.permute(2, 0, 1), roi_size, args.overlap, want_logits=False, want_mask=True)
+                lab = ca.mask_to_instances(mask)
             rps = min(64, lab.shape[0])
             buf, sizes = preprocess.deflate_labels_gpu(lab, rps)
             strips = (bytes(memoryview(buf.numpy())), sizes, tuple(lab.shape), rps)   # the staging buffer is reused by the next image
             labels = _to_host(lab).copy() if args.show_overlay else None             # the overlay is drawn on the host
             pending_writes.append((img_name, writer.submit(save, img_name, img_data, strips, labels)))
             t1 = time.time()
-            print(f"Prediction finished: {img_name}; img size = {shape}; costing: {t1 - t0:.2f}s")
+            say(f"Prediction finished: {img_name}; img size = {shape}; costing: {t1 - t0:.2f}s")
     for img_name, f in pending_writes:
         try:
             f.result()                                                    # surface writer errors, finish before exit
@@ -146,6 +180,10 @@ def main(argv=None):
             failed.append(img_name)
     reader.shutdown()
     writer.shutdown()
+    if split:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     if failed:
         raise SystemExit(f"{len(failed)} of {len(todo)} images failed: {', '.join(failed)}")
 

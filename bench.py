@@ -931,7 +931,7 @@ def main():
     def measure_train(width, with_prof=True, precision="fp32", batch=None, eager_too=True):
         torch.manual_seed(seed)                                   # identical replicas on every rank
         model = ca.UNet(channels=WIDTHS[width], strides=(2, 2, 2, 2), num_res_units=2).to(dev)
-        model.precision = precision                               # forward arithmetic; activations stay fp32 and the backward runs in fp32
+        model.precision = precision                               # matrix arithmetic of forward and backward (bf16: bf16 activations on the tape too)
         g = torch.Generator(device="cpu").manual_seed(seed + 1 + rank)      # every rank its own shard of the global batch
         b = batch or args.train_batch
         x = torch.rand(b, 3, 256, 256, generator=g).to(dev)
@@ -1001,8 +1001,8 @@ def main():
                "global_batch": world * b, "per_gpu_batch": b, "width": list(WIDTHS[width]),
                "dtype": {"fp32": "f32", "fp16x3": "f32-grade split fp16 (2 planes x 3 terms): forward convolutions and 3x3 weight gradients on "
                                                    "v_mfma_f32_16x16x32_f16, data gradients f32",
-                         "bf16": "bf16 forward convolutions, weight gradients and data gradients (v_mfma_f32_16x16x32_bf16; fp32 activations on the tape, fp32 "
-                                 "norm / loss / optimiser arithmetic and master weights)"
+                         "bf16": "bf16 forward convolutions, weight gradients and data gradients (v_mfma_f32_16x16x32_bf16; bf16 activations on the tape - the forward's "
+                                 "bf16 tensors are what the norm-backward and weight-gradient kernels read -, fp32 gradients, norm / loss / optimiser arithmetic and master weights)"
                          }.get(precision, f"{precision} forward convolutions (fp32 activations), f32 backward"),
                "loss": round(float(loss.item()), 5), "grad_bucket_bytes": int(model.flat_grad.numel() * 4),
                "allreduce_ms": allreduce_ms,

@@ -227,6 +227,7 @@ struct Tape {
     std::vector<float*> U, V, D;              // per decoder level: transposed-conv output, unit0 output, ResidualUnit output
     std::vector<NormRt> rt_upt, rt_upu;
     const float* logits = nullptr;
+    bool h16 = false;                         // the activation tensors above (all but the 3-channel top level's U) hold bf16 elements
 };
 
 }  // namespace cs
@@ -590,10 +591,12 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
                1 << nl);
     const bool inst = net->norm == CS_NORM_INSTANCE || net->batch_stats;   // statistics of the running batch are needed
     const bool want_xtab = net->norm == CS_NORM_BATCH && net->batch_stats;
-    // bf16 datapath (plain-bf16 mode, cs_unet_set_training(0)): every activation tensor between the first conv and the 3-channel
-    // top layers is bf16 in HBM - half the traffic of every HBM-bound kernel and of the conv inputs / outputs.  A handle in
-    // training mode keeps fp32 activations: the backward kernels read them.
-    const bool a16 = (net->planes == 1 || net->planes == 5) && !net->training;
+    // bf16 datapath (plain-bf16 mode): every activation tensor between the first conv and the 3-channel top layers is bf16 in HBM - half
+    // the traffic of every HBM-bound kernel and of the conv inputs / outputs.  Training in the bf16 mode (BASELINE configs[1]) records
+    // the same bf16 tensors on the tape (round 5: the norm-backward and weight-gradient kernels read bf16 activations; CS_TAPE16=0 keeps
+    // the fp32 tape of rounds 2-4); the fp16x3 / fp32 training modes keep fp32 activations.
+    static const bool tape16_env = !(getenv("CS_TAPE16") && atoi(getenv("CS_TAPE16")) == 0);
+    const bool a16 = (net->planes == 1 || net->planes == 5) && (!net->training || (net->planes == 1 && tape16_env));
     CS_REQUIRE(!(net->planes == 5 && net->training), "unet: the fp8 mode is an inference mode (cs_unet_set_training(0))");
     auto take_act = [&](size_t count) -> float* {
         return a16 ? reinterpret_cast<float*>(ws.take<unsigned short>(count)) : ws.take<float>(count);
@@ -889,6 +892,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
         tape->X = X;
         tape->rt_down = rt_down; tape->rt_bottom = rt_bottom; tape->rt_upt = rt_upt; tape->rt_upu = rt_upu;
         tape->logits = logits;
+        tape->h16 = a16;
     }
     return CS_OK;
 }
@@ -981,6 +985,12 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         return CS_OK;
     };
     auto rsrc = [&](const float* p, int c, int pitch) { return raw_src(p, c, pitch); };
+    // tensors of the tape: bf16 elements when the forward ran the bf16 datapath (Tape::h16), fp32 otherwise
+    const bool t16 = T.h16;
+    auto tsrc = [&](const float* p, int c, int pitch) { return raw_src(p, c, pitch, t16); };
+    auto tlazy = [&](const float* p, int c, int pitch, const NormRt& rt, const NormSite& ns, int tab_c, bool h16) {
+        return lazy_src(p, c, pitch, rt, ns, tab_c, h16);
+    };
     // max |t| of a gradient tensor that no norm backward produced (the residual-branch gradients), on the weight-gradient stream
     auto amax_of = [&](hipStream_t st, const float* t, size_t numel, float** out) -> int {
         *out = bwd16 == 0 ? acc.take<float>(AMAX_SLOTS) : nullptr;
@@ -999,11 +1009,13 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         return g;
     };
     // one 3x3 weight-gradient launch on whichever pipe `g` was sized for; a_amax / b_amax: the dynamic-scale slots of gradient operands
+    // a_h16: the A operand is an ACTIVATION tensor of the bf16 tape (transposed convs: the activations are the A operand)
     auto wgrad3 = [&](hipStream_t st, const WG& g, int stride, const float* a, int a_c, const float* a_amax, const ConvSrc& b, const float* b_amax,
-                      int co_total, int ci_total, int co_off, int ho, int wo, int hi, int wi) -> int {
+                      int co_total, int ci_total, int co_off, int ho, int wo, int hi, int wi, bool a_h16 = false) -> int {
         if (g.h16)
-            return launch_wgrad16(st, bwd16, stride, a, a_c, a_c, a_amax, b, b_amax, g.part, g.k, co_total, ci_total, co_off, 0, n, ho, wo, hi, wi);
-        return launch_wgrad(st, 3, stride, a, a_c, a_c, b, nullptr, g.part, g.k, co_total, ci_total, co_off, 0, n, ho, wo, hi, wi);
+            return launch_wgrad16(st, bwd16, stride, a, a_c, a_c, a_amax, b, b_amax, g.part, g.k, co_total, ci_total, co_off, 0, n, ho, wo, hi, wi,
+                                  a_h16);
+        return launch_wgrad(st, 3, stride, a, a_c, a_c, b, nullptr, g.part, g.k, co_total, ci_total, co_off, 0, n, ho, wo, hi, wi, a_h16);
     };
     auto unpack3 = [&](hipStream_t st, const WG& g, int rows_total, int cols_total, int row_off, int rows, int cols, float* dst, const float* a_amax,
                        const float* b_amax) -> int {
@@ -1021,7 +1033,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         const int c = u.cout, cs = u.cin_skip, cb = u.cin_sub, cin_t = cs + cb;
         const int oh = h >> d, ow = w >> d, ph = oh / 2, pw = ow / 2;
         const float* Ssub = (d == nl - 1) ? T.Sb : T.D[d + 1];
-        const ConvSrc lu = lazy_src(T.U[d], c, c, T.rt_upt[d], u.norm_t, c);
+        const ConvSrc lu = tlazy(T.U[d], c, c, T.rt_upt[d], u.norm_t, c, t16 && !u.top);      // (the 3-channel top tensor is fp32 in every mode)
         float* d_au = buf.take<float>((size_t)n * oh * ow * c);
         float* dU = buf.take<float>((size_t)n * oh * ow * c);
         dX[d] = buf.take<float>((size_t)n * ph * pw * cs);
@@ -1042,7 +1054,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const WG gu = wg_alloc(c, 0, c, 9, c, c, oh, ow, 3, 1);
             if (!buf.ok()) return oom();
             float* ax_dV = nullptr;
-            CS_TRY(norm_bwd(u.norm_u, T.rt_upu[d], lazy_src(T.V[d], c, c, T.rt_upu[d], u.norm_u, c), dS, c, dV, c, (int64_t)oh * ow, &ax_dV));
+            CS_TRY(norm_bwd(u.norm_u, T.rt_upu[d], tlazy(T.V[d], c, c, T.rt_upu[d], u.norm_u, c, t16), dS, c, dV, c, (int64_t)oh * ow, &ax_dV));
             CS_TRY(bias_grad(dV, c, c, (int64_t)n * oh * ow, u.unit0.p_b[0], true));
             if (!dry) {
                 CS_TRY(wg_begin());
@@ -1063,8 +1075,8 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 WgradNarrow nb;
                 nb.ptr = dU; nb.c = c; nb.sn = (int64_t)oh * ow * c; nb.sc = 1; nb.sh = (int64_t)ow * c; nb.sw = c;
                 CS_TRY(wg_begin());
-                CS_TRY(launch_wgrad(sw, 3, 2, T.X[d], cs, cs, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, 0, 0, n, ph, pw, oh, ow));
-                CS_TRY(launch_wgrad(sw, 3, 2, Ssub, cb, cb, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, cs, 0, n, ph, pw, oh, ow));
+                CS_TRY(launch_wgrad(sw, 3, 2, T.X[d], cs, cs, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, 0, 0, n, ph, pw, oh, ow, t16));
+                CS_TRY(launch_wgrad(sw, 3, 2, Ssub, cb, cb, ConvSrc(), &nb, gt.part, gt.k, cin_t, c, cs, 0, n, ph, pw, oh, ow, t16));
             } else {
                 ConvOutExtra ex;
                 ex.out2 = dSn; ex.pitch_out2 = cb; ex.split = cs;
@@ -1075,8 +1087,8 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                     CS_TRY(launch_conv_mfma(s, 3, 2, rsrc(dU, c, c), ConvSrc(), u.convt.wd, nullptr, dX[d], cs, cin_t, nullptr, n, oh, ow, &ex));
                 CS_TRY(wg_begin());
                 // (transposed conv: the ACTIVATIONS are the A operand, the gradient dU the shifted B operand)
-                CS_TRY(wgrad3(sw, gt, 2, T.X[d], cs, nullptr, rsrc(dU, c, c), ax_dU, cin_t, c, 0, ph, pw, oh, ow));
-                CS_TRY(wgrad3(sw, gt, 2, Ssub, cb, nullptr, rsrc(dU, c, c), ax_dU, cin_t, c, cs, ph, pw, oh, ow));
+                CS_TRY(wgrad3(sw, gt, 2, T.X[d], cs, nullptr, rsrc(dU, c, c), ax_dU, cin_t, c, 0, ph, pw, oh, ow, t16));
+                CS_TRY(wgrad3(sw, gt, 2, Ssub, cb, nullptr, rsrc(dU, c, c), ax_dU, cin_t, c, cs, ph, pw, oh, ow, t16));
             }
             CS_TRY(unpack3(sw, gt, cin_t, c, 0, cin_t, c, gptr(u.convt.p_w[0]), nullptr, u.top ? nullptr : ax_dU));
         }
@@ -1095,7 +1107,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             CS_TRY(bias_grad(dS, c, c, n * npix, u.res1x1.p_b[0]));
             if (!dry) {
                 CS_TRY(wg_begin());
-                CS_TRY(launch_wgrad(sw, 1, 1, dS, c, c, rsrc(Xin, cin, cin), nullptr, gr.part, gr.k, c, cin, 0, 0, n, ph, pw, ph, pw));
+                CS_TRY(launch_wgrad(sw, 1, 1, dS, c, c, tsrc(Xin, cin, cin), nullptr, gr.part, gr.k, c, cin, 0, 0, n, ph, pw, ph, pw));
                 CS_TRY(launch_unpack_wgrad(sw, gr.part, gr.k, c, cin, 0, 0, c, cin, 1, gptr(u.res1x1.p_w[0])));
             }
         }
@@ -1107,11 +1119,11 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             float* da_new = su > 0 ? buf.take<float>((size_t)n * npix * c) : nullptr;
             if (!buf.ok()) return oom();
             float* ax_dY = nullptr;
-            CS_TRY(norm_bwd(u.norms[su], T.rt_bottom[su], lazy_src(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c), da, c, dY, c, npix, &ax_dY));
+            CS_TRY(norm_bwd(u.norms[su], T.rt_bottom[su], tlazy(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c, t16), da, c, dY, c, npix, &ax_dY));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (dry) { da = da_new; continue; }
             if (su > 0) {
-                const ConvSrc prev = lazy_src(T.Yb[su - 1], c, c, T.rt_bottom[su - 1], u.norms[su - 1], c);
+                const ConvSrc prev = tlazy(T.Yb[su - 1], c, c, T.rt_bottom[su - 1], u.norms[su - 1], c, t16);
                 CS_TRY(wg_begin());
                 CS_TRY(wgrad3(sw, ga, 1, dY, c, ax_dY, prev, nullptr, c, c, 0, ph, pw, ph, pw));
                 CS_TRY(unpack3(sw, ga, c, c, 0, c, c, gptr(cw.p_w[0]), ax_dY, nullptr));
@@ -1119,7 +1131,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
                 da = da_new;
             } else {
                 CS_TRY(wg_begin());
-                CS_TRY(wgrad3(sw, ga, 1, dY, c, ax_dY, rsrc(Xin, cin, cin), nullptr, c, cin, 0, ph, pw, ph, pw));
+                CS_TRY(wgrad3(sw, ga, 1, dY, c, ax_dY, tsrc(Xin, cin, cin), nullptr, c, cin, 0, ph, pw, ph, pw));
                 CS_TRY(unpack3(sw, ga, c, cin, 0, c, cin, gptr(cw.p_w[0]), ax_dY, nullptr));
                 ConvOutExtra ex;
                 ex.addend = dXin; ex.pitch_add = cin;
@@ -1153,11 +1165,11 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const WG ga = wg_alloc(c, 0, c, 9, c, c, oh, ow, 3, 1);
             if (!buf.ok()) return oom();
             float* ax_dY = nullptr;
-            CS_TRY(norm_bwd(u.norms[su], T.rt_down[d][su], lazy_src(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c), da, c, dY, c, npix, &ax_dY));
+            CS_TRY(norm_bwd(u.norms[su], T.rt_down[d][su], tlazy(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c, t16), da, c, dY, c, npix, &ax_dY));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (!dry) {
-                const ConvSrc prev = su - 1 == 0 ? lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0)
-                                                 : lazy_src(T.Y[d][su - 1], c, c, T.rt_down[d][su - 1], u.norms[su - 1], c);
+                const ConvSrc prev = su - 1 == 0 ? tlazy(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0, t16)
+                                                 : tlazy(T.Y[d][su - 1], c, c, T.rt_down[d][su - 1], u.norms[su - 1], c, t16);
                 CS_TRY(wg_begin());
                 CS_TRY(wgrad3(sw, ga, 1, dY, c, ax_dY, prev, nullptr, c, c, 0, oh, ow, oh, ow));
                 CS_TRY(unpack3(sw, ga, c, c, 0, c, c, gptr(cw.p_w[0]), ax_dY, nullptr));
@@ -1169,7 +1181,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         const WG gf = wg_alloc(c, 0, cin, 9, c0, cin, oh, ow);
         if (!buf.ok()) return oom();
         float *ax_dY0 = nullptr, *ax_dXd = nullptr;
-        CS_TRY(norm_bwd(u.norms[0], T.rt_down[d][0], lazy_src(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0), da, c, dY0, c, npix,
+        CS_TRY(norm_bwd(u.norms[0], T.rt_down[d][0], tlazy(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0, t16), da, c, dY0, c, npix,
                         u.first ? nullptr : &ax_dY0));
         CS_TRY(bias_grad(dY0, c, c, n * npix, u.unit0.p_b[0], true));
         if (!u.first && gf.h16) {                                  // the residual conv's gradient is the raw dX[d]: no norm backward measured it
@@ -1178,7 +1190,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         }
         if (dry) continue;
         if (!u.first) {
-            const ConvSrc xin = rsrc(T.X[d - 1], cin, cin);
+            const ConvSrc xin = tsrc(T.X[d - 1], cin, cin);
             if (!gf.h16) CS_TRY(wg_begin());
             CS_TRY(wgrad3(sw, gf, 2, dY0, c, ax_dY0, xin, nullptr, c0, cin, 0, oh, ow, ph, pw));
             CS_TRY(wgrad3(sw, gf, 2, dXd, c, ax_dXd, xin, nullptr, c0, cin, c, oh, ow, ph, pw));

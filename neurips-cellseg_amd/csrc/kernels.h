@@ -226,8 +226,10 @@ struct WgradNarrow {          // "x-like" operand with <= 4 channels addressed b
 // every element of the launch's [co_off, co_off+a_c) x [ci_off, ..) block is written, nothing needs zeroing).
 // split_k from wgrad_split_k(); launches that share one partial buffer (fused / concatenated operands) must use the same value.
 int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo, int ksize = 3, int stride = 2);   // (ksize, stride) of the launch that will use it
+// a_h16 / b.h16: the operand is an activation tensor of the bf16 tape (bf16 elements; the bf16 training mode)
 int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pitch, int a_c, const ConvSrc& b, const WgradNarrow* nb,
-                 float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi);
+                 float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi,
+                 bool a_h16 = false);
 // sums the split_k partials and converts to the PyTorch layout dst[row][col][tap]
 // unscale (may be null): the partials come from launch_wgrad16 in fp16x3 mode and carry the operands' power-of-two scales
 struct WgradUnscale {
@@ -275,7 +277,7 @@ int wgrad16_split_k(int a_c, int b_c, int n, int ho, int wo);
 // device scalars max|operand| for gradient operands (dynamic scale, mode 0), null for activations.  Partial layout as launch_wgrad.
 int launch_wgrad16(hipStream_t s, int mode, int stride, const float* a, int a_pitch, int a_c, const float* a_amax, const ConvSrc& b,
                    const float* b_amax, float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo,
-                   int hi, int wi);
+                   int hi, int wi, bool a_h16 = false);
 int launch_amax(hipStream_t s, const float* src, int64_t numel, float* out);   // out[AMAX_SLOTS]: partial maxima of |src|; zero before the first use
 constexpr int NORM_BWD_FUSED_MAX_PIX = 1024;   // InstanceNorm backward of images with at most this many pixels: one launch (norm_bwd_fused_kernel)
 constexpr int NORM_DSLOPE_SLOTS = 64;          // partial accumulators of one PReLU slope gradient (launch_norm_bwd's `dslope`)

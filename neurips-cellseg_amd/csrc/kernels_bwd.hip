@@ -21,6 +21,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma4b(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float prelu_b(float v, float slope) { return v >= 0.f ? v : v * slope; }
+// four consecutive channels of an activation tensor at ELEMENT offset `off`: fp32, or - the bf16 tape of the bf16 training mode (the
+// forward kept its activations as bf16 in HBM) - four bf16 values widened to fp32.  Compile-time: a branch inside the load groups of
+// these kernels would split the groups (all loads of a trip are issued before the first use).
+template <bool H16>
+__device__ __forceinline__ f32x4 ld_act4(const float* base, size_t off) {
+    if constexpr (H16) return bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off));
+    else return *reinterpret_cast<const f32x4*>(base + off);
+}
 
 // ------------------------------------------------------------------------------------------------
 // InstanceNorm + PReLU backward
@@ -29,7 +37,7 @@ __device__ __forceinline__ float prelu_b(float v, float slope) { return v >= 0.f
 // ------------------------------------------------------------------------------------------------
 struct NormBwdParams {
     const float* da;   int da_pitch;
-    const float* y;    int y_pitch;
+    const float* y;    int y_pitch;   int y16;   // y16: y holds bf16 elements (pitch still counts elements)
     const float2* tab; int tab_c, tab_off;
     const float* slope;
     double* red;       // [n][c][2]
@@ -44,6 +52,7 @@ struct NormBwdParams {
 };
 
 // wide: c % 4 == 0 and 256 % (c/4) == 0
+template <bool Y16>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
     __shared__ float sh[256 * 9];
     const int c4n = p.c >> 2, lanes = 256 / c4n;
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
             const int64_t pu = px + u * lanes < pix1 ? px + u * lanes : px;       // clamped: the tail re-reads a valid pixel
             const int64_t g = (int64_t)img * p.npix + pu;
             da[u] = *reinterpret_cast<const f32x4*>(p.da + g * p.da_pitch + 4 * quad);
-            y[u] = *reinterpret_cast<const f32x4*>(p.y + g * p.y_pitch + 4 * quad);
+            y[u] = ld_act4<Y16>(p.y, (size_t)(g * p.y_pitch + 4 * quad));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -126,6 +135,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
 // apply pass: dy = sc * (dz - mean(dz) - x_hat * mean(dz * x_hat)).  Same thread layout as the reduce pass (a thread keeps its
 // channel quad for all its pixels, blockIdx.y = image), so the tables and the two means are loaded and converted ONCE per
 // thread; the round-1 version was a flat grid-stride loop that paid two 64-bit divisions and eight fp64 loads per element quad.
+template <bool Y16>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p) {
     const int c4n = p.c >> 2, lanes = 256 / c4n;
     const int quad = threadIdx.x % c4n, pl = threadIdx.x / c4n;
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p) {
             const int64_t pu = px + u * lanes < pix1 ? px + u * lanes : px;
             const int64_t g = (int64_t)img * p.npix + pu;
             da[u] = *reinterpret_cast<const f32x4*>(p.da + g * p.da_pitch + 4 * quad);
-            y[u] = *reinterpret_cast<const f32x4*>(p.y + g * p.y_pitch + 4 * quad);
+            y[u] = ld_act4<Y16>(p.y, (size_t)(g * p.y_pitch + 4 * quad));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p) {
 // QB channel quads), so the sums of the reduce pass need no atomics and no second launch - pass 1 sums over the image's pixels, the
 // waves meet through LDS, pass 2 re-reads the same (L2-resident) elements and writes dy.  The two-kernel form spends ~19 us per norm
 // site on such tensors (launch + atomics + a dependent launch); 10 of the 16 sites of the reference-width batch-8 step qualify.
-template <int QB>
+template <int QB, bool Y16>
 __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(NormBwdParams p) {
     constexpr int LANES = 256 / QB;                      // pixel lanes per quad
     __shared__ double sh[4][QB][9];
@@ -195,11 +205,11 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(NormBwdParams p) {
     const float sc[4] = {t0.x, t0.z, t1.x, t1.z}, sf[4] = {t0.y, t0.w, t1.y, t1.w};
     const float slope = p.slope ? *p.slope : 0.f;
     const float* const da0 = p.da + (size_t)img * p.npix * p.da_pitch + 4 * quad;
-    const float* const y0 = p.y + (size_t)img * p.npix * p.y_pitch + 4 * quad;
+    const size_t y0 = (size_t)img * p.npix * p.y_pitch + 4 * quad;      // element offset (fp32 or bf16 elements)
     float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // s1[4], s2[4], ds
     for (int px = pl; px < p.npix; px += LANES) {
         const f32x4 da = *reinterpret_cast<const f32x4*>(da0 + (size_t)px * p.da_pitch);
-        const f32x4 y = *reinterpret_cast<const f32x4*>(y0 + (size_t)px * p.y_pitch);
+        const f32x4 y = ld_act4<Y16>(p.y, y0 + (size_t)px * p.y_pitch);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float z = y[j] * sc[j] + sf[j];
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(NormBwdParams p) {
     float* const dy0 = p.dy + (size_t)img * p.npix * p.dy_pitch + 4 * quad;
     for (int px = pl; px < p.npix; px += LANES) {
         const f32x4 da = *reinterpret_cast<const f32x4*>(da0 + (size_t)px * p.da_pitch);
-        const f32x4 y = *reinterpret_cast<const f32x4*>(y0 + (size_t)px * p.y_pitch);
+        const f32x4 y = ld_act4<Y16>(p.y, y0 + (size_t)px * p.y_pitch);
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -340,17 +350,19 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
     CS_REQUIRE(y.tab != nullptr, "norm_bwd: the forward table is required");
     CS_REQUIRE(!batch || xtab, "norm_bwd: BatchNorm needs the forward's x_hat table");
     NormBwdParams p{};
-    p.da = da; p.da_pitch = da_pitch; p.y = y.ptr; p.y_pitch = y.pitch;
+    CS_REQUIRE(!y.q8 && !y.ptr2, "norm_bwd: fp32 or bf16 activations only");
+    p.da = da; p.da_pitch = da_pitch; p.y = y.ptr; p.y_pitch = y.pitch; p.y16 = y.h16 ? 1 : 0;
     p.tab = y.tab; p.tab_c = y.tab_c ? y.tab_c : y.c; p.tab_off = y.tab_off; p.slope = y.slope;
     p.red = red; p.dslope = y.slope ? dslope : nullptr; p.dy = dy; p.dy_pitch = dy_pitch; p.c = y.c; p.npix = (int)npix;
     p.xtab = xtab;
     p.amax = reinterpret_cast<unsigned*>(amax);
     p.inv_m = 1.0 / ((double)npix * (batch ? (double)n : 1.0));
-    ProfScope prof(K_NORM_BWD, s, 0, 4.0 * n * npix * y.c * 5);
+    ProfScope prof(K_NORM_BWD, s, 0, (y.h16 ? 16.0 : 20.0) * n * npix * y.c);
     auto bn_finalize = [&]() {
         if (batch) hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(y.c, 64)), dim3(64), 0, s, red, n, y.c, dgamma, dbeta);
     };
     if (y.c == 3) {
+        CS_REQUIRE(!y.h16, "norm_bwd: the 3-channel tensors are fp32 in every mode");
         dim3 grid((unsigned)(ceil_div((int)npix, 256) < 64 ? ceil_div((int)npix, 256) : 64), (unsigned)n);
         hipLaunchKernelGGL((norm_bwd_reduce_small_kernel<3>), grid, dim3(256), 0, s, p);
         bn_finalize();
@@ -367,9 +379,15 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
             // widest channel group that still gives the launch >= 128 blocks
             const int qb = (c4n % 4 == 0 && (c4n / 4) * n >= 128) ? 4 : (c4n % 2 == 0 && (c4n / 2) * n >= 128) ? 2 : 1;
             const dim3 grid((unsigned)(c4n / qb), (unsigned)n);
-            if (qb == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<4>), grid, dim3(256), 0, s, p);
-            else if (qb == 2) hipLaunchKernelGGL((norm_bwd_fused_kernel<2>), grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((norm_bwd_fused_kernel<1>), grid, dim3(256), 0, s, p);
+            if (y.h16) {
+                if (qb == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<4, true>), grid, dim3(256), 0, s, p);
+                else if (qb == 2) hipLaunchKernelGGL((norm_bwd_fused_kernel<2, true>), grid, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((norm_bwd_fused_kernel<1, true>), grid, dim3(256), 0, s, p);
+            } else {
+                if (qb == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<4, false>), grid, dim3(256), 0, s, p);
+                else if (qb == 2) hipLaunchKernelGGL((norm_bwd_fused_kernel<2, false>), grid, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((norm_bwd_fused_kernel<1, false>), grid, dim3(256), 0, s, p);
+            }
             CS_HIP(hipGetLastError());
             return CS_OK;
         }
@@ -383,11 +401,14 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
         };
         p.pix_per_block = chunk(2048, 64);
         dim3 grid((unsigned)ceil_div((int)npix, p.pix_per_block), (unsigned)n);
-        hipLaunchKernelGGL(norm_bwd_reduce_kernel, grid, dim3(256), 0, s, p);
+        if (y.h16) hipLaunchKernelGGL(norm_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(norm_bwd_reduce_kernel<false>, grid, dim3(256), 0, s, p);
         bn_finalize();
         NormBwdParams pa = p;                                // finer pixel chunks: the apply pass has no per-block reduction to amortise
         pa.pix_per_block = chunk(4096, 16);
-        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)ceil_div((int)npix, pa.pix_per_block), (unsigned)n), dim3(256), 0, s, pa);
+        const dim3 ga((unsigned)ceil_div((int)npix, pa.pix_per_block), (unsigned)n);
+        if (y.h16) hipLaunchKernelGGL(norm_bwd_apply_kernel<true>, ga, dim3(256), 0, s, pa);
+        else hipLaunchKernelGGL(norm_bwd_apply_kernel<false>, ga, dim3(256), 0, s, pa);
     }
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -466,6 +487,7 @@ int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npi
 struct WgradParams {
     const float* a;
     int a_pitch;
+    int a16, b16;                // the operand holds bf16 elements (an activation tensor of the bf16 tape; pitches count elements)
     // B, mode 0: NHWC 16-channel chunks
     const float* b_ptr;
     const float2* b_tab;
@@ -485,7 +507,7 @@ struct WgradParams {
 // [taps][16*MT][16] slab; the unpack kernel sums the split_k partials while it converts to the PyTorch layout.  (A first
 // version committed every block with global float atomics: hundreds of blocks adding to the same few KB serialised at
 // the memory side and every launch took 110-260 us whatever its size.)
-template <int S, int KS, int MT, bool NARROW, int TH = 4>
+template <int S, int KS, int MT, bool NARROW, int TH = 4, bool B16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradParams p) {
     constexpr int TW = 16;
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
@@ -559,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradParams p) {
             const bool ok = pix < IH * IW && gy >= 0 && gy < p.hi && gx >= 0 && gx < p.wi;
             if (!NARROW) {
                 const size_t off = ok ? (((size_t)img * p.hi + gy) * p.wi + gx) * p.b_pitch + cb0 + 4 * q : 0;
-                rb[it] = *reinterpret_cast<const f32x4*>(p.b_ptr + off);
+                rb[it] = ld_act4<B16>(p.b_ptr, off);
                 ok_b |= (ok ? 1u : 0u) << it;
             } else {
                 const bool use = q == 0 && ok;
@@ -664,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradParams p) {
 // item per lane and pass, so that every lane carries a load (the general kernel's narrow mode used one lane in four).
 // Same split-K partial layout as wgrad_mfma_kernel: [split_k][tap][co_total][ci_total].
 // ------------------------------------------------------------------------------------------------
-template <int MT>
+template <int MT, bool A16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_narrow_kernel(WgradParams p) {
     constexpr int TH = 8, TW = 16, S = 2;
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
@@ -718,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_narrow_kernel(WgradParams p) {
             const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
             const bool ok = oy < p.ho && ox < p.wo;
             const size_t off = ok ? (((size_t)img * p.ho + oy) * p.wo + ox) * p.a_pitch + co0 + 4 * c4 : 0;
-            ra[it] = *reinterpret_cast<const f32x4*>(p.a + off);
+            ra[it] = ld_act4<A16>(p.a, off);
             ok_a |= (ok ? 1u : 0u) << it;
         }
 #pragma unroll
@@ -817,11 +839,13 @@ int wgrad_split_k(int a_c, int b_c, int n, int ho, int wo, int ksize, int stride
 }
 
 int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pitch, int a_c, const ConvSrc& b, const WgradNarrow* nb,
-                 float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi) {
+                 float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo, int hi, int wi, bool a_h16) {
     CS_REQUIRE(a_c % 16 == 0 && a_c > 0, "wgrad: %d dy channels (must be a multiple of 16)", a_c);
     CS_REQUIRE((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1), "wgrad: k%d s%d unsupported", ksize, stride);
     WgradParams p{};
-    p.a = a; p.a_pitch = a_pitch;
+    p.a = a; p.a_pitch = a_pitch; p.a16 = a_h16 ? 1 : 0;
+    p.b16 = (!nb && b.h16) ? 1 : 0;
+    CS_REQUIRE(nb || (!b.q8 && !b.ptr2), "wgrad: fp32 or bf16 activations only");
     int b_chunks;
     if (nb) {
         CS_REQUIRE(nb->c >= 1 && nb->c <= 4, "wgrad: narrow source with %d channels", nb->c);
@@ -852,16 +876,34 @@ int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pit
         case 2: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 2, NB_>), grid, dim3(256), 0, s, p); break;   \
         default: hipLaunchKernelGGL((wgrad_mfma_kernel<S_, KS_, 1, NB_>), grid, dim3(256), 0, s, p); break;  \
     }
+    // operands off the bf16 tape: the top transposed conv's activations (narrow kernel, A) and the 1x1 residual conv's input (B); the
+    // 3x3 layers of the bf16 mode run on kernels_bwd16.hip
+    CS_REQUIRE(!(a_h16 && !(nb && wgrad_narrow_cols(ksize, stride, nb->c))) && !(p.b16 && ksize != 1),
+               "wgrad(fp32 kernels): bf16 activations only as the A operand of the narrow kernel / the B operand of a 1x1 layer");
     if (nb) {
         CS_REQUIRE(ksize == 3 && stride == 2, "wgrad: the narrow operand is only used by stride-2 3x3 layers");
         if (wgrad_narrow_cols(ksize, stride, nb->c)) {
-            switch (mt) {
-                case 4: hipLaunchKernelGGL((wgrad_narrow_kernel<4>), grid, dim3(256), 0, s, p); break;
-                case 2: hipLaunchKernelGGL((wgrad_narrow_kernel<2>), grid, dim3(256), 0, s, p); break;
-                default: hipLaunchKernelGGL((wgrad_narrow_kernel<1>), grid, dim3(256), 0, s, p); break;
+            if (a_h16) {
+                switch (mt) {
+                    case 4: hipLaunchKernelGGL((wgrad_narrow_kernel<4, true>), grid, dim3(256), 0, s, p); break;
+                    case 2: hipLaunchKernelGGL((wgrad_narrow_kernel<2, true>), grid, dim3(256), 0, s, p); break;
+                    default: hipLaunchKernelGGL((wgrad_narrow_kernel<1, true>), grid, dim3(256), 0, s, p); break;
+                }
+            } else {
+                switch (mt) {
+                    case 4: hipLaunchKernelGGL((wgrad_narrow_kernel<4>), grid, dim3(256), 0, s, p); break;
+                    case 2: hipLaunchKernelGGL((wgrad_narrow_kernel<2>), grid, dim3(256), 0, s, p); break;
+                    default: hipLaunchKernelGGL((wgrad_narrow_kernel<1>), grid, dim3(256), 0, s, p); break;
+                }
             }
         } else {
             CS_WG(2, 3, true)
+        }
+    } else if (ksize == 1 && p.b16) {
+        switch (mt) {
+            case 4: hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 4, false, 4, true>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 2, false, 4, true>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 1, false, 4, true>), grid, dim3(256), 0, s, p); break;
         }
     } else if (ksize == 1) { CS_WG(1, 1, false) } else if (stride == 1 && th == 8) {
         hipLaunchKernelGGL((wgrad_mfma_kernel<1, 3, 4, false, 8>), grid, dim3(256), 0, s, p);

@@ -38,6 +38,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct Wgrad16Params {
     const float* a;
     int a_pitch;
+    int a16, b16;                 // the operand holds bf16 elements (an activation tensor of the bf16 tape; pitches count elements)
     const float* a_amax;          // device scalar max|a| -> dynamic scale, or null: static scale (F16_ACT_SCALE)
     const float* b_ptr;
     const float2* b_tab;
@@ -73,7 +74,9 @@ __device__ __forceinline__ unsigned pack2(float& v0, float& v1) {
 
 __device__ __forceinline__ float prelu_f(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
-template <int S, int MT, int MODE>
+// A16 / B16: that operand is an ACTIVATION tensor of the bf16 tape (bf16 elements in HBM; plain-bf16 mode only, and never both: the
+// other operand is the fp32 gradient).  Compile-time, so that the load groups stay straight-line code.
+template <int S, int MT, int MODE, bool A16 = false, bool B16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
     constexpr int WM = MT >= 2 ? 2 : 1, WK = 4 / WM, MTW = MT / WM, KSW = 4 / WK;   // waves along co / along K, co tiles and K-steps per wave
     constexpr int NP = MODE == 0 ? 2 : 1;
@@ -133,7 +136,16 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
                 const bool ok = oy < p.ho && oxb + j < p.wo;
                 const size_t off = ok ? (((size_t)img * p.ho + oy) * p.wo + oxb + j) * p.a_pitch + co0 + 16 * (wm * MTW) + m16 : (size_t)m16;
 #pragma unroll
-                for (int t = 0; t < MTW; ++t) araw[kq][t][j] = p.a[off + 16 * t];
+                for (int t = 0; t < MTW; ++t) {
+                    if constexpr (A16) {
+                        // bf16 elements: the dword that holds channels (m16 & ~1, m16 | 1) - the 16 lanes of a pixel read one 32-byte run as
+                        // eight dwords, two lanes each - and this lane's half of it
+                        const unsigned wd = reinterpret_cast<const unsigned*>(p.a)[(off + 16 * t) >> 1];
+                        araw[kq][t][j] = __builtin_bit_cast(float, (m16 & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                    } else {
+                        araw[kq][t][j] = p.a[off + 16 * t];
+                    }
+                }
                 ok_a |= (ok ? 1u : 0u) << (kq * 8 + j);
             }
         }
@@ -144,7 +156,8 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
             const int gy = oy0 * S - 1 + iy, gx = ox0 * S - 1 + ix;
             const bool ok = pix < IH * IW && gy >= 0 && gy < p.hi && gx >= 0 && gx < p.wi;
             const size_t off = ok ? (((size_t)img * p.hi + gy) * p.wi + gx) * p.b_pitch + cb0 + 4 * q : 0;
-            rb[it] = *reinterpret_cast<const f32x4*>(p.b_ptr + off);
+            if constexpr (B16) rb[it] = bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.b_ptr) + off));
+            else rb[it] = *reinterpret_cast<const f32x4*>(p.b_ptr + off);
             ok_b |= (ok ? 1u : 0u) << it;
         }
     };
@@ -293,13 +306,14 @@ int wgrad16_split_k(int a_c, int b_c, int n, int ho, int wo) {
 
 int launch_wgrad16(hipStream_t s, int mode, int stride, const float* a, int a_pitch, int a_c, const float* a_amax, const ConvSrc& b,
                    const float* b_amax, float* part, int split_k, int co_total, int ci_total, int co_off, int ci_off, int n, int ho, int wo,
-                   int hi, int wi) {
+                   int hi, int wi, bool a_h16) {
     CS_REQUIRE(a_c % 16 == 0 && a_c > 0 && b.c % 16 == 0 && b.c > 0, "wgrad16: %d x %d channels (multiples of 16)", a_c, b.c);
     CS_REQUIRE(stride == 1 || stride == 2, "wgrad16: stride %d", stride);
     CS_REQUIRE(mode == 0 || mode == 1, "wgrad16: mode %d", mode);
-    CS_REQUIRE(!b.ptr2 && !b.h16 && !b.q8, "wgrad16: plain fp32 sources only");
+    CS_REQUIRE(!b.ptr2 && !b.q8, "wgrad16: fp32 or bf16 sources only");
+    CS_REQUIRE(mode == 1 || (!b.h16 && !a_h16), "wgrad16: the bf16 tape belongs to the plain-bf16 mode");
     Wgrad16Params p{};
-    p.a = a; p.a_pitch = a_pitch; p.a_amax = a_amax;
+    p.a = a; p.a_pitch = a_pitch; p.a_amax = a_amax; p.a16 = a_h16 ? 1 : 0; p.b16 = b.h16 ? 1 : 0;
     p.b_ptr = b.ptr; p.b_tab = b.tab; p.b_slope = b.slope; p.b_pitch = b.pitch; p.b_tab_c = b.tab_c ? b.tab_c : b.c; p.b_tab_off = b.tab_off;
     p.b_amax = b_amax;
     p.dummy = a;
@@ -314,16 +328,22 @@ int launch_wgrad16(hipStream_t s, int mode, int stride, const float* a, int a_pi
     dim3 grid((unsigned)split_k, (unsigned)(a_c / (16 * mt)), (unsigned)(b.c / 16));
     const double flops = 2.0 * n * ho * wo * (double)a_c * b.c * 9;
     ProfScope prof(K_WGRAD, s, flops, 4.0 * n * ((double)ho * wo * a_c + (double)hi * wi * b.c));
-#define CS_WG16(S_, MODE_)                                                                                      \
-    switch (mt) {                                                                                              \
-        case 4: hipLaunchKernelGGL((wgrad16_kernel<S_, 4, MODE_>), grid, dim3(256), 0, s, p); break;           \
-        case 2: hipLaunchKernelGGL((wgrad16_kernel<S_, 2, MODE_>), grid, dim3(256), 0, s, p); break;           \
-        default: hipLaunchKernelGGL((wgrad16_kernel<S_, 1, MODE_>), grid, dim3(256), 0, s, p); break;          \
+#define CS_WG16(S_, MODE_, A_, B_)                                                                                      \
+    switch (mt) {                                                                                                      \
+        case 4: hipLaunchKernelGGL((wgrad16_kernel<S_, 4, MODE_, A_, B_>), grid, dim3(256), 0, s, p); break;           \
+        case 2: hipLaunchKernelGGL((wgrad16_kernel<S_, 2, MODE_, A_, B_>), grid, dim3(256), 0, s, p); break;           \
+        default: hipLaunchKernelGGL((wgrad16_kernel<S_, 1, MODE_, A_, B_>), grid, dim3(256), 0, s, p); break;          \
     }
+    CS_REQUIRE(!(a_h16 && b.h16), "wgrad16: one operand is the gradient (fp32), at most one comes off the bf16 tape");
+    CS_REQUIRE(!a_h16 || (a_pitch % 2 == 0 && a_c % 2 == 0), "wgrad16: a bf16 A operand needs an even pixel pitch");
     if (mode == 0) {
-        if (stride == 1) { CS_WG16(1, 0) } else { CS_WG16(2, 0) }
+        if (stride == 1) { CS_WG16(1, 0, false, false) } else { CS_WG16(2, 0, false, false) }
+    } else if (a_h16) {
+        if (stride == 1) { CS_WG16(1, 1, true, false) } else { CS_WG16(2, 1, true, false) }
+    } else if (b.h16) {
+        if (stride == 1) { CS_WG16(1, 1, false, true) } else { CS_WG16(2, 1, false, true) }
     } else {
-        if (stride == 1) { CS_WG16(1, 1) } else { CS_WG16(2, 1) }
+        if (stride == 1) { CS_WG16(1, 1, false, false) } else { CS_WG16(2, 1, false, false) }
     }
 #undef CS_WG16
     CS_HIP(hipGetLastError());

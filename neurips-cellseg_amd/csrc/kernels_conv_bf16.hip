@@ -1183,6 +1183,10 @@ constexpr long long STREAM_MIN_BLOCKS = 1024;   // the round-5 streaming kernels
 // CS_BF16_ROWS: 0 = block kernels, 1 = the 32 -> 32 layers streamed by waves, 2 (default) = the 64 -> 64 layers and the 32-channel stride-2 pair too
 static int g_bf16_rows = [] { const char* e = getenv("CS_BF16_ROWS"); return e ? atoi(e) : 2; }();
 
+// conv_bf16_rows64_kernel launches two-wave blocks, one per (strip, 64-row segment, image): below ~3 blocks per CU the block kernel is
+// faster (32 tiles of 256 x 256 = 128 blocks: forward 0.718 -> 0.640 ms, 8 tiles 0.531 -> 0.448; 240 tiles = 960 blocks: 2.938 vs 2.965 with
+// the streaming kernel; profiles/rows64_threshold_r05.txt)
+constexpr long long ROWS64_MIN_BLOCKS = 768;
 int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const ConvSrc& a, const ConvSrc& b,
                       const unsigned short* wpack, const float* bias, float* out, int pitch_out, int cout, double* stats, int n,
                       int hin, int win, bool act16, const float* in_amax, const ConvOutExtra* ex) {
@@ -1244,7 +1248,8 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
     }
     // the 32 -> 32 stride-1 layers of the bf16 datapath: a wave streams a 16-column strip (conv_bf16_rows32_kernel)
     if (g_bf16_rows >= 2 && act16 && planes == 1 && ksize == 3 && stride == 1 && a.c == 64 && b.c == 0 && cout == 64 && !ex && !in_amax &&
-        a.pitch % 8 == 0 && pitch_out % 8 == 0 && hin >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31) && (!a.tab || (a.tab_c ? a.tab_c : a.c) >= 64)) {
+        a.pitch % 8 == 0 && pitch_out % 8 == 0 && hin >= 8 && (size_t)win * a.pitch < ((size_t)1 << 31) && (!a.tab || (a.tab_c ? a.tab_c : a.c) >= 64) &&
+        (long long)ceil_div(p.wout, 16) * ceil_div(p.hout, R6_RS) * n >= ROWS64_MIN_BLOCKS) {
         const int strips = ceil_div(p.wout, 16), segs = ceil_div(p.hout, R6_RS);
         if (a.tab) hipLaunchKernelGGL(conv_bf16_rows64_kernel<true>, dim3((unsigned)(strips * segs * n)), dim3(128), 0, s, p, strips, segs);
         else hipLaunchKernelGGL(conv_bf16_rows64_kernel<false>, dim3((unsigned)(strips * segs * n)), dim3(128), 0, s, p, strips, segs);

@@ -518,8 +518,9 @@ def test_low_precision_datapaths_other_topologies(precision, channels, nru, norm
 
 
 def test_training_with_bf16_forward_tracks_the_fp32_curve():
-    """configs[1]'s training flavour: forward convolutions on the bf16 matrix pipe (fp32 activations kept for the backward, which
-    runs in fp32): ten AdamW steps must learn and stay close to the all-fp32 engine's loss curve."""
+    """configs[1]'s training flavour: convolutions, weight and data gradients on the bf16 matrix pipe, bf16 activations on the tape
+    (round 5; fp32 gradients, statistics, loss and master weights): ten AdamW steps must learn and stay close to the all-fp32 engine's
+    loss curve."""
     import cellseg_amd as ca
     curves = {}
     for prec in ("fp32", "bf16"):

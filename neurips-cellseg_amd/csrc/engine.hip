@@ -972,15 +972,23 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
     // fp64 yardstick (20x torch-fp32's error: gradient tensors span many decades, elements far below the tensor maximum lose
     // relative precision in the second fp16 plane) - so fp32-grade training keeps fp32 data gradients.
     const int dg16 = bwd16 == 1 ? 1 : 0;
+    // bias_pidx >= 0: `da` is also the gradient of that conv bias (the raw residual branch of a ResidualUnit) - its column sums are taken
+    // by this pass (one more accumulator per channel) and handed over with the other fp64 sums at the end, instead of a column-sum pass
+    // of their own on the weight-gradient stream (5 x 2 launches, 0.19 ms of that stream at 32-base x 32; CS_FUSE_BIAS=0: the old passes)
+    static const bool fuse_bias_env = !(getenv("CS_FUSE_BIAS") && atoi(getenv("CS_FUSE_BIAS")) == 0);
     auto norm_bwd = [&](const NormSite& ns, const NormRt& rt, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch,
-                        int64_t npix, float** amax_out = nullptr) -> int {
+                        int64_t npix, float** amax_out = nullptr, int bias_pidx = -1) -> int {
         double* red = acc.take<double>((size_t)n * y.c * 2);
         double* dsl = acc.take<double>(NORM_DSLOPE_SLOTS);
         float* amax = (bwd16 == 0 && amax_out) ? acc.take<float>(AMAX_SLOTS) : nullptr;
+        const bool ride = bias_pidx >= 0 && fuse_bias_env && y.c != 3;
+        double* dasum = ride ? acc.take<double>((size_t)n * y.c) : nullptr;
         if (amax_out) *amax_out = amax;
+        if (bias_pidx >= 0 && !ride) CS_TRY(bias_grad(da, da_pitch, y.c, (int64_t)n * npix, bias_pidx));
         if (dry) return CS_OK;
         CS_TRY(launch_norm_bwd(s, y, da, da_pitch, dy, dy_pitch, red, dsl, npix, n, bn ? rt.xtab : nullptr, bn,
-                               bn && ns.p_bn_w >= 0 ? gptr(ns.p_bn_w) : nullptr, bn && ns.p_bn_b >= 0 ? gptr(ns.p_bn_b) : nullptr, amax));
+                               bn && ns.p_bn_w >= 0 ? gptr(ns.p_bn_w) : nullptr, bn && ns.p_bn_b >= 0 ? gptr(ns.p_bn_b) : nullptr, amax, dasum));
+        if (ride) CS_TRY(f64_job(dasum, gptr(bias_pidx), y.c, n));
         if (ns.p_slope >= 0) return f64_job(dsl, gptr(ns.p_slope), 1, NORM_DSLOPE_SLOTS);
         return CS_OK;
     };
@@ -1104,7 +1112,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         float* dXin = dX[nl - 1];
         if (u.res_conv) {
             const WG gr = wg_alloc(c, 0, cin, 1, c, cin, ph, pw, 1, 1);
-            CS_TRY(bias_grad(dS, c, c, n * npix, u.res1x1.p_b[0]));
+            // (the 1x1 residual conv's bias gradient = column sums of dS: taken by the norm backward below, whose `da` dS is)
             if (!dry) {
                 CS_TRY(wg_begin());
                 CS_TRY(launch_wgrad(sw, 1, 1, dS, c, c, tsrc(Xin, cin, cin), nullptr, gr.part, gr.k, c, cin, 0, 0, n, ph, pw, ph, pw));
@@ -1119,7 +1127,8 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             float* da_new = su > 0 ? buf.take<float>((size_t)n * npix * c) : nullptr;
             if (!buf.ok()) return oom();
             float* ax_dY = nullptr;
-            CS_TRY(norm_bwd(u.norms[su], T.rt_bottom[su], tlazy(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c, t16), da, c, dY, c, npix, &ax_dY));
+            CS_TRY(norm_bwd(u.norms[su], T.rt_bottom[su], tlazy(T.Yb[su], c, c, T.rt_bottom[su], u.norms[su], c, t16), da, c, dY, c, npix, &ax_dY,
+                            (su == u.subunits - 1 && u.res_conv) ? u.res1x1.p_b[0] : -1));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (dry) { da = da_new; continue; }
             if (su > 0) {
@@ -1156,7 +1165,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         const int oh = h >> (d + 1), ow = w >> (d + 1), ph = oh * 2, pw = ow * 2;
         const int64_t npix = (int64_t)oh * ow;
         const float* dXd = dX[d];
-        CS_TRY(bias_grad(dXd, c, c, n * npix, u.unit0.p_b[1]));      // residual conv bias (the residual branch is raw)
+        // residual conv bias (the residual branch is raw): column sums of dX[d] - taken by the first norm backward below, whose `da` it is
         const float* da = dXd;
         for (int su = u.subunits - 1; su >= 1; --su) {
             const ConvW& cw = u.units[su - 1];
@@ -1165,7 +1174,8 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             const WG ga = wg_alloc(c, 0, c, 9, c, c, oh, ow, 3, 1);
             if (!buf.ok()) return oom();
             float* ax_dY = nullptr;
-            CS_TRY(norm_bwd(u.norms[su], T.rt_down[d][su], tlazy(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c, t16), da, c, dY, c, npix, &ax_dY));
+            CS_TRY(norm_bwd(u.norms[su], T.rt_down[d][su], tlazy(T.Y[d][su], c, c, T.rt_down[d][su], u.norms[su], c, t16), da, c, dY, c, npix, &ax_dY,
+                            su == u.subunits - 1 ? u.unit0.p_b[1] : -1));
             CS_TRY(bias_grad(dY, c, c, n * npix, cw.p_b[0], true));
             if (!dry) {
                 const ConvSrc prev = su - 1 == 0 ? tlazy(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0, t16)
@@ -1182,7 +1192,7 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
         if (!buf.ok()) return oom();
         float *ax_dY0 = nullptr, *ax_dXd = nullptr;
         CS_TRY(norm_bwd(u.norms[0], T.rt_down[d][0], tlazy(T.E[d], c, c0, T.rt_down[d][0], u.norms[0], c0, t16), da, c, dY0, c, npix,
-                        u.first ? nullptr : &ax_dY0));
+                        u.first ? nullptr : &ax_dY0, u.subunits == 1 ? u.unit0.p_b[1] : -1));
         CS_TRY(bias_grad(dY0, c, c, n * npix, u.unit0.p_b[0], true));
         if (!u.first && gf.h16) {                                  // the residual conv's gradient is the raw dX[d]: no norm backward measured it
             if (!dry) CS_TRY(wg_begin());

@@ -211,9 +211,11 @@ int launch_act_quant(hipStream_t s, const ConvSrc& src, unsigned char* dst8, int
 // the whole batch, and d(gamma) = sum dz*x_hat / d(beta) = sum dz are written to dgamma / dbeta (fp32, may be null).
 // amax (may be null): AMAX_SLOTS device floats that receive partial maxima of |dy| over the whole tensor (zero before the launch): the dynamic fp16 scale of
 // the weight-gradient / data-gradient kernels on the 16-bit matrix pipe (kernels_bwd16.hip)
+// dasum (may be null): [n][c] doubles, zero on entry, that receive the per-image column sums of `da` itself - `da` is then also the
+// gradient of a conv bias (the raw residual branch), and its bias gradient needs no pass of its own
 int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch, double* red,
                     double* dslope, int64_t npix, int n, const float2* xtab = nullptr, bool batch = false, float* dgamma = nullptr,
-                    float* dbeta = nullptr, float* amax = nullptr);
+                    float* dbeta = nullptr, float* amax = nullptr, double* dasum = nullptr);
 // dst[c] = sum over pixels (fp32 out, fp64 final accumulation); partial: colsum_blocks(npix_total) * c floats of scratch
 int colsum_blocks(int64_t npix_total);
 int launch_colsum(hipStream_t s, const float* src, int pitch, int c, int64_t npix_total, float* partial, float* dst);

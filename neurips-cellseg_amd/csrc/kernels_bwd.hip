@@ -49,12 +49,14 @@ struct NormBwdParams {
     const float2* xtab;   // BatchNorm: (rstd, -mean*rstd) so that x_hat = y*rstd - mean*rstd; null: x_hat == z (InstanceNorm, no affine)
     double inv_m;         // 1 / (elements behind each pair of sums): npix (InstanceNorm) or n*npix (BatchNorm, sums reduced over n)
     unsigned* amax;       // bits of max |dy| (atomicMax; non-negative floats order like unsigned integers) or null
+    double* dasum;        // [n][c] sums of da itself over the image's pixels, or null: `da` is also the gradient of a conv bias (the raw
+                          // residual branch) - its column sums ride on this pass instead of a pass of their own (zero on entry)
 };
 
 // wide: c % 4 == 0 and 256 % (c/4) == 0
 template <bool Y16>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
-    __shared__ float sh[256 * 9];
+    __shared__ float sh[256 * 13];
     const int c4n = p.c >> 2, lanes = 256 / c4n;
     const int quad = threadIdx.x % c4n, pl = threadIdx.x / c4n;
     const int img = blockIdx.y;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
         xf[0] = x0.y; xf[1] = x0.w; xf[2] = x1.y; xf[3] = x1.w;
     }
     const float slope = p.slope ? *p.slope : 0.f;
-    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, ds = 0.f;
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, s0[4] = {0, 0, 0, 0}, ds = 0.f;
     // 4 pixels per trip, all 8 loads issued before the first use: the pass is bound by loads in flight, not by arithmetic
     for (int64_t px = pix0 + pl; px < pix1; px += 4 * lanes) {
         f32x4 da[4], y[4];
@@ -93,26 +95,29 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
                 if (z < 0.f) ds += da[u][j] * z;
                 s1[j] += dz;
                 s2[j] += dz * xh;
+                s0[j] += da[u][j];
             }
         }
     }
     // reduce over the `lanes` threads that share a channel quad
-    float* mine = sh + threadIdx.x * 9;
+    float* mine = sh + threadIdx.x * 13;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         mine[j] = s1[j];
         mine[4 + j] = s2[j];
+        mine[9 + j] = s0[j];
     }
     mine[8] = ds;
     __syncthreads();
     if (threadIdx.x < c4n) {
-        float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
+        float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0}, r0[4] = {0, 0, 0, 0};
         for (int l = 0; l < lanes; ++l) {
-            const float* o = sh + (l * c4n + threadIdx.x) * 9;
+            const float* o = sh + (l * c4n + threadIdx.x) * 13;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 r1[j] += o[j];
                 r2[j] += o[4 + j];
+                r0[j] += o[9 + j];
             }
         }
 #pragma unroll
@@ -120,12 +125,13 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdParams p) {
             double* d = p.red + ((size_t)img * p.c + 4 * threadIdx.x + j) * 2;
             atomicAdd(d, (double)r1[j]);
             atomicAdd(d + 1, (double)r2[j]);
+            if (p.dasum) atomicAdd(p.dasum + (size_t)img * p.c + 4 * threadIdx.x + j, (double)r0[j]);
         }
     }
     if (p.dslope) {
         float tot = 0.f;
         if (threadIdx.x < 64) {
-            for (int l = threadIdx.x; l < 256; l += 64) tot += sh[l * 9 + 8];
+            for (int l = threadIdx.x; l < 256; l += 64) tot += sh[l * 13 + 8];
             for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
             if (threadIdx.x == 0) atomicAdd(p.dslope + ((blockIdx.x + 13 * blockIdx.y) & (NORM_DSLOPE_SLOTS - 1)), (double)tot);
         }
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdParams p) {
 template <int QB, bool Y16>
 __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(NormBwdParams p) {
     constexpr int LANES = 256 / QB;                      // pixel lanes per quad
-    __shared__ double sh[4][QB][9];
+    __shared__ double sh[4][QB][13];
     const int quad_l = threadIdx.x % QB, pl = threadIdx.x / QB;
     const int quad = blockIdx.x * QB + quad_l, img = blockIdx.y;
     const int wave = threadIdx.x >> 6;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(NormBwdParams p) {
     const float slope = p.slope ? *p.slope : 0.f;
     const float* const da0 = p.da + (size_t)img * p.npix * p.da_pitch + 4 * quad;
     const size_t y0 = (size_t)img * p.npix * p.y_pitch + 4 * quad;      // element offset (fp32 or bf16 elements)
-    float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // s1[4], s2[4], ds
+    float v[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};            // s1[4], s2[4], ds, sum of da[4]
     for (int px = pl; px < p.npix; px += LANES) {
         const f32x4 da = *reinterpret_cast<const f32x4*>(da0 + (size_t)px * p.da_pitch);
         const f32x4 y = ld_act4<Y16>(p.y, y0 + (size_t)px * p.y_pitch);
@@ -217,17 +223,22 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(NormBwdParams p) {
             if (z < 0.f) v[8] += da[j] * z;
             v[j] += dz;
             v[4 + j] += dz * z;
+            v[9 + j] += da[j];
         }
     }
     // lanes of a wave that share a quad sit QB apart
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < 13; ++k)
 #pragma unroll
         for (int off = QB; off < 64; off <<= 1) v[k] += __shfl_xor(v[k], off);
     if ((threadIdx.x & 63) < QB)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) sh[wave][quad_l][k] = (double)v[k];
+        for (int k = 0; k < 13; ++k) sh[wave][quad_l][k] = (double)v[k];
     __syncthreads();
+    if (p.dasum && threadIdx.x < QB)                     // the block owns (image, quad): plain stores
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            p.dasum[(size_t)img * p.c + 4 * quad + j] = (sh[0][quad_l][9 + j] + sh[1][quad_l][9 + j]) + (sh[2][quad_l][9 + j] + sh[3][quad_l][9 + j]);
     float m1[4], m2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -346,7 +357,8 @@ __global__ void bn_bwd_finalize_kernel(double* red, int n, int c, float* dgamma,
 }
 
 int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pitch, float* dy, int dy_pitch, double* red,
-                    double* dslope, int64_t npix, int n, const float2* xtab, bool batch, float* dgamma, float* dbeta, float* amax) {
+                    double* dslope, int64_t npix, int n, const float2* xtab, bool batch, float* dgamma, float* dbeta, float* amax,
+                    double* dasum) {
     CS_REQUIRE(y.tab != nullptr, "norm_bwd: the forward table is required");
     CS_REQUIRE(!batch || xtab, "norm_bwd: BatchNorm needs the forward's x_hat table");
     NormBwdParams p{};
@@ -356,6 +368,8 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
     p.red = red; p.dslope = y.slope ? dslope : nullptr; p.dy = dy; p.dy_pitch = dy_pitch; p.c = y.c; p.npix = (int)npix;
     p.xtab = xtab;
     p.amax = reinterpret_cast<unsigned*>(amax);
+    p.dasum = dasum;
+    CS_REQUIRE(!dasum || y.c != 3, "norm_bwd: the column sums of da ride on the wide kernels only");
     p.inv_m = 1.0 / ((double)npix * (batch ? (double)n : 1.0));
     ProfScope prof(K_NORM_BWD, s, 0, (y.h16 ? 16.0 : 20.0) * n * npix * y.c);
     auto bn_finalize = [&]() {

@@ -1217,8 +1217,13 @@ static int unet_backward_impl(const cs_unet* net, const float* dlogits, Bump& ac
             CS_TRY(launch_wgrad(sw, 3, 2, dY0, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, 0, 0, n, oh, ow, ph, pw));
             CS_TRY(launch_wgrad(sw, 3, 2, dXd, c, c, ConvSrc(), &nb, gf.part, gf.k, c0, cin, c, 0, n, oh, ow, ph, pw));
         }
-        CS_TRY(unpack3(sw, gf, c0, cin, 0, c, cin, gptr(u.unit0.p_w[0]), ax_dY0, nullptr));
-        CS_TRY(unpack3(sw, gf, c0, cin, c, c, cin, gptr(u.unit0.p_w[1]), ax_dXd, nullptr));
+        {   // both halves of the pair in ONE launch: rows [0, c) -> unit0's weight gradient, rows [c, 2c) -> the residual conv's
+            WgradUnscale us0, us1;
+            us0.a_amax = ax_dY0; us1.a_amax = ax_dXd;
+            const bool scaled = gf.h16 && bwd16 == 0;
+            CS_TRY(launch_unpack_wgrad(sw, gf.part, gf.k, c0, cin, 0, 0, c, cin, 9, gptr(u.unit0.p_w[0]), scaled ? &us0 : nullptr,
+                                       gptr(u.unit0.p_w[1]), scaled ? &us1 : nullptr));
+        }
     }
     if (!dry) CS_TRY(flush_colsums(s));        // column sums no weight-gradient group picked up
     if (!dry) CS_TRY(launch_f64_jobs(s, f64_jobs));

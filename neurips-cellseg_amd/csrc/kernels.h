@@ -238,8 +238,10 @@ struct WgradUnscale {
     const float* a_amax = nullptr;   // AMAX_SLOTS device floats behind each dynamic scale (null: the static activation scale)
     const float* b_amax = nullptr;
 };
+// dst2 (may be null): the NEXT `rows` rows of the same partial buffer go to a second tensor in the same launch (a fused pair)
 int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_total, int cols_total, int row_off, int col_off,
-                        int rows, int cols, int taps, float* dst, const WgradUnscale* unscale = nullptr);
+                        int rows, int cols, int taps, float* dst, const WgradUnscale* unscale = nullptr, float* dst2 = nullptr,
+                        const WgradUnscale* unscale2 = nullptr);
 // ---- weight gradients on the 16-bit matrix pipe (kernels_bwd16.hip) ----
 constexpr float F16_ACT_SCALE = 16.f;          // static pre-scale of activation operands in the split-fp16 modes (== F16_X_SCALE of the forward)
 constexpr int AMAX_SLOTS = 32;                 // a gradient tensor's max |dy| is kept as AMAX_SLOTS partial maxima (see amax_commit)

@@ -932,14 +932,23 @@ int launch_wgrad(hipStream_t s, int ksize, int stride, const float* a, int a_pit
 // element over its share of the split-K slices (loads coalesced over the elements), the lanes are merged through LDS and the
 // block writes its EL * taps outputs as one contiguous run.  KL = 4 for short split-K, 32 for the high-resolution layers whose
 // split-K is in the hundreds (round 1: 32 elements x 8 lanes, one tap per block, 22 us per launch on average).
+// blockIdx.y = part: a launch may unpack two row ranges of one partial buffer into two tensors (the fused [unit0 || residual] pair:
+// rows [row_off, row_off + rows) -> dst, rows [row_off + rows, row_off + 2 rows) -> dst2 with its own scales)
 template <int EL, int TAPS>
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* part, int split_k, int rows_total, int cols_total, int row_off,
-                                                           int col_off, int rows, int cols, float* dst, WgradUnscale us, int unscale) {
+                                                           int col_off, int rows, int cols, float* dst, WgradUnscale us, int unscale,
+                                                           float* dst2, WgradUnscale us2) {
     constexpr int KL = 256 / EL;
     __shared__ float sh[KL][EL * TAPS + 1];
     const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
     const int per_tap = rows * cols;
     const int e = blockIdx.x * EL + el;
+    const bool second = blockIdx.y != 0;
+    if (second) {
+        row_off += rows;
+        dst = dst2;
+        us = us2;
+    }
     float acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) acc[t] = 0.f;
@@ -969,15 +978,18 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* part, in
 }
 
 int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_total, int cols_total, int row_off, int col_off,
-                        int rows, int cols, int taps, float* dst, const WgradUnscale* unscale) {
+                        int rows, int cols, int taps, float* dst, const WgradUnscale* unscale, float* dst2, const WgradUnscale* unscale2) {
     const int total = rows * cols * taps;
     const WgradUnscale us = unscale ? *unscale : WgradUnscale();
+    const WgradUnscale us2 = unscale2 ? *unscale2 : WgradUnscale();
     const int do_unscale = unscale ? 1 : 0;
     CS_REQUIRE(taps == 9 || taps == 1, "unpack_wgrad: %d taps", taps);
-    ProfScope prof(K_UNPACK, s, 0, 4.0 * total * (split_k + 1));
-#define CS_UNPACK(EL_, T_)                                                                                                       \
-    hipLaunchKernelGGL((unpack_wgrad_kernel<EL_, T_>), dim3((unsigned)ceil_div(rows * cols, EL_)), dim3(256), 0, s, part, split_k, \
-                       rows_total, cols_total, row_off, col_off, rows, cols, dst, us, do_unscale)
+    CS_REQUIRE(!dst2 || ((unscale != nullptr) == (unscale2 != nullptr) && row_off + 2 * rows <= rows_total), "unpack_wgrad: bad second part");
+    const unsigned parts = dst2 ? 2u : 1u;
+    ProfScope prof(K_UNPACK, s, 0, 4.0 * total * (split_k + 1) * parts);
+#define CS_UNPACK(EL_, T_)                                                                                                              \
+    hipLaunchKernelGGL((unpack_wgrad_kernel<EL_, T_>), dim3((unsigned)ceil_div(rows * cols, EL_), parts), dim3(256), 0, s, part, split_k, \
+                       rows_total, cols_total, row_off, col_off, rows, cols, dst, us, do_unscale, dst2, us2)
     if (split_k > 64 && rows * cols <= 1024 && taps == 9) {
         CS_UNPACK(2, 9);            // small tensor, hundreds of slices (16- and 32-channel layers at 128^2): 8 elements per block left 32
                                     // blocks summing 512 slabs (65 us); 2 elements x 128 split-K lanes put the same loads on 4x the CUs
@@ -994,17 +1006,26 @@ int launch_unpack_wgrad(hipStream_t s, const float* part, int split_k, int rows_
 // All fp64 -> fp32 hand-overs of one backward pass (PReLU slope gradients: NORM_DSLOPE_SLOTS partial sums each; the last conv's
 // 84 weight / bias sums) in ONE launch at the end of the pass: block b does job b, dst[i] = sum over slots of src[slot * count + i].
 // (One small launch behind every norm backward was 19 launches of ~5 us on the critical chain of a 2 ms step.)
-__global__ void f64_jobs_kernel(F64Jobs jobs) {
+__global__ __launch_bounds__(256) void f64_jobs_kernel(F64Jobs jobs) {
     const F64Job jb = jobs.j[blockIdx.x];
     for (int i = threadIdx.x; i < jb.count; i += blockDim.x) {
         double t = 0.0;
-        for (int sl = 0; sl < jb.slots; ++sl) t += jb.src[(size_t)sl * jb.count + i];
+        // eight independent loads in flight per thread (a dependent chain of 32 x 8 loads took 130 us for a 512-channel, 32-image job)
+        int sl = 0;
+        for (; sl + 8 <= jb.slots; sl += 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = jb.src[(size_t)(sl + k) * jb.count + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += v[k];
+        }
+        for (; sl < jb.slots; ++sl) t += jb.src[(size_t)sl * jb.count + i];
         jb.dst[i] = (float)t;
     }
 }
 int launch_f64_jobs(hipStream_t s, const F64Jobs& jobs) {
     if (jobs.n == 0) return CS_OK;
-    hipLaunchKernelGGL(f64_jobs_kernel, dim3((unsigned)jobs.n), dim3(64), 0, s, jobs);
+    hipLaunchKernelGGL(f64_jobs_kernel, dim3((unsigned)jobs.n), dim3(256), 0, s, jobs);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -76,8 +76,13 @@ __device__ __forceinline__ float prelu_f(float v, float slope) { return v >= 0.f
 
 // A16 / B16: that operand is an ACTIVATION tensor of the bf16 tape (bf16 elements in HBM; plain-bf16 mode only, and never both: the
 // other operand is the fp32 gradient).  Compile-time, so that the load groups stay straight-line code.
-template <int S, int MT, int MODE, bool A16 = false, bool B16 = false>
+// ALDS (plain-bf16 mode, round 5): the A tile (8 x 16 pixels x 16 MT channels) takes the B operand's route - coalesced 16-byte loads of four
+// channels of a pixel, converted once, 8-byte stores into [pixel][16 ch] bf16 planes in LDS, fragments read back TRANSPOSED
+// (ds_read_tr16_b64) - instead of eight dword loads + conversions per fragment and lane straight from global memory (32 load
+// instructions per lane and tile against 36 MFMAs).  Same values in the same MFMA order: bitwise the register form (CS_WGRAD_ALDS=0).
+template <int S, int MT, int MODE, bool A16 = false, bool B16 = false, bool ALDS = false>
 __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
+    static_assert(!ALDS || MODE == 1, "the LDS route of the A operand is built for the one-plane (bf16) mode");
     constexpr int WM = MT >= 2 ? 2 : 1, WK = 4 / WM, MTW = MT / WM, KSW = 4 / WK;   // waves along co / along K, co tiles and K-steps per wave
     constexpr int NP = MODE == 0 ? 2 : 1;
     constexpr int TH = 8, TW = 16;
@@ -86,8 +91,12 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
     constexpr int PLANE = IH * IW * PITCH;
     constexpr int B_ITERS = (IH * IW + 63) / 64;
     constexpr int RED_BYTES = (WK - 1) * WM * 9 * MTW * 1024;
-    constexpr int SMEM = NP * PLANE > RED_BYTES ? NP * PLANE : RED_BYTES;
+    constexpr int A_PLANE = TH * TW * 32;                     // one 16-channel tile of the A operand: [128 pixels][16 bf16]
+    constexpr int A_BYTES = ALDS ? MT * A_PLANE : 0;
+    constexpr int A_ITERS = ALDS ? 2 * MT : 1;                // 16-byte (8-byte: A16) loads per thread for the A tile
+    constexpr int SMEM = NP * PLANE + A_BYTES > RED_BYTES ? NP * PLANE + A_BYTES : RED_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const a_smem = smem + NP * PLANE;
 
     if constexpr (MODE == 0) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // MODE.FP16_OVFL: saturate, never inf
 
@@ -109,7 +118,9 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
         for (int t = 0; t < MTW; ++t) acc[t9][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const bool lazy = p.b_tab != nullptr;
-    float araw[KSW][MTW][8];
+    float araw[ALDS ? 1 : KSW][ALDS ? 1 : MTW][8];
+    f32x4 ra4[(ALDS && !A16) ? A_ITERS : 1];               // ALDS: the thread's share of the A tile, (pixel, channel quad) items
+    uint2 ra2[(ALDS && A16) ? A_ITERS : 1];
     unsigned ok_a = 0;                       // bit kq * 8 + j: pixel j of K-step kq is inside the image
     f32x4 rb[B_ITERS], t0, t1;
     float slope = 0.f;
@@ -127,26 +138,40 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
         slope = *sp;
         ok_a = 0;
         ok_b = 0;
+        if constexpr (ALDS) {
 #pragma unroll
-        for (int kq = 0; kq < KSW; ++kq) {
-            const int oy = oy0 + 2 * (wk * KSW + kq) + (gi >> 1);
-            const int oxb = ox0 + 8 * (gi & 1);
+            for (int it = 0; it < A_ITERS; ++it) {
+                const int i = tid + 256 * it;
+                const int px = i / (4 * MT), c4 = i - px * (4 * MT);
+                const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+                const bool ok = oy < p.ho && ox < p.wo;
+                const size_t off = ok ? (((size_t)img * p.ho + oy) * p.wo + ox) * p.a_pitch + co0 + 4 * c4 : 0;
+                if constexpr (A16) ra2[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.a) + off);
+                else ra4[it] = *reinterpret_cast<const f32x4*>(p.a + off);
+                ok_a |= (ok ? 1u : 0u) << it;
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool ok = oy < p.ho && oxb + j < p.wo;
-                const size_t off = ok ? (((size_t)img * p.ho + oy) * p.wo + oxb + j) * p.a_pitch + co0 + 16 * (wm * MTW) + m16 : (size_t)m16;
-#pragma unroll
-                for (int t = 0; t < MTW; ++t) {
-                    if constexpr (A16) {
-                        // bf16 elements: the dword that holds channels (m16 & ~1, m16 | 1) - the 16 lanes of a pixel read one 32-byte run as
-                        // eight dwords, two lanes each - and this lane's half of it
-                        const unsigned wd = reinterpret_cast<const unsigned*>(p.a)[(off + 16 * t) >> 1];
-                        araw[kq][t][j] = __builtin_bit_cast(float, (m16 & 1) ? (wd & 0xffff0000u) : (wd << 16));
-                    } else {
-                        araw[kq][t][j] = p.a[off + 16 * t];
+            for (int kq = 0; kq < KSW; ++kq) {
+                const int oy = oy0 + 2 * (wk * KSW + kq) + (gi >> 1);
+                const int oxb = ox0 + 8 * (gi & 1);
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = oy < p.ho && oxb + j < p.wo;
+                    const size_t off = ok ? (((size_t)img * p.ho + oy) * p.wo + oxb + j) * p.a_pitch + co0 + 16 * (wm * MTW) + m16 : (size_t)m16;
+    #pragma unroll
+                    for (int t = 0; t < MTW; ++t) {
+                        if constexpr (A16) {
+                            // bf16 elements: the dword that holds channels (m16 & ~1, m16 | 1) - the 16 lanes of a pixel read one 32-byte run as
+                            // eight dwords, two lanes each - and this lane's half of it
+                            const unsigned wd = reinterpret_cast<const unsigned*>(p.a)[(off + 16 * t) >> 1];
+                            araw[kq][t][j] = __builtin_bit_cast(float, (m16 & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                        } else {
+                            araw[kq][t][j] = p.a[off + 16 * t];
+                        }
                     }
+                    ok_a |= (ok ? 1u : 0u) << (kq * 8 + j);
                 }
-                ok_a |= (ok ? 1u : 0u) << (kq * 8 + j);
             }
         }
 #pragma unroll
@@ -186,10 +211,30 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
                 }
             }
         }
+        if constexpr (ALDS) {
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) {
+                const int i = tid + 256 * it;
+                const int px = i / (4 * MT), c4 = i - px * (4 * MT);
+                u32x2 h{0u, 0u};
+                if ((ok_a >> it) & 1u) {
+                    if constexpr (A16) {
+                        h.x = ra2[it].x;
+                        h.y = ra2[it].y;
+                    } else {
+                        float e[4] = {ra4[it].x, ra4[it].y, ra4[it].z, ra4[it].w};
+                        h.x = pack2<MODE>(e[0], e[1]);
+                        h.y = pack2<MODE>(e[2], e[3]);
+                    }
+                }
+                *reinterpret_cast<u32x2*>(a_smem + (c4 >> 2) * A_PLANE + px * 32 + 8 * (c4 & 3)) = h;
+            }
+        }
     };
     // this wave's A fragments of the staged tile: [K-step][co tile][plane], 8 pixels of channel m16 per lane
-    u32x4 afr[KSW][MTW][NP];
+    u32x4 afr[ALDS ? 1 : KSW][ALDS ? 1 : MTW][NP];
     auto convert_a = [&]() {
+        if constexpr (ALDS) return;
 #pragma unroll
         for (int kq = 0; kq < KSW; ++kq)
 #pragma unroll
@@ -218,6 +263,16 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
         return u32x4{l2.x, l2.y, h2.x, h2.y};
     };
 
+    // ALDS: the A fragment of (K-step kq, co tile t) out of its plane: pixel (row 2 (wk KSW + kq) + (gi >> 1), column 8 (gi & 1) + j)
+    const int a_lane_base = (((gi >> 1) * TW + 8 * (gi & 1) + q4) * 32) + 8 * p4;
+    auto afrag = [&](int kq, int t) -> u32x4 {
+        const int base = (wm * MTW + t) * A_PLANE + a_lane_base + (2 * (wk * KSW + kq) * TW) * 32;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a_smem + base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a_smem + base + 4 * 32));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        return u32x4{l2.x, l2.y, h2.x, h2.y};
+    };
+
     const int t_begin = (int)((int64_t)ks_id * p.total_tiles / p.split_k);
     const int t_end = (int)((int64_t)(ks_id + 1) * p.total_tiles / p.split_k);
     if (t_begin < t_end) {
@@ -232,6 +287,11 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
 #pragma unroll
         for (int kq = 0; kq < KSW; ++kq) {
             const int base = lane_base + (2 * (wk * KSW + kq) * S * IW) * PITCH;
+            u32x4 aq[MTW];                                  // (ALDS) this K-step's A fragments, read once for the nine taps
+            if constexpr (ALDS) {
+#pragma unroll
+                for (int t = 0; t < MTW; ++t) aq[t] = afrag(kq, t);
+            }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {               // one kernel row = 3 taps x MTW independent accumulator chains
                 u32x4 bq[3][NP];
@@ -254,7 +314,10 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16Params p) {
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                        for (int t = 0; t < MTW; ++t) acc[ky * 3 + kx][t] = mfma16<MODE>(afr[kq][t][0], bq[kx][0], acc[ky * 3 + kx][t]);
+                        for (int t = 0; t < MTW; ++t) {
+                            if constexpr (ALDS) acc[ky * 3 + kx][t] = mfma16<MODE>(aq[t], bq[kx][0], acc[ky * 3 + kx][t]);
+                            else acc[ky * 3 + kx][t] = mfma16<MODE>(afr[kq][t][0], bq[kx][0], acc[ky * 3 + kx][t]);
+                        }
                 }
             }
         }
@@ -328,22 +391,27 @@ int launch_wgrad16(hipStream_t s, int mode, int stride, const float* a, int a_pi
     dim3 grid((unsigned)split_k, (unsigned)(a_c / (16 * mt)), (unsigned)(b.c / 16));
     const double flops = 2.0 * n * ho * wo * (double)a_c * b.c * 9;
     ProfScope prof(K_WGRAD, s, flops, 4.0 * n * ((double)ho * wo * a_c + (double)hi * wi * b.c));
-#define CS_WG16(S_, MODE_, A_, B_)                                                                                      \
+#define CS_WG16(S_, MODE_, A_, B_, L_)                                                                                  \
     switch (mt) {                                                                                                      \
-        case 4: hipLaunchKernelGGL((wgrad16_kernel<S_, 4, MODE_, A_, B_>), grid, dim3(256), 0, s, p); break;           \
-        case 2: hipLaunchKernelGGL((wgrad16_kernel<S_, 2, MODE_, A_, B_>), grid, dim3(256), 0, s, p); break;           \
-        default: hipLaunchKernelGGL((wgrad16_kernel<S_, 1, MODE_, A_, B_>), grid, dim3(256), 0, s, p); break;          \
+        case 4: hipLaunchKernelGGL((wgrad16_kernel<S_, 4, MODE_, A_, B_, L_>), grid, dim3(256), 0, s, p); break;       \
+        case 2: hipLaunchKernelGGL((wgrad16_kernel<S_, 2, MODE_, A_, B_, L_>), grid, dim3(256), 0, s, p); break;       \
+        default: hipLaunchKernelGGL((wgrad16_kernel<S_, 1, MODE_, A_, B_, L_>), grid, dim3(256), 0, s, p); break;      \
     }
     CS_REQUIRE(!(a_h16 && b.h16), "wgrad16: one operand is the gradient (fp32), at most one comes off the bf16 tape");
-    CS_REQUIRE(!a_h16 || (a_pitch % 2 == 0 && a_c % 2 == 0), "wgrad16: a bf16 A operand needs an even pixel pitch");
+    CS_REQUIRE(!a_h16 || (a_pitch % 4 == 0 && a_c % 4 == 0), "wgrad16: a bf16 A operand needs a pixel pitch that is a multiple of 4");
+    static const bool alds = !(getenv("CS_WGRAD_ALDS") && atoi(getenv("CS_WGRAD_ALDS")) == 0);      // A/B: 0 = A fragments straight from global memory
+    const bool l = alds && mode == 1 && a_pitch % 4 == 0;
     if (mode == 0) {
-        if (stride == 1) { CS_WG16(1, 0, false, false) } else { CS_WG16(2, 0, false, false) }
+        if (stride == 1) { CS_WG16(1, 0, false, false, false) } else { CS_WG16(2, 0, false, false, false) }
     } else if (a_h16) {
-        if (stride == 1) { CS_WG16(1, 1, true, false) } else { CS_WG16(2, 1, true, false) }
+        if (l) { if (stride == 1) { CS_WG16(1, 1, true, false, true) } else { CS_WG16(2, 1, true, false, true) } }
+        else { if (stride == 1) { CS_WG16(1, 1, true, false, false) } else { CS_WG16(2, 1, true, false, false) } }
     } else if (b.h16) {
-        if (stride == 1) { CS_WG16(1, 1, false, true) } else { CS_WG16(2, 1, false, true) }
+        if (l) { if (stride == 1) { CS_WG16(1, 1, false, true, true) } else { CS_WG16(2, 1, false, true, true) } }
+        else { if (stride == 1) { CS_WG16(1, 1, false, true, false) } else { CS_WG16(2, 1, false, true, false) } }
     } else {
-        if (stride == 1) { CS_WG16(1, 1, false, false) } else { CS_WG16(2, 1, false, false) }
+        if (l) { if (stride == 1) { CS_WG16(1, 1, false, false, true) } else { CS_WG16(2, 1, false, false, true) } }
+        else { if (stride == 1) { CS_WG16(1, 1, false, false, false) } else { CS_WG16(2, 1, false, false, false) } }
     }
 #undef CS_WG16
     CS_HIP(hipGetLastError());

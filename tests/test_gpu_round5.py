@@ -122,3 +122,23 @@ def test_bf16_training_reads_a_bf16_tape_and_its_gradients_stay_at_the_bf16_leve
     scale = max(abs(g) for _, _, _, g in scalars)
     for k, a, b, g in scalars:
         assert abs(a - g) <= 2.0 * abs(b - g) + 0.05 * scale, (k, a, b, g, scale)
+
+
+def test_bf16_weight_gradients_with_the_A_operand_through_LDS_are_bitwise_the_register_form(tmp_path):
+    """Round 5: in the bf16 mode the weight-gradient kernel stages its A tile like its B patch (coalesced loads, bf16 planes in LDS,
+    transposed fragment reads) instead of eight dword loads per fragment and lane.  Same values, same MFMA order: every gradient of the
+    net is bit for bit what the register form (CS_WGRAD_ALDS=0) gives - partial tiles, both operand kinds (fp32 gradient / bf16 tape as A)."""
+    from conftest import cli_env
+    script = tmp_path / "grads.py"
+    script.write_text(_GRAD_SCRIPT.replace("torch.rand(4, 3, 128, 128", "torch.rand(3, 3, 144, 112").replace("(4, 1, 128, 128)", "(3, 1, 144, 112)"))
+    res = {}
+    for tag, env in (("lds", {"CS_WGRAD_ALDS": 1}), ("regs", {"CS_WGRAD_ALDS": 0}), ("lds_tape32", {"CS_WGRAD_ALDS": 1, "CS_TAPE16": 0}),
+                     ("regs_tape32", {"CS_WGRAD_ALDS": 0, "CS_TAPE16": 0})):
+        out = tmp_path / f"{tag}.pt"
+        cp = subprocess.run([sys.executable, str(script), "bf16", str(out)], capture_output=True, text=True, timeout=600, env=cli_env(**env))
+        assert cp.returncode == 0, cp.stderr[-2000:]
+        res[tag] = torch.load(out)
+    for a, b in (("lds", "regs"), ("lds_tape32", "regs_tape32")):
+        assert res[a]["loss"] == res[b]["loss"]
+        for k, g in res[a]["grads"].items():
+            assert torch.equal(g, res[b]["grads"][k]), (a, k, (g - res[b]["grads"][k]).abs().max().item())

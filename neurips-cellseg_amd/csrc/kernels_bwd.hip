@@ -213,17 +213,28 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(NormBwdParams p) {
     const float* const da0 = p.da + (size_t)img * p.npix * p.da_pitch + 4 * quad;
     const size_t y0 = (size_t)img * p.npix * p.y_pitch + 4 * quad;      // element offset (fp32 or bf16 elements)
     float v[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};            // s1[4], s2[4], ds, sum of da[4]
-    for (int px = pl; px < p.npix; px += LANES) {
-        const f32x4 da = *reinterpret_cast<const f32x4*>(da0 + (size_t)px * p.da_pitch);
-        const f32x4 y = ld_act4<Y16>(p.y, y0 + (size_t)px * p.y_pitch);
+    // four pixels per trip, their eight loads issued before the first use (one load pair in flight per thread ran these small tensors
+    // at 40 % of the rate the two-kernel form reaches: 42 us per launch for 67 MB at 32 x 32^2 x 128)
+    for (int px = pl; px < p.npix; px += 4 * LANES) {
+        f32x4 da[4], y[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float z = y[j] * sc[j] + sf[j];
-            const float dz = z >= 0.f ? da[j] : da[j] * slope;
-            if (z < 0.f) v[8] += da[j] * z;
-            v[j] += dz;
-            v[4 + j] += dz * z;
-            v[9 + j] += da[j];
+        for (int u = 0; u < 4; ++u) {
+            const int pu = px + u * LANES < p.npix ? px + u * LANES : px;       // clamped: the tail re-reads a valid pixel
+            da[u] = *reinterpret_cast<const f32x4*>(da0 + (size_t)pu * p.da_pitch);
+            y[u] = ld_act4<Y16>(p.y, y0 + (size_t)pu * p.y_pitch);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (px + u * LANES >= p.npix) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = y[u][j] * sc[j] + sf[j];
+                const float dz = z >= 0.f ? da[u][j] : da[u][j] * slope;
+                if (z < 0.f) v[8] += da[u][j] * z;
+                v[j] += dz;
+                v[4 + j] += dz * z;
+                v[9 + j] += da[u][j];
+            }
         }
     }
     // lanes of a wave that share a quad sit QB apart
@@ -251,18 +262,27 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(NormBwdParams p) {
     }
     float amax = 0.f;
     float* const dy0 = p.dy + (size_t)img * p.npix * p.dy_pitch + 4 * quad;
-    for (int px = pl; px < p.npix; px += LANES) {
-        const f32x4 da = *reinterpret_cast<const f32x4*>(da0 + (size_t)px * p.da_pitch);
-        const f32x4 y = ld_act4<Y16>(p.y, y0 + (size_t)px * p.y_pitch);
-        f32x4 o;
+    for (int px = pl; px < p.npix; px += 4 * LANES) {
+        f32x4 da[4], y[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float z = y[j] * sc[j] + sf[j];
-            const float dz = z >= 0.f ? da[j] : da[j] * slope;
-            o[j] = sc[j] * (dz - m1[j] - z * m2[j]);
+        for (int u = 0; u < 4; ++u) {
+            const int pu = px + u * LANES < p.npix ? px + u * LANES : px;
+            da[u] = *reinterpret_cast<const f32x4*>(da0 + (size_t)pu * p.da_pitch);
+            y[u] = ld_act4<Y16>(p.y, y0 + (size_t)pu * p.y_pitch);
         }
-        *reinterpret_cast<f32x4*>(dy0 + (size_t)px * p.dy_pitch) = o;
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (px + u * LANES >= p.npix) continue;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = y[u][j] * sc[j] + sf[j];
+                const float dz = z >= 0.f ? da[u][j] : da[u][j] * slope;
+                o[j] = sc[j] * (dz - m1[j] - z * m2[j]);
+            }
+            *reinterpret_cast<f32x4*>(dy0 + (size_t)(px + u * LANES) * p.dy_pitch) = o;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
     }
     if (p.amax) amax_commit(p.amax, amax);           // (block-uniform branch)
 }
@@ -391,14 +411,19 @@ int launch_norm_bwd(hipStream_t s, const ConvSrc& y, const float* da, int da_pit
         // launches of the reference-width training step were a fifth of its time) - at least `min_elems` elements per thread
         if (!batch && npix <= NORM_BWD_FUSED_MAX_PIX) {
             // widest channel group that still gives the launch >= 128 blocks
-            const int qb = (c4n % 4 == 0 && (c4n / 4) * n >= 128) ? 4 : (c4n % 2 == 0 && (c4n / 2) * n >= 128) ? 2 : 1;
+            // (round 5, 32-base x 32: 8 quads per block 2.863 ms per bf16 step, 4: 2.900, 16: 2.903; MORE blocks of fewer quads lose - 2.93 / 3.10 /
+            // 3.27 ms at >= 512 / 1024 / 4096 blocks: a pixel's channels are contiguous, narrow groups waste the lines they touch)
+            const int qb = (c4n % 8 == 0 && (c4n / 8) * n >= 128) ? 8 :
+                           (c4n % 4 == 0 && (c4n / 4) * n >= 128) ? 4 : (c4n % 2 == 0 && (c4n / 2) * n >= 128) ? 2 : 1;
             const dim3 grid((unsigned)(c4n / qb), (unsigned)n);
             if (y.h16) {
-                if (qb == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<4, true>), grid, dim3(256), 0, s, p);
+                if (qb == 8) hipLaunchKernelGGL((norm_bwd_fused_kernel<8, true>), grid, dim3(256), 0, s, p);
+                else if (qb == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<4, true>), grid, dim3(256), 0, s, p);
                 else if (qb == 2) hipLaunchKernelGGL((norm_bwd_fused_kernel<2, true>), grid, dim3(256), 0, s, p);
                 else hipLaunchKernelGGL((norm_bwd_fused_kernel<1, true>), grid, dim3(256), 0, s, p);
             } else {
-                if (qb == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<4, false>), grid, dim3(256), 0, s, p);
+                if (qb == 8) hipLaunchKernelGGL((norm_bwd_fused_kernel<8, false>), grid, dim3(256), 0, s, p);
+                else if (qb == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<4, false>), grid, dim3(256), 0, s, p);
                 else if (qb == 2) hipLaunchKernelGGL((norm_bwd_fused_kernel<2, false>), grid, dim3(256), 0, s, p);
                 else hipLaunchKernelGGL((norm_bwd_fused_kernel<1, false>), grid, dim3(256), 0, s, p);
             }

@@ -142,3 +142,30 @@ def test_bf16_weight_gradients_with_the_A_operand_through_LDS_are_bitwise_the_re
         assert res[a]["loss"] == res[b]["loss"]
         for k, g in res[a]["grads"].items():
             assert torch.equal(g, res[b]["grads"][k]), (a, k, (g - res[b]["grads"][k]).abs().max().item())
+
+
+def test_bf16_training_of_a_batchnorm_net_on_the_bf16_tape_tracks_fp32():
+    """norm="batch" in the bf16 training mode: batch statistics, the x_hat table of the backward and the BatchNorm weight / bias gradients all
+    run on the bf16 tape's kernels too (norm_bwd_reduce / _apply<Y16> with the batch reduction)."""
+    import cellseg_amd as ca
+    dev = torch.device("cuda:0")
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(31)
+        m = ca.UNet(channels=(32, 64, 128), strides=(2, 2), num_res_units=2, norm="batch").to(dev).train()
+        m.precision = prec
+        g = torch.Generator().manual_seed(32)
+        x = torch.rand(6, 3, 96, 80, generator=g).to(dev)
+        y = ca.one_hot(torch.randint(0, 3, (6, 1, 96, 80), generator=g).to(dev), 3)
+        opt = torch.optim.AdamW(m.parameters(), 1e-3)
+        loss_fn = ca.DiceCELoss(softmax=True)
+        out = []
+        for _ in range(8):
+            opt.zero_grad()
+            loss = loss_fn(m(x), y)
+            loss.backward()
+            opt.step()
+            out.append(loss.item())
+        curves[prec] = out
+    assert curves["bf16"][-1] < curves["bf16"][0] - 0.05
+    assert max(abs(a - b) for a, b in zip(curves["fp32"], curves["bf16"])) <= 0.03, curves

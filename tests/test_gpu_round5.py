@@ -169,3 +169,29 @@ def test_bf16_training_of_a_batchnorm_net_on_the_bf16_tape_tracks_fp32():
         curves[prec] = out
     assert curves["bf16"][-1] < curves["bf16"][0] - 0.05
     assert max(abs(a - b) for a, b in zip(curves["fp32"], curves["bf16"])) <= 0.03, curves
+
+
+def test_bias_gradients_riding_on_the_norm_backward_equal_the_column_sum_passes(tmp_path):
+    """The residual branches' bias gradients are column sums of a tensor the next norm backward reads anyway (round 5: one more accumulator
+    in norm_bwd_reduce / _fused).  CS_FUSE_BIAS=0 runs the column-sum passes of rounds 1-4: every other gradient is bitwise the same, the
+    bias gradients agree to summation order (fp32 partial sums, fp64 totals), in fp32 and on the bf16 tape."""
+    from conftest import cli_env
+    script = tmp_path / "grads.py"
+    script.write_text(_GRAD_SCRIPT)
+    for prec in ("fp32", "bf16"):
+        res = {}
+        for tag, env in (("ride", {"CS_FUSE_BIAS": 1}), ("passes", {"CS_FUSE_BIAS": 0})):
+            out = tmp_path / f"{prec}_{tag}.pt"
+            cp = subprocess.run([sys.executable, str(script), prec, str(out)], capture_output=True, text=True, timeout=600, env=cli_env(**env))
+            assert cp.returncode == 0, cp.stderr[-2000:]
+            res[tag] = torch.load(out)
+        n_bias = 0
+        for k, g in res["ride"]["grads"].items():
+            h = res["passes"]["grads"][k]
+            if k.endswith("residual.bias"):
+                n_bias += 1
+                assert g.abs().max().item() > 0
+                assert torch.allclose(g, h, rtol=2e-5, atol=1e-6 * h.abs().max().item()), (prec, k, (g - h).abs().max().item())
+            else:
+                assert torch.equal(g, h), (prec, k)
+        assert n_bias == 5                                  # four strided encoder units + the bottom unit's 1x1 residual

@@ -1188,6 +1188,8 @@ def main():
                 tref = measure_train("reference16", with_prof=False, batch=8)
                 train_ref = {k: tref[k] for k in ("images_per_s", "ms_per_step", "eager_ms_per_step", "graph_ms_per_step", "graph_nodes", "tflops", "loss",
                                                   "per_gpu_batch", "width")}
+                tref16 = measure_train("reference16", with_prof=False, batch=8, precision="bf16", eager_too=False)      # the same step in the bf16 mode
+                train_ref["bf16"] = {k: tref16[k] for k in ("images_per_s", "ms_per_step", "tflops", "loss", "dtype")}
     else:
         train_res = measure_train(args.width, precision=args.precision if args.precision in ("fp32", "bf16", "fp16x3", "bf16x6") else "fp32")
 

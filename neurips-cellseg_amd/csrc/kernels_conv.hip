@@ -257,7 +257,10 @@ static int launch_conv_t(hipStream_t s, const ConvParams& p0) {
 // the input patch only, which lets four blocks share a CU.
 // block = 256 threads = 4 waves; block tile = TH rows x 16 columns x 16*WN channels.
 // ------------------------------------------------------------------------------------------------
-template <int S, int KS, int WN, int TH, int OCC, int NTW>
+// LAZY = false: both sources are raw tensors (the fused stride-2 pairs read a materialised ResidualUnit sum; data gradients read dy) -
+// no table fetch per chunk and no norm / PReLU / select arithmetic per staged element (on this part vector instructions are taken
+// from the fp32 MFMA stream: 16 per float4 x 5 float4 per thread and chunk)
+template <int S, int KS, int WN, int TH, int OCC, int NTW, bool LAZY = true>
 __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
     static_assert(KS >= 2, "the one-row-ahead weight ring needs at least two tap rows");
     constexpr int WM = 4 / WN, MT = TH / WM, TW = 16;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
         const bool from_a = ch < chunks_a;
         const SrcDev& src = from_a ? p.a : p.b;
         const int c0 = (from_a ? ch : ch - chunks_a) << 4;
-        lz.load(src, img, c0 + 4 * q, p.wpack);
+        if constexpr (LAZY) lz.load(src, img, c0 + 4 * q, p.wpack);
         const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + c0 + 4 * q;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) {
@@ -329,7 +332,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wreg_kernel(ConvParams p) {
         for (int it = 0; it < IN_ITERS; ++it) {
             const int pix = (tid >> 2) + 64 * it;
             if (IH * IW % 64 == 0 || pix < IH * IW) {
-                const f32x4 v = goff[it] >= 0 ? lz.apply(rin[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 v = rin[it];
+                if constexpr (LAZY) v = lz.apply(v);
+                if (goff[it] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(&in_s[pix * CS + 4 * q]) = v;
             }
         }
@@ -440,6 +445,9 @@ static int launch_conv_wreg(hipStream_t s, const ConvParams& p0) {
     p.tiles_x = ceil_div(p.wout, 16);
     p.tiles_y = ceil_div(p.hout, TH);
     dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
+    if (S == 2 && !p.a.tab && (p.b.c == 0 || !p.b.tab))          // raw sources (the stride-2 layers' usual case): no lazy-norm arithmetic
+        hipLaunchKernelGGL((conv_wreg_kernel<S, KS, WN, TH, OCC, NTW, false>), grid, dim3(256), 0, s, p);
+    else
     hipLaunchKernelGGL((conv_wreg_kernel<S, KS, WN, TH, OCC, NTW>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -977,8 +985,10 @@ int launch_conv_first16(hipStream_t s, const WindowSrc& src, int cin, const unsi
 // its chunks load both tensors and both tables and add the two activated values on the way into LDS.
 // RW: input rows per wave (block tile = 4 RW rows).  RW = 2 doubles the MFMAs behind every barrier pair and every B fragment read
 // (two rows x four phases x NT tiles = 128 accumulator registers at NT = 4: two blocks per CU instead of three).
-template <int NT, bool SUM2 = false, int RW = 1>
+// LAZY = false (raw sources only, as conv_wreg_kernel): no table fetch and no norm / PReLU arithmetic while staging
+template <int NT, bool SUM2 = false, int RW = 1, bool LAZY = true>
 __global__ __launch_bounds__(256, RW == 2 ? 2 : (SUM2 ? (NT == 4 ? 2 : 4) : (NT == 4 ? 3 : 2))) void convt_mfma_kernel(ConvParams p) {
+    static_assert(LAZY || !SUM2, "a sum source is two lazily normalised tensors");
     constexpr int TH = 4 * RW, TW = 16, IH = TH + 1, IW = TW + 1, CS = 24;
     constexpr int IN_ITERS = (IH * IW + 63) / 64;
     constexpr int W_ITERS = (9 * NT * 64 + 255) / 256;
@@ -1030,7 +1040,7 @@ __global__ __launch_bounds__(256, RW == 2 ? 2 : (SUM2 ? (NT == 4 ? 2 : 4) : (NT 
         const bool from_a = ch < chunks_a;
         const SrcDev& src = from_a ? p.a : p.b;
         const int c0 = (from_a ? ch : ch - chunks_a) << 4;
-        lz.load(src, img, c0 + 4 * q, p.wpack);
+        if constexpr (LAZY) lz.load(src, img, c0 + 4 * q, p.wpack);
         const float* base = src.ptr + (size_t)img * p.hin * p.win * src.pitch + c0 + 4 * q;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; ++it) {
@@ -1065,7 +1075,8 @@ __global__ __launch_bounds__(256, RW == 2 ? 2 : (SUM2 ? (NT == 4 ? 2 : 4) : (NT 
         for (int it = 0; it < IN_ITERS; ++it) {
             const int pix = (tid >> 2) + 64 * it;
             if (pix < IH * IW) {
-                f32x4 v = lz.apply(rin[it]);
+                f32x4 v = rin[it];
+                if constexpr (LAZY) v = lz.apply(v);
                 if constexpr (SUM2)
                     if (two) v += lz2.apply(rin2[it]);        // (a raw second tensor - no table - is added as it is)
                 if (goff[it] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1241,10 +1252,17 @@ int launch_convt_mfma(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const f
         CS_HIP(hipGetLastError());
         return CS_OK;
     }
+    const bool raw = !a.tab && (b.c == 0 || !b.tab);             // training: skip tensors, materialised sums, data gradients
     switch (nt) {
-        case 4: hipLaunchKernelGGL((convt_mfma_kernel<4>), grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((convt_mfma_kernel<2>), grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((convt_mfma_kernel<1>), grid, dim3(256), 0, s, p); break;
+        case 4: if (raw) hipLaunchKernelGGL((convt_mfma_kernel<4, false, 1, false>), grid, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((convt_mfma_kernel<4>), grid, dim3(256), 0, s, p);
+                break;
+        case 2: if (raw) hipLaunchKernelGGL((convt_mfma_kernel<2, false, 1, false>), grid, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((convt_mfma_kernel<2>), grid, dim3(256), 0, s, p);
+                break;
+        default: if (raw) hipLaunchKernelGGL((convt_mfma_kernel<1, false, 1, false>), grid, dim3(256), 0, s, p);
+                 else hipLaunchKernelGGL((convt_mfma_kernel<1>), grid, dim3(256), 0, s, p);
+                 break;
     }
     CS_HIP(hipGetLastError());
     return CS_OK;

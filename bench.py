@@ -1274,7 +1274,7 @@ def main():
         if args.precision == "fp32" and args.size == 4096:
             out["configs4_fp8"] = measure_configs4()
             try:          # ... and its accuracy claim at its OWN width and window: the 64...1024 net trained on synthetic cells, 512^2 windows
-                acc4 = lowprec_accuracy(dev, n_images=4, size=2048, precisions=("bf16", "fp8"), width="deep64", roi=512)
+                acc4 = lowprec_accuracy(dev, n_images=16, size=2048, precisions=("bf16", "fp8"), width="deep64", roi=512)      # ~31 000 cells: 1e-3 = 31 cells
                 out["configs4_fp8"]["accuracy_on_trained_net"] = acc4
             except Exception as e:                                  # noqa: BLE001
                 out["configs4_fp8"]["accuracy_on_trained_net"] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -318,14 +318,16 @@ def test_low_precision_modes_against_the_fp32_path_and_the_ground_truth():
 
 def test_configs4_accuracy_at_its_own_width_and_window():
     """BASELINE.json configs[4] names a 64-base U-Net on 512 x 512 windows with fp8 weights: the accuracy claim is made THERE - the
-    64...1024 net trained on synthetic cells (150 AdamW steps, fp32 engine), four held-out 2048^2 images segmented with 512^2 windows in
-    fp32, on the bf16 datapath and in the mixed fp8 mode; instance F1@0.5 against the ground truth (compute_metric.py:107-122 semantics)
-    within 1e-3 of the fp32 path's, north_star's bound."""
+    64...1024 net trained on synthetic cells (150 AdamW steps, fp32 engine), SIXTEEN held-out 2048^2 images (~31 000 cells) segmented with
+    512^2 windows in fp32, on the bf16 datapath and in the mixed fp8 mode; instance F1@0.5 against the ground truth
+    (compute_metric.py:107-122 semantics) within 1e-3 of the fp32 path's, north_star's bound.  (Round 5: with four images - 7 700 cells, 1e-3 =
+    8 cells - the figure is dominated by the sample and by WHICH net the 150 steps produce: -1.3e-3 / -0.7e-3 on four images, -0.9e-3 /
+    -0.8e-3 on sixteen with the net of the round's end, +0.7e-3 / -0.7e-3 with the net of its start; profiles/configs4_accuracy_vs_sample_r05.txt.)"""
     sys.path[:0] = [ROOT, PKG]
     from bench import lowprec_accuracy
-    res = lowprec_accuracy(_dev(), n_images=4, size=2048, precisions=("bf16", "fp8"), width="deep64", roi=512)
+    res = lowprec_accuracy(_dev(), n_images=16, size=2048, precisions=("bf16", "fp8"), width="deep64", roi=512)
     assert res["trained_net"]["channels"] == [64, 128, 256, 512, 1024] and res["trained_net"]["window"] == 512
-    assert res["trained_net"]["cells_found_fp32"] > 3000 and res["trained_net"]["f1_vs_truth_fp32"] > 0.6, res["trained_net"]
+    assert res["trained_net"]["cells_found_fp32"] > 12000 and res["trained_net"]["f1_vs_truth_fp32"] > 0.6, res["trained_net"]
     for prec in ("bf16", "fp8"):
         assert res[prec]["f1_vs_fp32"] >= 0.995 and res[prec]["pixel_agreement"] >= 0.998, (prec, res[prec])
         assert abs(res[prec]["delta_f1_vs_truth"]) <= 1e-3, (prec, res[prec])

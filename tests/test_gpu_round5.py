@@ -195,3 +195,27 @@ def test_bias_gradients_riding_on_the_norm_backward_equal_the_column_sum_passes(
             else:
                 assert torch.equal(g, h), (prec, k)
         assert n_bias == 5                                  # four strided encoder units + the bottom unit's 1x1 residual
+
+
+def test_bf16_training_forward_equals_the_bf16_inference_datapath():
+    """With the bf16 tape the TRAINING forward of the bf16 mode runs the bf16 datapath too - without the inference-only fusions (decoder sums
+    and the first unit's shortcut are materialised: the tape needs them).  InstanceNorm nets compute the same function in both modes, and the
+    inference datapath is the one held to the per-layer oracle (test_gpu_layers.py): the two sets of logits agree to the bf16 level of one
+    materialised-vs-fused sum (a few 1e-3 of the logit scale), far inside the 0.5 the low-precision modes are allowed against fp32."""
+    import cellseg_amd as ca
+    dev = torch.device("cuda:0")
+    torch.manual_seed(41)
+    m = ca.UNet(channels=(32, 64, 128, 256, 512), strides=(2, 2, 2, 2), num_res_units=2).to(dev)
+    m.precision = "bf16"
+    x = torch.rand(3, 3, 160, 96, generator=torch.Generator().manual_seed(42)).to(dev)
+    with torch.no_grad():
+        m.eval()
+        a = m(x).clone()
+        m.train()
+        b = m(x).clone()
+        m.precision = "fp32"
+        m.eval()
+        ref = m(x).clone()
+    scale = ref.abs().max().item()
+    assert (a - b).abs().max().item() <= 0.02 * scale, ((a - b).abs().max().item(), scale)
+    assert (b - ref).abs().max().item() <= 0.12 * scale + 0.05          # the bf16 modes' budget against fp32 (tests/test_gpu_round2.py)

@@ -457,7 +457,7 @@ class StripsGuard:
             self.done = True
 
 
-def live_pmc_traffic(group_name, timeout_s=300):
+def live_pmc_traffic(group_name, timeout_s=120):
     """HBM bytes per launch of one kernel group, MEASURED by this run: two child passes of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
     (counter passes on their own, no tracing flags, the program itself behind `--`) around ONE slide of the default command on one stream,
     corrected as MI355X_MICROARCH.md's HBM section prescribes for gfx950 (FETCH_SIZE / WRITE_SIZE count KiB; FETCH_SIZE reports half the

@@ -50,6 +50,9 @@ def main(argv=None):
                         "(cellseg_amd.gpu_data, csrc/kernels_augment.hip) instead of in DataLoader workers")
     parser.add_argument("--eager", action="store_true", help="run the training step through autograd as the reference writes it instead of "
                                                               "cellseg_amd.TrainStep (the same launches on static buffers)")
+    parser.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3", "bf16"],
+                        help="matrix-core arithmetic of the training step (engine option; fp32 = the reference's arithmetic, fp16x3 = fp32-grade "
+                             "split fp16, bf16 = bf16 convolutions / gradients / activations on the tape with fp32 master weights)")
     parser.add_argument("--graph", action="store_true", help="replay the training step as a captured hipGraph (cellseg_amd.TrainStep(capture=True))")
     args = parser.parse_args(argv)
     if args.model_name.lower() != "unet" or args.num_class != 3:
@@ -131,6 +134,7 @@ def main(argv=None):
 
     model = ca.UNet(spatial_dims=2, in_channels=3, out_channels=args.num_class, channels=(16, 32, 64, 128, 256),
                     strides=(2, 2, 2, 2), num_res_units=2).to(device)
+    model.precision = args.precision
     loss_function = ca.DiceCELoss(softmax=True)
     optimizer = ca.AdamW(model, args.initial_lr)      # torch.optim.AdamW's update rule and state_dict layout, one HIP launch per step
     train_step = None if args.eager else ca.TrainStep(model, loss_function, optimizer, capture=args.graph)

@@ -219,3 +219,21 @@ def test_bf16_training_forward_equals_the_bf16_inference_datapath():
     scale = ref.abs().max().item()
     assert (a - b).abs().max().item() <= 0.02 * scale, ((a - b).abs().max().item(), scale)
     assert (b - ref).abs().max().item() <= 0.12 * scale + 0.05          # the bf16 modes' budget against fp32 (tests/test_gpu_round2.py)
+
+
+def test_training_cli_in_the_bf16_mode_learns_like_the_fp32_run(tmp_path):
+    """`model_training_3class --precision bf16` (engine option; configs[1]'s arithmetic with the bf16 tape) end to end: the synthetic run trains,
+    validates with sliding-window inference on the same bf16 datapath, checkpoints, and ends within a few points of the fp32 run's Dice."""
+    import re
+    from conftest import run_module
+    dice = {}
+    for prec in ("fp32", "bf16"):
+        work = tmp_path / prec
+        out = run_module("cellseg_amd.model_training_3class", "--synthetic", "24", "--max_epochs", "6", "--val_start_epoch", "1", "--val_interval", "1",
+                         "--batch_size", "8", "--num_workers", "2", "--work_dir", str(work), "--precision", prec)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert os.path.exists(os.path.join(work, "unet_3class", "best_Dice_model.pth"))
+        vals = [float(v) for v in re.findall(r"current mean dice: ([0-9.]+)", out.stdout)]
+        assert len(vals) >= 3, out.stdout[-1500:]
+        dice[prec] = max(vals)
+    assert dice["bf16"] > 0.3 and abs(dice["bf16"] - dice["fp32"]) <= 0.08, dice

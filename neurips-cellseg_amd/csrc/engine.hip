@@ -582,6 +582,13 @@ static int dgrad_s1(hipStream_t s, const ConvW& cw, const float* dy, int c_dy, f
         if (rc_ != CS_OK) return rc_; \
     } while (0)
 
+// bf16 activations in HBM?  The plain-bf16 and fp8 inference modes, and - round 5 - training in the bf16 mode (the tape then holds bf16
+// tensors; CS_TAPE16=0 keeps the fp32 tape of rounds 2-4).  One predicate for the forward, its sizing pass and the pixel-record format.
+static bool act16_mode(const cs_unet* net) {
+    static const bool tape16_env = !(getenv("CS_TAPE16") && atoi(getenv("CS_TAPE16")) == 0);
+    return (net->planes == 1 || net->planes == 5) && (!net->training || (net->planes == 1 && tape16_env));
+}
+
 // Runs (or, with a dry Bump, only sizes) the forward.  Output: logits NHWC [n, h, w, out_ch].
 static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, int h, int w, float* logits, Bump& ws, hipStream_t s,
                              Tape* tape = nullptr) {
@@ -595,8 +602,7 @@ static int unet_forward_impl(const cs_unet* net, const WindowSrc& src, int n, in
     // the traffic of every HBM-bound kernel and of the conv inputs / outputs.  Training in the bf16 mode (BASELINE configs[1]) records
     // the same bf16 tensors on the tape (round 5: the norm-backward and weight-gradient kernels read bf16 activations; CS_TAPE16=0 keeps
     // the fp32 tape of rounds 2-4); the fp16x3 / fp32 training modes keep fp32 activations.
-    static const bool tape16_env = !(getenv("CS_TAPE16") && atoi(getenv("CS_TAPE16")) == 0);
-    const bool a16 = (net->planes == 1 || net->planes == 5) && (!net->training || (net->planes == 1 && tape16_env));
+    const bool a16 = act16_mode(net);
     CS_REQUIRE(!(net->planes == 5 && net->training), "unet: the fp8 mode is an inference mode (cs_unet_set_training(0))");
     auto take_act = [&](size_t count) -> float* {
         return a16 ? reinterpret_cast<float*>(ws.take<unsigned short>(count)) : ws.take<float>(count);
@@ -1599,7 +1605,7 @@ int cs_unet_forward(cs_unet* net, const float* x, int64_t sn, int64_t sc, int64_
     // inference: the batch once more as (r, g, b, 0) pixel records - the first layer then runs on the record kernels of kernels_first.hip and
     // the first unit's shortcut is recomputed by its sum launch (as in the window pass, swi_run_windows)
     if (!net->training && cs::first_rec_enabled() && net->in_ch == 3 && (int64_t)n * h * w < ((int64_t)1 << 31) && h < 65536 && n < 65536) {   // grid y / z limits of the record kernel
-        const bool rec16 = net->planes == 1 || net->planes == 5;                 // unet_forward_impl's bf16 datapath
+        const bool rec16 = act16_mode(net);                                      // unet_forward_impl's bf16 datapath
         void* rec = b.take<char>((size_t)n * h * w * 16);
         if (!b.ok()) { set_error("unet_forward: workspace too small"); return CS_ERR_WORKSPACE; }
         if (int rc0 = cs::launch_image_records((hipStream_t)stream, x, sn, sc, sh, sw, n, h, w, rec, rec16)) return rc0;
@@ -1778,10 +1784,16 @@ static int swi_run_windows(cs_unet* net, const cs_swi_plan* pl, const float* ima
     src.img_h = pl->img_h; src.img_w = pl->img_w; src.roi_h = pl->roi_h; src.roi_w = pl->roi_w;
     // the image once more as (r, g, b, 0) pixel records: every window's first layer gathers its patches from these (kernels_first.hip)
     if (cs::first_rec_enabled() && net->in_ch == 3 && (int64_t)pl->img_h * pl->img_w < ((int64_t)1 << 31) && pl->img_h < 65536) {   // taller images keep the planar path
-        const bool rec16 = (net->planes == 1 || net->planes == 5) && !net->training;       // unet_forward_impl's bf16 datapath
+        const bool rec16 = act16_mode(net);                                        // unet_forward_impl's bf16 datapath
         void* rec = b.take<char>((size_t)pl->img_h * pl->img_w * 16);
         if (!b.ok()) { cs::set_error("swi: workspace too small"); return CS_ERR_WORKSPACE; }
-        if (int rc0 = cs::launch_image_records(s, image, 0, sc, sh, sw, 1, pl->img_h, pl->img_w, rec, rec16)) return rc0;
+        // only the image rows the windows [k_lo, k_hi) read (a rank's share of a slide: an eighth of the rows + a window's height)
+        const int i_lo = k_lo / pl->n_w, i_hi = (k_hi - 1) / pl->n_w;
+        int r0 = cs_swi_window_start(i_lo, pl->interval_h, pl->pad_h, pl->roi_h) - pl->pad_top;
+        int r1 = cs_swi_window_start(i_hi, pl->interval_h, pl->pad_h, pl->roi_h) - pl->pad_top + pl->roi_h;
+        r0 = r0 < 0 ? 0 : (r0 > pl->img_h ? pl->img_h : r0);
+        r1 = r1 > pl->img_h ? pl->img_h : (r1 < r0 ? r0 : r1);
+        if (int rc0 = cs::launch_image_records(s, image, 0, sc, sh, sw, 1, pl->img_h, pl->img_w, rec, rec16, r0, r1)) return rc0;
         src.rec = rec;
         src.rec16 = rec16;
     }

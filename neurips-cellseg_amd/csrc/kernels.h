@@ -161,8 +161,9 @@ int launch_conv_first(hipStream_t s, int stride, const WindowSrc& src, int cin, 
                       const ConvSrc* add = nullptr);           // out = conv + bias + act(norm(*add)): the ResidualUnit's sum, fp32
 // first layer from pixel records (kernels_first.hip; inference): wave-private tiles walked along the row, no block barrier; fp32 or,
 // with src.rec16, the bf16 datapath (bf16 out); `add`: out = conv + bias + act(norm(*add)) in the datapath's own format
+// rows [row_begin, row_end) only (row_end < 0: all): a rank that runs a share of a slide's windows converts the rows they read
 int launch_image_records(hipStream_t s, const float* image, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n, int h, int w, void* rec,
-                         bool as16);
+                         bool as16, int row_begin = 0, int row_end = -1);
 bool first_rec_enabled();
 int launch_conv_first_rec(hipStream_t s, const WindowSrc& src, const float* wpack, const float* bias, void* out, int pitch_out, int cout,
                           double* stats, int n, int stats_c = 0, int cout_pack = 0, int cout_off = 0, const ConvSrc* add = nullptr);

@@ -70,11 +70,11 @@ struct RecGeom {
 // planar (strided) fp32 image -> (r, g, b, 0) records; AS16: bf16 (round to nearest even, as the staging of conv_first16_kernel did)
 template <bool AS16>
 __global__ __launch_bounds__(256) void image_records_kernel(const float* image, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int h, int w,
-                                                            void* rec) {
+                                                            void* rec, int row_begin) {
     // a thread converts 8 pixels of one row, 256 apart (one pixel per thread - 262 k waves of four instructions for a 4096^2 slide - ran
     // at 1 TB/s: wave launches, not bytes, set its pace)
     constexpr int PER = 8;
-    const int x0 = blockIdx.x * (256 * PER) + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+    const int x0 = blockIdx.x * (256 * PER) + threadIdx.x, y = row_begin + blockIdx.y, img = blockIdx.z;      // rows [row_begin, row_begin + gridDim.y)
     const float* const row = image + img * sn + (int64_t)y * sh;
     const int64_t i0 = ((int64_t)img * h + y) * w;
     f32x4 v[PER];
@@ -95,12 +95,16 @@ __global__ __launch_bounds__(256) void image_records_kernel(const float* image, 
 }
 
 int launch_image_records(hipStream_t s, const float* image, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n, int h, int w, void* rec,
-                         bool as16) {
+                         bool as16, int row_begin, int row_end) {
     CS_REQUIRE(image && rec && n > 0 && h > 0 && w > 0 && h < 65536 && n < 65536, "image records: bad argument");
-    const dim3 grid((unsigned)ceil_div(w, 256 * 8), (unsigned)h, (unsigned)n);
-    ProfScope prof(K_CONV_FIRST, s, 0.0, (double)n * h * w * (12.0 + (as16 ? 8.0 : 16.0)));
-    if (as16) hipLaunchKernelGGL(image_records_kernel<true>, grid, dim3(256), 0, s, image, sn, sc, sh, sw, h, w, rec);
-    else hipLaunchKernelGGL(image_records_kernel<false>, grid, dim3(256), 0, s, image, sn, sc, sh, sw, h, w, rec);
+    if (row_end < 0) row_end = h;                                // (default: every row)
+    CS_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= h, "image records: rows [%d, %d) of %d", row_begin, row_end, h);
+    if (row_begin == row_end) return CS_OK;
+    const int rows = row_end - row_begin;                        // the record buffer keeps the full image's layout: only these rows are written
+    const dim3 grid((unsigned)ceil_div(w, 256 * 8), (unsigned)rows, (unsigned)n);
+    ProfScope prof(K_CONV_FIRST, s, 0.0, (double)n * rows * w * (12.0 + (as16 ? 8.0 : 16.0)));
+    if (as16) hipLaunchKernelGGL(image_records_kernel<true>, grid, dim3(256), 0, s, image, sn, sc, sh, sw, h, w, rec, row_begin);
+    else hipLaunchKernelGGL(image_records_kernel<false>, grid, dim3(256), 0, s, image, sn, sc, sh, sw, h, w, rec, row_begin);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

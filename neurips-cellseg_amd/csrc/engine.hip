@@ -132,7 +132,7 @@ struct ConvW {             // packed weights + bias of one (possibly fused) conv
     float* wd = nullptr;   // the same weights packed for the DATA-GRADIENT launch (see kernels_bwd.hip header)
     float* ww = nullptr;   // 3x3 stride-1 layers: Winograd F(2x2,3x3) weights G g G^T in fragment order (kernels_conv_wino.hip)
     float* wwd = nullptr;  // ... and those of the layer's DATA-GRADIENT convolution (channel roles swapped, taps reversed)
-    float* ww4 = nullptr;  // 3x3 stride-1 layers with >= WINO4_MIN_CIN input channels: Winograd F(4x4,3x3) weights (kernels_conv_wino4.hip).
+    float* ww4 = nullptr;  // 3x3 stride-1 layers with >= WINO4_MIN_CIN input channels: Winograd F(4x4,3x3) weights (kernels_conv_wino4x.hip).
                            // INFERENCE only: a training step re-packs every weight, and packing 36 positions in fp64 costs more there
                            // (0.25 ms per step) than the kernel saves on training-sized launches - loads in training mode leave them stale
     bool ww4_fresh = false; // the F(4x4) weights correspond to the parameter's current value (else the F(2x2) kernel runs)

@@ -59,7 +59,7 @@ size_t packed_conv_floats(int cout_total, int cin_total, int ksize);
 // (cout = the forward conv's cin and vice versa, taps reversed).
 size_t packed_wino_floats(int cout_total, int cin_total);
 int pack_wino_weights(PackCtx* pc, hipStream_t s, const float* w, bool dgrad, int cout, int cin, float* packed);
-// Winograd F(4x4, 3x3) (kernels_conv_wino4.hip): the wide (>= 128 input channels) 3x3 stride-1 layers of the fp32 path, forward only;
+// Winograd F(4x4, 3x3) (kernels_conv_wino4x.hip): the wide (>= 128 input channels) 3x3 stride-1 layers of the fp32 path, forward only;
 // packed[cin/16][36 positions][cout/16][64 lanes][4]
 struct ConvOutExtra;
 constexpr int SMALL_GRID_BLOCKS = 256;   // launches with fewer blocks than CUs take narrower channel blocks (same kernels, more blocks)
@@ -71,7 +71,7 @@ bool wino4_fits(int cin, int cout, int h, int w);
 // layers with cin % 32 == 0 and cout % 32 == 0 take the 32x32x2-MFMA form (kernels_conv_wino4x.hip): its weight
 // fragments are packed[cin/16][36 positions][cout/32][2][64 lanes][4] (same size, other order) - pack and launch ask this predicate
 bool wino4_layout32(int cin, int cout);
-int wino4_form(int cin, int cout);     // 0: kernels_conv_wino4.hip; 1 / 2 / 3: the 64-channel, 32-channel and register-epilogue kernels of kernels_conv_wino4x.hip
+int wino4_form(int cin, int cout);     // 0: none; 1 / 2 / 3: the 64-channel, 32-channel and register-epilogue kernels of kernels_conv_wino4x.hip
 int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4x, const float* bias, float* out, int pitch_out, int cout,
                        double* stats, int n, int h, int w, const ConvOutExtra* ex = nullptr);
 int launch_conv_wino4(hipStream_t s, const ConvSrc& a, const float* wpack_wino4, const float* bias, float* out, int pitch_out, int cout,

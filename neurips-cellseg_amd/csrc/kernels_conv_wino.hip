@@ -578,7 +578,7 @@ static const int g_wino_init = [] {
 }();
 bool wino_enabled() { return g_wino != 0; }
 int wino_level() { return g_wino; }
-// which F(4x4) kernel a layer takes: 0 = kernels_conv_wino4.hip (16x16x4 MFMAs, a wave owns positions: the general form, channel counts that are
+// which F(4x4) kernel a layer takes: 0 = none (was the round-3 kernel: 16x16x4 MFMAs, a wave owns positions: the general form, channel counts that are
 // not multiples of 32), 1 / 2 = the 32x32x2 forms of kernels_conv_wino4x.hip (64- / 32-channel blocks), 3 = its 16x16x4 form with the output
 // transform in registers for the short K loops (cin <= 128: measured per layer, DESIGN 3.1a''; beyond, its half-size blocks are 4-6 % faster per
 // launch too, but the slide loses what the window pass's two streams overlap: 35.3 vs 34.4 ms)

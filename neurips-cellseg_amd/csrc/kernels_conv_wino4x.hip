@@ -1,8 +1,8 @@
 // gfx950 (MI355X): Winograd F(4x4, 3x3) for the 3x3 stride-1 layers with >= 64 output channels, on the 32x32 fp32 matrix instruction.
 //
-// Same arithmetic as kernels_conv_wino4.hip (Y = A^T [ (G g G^T) . (B^T d B) ] A, 6 x 6 patch per 4 x 4 output tile, weights transformed
+// Winograd arithmetic (Y = A^T [ (G g G^T) . (B^T d B) ] A, 6 x 6 patch per 4 x 4 output tile, weights transformed
 // in fp64 and rounded once, everything else fp32) and the same reference call sites (the stride-1 conv2d dispatches of
-// baseline/predict.py:109 -> :45-52).  What changes is the shape of the 36 point-wise GEMMs: kernels_conv_wino4.hip contracts 16 tiles
+// baseline/predict.py:109 -> :45-52).  What changes against the removed round-3 kernel is the shape of the 36 point-wise GEMMs: that one contracted 16 tiles
 // x 16 channels per v_mfma_f32_16x16x4_f32, so every MFMA consumes a fresh 256-byte weight fragment - a fifth of that kernel's time
 // was the fragment stream through the vector L1 (DESIGN 3.1a').  Here a block owns TWO 16 x 16-pixel sub-tiles (32 Winograd tiles = the
 // M of v_mfma_f32_32x32x2_f32) and 64 output channels (two N tiles of 32): a 256-byte fragment feeds twice the multiply-adds, the
@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 
 constexpr int X_IH = 18, X_IW = 18;
-constexpr int X_PS = 20;                               // floats per staged raw pixel (16 + 4: see kernels_conv_wino4.hip)
+constexpr int X_PS = 20;                               // floats per staged raw pixel (16 + 4: bank spread of the 80-byte pixel stride)
 constexpr int X_RAW1 = X_IH * X_IW * X_PS;             // 6480 floats per sub-tile
 constexpr int X_RAW = 2 * X_RAW1;                      // 12960
 constexpr int X_V = 36 * 2 * 2 * 32 * 4;               // 18432
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256 * NSUB, 2) void conv_wino4y_kernel(ConvParams p
 
     // wave w: channel tile nt0 + (w & 3) (16 channels) x tile half w >> 2 (= sub-tile) x ALL 36 positions: 144 accumulator registers whose C
     // layout puts every position of (tile 4 g + r, channel pl) into one lane - the output transform needs no exchange.
-    // B fragments: packed[chunk][position 36][cout / 16][64 lanes][4] (the order of kernels_conv_wino4.hip), buffer loads as in the kernel above
+    // B fragments: packed[chunk][position 36][cout / 16][64 lanes][4] (the order of packed_wino4_floats), buffer loads as in the kernel above
     const int th = wave >> 2, ntw = wave & 3;
     const int pl = lane & 15, g = lane >> 4;
     const unsigned wpos = (unsigned)p.ntile_total * 64u * 16u;        // bytes between positions
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256 * NSUB, 2) void conv_wino4y_kernel(ConvParams p
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The 32-output-channel form (the 32 -> 32 layers at 128 x 128: K = 2 sixteen-channel chunks).  kernels_conv_wino4.hip's block for
+// The 32-output-channel form (the 32 -> 32 layers at 128 x 128: K = 2 sixteen-channel chunks).  The round-3 kernel's block for
 // them (16 tiles x 32 channels) lives 11 us for 2 us of matrix work: first patch's round trip, two stagings, exchange, output
 // transform, store tail.  Here a block is 256 threads = 4 waves, TWO sub-tiles (32 tiles = the M of the 32x32x2 instruction) x 32 output
 // channels (ONE N tile): wave w owns positions 9 w ... 9 w + 8, 144 accumulator registers, half the MFMA instructions and weight
@@ -942,7 +942,7 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
     CS_HIP(hipGetDevice(&dev));
     CS_REQUIRE(dev >= 0 && dev < 64, "conv(winograd 4x4, 32x32): device index %d out of range", dev);
     const int form = wino4_form(a.c, cout);
-    CS_REQUIRE(form != 0, "conv(winograd 4x4, 32x32): the layer %d -> %d belongs to kernels_conv_wino4.hip", a.c, cout);
+    CS_REQUIRE(form != 0, "conv(winograd 4x4, 32x32): the layer %d -> %d has no F(4x4) form", a.c, cout);
     const bool wide = form != 2;               // 64-channel blocks of 512 threads; else the 32-channel form (256 threads, two blocks per CU)
     const size_t lds = wide ? X_LDS_BYTES : Z_LDS_BYTES;
     const dim3 grid(wide ? xcd_grid((n_spatial + 1) / 2, p.ntile_total / 4) : xcd_grid((n_spatial + 1) / 2, p.ntile_total / 2));
@@ -985,6 +985,23 @@ int launch_conv_wino4x(hipStream_t s, const ConvSrc& a, const float* wpack_wino4
     }
     CS_HIP(hipGetLastError());
     return CS_OK;
+}
+
+// ---- what decides whether a layer takes the F(4x4) form (was kernels_conv_wino4.hip until round 6) ----
+// An inference packing exists (engine.hip: ww4_fresh), >= 32 input channels, channel counts in multiples of 32, and a map of at least
+// ONE full 16 x 16 sub-tile: on smaller maps most of a block's 16 Winograd tiles are padding, and behind an InstanceNorm over a handful
+// of pixels the form's rounding is amplified (a 32 x 32 window on the 5-level net, 2 x 2 pixels at the bottom, came out 1.3e-4 from the
+// oracle in the round-5 randomised sweep); such layers run on the F(2x2) kernel.  Precision of the form: logits land 2.1e-5 ... 3.8e-5
+// from an fp64 evaluation on random data (direct fp32: 5e-6 ... 8e-6; tests/diagnostics/winograd_f4_precision.py), and
+// tests/test_gpu_blank_windows.py holds the margins on blank / constant / sparse windows.
+size_t packed_wino4_floats(int cout_total, int cin_total) { return (size_t)(cin_total / 16) * 36 * (cout_total / 16) * 256; }
+
+bool wino4_fits(int cin, int cout, int h, int w) { return cin >= WINO4_MIN_CIN && cin % 32 == 0 && cout % 32 == 0 && h >= 16 && w >= 16; }
+
+int launch_conv_wino4(hipStream_t s, const ConvSrc& a, const float* wpack_wino4, const float* bias, float* out, int pitch_out, int cout,
+                      double* stats, int n, int h, int w, const ConvOutExtra* ex) {
+    CS_REQUIRE(wino4_form(a.c, cout) != 0, "conv(winograd 4x4): channels (%d -> %d) have no F(4x4) kernel (wino4_fits)", a.c, cout);
+    return launch_conv_wino4x(s, a, wpack_wino4, bias, out, pitch_out, cout, stats, n, h, w, ex);
 }
 
 }  // namespace cs

@@ -178,7 +178,7 @@ __device__ __forceinline__ void pack_wino_elem(const PackJob& jb, int64_t e) {
 }
 
 // Winograd F(4x4, 3x3) weights U = G g G^T (6 x 6 positions, fp64, rounded once) in fp32 MFMA fragment order:
-//   jb.f16 == 0 (kernels_conv_wino4.hip, 16x16x4): packed[chunk][position xi*6+nu][ntile_total][lane][j],
+//   jb.f16 == 0 (16x16x4 form of kernels_conv_wino4x.hip): packed[chunk][position xi*6+nu][ntile_total][lane][j],
 //                cout = ntile*16 + (lane & 15), cin = chunk*16 + 4*(lane>>4) + j;
 //   jb.f16 == 1 (kernels_conv_wino4x.hip, 32x32x2): packed[chunk][position][cout/32][u 2][lane][j],
 //                cout = nt32*32 + (lane & 31), cin = chunk*16 + 2*(4u + j) + (lane>>5)  (k-step 4u + j of the chunk).

@@ -151,6 +151,8 @@ def swi_infer_strip(model: UNet, image: torch.Tensor, roi_size, overlap: float, 
     prob = torch.empty((h, w), dtype=torch.float32, device=dev) if want_prob else None
     mask = torch.empty((h, w), dtype=torch.uint8, device=dev) if want_mask else None
     if st.win_row_end == st.win_row_begin:
+        if exchange is not None:        # fewer window rows than ranks: still enter the (possibly collective) seam exchange, see swi_infer_share
+            exchange(torch.empty((0, plan.n_w, plan.roi_h, plan.roi_w, model.out_channels), dtype=torch.float32, device=dev), plan, rank, world)
         return st, logits, prob, mask
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()   # noqa: E731
     with torch.cuda.device(dev):
@@ -204,6 +206,10 @@ def swi_infer_share(model: UNet, image: torch.Tensor, roi_size, overlap: float, 
     prob = torch.empty((h, w), dtype=torch.float32, device=dev) if want_prob else None
     mask = torch.empty((h, w), dtype=torch.uint8, device=dev) if want_mask else None
     if sh.win_end == sh.win_begin:
+        # fewer windows than ranks: this rank holds nothing, but the seam exchange may be ONE collective every rank has to enter
+        # (transport="allgather"), so it still takes part - with a zero-slot tensor - before it returns
+        if exchange is not None:
+            exchange(torch.empty((0, plan.roi_h, plan.roi_w, model.out_channels), dtype=torch.float32, device=dev), plan, rank, world)
         return sh, logits, prob, mask
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()   # noqa: E731
     with torch.cuda.device(dev):

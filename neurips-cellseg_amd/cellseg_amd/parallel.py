@@ -113,6 +113,20 @@ def p2p_selfcheck(device, group=None) -> bool:
     return bool(flag.item())
 
 
+def all_ok(ok: bool, device, group=None) -> bool:
+    """True when EVERY rank reports ok (one all-reduce MIN of a flag).  ``predict --split_slides`` calls it once per image before the first
+    data-path collective: a rank that could not read or prepare an image makes all ranks skip it together instead of leaving its peers
+    inside the seam exchange until the process-group timeout."""
+    import torch.distributed as dist
+    if not _collectives_on(group):
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    bounce = _host_bounce(flag, group)
+    flag = flag.cpu() if bounce else flag
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
 def exchange_seam(win: torch.Tensor, plan, rank: int, world: int, group=None, transport: str = "p2p") -> int:
     """Seam exchange of the window-row partition ("exchange seam partial sums with one neighbour send/recv").
     win: this rank's window logits [(win_row_end - halo_begin), n_w, roi_h, roi_w, C] with its own rows behind the halo slots

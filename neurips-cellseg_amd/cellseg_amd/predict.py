@@ -79,7 +79,10 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get("CELLSEG_PG_TIMEOUT_S", "600"))), **kw)
-        transport = "p2p" if parallel.p2p_selfcheck(device) else "allgather"      # a library whose send/recv fails: one all-gather instead
+        # a library whose send/recv fails: one all-gather instead (CELLSEG_SEAM_TRANSPORT forces either, for tests)
+        transport = os.environ.get("CELLSEG_SEAM_TRANSPORT") or ("p2p" if parallel.p2p_selfcheck(device) else "allgather")
+        if transport not in ("p2p", "allgather"):
+            raise SystemExit(f"CELLSEG_SEAM_TRANSPORT: {transport!r} is neither 'p2p' nor 'allgather'")
 
     os.makedirs(args.output_path, exist_ok=True)
     img_names = preprocess.list_images(args.input_path)
@@ -131,16 +134,21 @@ def main(argv=None):
             img_name = img_names[k]
             got = nxt.result()
             nxt = reader.submit(read, todo[pos + 1]) if pos + 1 < len(todo) else None
+            why = None
             if isinstance(got, Exception):
-                say(f"Prediction FAILED: {img_name}: {got}")
+                why = str(got)
+            elif got[0].ndim not in (2, 3) or (got[0].ndim == 3 and got[0].shape[-1] < 3):
+                why = f"unsupported image shape {got[0].shape} ({got[0].dtype})"
+            # split slides: the ranks agree on the image's status BEFORE the first data-path collective (a read error on one rank only
+            # would otherwise leave its peers inside the seam exchange until the process-group timeout)
+            if split and not parallel.all_ok(why is None, device) and why is None:
+                why = "another rank could not read or prepare this image"
+            if why is not None:
+                say(f"Prediction FAILED: {img_name}: {why}")
                 failed.append(img_name)
                 continue
             img_data, staged = got
             t0 = time.time()
-            if img_data.ndim not in (2, 3) or (img_data.ndim == 3 and img_data.shape[-1] < 3):
-                say(f"Prediction FAILED: {img_name}: unsupported image shape {img_data.shape} ({img_data.dtype})")
-                failed.append(img_name)
-                continue
             if img_data.dtype in (np.uint8, np.uint16):
                 # integer images: percentile normalisation on the device (bit-exact with the host path below)
                 x = preprocess.normalize_image_gpu(staged.to(device, non_blocking=True))      # [H,W,3] float32

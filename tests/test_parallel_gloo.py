@@ -291,9 +291,15 @@ def _share_worker(rank, world, port, h, w, overlap, q, transport):
         me = ca.share_partition(plan, rank, world)
         base = me.slot_row_begin * plan.n_w
         n_slots = (me.slot_row_end - me.slot_row_begin) * plan.n_w
-        win = torch.full((max(n_slots, 1), roi, roi, 3), float("nan"))
-        win[me.win_begin - base:me.win_end - base] = every[me.win_begin:me.win_end]
+        if me.win_end == me.win_begin:
+            win = torch.empty((0, roi, roi, 3))          # fewer windows than ranks: what inferers.swi_infer_share enters the exchange with
+        else:
+            win = torch.full((max(n_slots, 1), roi, roi, 3), float("nan"))
+            win[me.win_begin - base:me.win_end - base] = every[me.win_begin:me.win_end]
         n = parallel.exchange_share(win, plan, rank, world, transport=transport)
+        # the flag agreement predict --split_slides runs before an image's first collective: one rank's failure is everyone's
+        ok_all = parallel.all_ok(True, torch.device("cpu")) and not parallel.all_ok(rank != world - 1, torch.device("cpu"))
+        assert ok_all or world == 1
         ok = True
         for src, dst, k, lo, hi in parallel.share_transfers(plan, world):
             if dst == rank:
@@ -311,7 +317,8 @@ def _share_worker(rank, world, port, h, w, overlap, q, transport):
 
 
 @pytest.mark.parametrize("transport", ["p2p", "allgather"])
-@pytest.mark.parametrize("world,h,w,overlap", [(2, 200, 70, 0.5), (3, 200, 130, 0.5), (3, 171, 90, 0.25), (4, 97, 97, 0.5), (1, 120, 70, 0.5), (5, 64, 200, 0.75)])
+@pytest.mark.parametrize("world,h,w,overlap", [(2, 200, 70, 0.5), (3, 200, 130, 0.5), (3, 171, 90, 0.25), (4, 97, 97, 0.5), (1, 120, 70, 0.5), (5, 64, 200, 0.75),
+                                                (3, 30, 30, 0.5), (4, 40, 33, 0.5), (5, 48, 48, 0.5)])     # fewer windows than ranks: 1, 2 and 4 windows
 def test_share_exchange_and_rectangle_gather(world, h, w, overlap, transport):
     """Both transports of the window-list seam exchange deliver exactly the window parts the partition asks for, and the all-gather of
     the finalised rectangles re-assembles the image."""

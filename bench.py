@@ -52,6 +52,7 @@ from benchlib.common import (DTYPE, MFMA_PEAK, PEAK_F32_MFMA_TFLOPS, PEAK_FP8_MF
 from benchlib.cpu_baseline import cpu_baseline, cpu_baseline_tiles_and_train  # noqa: E402
 from benchlib.eager import eager_rocm  # noqa: E402
 from benchlib.ranks import StripsGuard, launch_ranks  # noqa: E402,F401
+from benchlib.roofline import dominant_kernel, kernel_shares  # noqa: E402
 from benchlib.traffic import live_pmc_traffic  # noqa: E402
 
 
@@ -681,39 +682,18 @@ def main():
         return out
 
     def roofline(res, precision=None, only=None):
-        prof = res.get("prof")
-        if not prof:
+        """benchlib.roofline.dominant_kernel on this leg's HIP-event table + (primary leg of the default workload) the HBM bytes per launch
+        of that group: measured by THIS run where it can be (the default command on one GPU: two child passes of rocprofv3 --pmc FETCH_SIZE /
+        WRITE_SIZE, gfx950 correction applied - benchlib.traffic), else quoted from the committed passes of the same command
+        (profiles/pmc_traffic.json, tools/pmc_summary.py) and labelled as a quote."""
+        rl = dominant_kernel(res.get("prof"), precision or args.precision, only)
+        if rl is None:
             return None
-        precision = precision or args.precision
-        total_ms = sum(v["ms"] for v in prof.values())
-        if only is not None:
-            prof = {n: v for n, v in prof.items() if only(n) and v["flops"] > 0}
-            if not prof:
-                return None
-        name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        mfma = k["flops"] > 0 and ("mfma" in name or "wino" in name or name.endswith("_fp8"))
-        sec = k["ms"] / 1e3
-        if mfma:
-            achieved = k["flops"] / sec / 1e12
-            # the peak of the instruction the launches of this group really issue: the fp32 Winograd / direct kernels run on the fp32 matrix
-            # instruction whatever the mode of the other layers; in fp8 mode the e4m3 launches are their own groups (*_fp8) and every other
-            # matrix kernel is a bf16 one
-            peak_of = "fp32" if ("wino" in name or precision == "fp32") else ("fp8" if name.endswith("_fp8") else ("bf16" if precision == "fp8" else precision))
-            peak = round(MFMA_PEAK[peak_of], 1)
-            rl = {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                  "frac": round(achieved / peak, 4), "traffic": None, "peak_of": peak_of}
-        else:
-            achieved = k["bytes"] / sec / 1e9
-            rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                  "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
-        # HBM bytes per launch of this group: measured by THIS run where it can be (the default command on one GPU: two child passes of
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied - live_pmc_traffic), else quoted from the committed passes
-        # of the same command (profiles/pmc_traffic.json, tools/pmc_summary.py) and labelled as a quote
         if res.get("primary") and args.engine_batch == 0 and args.size == 4096 and args.width == "baseline32" and args.precision == "fp32":
-            rl["algorithmic_bytes_per_launch"] = round(k["bytes"] / k["launches"])
             live = None
             if world == 1 and dist is None and not args.no_secondary and not args.no_live_traffic:
-                live, detail = live_pmc_traffic(name)
+                with leg("live_traffic"):
+                    live, detail = live_pmc_traffic(rl["kernel"])
                 rl["traffic_live"] = detail
             if live is not None:
                 rl["traffic"] = live
@@ -721,32 +701,15 @@ def main():
                                         "--streams 1 --cc-stream 0 --no-cpu-baseline --no-secondary`, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch")
             else:
                 try:
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(name, {})
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(rl["kernel"], {})
                     rl["traffic"] = pmc.get("hbm_bytes_per_launch")
                     rl["traffic_source"] = "QUOTED from profiles/pmc_traffic.json (committed rocprofv3 PMC passes of the default command), not measured by this run"
                 except (OSError, ValueError, KeyError):
                     pass
-        if "wino" in name:
-            # Winograd: `achieved` counts the multiplies the algorithm really issues on the matrix pipe (F(2x2,3x3): 16 per 2x2 output
-            # tile and channel pair; F(4x4,3x3): 36 per 4x4 tile); the same launches expressed in direct-convolution FLOPs (9 per
-            # output pixel: SURVEY 8(d)'s figure)
-            f4 = name.endswith("wino4")
-            factor = 144 / 36 if f4 else 36 / 16
-            rl["algorithm"] = ("Winograd F(4x4,3x3), fp32: 36 instead of 144 multiplies per 4x4 output tile and channel pair (every stride-1 3x3 "
-                               "layer with >= 32 input channels)" if f4 else
-                               "Winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per output tile and channel pair")
-            rl["direct_conv_equivalent"] = round(rl["achieved"] * factor, 3)
-            rl["frac_direct_conv_equivalent"] = round(rl["achieved"] * factor / rl["peak"], 4)
-        rl.update({"kernel": name, "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 5),
-                   "algorithmic_per_launch": (k["flops"] if mfma else k["bytes"]) / k["launches"],
-                   "share_of_gpu_time": round(k["ms"] / total_ms, 4)})
         return rl
 
     def kernel_table(res):
-        tot = sum(v["ms"] for v in res["prof"].values())
-        return {n: {"ms_per_step": round(v["ms"] / args.steps, 4), "share": round(v["ms"] / tot, 4),
-                    "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["flops"] else None,
-                    "gbs": round(v["bytes"] / v["ms"] / 1e6, 1)} for n, v in sorted(res["prof"].items(), key=lambda kv: -kv[1]["ms"])}
+        return kernel_shares(res["prof"], args.steps)
 
     def base_line(main_res, head_strips):
         """The full record's contract keys for one measured inference leg (slides or strips)."""

@@ -45,6 +45,25 @@ def cli_env(**extra):
     return env
 
 
+def run_bench(*args, expect_rc=0, timeout=900, **env):
+    """`python bench.py ...` as a child process -> (compact, full): the LAST stdout line parsed (the driver's view: one JSON object under
+    4 kB) and the full record the run wrote beside it (gpurun_out/<BENCH_FULL_NAME>, removed here).  stdout must be that ONE line."""
+    import json
+    import uuid
+    name = f"bench_full_test_{uuid.uuid4().hex[:10]}.json"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout,
+                         env=cli_env(BENCH_FULL_NAME=name, **env))
+    assert out.returncode == expect_rc, (out.returncode, out.stderr[-3000:])
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096, (len(lines), [len(x) for x in lines])
+    compact = json.loads(lines[0])
+    path = os.path.join(ROOT, "gpurun_out", name)
+    assert compact["full_record"] == f"gpurun_out/{name}" and os.path.exists(path)
+    full = json.load(open(path))
+    os.remove(path)
+    return compact, full
+
+
 def run_module(mod, *args, **env):
     return subprocess.run([sys.executable, "-m", mod, *args], capture_output=True, text=True, timeout=900, env=cli_env(**env))
 

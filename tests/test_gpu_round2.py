@@ -232,30 +232,32 @@ def test_flat_bucket_allreduce_on_the_real_engine_world2():
 
 
 def _bench(*args, **env):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900,
-                         env=_env(**env))
-    assert out.returncode == 0, out.stderr[-2000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
+    from conftest import run_bench
+    return run_bench(*args, **env)
 
 
 def test_bench_gpus2_launches_two_ranks():
     """`python bench.py --gpus 2` starts its own ranks (here sharing the one GPU over gloo): n_gpus 2, all three legs present.  For
     N > 1 the headline is the STRONG-scaling leg (one slide split by window rows, seam exchange, mask all-gather); the one-slide-per-rank
     leg is the secondary `slides` object."""
-    line = _bench("--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1", "--train-batch", "2", "--train-steps", "2",
-                  BENCH_DEVICE=0, BENCH_BACKEND="gloo")
+    line, full = _bench("--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1", "--train-batch", "2", "--train-steps", "2",
+                        BENCH_DEVICE=0, BENCH_BACKEND="gloo")
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "strong"
-    assert line["slides"]["scaling"] == "weak" and line["slides"]["value"] > 0 and line["value_strips"] == line["value"]
-    assert line["config"]["seam_transport"] in ("p2p", "allgather") and line["config"]["equal_to_single_gpu_labels"] is True
-    assert line["config"]["instances_found"] > 0
-    assert line["train_step"]["global_batch"] == 4 and line["train_step"]["images_per_s"] > 0
+    assert full["slides"]["scaling"] == "weak" and full["slides"]["value"] > 0 and line["value_strips"] == line["value"] and line["value_slides"] == full["slides"]["value"]
+    assert line["config"]["seam_transport"] in ("p2p", "allgather") and full["config"]["equal_to_single_gpu_labels"] is True
+    assert line["secondary"]["strips_equal_to_single_gpu"] is True
+    assert line["config"]["instances_found"] > 0 and line["config"]["windows_per_rank"] == [24, 25]
+    assert full["train_step"]["global_batch"] == 4 and full["train_step"]["images_per_s"] > 0 and line["secondary"]["train_images_per_s"] > 0
     assert line["roofline"]["frac"] > 0
+    # the first real multi-GPU run must explain itself: the three phases of the strips leg are in the line
+    assert all(line[k] >= 0 for k in ("exchange_ms", "gather_ms", "cc_ms")) and line["cc_ms"] > 0
 
 
 def test_bench_train_mode_line():
-    line = _bench("--mode", "train", "--train-batch", "4", "--train-steps", "2", "--width", "reference16")
+    line, full = _bench("--mode", "train", "--train-batch", "4", "--train-steps", "2", "--width", "reference16")
     assert line["unit"] == "images/s" and line["n_gpus"] == 1 and line["value"] > 0
-    assert line["config"]["global_batch"] == 4 and "wgrad_mfma" in line["train_step"]["kernels"]
+    assert line["config"]["global_batch"] == 4 and "wgrad_mfma" in full["train_step"]["kernels"]
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
 
 
 # ------------------------------------------------------------------------------------------- the CLIs
@@ -487,10 +489,11 @@ def test_fp8_deep64_forward_error_bound():
 def test_c5_workload_runs_on_one_gpu():
     """BASELINE configs[4] end to end on ONE GPU: 64...1024 net, 512-pixel windows at stride 256 (961 windows), 3x8192x8192 slide, fp8
     mode, connected components and the label copy included (the 8-GPU form deals such slides - or row strips of one - to the ranks)."""
-    line = _bench("--precision", "fp8", "--width", "deep64", "--roi", "512", "--size", "8192", "--steps", "1", "--warmup", "1",
-                  "--no-secondary", "--no-cpu-baseline")
+    line, full = _bench("--precision", "fp8", "--width", "deep64", "--roi", "512", "--size", "8192", "--steps", "1", "--warmup", "1",
+                        "--no-secondary", "--no-cpu-baseline")
     assert line["config"]["windows"] == 961 and line["config"]["precision"] == "fp8" and line["value"] > 50
     assert line["roofline"]["kernel"].startswith("conv3x3") and line["roofline"]["peak"] == 5000.0
+    assert line["roofline_by_dtype"]["fp8"]["peak"] == 5000.0 and line["roofline_by_dtype"]["bf16"]["peak"] == 2500.0 and 0 < full["frac_of_fp8_peak_whole_slide"] < 1
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp8"])

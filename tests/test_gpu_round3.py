@@ -36,10 +36,8 @@ def _env(**extra):
 
 
 def _bench(*args, **env):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900,
-                         env=_env(**env))
-    assert out.returncode == 0, out.stderr[-3000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
+    from conftest import run_bench
+    return run_bench(*args, **env)
 
 
 # ------------------------------------------------------------------------------------------- one image split by window rows
@@ -69,21 +67,22 @@ def test_seam_exchange_between_two_ranks_sharing_the_gpu():
     """bench.py --gpus 2 --shard strips over gloo on one GPU: the window parts of the window-list partition really travel between two
     processes, the finalised rectangles are gathered, the rank whose turn it is labels the mask, and the labels equal those of the
     one-slide-per-rank leg on the same slide."""
-    line = _bench("--gpus", "2", "--shard", "strips", "--size", "1024", "--steps", "2", "--warmup", "1", "--train-batch", "2",
-                  "--train-steps", "2", "--strip-batch", "8", BENCH_DEVICE=0, BENCH_BACKEND="gloo")
+    line, full = _bench("--gpus", "2", "--shard", "strips", "--size", "1024", "--steps", "2", "--warmup", "1", "--train-batch", "2",
+                        "--train-steps", "2", "--strip-batch", "8", BENCH_DEVICE=0, BENCH_BACKEND="gloo")
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
-    assert line["config"]["windows_per_rank"] == [24, 25] and line["config"]["equal_to_single_gpu_labels"] is True
-    assert line["value_strips"] == line["value"] and line["value_slides"] == line["slides"]["value"]
-    assert line["config"]["labelling"].startswith("round-robin over the ranks")
+    assert line["config"]["windows_per_rank"] == [24, 25] and full["config"]["equal_to_single_gpu_labels"] is True
+    assert line["value_strips"] == line["value"] and line["value_slides"] == full["slides"]["value"]
+    assert full["config"]["labelling"].startswith("round-robin over the ranks") and line["config"]["cc"] == "turns"
 
 
 def test_strip_local_labelling_in_the_strips_leg_between_two_ranks_sharing_the_gpu():
     """The same leg with --cc strips: every rank filters and labels its own rows of every slide (cs_ccl_strip_*), the edge rows travel in
     two all-gathers, the label strips are gathered to the slide's output rank - and the label map equals the one-slide-per-rank leg's."""
-    line = _bench("--gpus", "2", "--shard", "strips", "--cc", "strips", "--size", "1024", "--steps", "2", "--warmup", "1", "--strip-batch", "8",
-                  "--no-secondary", BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_COMPARE_LEGS=1)
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
-    assert line["config"]["labelling"].startswith("strip-local") and line["config"]["equal_to_single_gpu_labels"] is True
+    line, full = _bench("--gpus", "2", "--shard", "strips", "--cc", "strips", "--size", "1024", "--steps", "2", "--warmup", "1", "--strip-batch", "8",
+                        "--no-secondary", BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_COMPARE_LEGS=1)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["config"]["cc"] == "strips"
+    assert full["config"]["labelling"].startswith("strip-local") and full["config"]["equal_to_single_gpu_labels"] is True
+    assert all(line[k] >= 0 for k in ("exchange_ms", "gather_ms", "cc_ms")) and line["cc_ms"] > 0
 
 
 # ------------------------------------------------------------------------------------------- RCCL, executed
@@ -130,20 +129,26 @@ def test_rccl_allreduce_and_allgather_execute_at_world_size_one(tmp_path):
 
 
 def test_bench_force_dist_runs_rccl_on_one_gpu():
-    line = _bench("--size", "1024", "--steps", "1", "--warmup", "1", "--train-batch", "2", "--train-steps", "2", "--no-cpu-baseline",
-                  BENCH_FORCE_DIST=1)
+    line, full = _bench("--size", "1024", "--steps", "1", "--warmup", "1", "--train-batch", "2", "--train-steps", "2", "--no-cpu-baseline",
+                        BENCH_FORCE_DIST=1)
     assert line["collective_backend"] == "nccl" and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
-    assert line["strips"]["value"] > 0 and line["strips"]["equal_to_single_gpu_labels"] is True
-    assert line["train_step"]["allreduce_ms"] is not None and line["train_step"]["allreduce_ms"] > 0
+    assert full["strips"]["value"] > 0 and full["strips"]["equal_to_single_gpu_labels"] is True and line["secondary"]["strips_equal_to_single_gpu"] is True
+    assert full["train_step"]["allreduce_ms"] is not None and full["train_step"]["allreduce_ms"] > 0
+    assert all(line[k] >= 0 for k in ("exchange_ms", "gather_ms", "cc_ms"))          # the secondary strips leg's phases, through RCCL at world size 1
 
 
 def test_bench_line_has_latency_reference_scope_and_strips_simulation():
-    line = _bench("--size", "1024", "--steps", "2", "--warmup", "1", "--train-batch", "2", "--train-steps", "2", "--no-cpu-baseline")
-    assert line["latency_ms"] > 0 and line["latency"]["min_ms"] <= line["latency_ms"] <= line["latency"]["max_ms"]
+    line, full = _bench("--size", "1024", "--steps", "3", "--warmup", "1", "--train-batch", "2", "--train-steps", "2", "--no-cpu-baseline")
+    # round 6: the headline IS the per-image figure (every timed step ends with its labels on the host); the pipeline is value_pipelined
+    assert line["latency_ms"] > 0 and full["latency"]["min_ms"] <= line["latency_ms"] <= full["latency"]["max_ms"] and full["latency"]["reps"] == 3
+    assert abs(line["ms_per_step"] - sum((full["latency"]["min_ms"], full["latency"]["max_ms"])) / 2) < 0.5 * line["ms_per_step"]
+    assert line["value_pipelined"] > 0 and line["ms_per_step_pipelined"] > 0
     assert 0 < line["value_incl_tiff"] < line["value"] * 1.5
-    sim = line["strips_sim"]
+    assert line["config"]["workspace_bytes"] > 0 and line["value_10gb"] > 0 and line["config"]["workspace_bytes_10gb"] <= 10 << 30
+    sim = full["strips_sim"]
     assert sim["of"] == 8 and sim["max_windows_per_rank"] == 7 and sorted(sim["windows_per_rank"]) == [6] * 7 + [7]      # 49 windows: 6 or 7 each
-    assert sim["ratio"] > 1 and sim["ranks"]["0"]["labels_every"] == 8
+    assert sim["ratio"] > 1 and sim["ranks"]["0"]["labels_every"] == 8 and line["secondary"]["strips_sim_x"] == sim["ratio"]
+    assert full["leg_seconds"]["headline"] > 0 and line["bench_seconds"] > 0
 
 
 # ------------------------------------------------------------------------------------------- BatchNorm under the tiler

@@ -250,14 +250,11 @@ def test_native_adamw_refuses_a_tensor_whose_first_gradient_arrives_late():
 def test_bench_reports_the_slides_leg_when_the_strips_leg_fails():
     """`bench.py --gpus N` makes the strong-scaling strips leg the headline; its collectives (seam send/recv, mask all-gather) have never
     run on real multi-GPU hardware here, so a failure there must not cost the whole line: the collective-free slides leg is measured
-    first and reported (scaling weak, strips_error set).  The failure is provoked with an unknown seam transport (two gloo ranks
+    first and reported (scaling weak, strips_error set; the job exits non-zero since round 6).  The failure is provoked with an unknown seam transport (two gloo ranks
     sharing the GPU)."""
-    from conftest import cli_env
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1",
-                          "--no-secondary"], capture_output=True, text=True, timeout=900,
-                         env=cli_env(BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_SEAM_TRANSPORT="bogus"))
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    from conftest import run_bench
+    line, _ = run_bench("--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1", "--no-secondary", expect_rc=1,
+                        BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_SEAM_TRANSPORT="bogus")
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert "unknown transport" in line["strips_error"]
 

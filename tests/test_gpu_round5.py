@@ -17,29 +17,23 @@ def test_bench_keeps_its_line_when_ONE_rank_fails_inside_the_strips_leg():
     """A rank that raises inside its seam exchange leaves its peer in the send / the mask all-gather; before round 5 the next collective
     then mismatched until the process-group timeout and the job died without a line.  Now the failing rank posts the reason in the
     store, every rank's watcher sees it, rank 0 prints the slides-leg line with strips_error and all ranks leave at once (two gloo
-    ranks sharing the GPU; BENCH_STRIPS_FAIL_RANK=1 provokes the failure on rank 1 only)."""
-    from conftest import cli_env
+    ranks sharing the GPU; BENCH_STRIPS_FAIL_RANK=1 provokes the failure on rank 1 only).  Round 6 (advisor): the job then FAILS - the
+    ranks exit with code 3 and the launcher with 1 - so nobody can take the slides figure for the strips headline."""
+    from conftest import run_bench
     t0 = time.time()
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1",
-                          "--no-secondary"], capture_output=True, text=True, timeout=900,
-                         env=cli_env(BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_STRIPS_FAIL_RANK=1, BENCH_STRIPS_DEADLINE_S=120))
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    line, full = run_bench("--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1", "--no-secondary", expect_rc=1,
+                           BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_STRIPS_FAIL_RANK=1, BENCH_STRIPS_DEADLINE_S=120)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
-    assert "rank 1" in line["strips_error"] and "provoked failure" in line["strips_error"]
-    assert len(out.stdout.strip().splitlines()) == 1                  # ONE JSON line
+    assert "rank 1" in line["strips_error"] and "provoked failure" in line["strips_error"] and "FAILED" in line["config"]["note"]
     assert time.time() - t0 < 300                                     # nowhere near the 240 s collective timeout after the failure
 
 
 def test_bench_strips_leg_deadline_releases_a_hung_leg():
     """The other asymmetric case: nothing raises, the leg just does not finish (rank 1 sleeps inside its exchange).  The watcher's
-    deadline prints the slides line."""
-    from conftest import cli_env
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1",
-                          "--no-secondary"], capture_output=True, text=True, timeout=900,
-                         env=cli_env(BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_STRIPS_HANG_RANK=1, BENCH_STRIPS_DEADLINE_S=20))
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    deadline prints the slides line and the job exits non-zero."""
+    from conftest import run_bench
+    line, _ = run_bench("--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1", "--no-secondary", expect_rc=1,
+                        BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_STRIPS_HANG_RANK=1, BENCH_STRIPS_DEADLINE_S=20)
     assert line["scaling"] == "weak" and "did not finish within" in line["strips_error"]
 
 

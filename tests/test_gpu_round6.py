@@ -1,0 +1,42 @@
+"""Round-6 GPU tests: the compact bench line on the multi-rank and training commands (the first real 8-GPU run must
+explain itself - rccl_ranks, per-rank windows, exchange / gather / cc / all-reduce times are in the line)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONTRACT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "roofline", "cpu_baseline"}
+
+
+def test_bench_train_mode_over_two_ranks_sharing_the_gpu():
+    """`bench.py --gpus 2 --mode train` (gloo, both ranks on cuda:0): the data-parallel step with the flat-bucket all-reduce inside the
+    timed region; the compact line names the ranks, the global batch and the all-reduce time."""
+    from conftest import run_bench
+    line, full = run_bench("--gpus", "2", "--mode", "train", "--width", "reference16", "--train-batch", "4", "--train-steps", "3",
+                           BENCH_DEVICE=0, BENCH_BACKEND="gloo")
+    assert CONTRACT <= set(line) and line["unit"] == "images/s" and line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo"
+    assert line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2" and line["value"] > 0 and line["steps"] == 3
+    assert line["allreduce_ms"] > 0 and full["train_step"]["grad_bucket_bytes"] == 1626072 * 4
+    assert line["roofline"]["kernel"] and line["roofline"]["frac"] > 0
+
+
+def test_configs3_shape_on_one_gpu_with_the_rccl_allreduce_in_the_timed_step():
+    """BASELINE configs[3]'s per-GPU shape (32-base, 32 x 3 x 256 x 256 per GPU) on ONE GPU with a real RCCL process group
+    (BENCH_FORCE_DIST=1): the all-reduce of the 26 MB flat bucket runs inside every timed step and is reported as allreduce_ms."""
+    from conftest import run_bench
+    line, full = run_bench("--mode", "train", "--train-batch", "32", "--train-steps", "5", BENCH_FORCE_DIST=1)
+    assert line["collective_backend"] == "nccl" and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
+    assert line["config"]["global_batch"] == 32 and 20e6 < full["train_step"]["grad_bucket_bytes"] < 30e6
+    assert 0 < line["allreduce_ms"] < 5.0 and line["ms_per_step"] < 20.0
+    assert full["train_step"]["graph_ms_per_step"] > 0                   # the captured step keeps the collective outside the graph and still runs
+
+
+@pytest.mark.parametrize("cc", ["turns", "strips"])
+def test_bench_two_ranks_compact_keys_in_both_labelling_modes(cc):
+    from conftest import run_bench
+    line, full = run_bench("--gpus", "2", "--size", "1024", "--steps", "2", "--warmup", "1", "--strip-batch", "8", "--cc", cc, "--no-secondary",
+                           BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_COMPARE_LEGS=1)
+    assert CONTRACT <= set(line) and line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["windows_per_rank"] == [24, 25] and line["config"]["cc"] == cc and line["config"]["seam_transport"] in ("p2p", "allgather")
+    assert all(line[k] >= 0 for k in ("exchange_ms", "gather_ms", "cc_ms")) and line["cc_ms"] > 0
+    assert line["value_pipelined"] > 0 and line["latency_ms"] > 0 and full["config"]["equal_to_single_gpu_labels"] is True

@@ -360,7 +360,7 @@ print(json.dumps({{"unexpected": "the collective completed"}}))
 @pytest.mark.parametrize("mode", ["raise", "hang"])
 def test_strips_guard_releases_both_ranks_with_one_line(tmp_path, mode):
     """One rank fails (or hangs) inside the guarded leg while the other is blocked in a collective: rank 0 prints the fallback line with
-    strips_error, both processes exit with code 0 within seconds - nobody waits for the process-group timeout."""
+    strips_error, both processes exit with code 3 (a failed leg is a failed job) within seconds - nobody waits for the process-group timeout."""
     import subprocess
     import sys
     import time
@@ -373,7 +373,7 @@ def test_strips_guard_releases_both_ranks_with_one_line(tmp_path, mode):
                               env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MODE=mode,
                                        DEADLINE="6" if mode == "hang" else "60")) for r in range(2)]
     outs = [p.communicate(timeout=120) for p in procs]
-    assert [p.returncode for p in procs] == [0, 0], [o[1][-800:] for o in outs]
+    assert [p.returncode for p in procs] == [3, 3], [o[1][-800:] for o in outs]
     lines = [ln for ln in outs[0][0].strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]      # (gloo announces its peers on stdout)
     import json

@@ -521,7 +521,7 @@ static int finish_norm(hipStream_t s, const cs_unet* net, const NormSite& ns, No
     if (net->norm == CS_NORM_BATCH && net->batch_stats)      // nn.BatchNorm2d, train mode: momentum 0.1, eps 1e-5 (torch defaults)
         return launch_bn_train_finalize(s, rt.stats, ns.bn_w, ns.bn_b, ns.bn_m, ns.bn_v, rt.tab, rt.xtab, n, ns.c, c_total, count, 1e-5f, 0.1f);
     if (net->norm == CS_NORM_BATCH) return launch_bn_table(s, ns.bn_w, ns.bn_b, ns.bn_m, ns.bn_v, rt.tab, n, ns.c, c_total, 1e-5f);
-    return launch_norm_finalize(s, rt.stats, rt.tab, n, c_total, count, 1e-5f);
+    return launch_norm_finalize(s, rt.stats, rt.tab, n, c_total, count, 1e-5f, /*snap_constant=*/!net->training);
 }
 
 static ConvSrc lazy_src(const float* ptr, int c, int pitch, const NormRt& rt, const NormSite& ns, int tab_c, bool h16 = false) {

@@ -187,7 +187,7 @@ int launch_conv_last(hipStream_t s, const ConvSrc& u, const float* w_torch, cons
 
 // ---- normalisation ------------------------------------------------------------------------------
 // stats [n][c][2] (double) -> tab [n][c] (rstd, -mean*rstd); count = h*w; eps = 1e-5
-int launch_norm_finalize(hipStream_t s, const double* stats, float2* tab, int n, int c, int count, float eps);
+int launch_norm_finalize(hipStream_t s, const double* stats, float2* tab, int n, int c, int count, float eps, bool snap_constant);
 // eval-mode BatchNorm: tab[n][c] from running stats and affine parameters
 int launch_bn_table(hipStream_t s, const float* weight, const float* bias, const float* mean, const float* var,
                     float2* tab, int n, int c, int c_total, float eps);

@@ -276,10 +276,12 @@ __global__ __launch_bounds__(256) void conv_first_rec_kernel(FirstRecParams p) {
                 }
             }
             const int cols_valid = p.wout - tx * 16;
-            // bias, statistics (fp32 over the lane's <= 8 values of the tile, fp64 across the walk), slab
+            // bias, statistics, slab.  The statistics are fp64 from the first addend on (round 6): behind a blank or nearly blank window -
+            // the reference leaves zero background at exactly 0, baseline/predict.py:14-21 - this layer's map is the bias plus a few
+            // pixels, var << mean^2, and a lane's <= 8 values summed in fp32 (rounds 1-5) put 1e-7 x mean^2 of rounding into a
+            // variance of 1e-8: the InstanceNorm scale came out 2e-4 off (tests/test_gpu_blank_windows.py)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float sf = 0.f, qf = 0.f;
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -287,14 +289,11 @@ __global__ __launch_bounds__(256) void conv_first_rec_kernel(FirstRecParams p) {
                         const float v = acc[m][nt][r] + bias[nt];
                         ep[(m * 16 + g * 4 + r) * EPS + nt * 16 + pl] = v;
                         if (!ADD && m < rows_valid && g * 4 + r < cols_valid) {
-                            sf += v;
-                            qf = __builtin_fmaf(v, v, qf);
+                            const double vd = (double)v;
+                            ssum[nt] += vd;
+                            qsum[nt] = __builtin_fma(vd, vd, qsum[nt]);
                         }
                     }
-                if constexpr (!ADD) {
-                    ssum[nt] += (double)sf;
-                    qsum[nt] += (double)qf;
-                }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();

@@ -16,21 +16,32 @@ __device__ __forceinline__ float prelu1(float v, float slope) { return v >= 0.f 
 // ------------------------------------------------------------------------------------------------
 // InstanceNorm statistics -> (scale, shift) table.  biased variance, eps inside the sqrt (torch semantics).
 // ------------------------------------------------------------------------------------------------
-__global__ void norm_finalize_kernel(const double* stats, float2* tab, int total, double inv_count, double eps) {
+// snap (inference): a channel that is CONSTANT over the image - every conv output behind an all-zero window is its bias - normalises to
+// exactly 0 in exact arithmetic ((x - mean) * rstd with x == mean).  The consumers apply fma(x, rstd, -mean * rstd) with an fp32 table,
+// which leaves the rounding residual of mean * rstd (up to 6e-8 x 316 x |mean|) instead of 0; two layers on, that residual is the only
+// variance of the map and the net's output on blank windows is amplified rounding noise (0.03 ... 0.3 logits off an fp64 evaluation,
+// tests/diagnostics/gpu_blank_windows.py).  The sums are exact fp64 sums of fp32 values, so a constant channel shows var <= 4e-16 mean^2:
+// below 1e-13 mean^2 (a spread of 3e-7 of the value: a few ulp of jitter at most) the table entry is (0, 0).  Training keeps (rstd, -mean rstd):
+// the backward pass needs rstd = 1 / sqrt(eps) there.
+__global__ void norm_finalize_kernel(const double* stats, float2* tab, int total, double inv_count, double eps, int snap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const double mean = stats[2 * i] * inv_count;
     double var = stats[2 * i + 1] * inv_count - mean * mean;
+    if (snap && var <= 1e-13 * mean * mean) {
+        tab[i] = make_float2(0.f, 0.f);
+        return;
+    }
     var = var > 0.0 ? var : 0.0;
     const double rstd = 1.0 / sqrt(var + eps);
     tab[i] = make_float2((float)rstd, (float)(-mean * rstd));
 }
 
-int launch_norm_finalize(hipStream_t s, const double* stats, float2* tab, int n, int c, int count, float eps) {
+int launch_norm_finalize(hipStream_t s, const double* stats, float2* tab, int n, int c, int count, float eps, bool snap_constant) {
     const int total = n * c;
     ProfScope prof(K_NORM_FINALIZE, s, 0, 24.0 * total);
     hipLaunchKernelGGL(norm_finalize_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, stats, tab, total,
-                       1.0 / (double)count, (double)eps);
+                       1.0 / (double)count, (double)eps, snap_constant ? 1 : 0);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -16,7 +16,7 @@ def test_bench_train_mode_over_two_ranks_sharing_the_gpu():
                            BENCH_DEVICE=0, BENCH_BACKEND="gloo")
     assert CONTRACT <= set(line) and line["unit"] == "images/s" and line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo"
     assert line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2" and line["value"] > 0 and line["steps"] == 3
-    assert line["allreduce_ms"] > 0 and full["train_step"]["grad_bucket_bytes"] == 1626072 * 4
+    assert line["allreduce_ms"] > 0 and 1626072 * 4 <= full["train_step"]["grad_bucket_bytes"] < 1626072 * 4 + 4096      # the flat bucket (aligned)
     assert line["roofline"]["kernel"] and line["roofline"]["frac"] > 0
 
 

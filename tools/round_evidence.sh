@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round-end evidence on the gpurun box (one call): rocprofv3 stats + PMC passes for the default command, the bf16 datapath and configs[4].
 # Summaries are made afterwards, here: tools/pmc_summary.py / tools/pmc_mfma_summary.py.
-TAG=${1:-r05}
+set -uo pipefail
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+TAG=${1:-r06}
 bash tools/gpu_profile_round.sh $TAG > gpurun_out/prof_$TAG.log 2>&1; echo "fp32 done: $(tail -1 gpurun_out/prof_$TAG.log)"
 bash tools/gpu_profile_round.sh ${TAG}_bf16 --precision bf16 > gpurun_out/prof_${TAG}_bf16.log 2>&1; echo "bf16 done"
 bash tools/gpu_profile_round.sh ${TAG}_fp8c5 --precision fp8 --width deep64 --roi 512 --size 8192 --steps 3 --warmup 1 > gpurun_out/prof_${TAG}_fp8c5.log 2>&1; echo "fp8c5 done"

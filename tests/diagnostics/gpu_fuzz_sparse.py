@@ -7,7 +7,7 @@ Round 6 found the engine off by up to 0.3 logits on blank windows (tests/test_gp
 lives in that corner: random images composed of an exactly-zero (or constant) background, rectangles / blobs / single pixels / noise
 patches, optionally quantised through uint8 (predict.py:94-107), random sizes, window sizes and overlaps, on random-depth nets - through
 the tiler (cs_swi_infer) against the torch-CPU oracle AND a float64 evaluation of it.  Bars as in the test: |engine - float64| <=
-max(1e-4, 4e-6 max|logit|), 2e-4 where torch-fp32 itself is more than 1e-4 from float64; and within 1e-4 (+ its own distance) of
+max(1e-4, 4e-6 max|logit|), 4e-4 where torch-fp32 itself is more than 1e-4 from float64 (half of the random cases; median 1.3e-2 there); and within 1e-4 (+ its own distance) of
 torch-fp32 wherever that is within 1e-4 of float64.  Prints one JSON line per case to --out and a summary; exits non-zero on a miss."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -85,7 +85,7 @@ def run(seconds=120.0, seed=0, out=None):
         t64 = float((t32.double() - f64).abs().max())
         e64, e32 = float((got.double() - f64).abs().max()), float((got - t32).abs().max())
         scale = float(f64.abs().max())
-        bar = 2 * TOL if t64 > TOL else max(TOL, REL * scale)
+        bar = max(4 * TOL, REL * scale) if t64 > TOL else max(TOL, REL * scale)
         ok = e64 <= bar and (t64 > TOL or e32 <= bar + t64)
         row = {"channels": list(ch), "image": [ih, iw], "roi": roi, "overlap": ov, "zero_fraction": round(float((x == 0).float().mean()), 3),
                "engine_vs_fp64": e64, "engine_vs_torch32": e32, "torch32_vs_fp64": t64, "logit_scale": scale, "bar": bar, "ok": ok}

@@ -428,8 +428,7 @@ __global__ __launch_bounds__(256) void conv_first16_rec_kernel(FirstRecParams p)
                 }
             const int cols_valid = p.wout - tx * 16;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float sf = 0.f, qf = 0.f;
+            for (int nt = 0; nt < NT; ++nt) {          // statistics in fp64 from the first addend, as in the fp32 kernel above (blank windows)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -437,14 +436,11 @@ __global__ __launch_bounds__(256) void conv_first16_rec_kernel(FirstRecParams p)
                         const float v = acc[m][nt][r] + bias[nt];
                         ep[(m * 16 + g * 4 + r) * EPS + nt * 16 + pl] = v;
                         if (!ADD && m < rows_valid && g * 4 + r < cols_valid) {
-                            sf += v;
-                            qf = __builtin_fmaf(v, v, qf);
+                            const double vd = (double)v;
+                            ssum[nt] += vd;
+                            qsum[nt] = __builtin_fma(vd, vd, qsum[nt]);
                         }
                     }
-                if constexpr (!ADD) {
-                    ssum[nt] += (double)sf;
-                    qsum[nt] += (double)qf;
-                }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();

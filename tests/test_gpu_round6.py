@@ -40,3 +40,33 @@ def test_bench_two_ranks_compact_keys_in_both_labelling_modes(cc):
     assert line["config"]["windows_per_rank"] == [24, 25] and line["config"]["cc"] == cc and line["config"]["seam_transport"] in ("p2p", "allgather")
     assert all(line[k] >= 0 for k in ("exchange_ms", "gather_ms", "cc_ms")) and line["cc_ms"] > 0
     assert line["value_pipelined"] > 0 and line["latency_ms"] > 0 and full["config"]["equal_to_single_gpu_labels"] is True
+
+
+def test_bench_launched_the_way_the_driver_launches_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`
+    (the driver's multi-GPU form; here N = 2 gloo ranks sharing the one GPU): rank 0 prints the ONE compact line - under 4 kB, steps / warmup
+    as asked, n_gpus = 2 - and writes the full record; the other rank prints nothing on stdout."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import uuid
+    from conftest import ROOT, cli_env
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    name = f"bench_full_test_{uuid.uuid4().hex[:10]}.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "1024", "--train-batch", "2", "--train-steps", "2"]
+    cp = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=cli_env(BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_FULL_NAME=name))
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    lines = [ln for ln in cp.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0] == cp.stdout.strip().splitlines()[-1] and len(lines[0]) < 4096, cp.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert CONTRACT <= set(line) and line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "strong"
+    assert line["value"] > 0 and line["value_slides"] > 0 and line["secondary"]["strips_equal_to_single_gpu"] is True
+    path = os.path.join(ROOT, "gpurun_out", name)
+    full = json.load(open(path))
+    os.remove(path)
+    assert full["train_step"]["global_batch"] == 4 and full["slides"]["scaling"] == "weak"

@@ -323,19 +323,20 @@ def test_low_precision_modes_against_the_fp32_path_and_the_ground_truth():
 
 def test_configs4_accuracy_at_its_own_width_and_window():
     """BASELINE.json configs[4] names a 64-base U-Net on 512 x 512 windows with fp8 weights: the accuracy claim is made THERE - the
-    64...1024 net trained on synthetic cells (150 AdamW steps, fp32 engine), SIXTEEN held-out 2048^2 images (~31 000 cells) segmented with
+    64...1024 net trained on synthetic cells (150 AdamW steps, fp32 engine), 48 held-out 2048^2 images (~92 000 cells) segmented with
     512^2 windows in fp32, on the bf16 datapath and in the mixed fp8 mode; instance F1@0.5 against the ground truth
-    (compute_metric.py:107-122 semantics) within 1e-3 of the fp32 path's, north_star's bound.  (Round 5: with four images - 7 700 cells, 1e-3 =
-    8 cells - the figure is dominated by the sample and by WHICH net the 150 steps produce: -1.3e-3 / -0.7e-3 on four images, -0.9e-3 /
-    -0.8e-3 on sixteen with the net of the round's end, +0.7e-3 / -0.7e-3 with the net of its start; profiles/configs4_accuracy_vs_sample_r05.txt.)"""
+    (compute_metric.py:107-122 semantics).  north_star's bound is 1e-3; the gate is VERDICT r05's formulation of it: |mean| + 2 standard
+    errors of the per-image delta F1 <= 1e-3 (round 6; before, the gate was |delta| <= 1e-3 on sixteen images, where the figure sat AT the
+    bound: the first sixteen images of this set give -0.98e-3 +- 0.24e-3, all 48 -0.30e-3 +- 0.14e-3; three training seeds pooled:
+    bf16 -1.4e-4 +- 0.8e-4, fp8 +0.4e-4 +- 1.1e-4, profiles/configs4_accuracy_r06.json)."""
     sys.path[:0] = [ROOT, PKG]
     from bench import lowprec_accuracy
-    res = lowprec_accuracy(_dev(), n_images=16, size=2048, precisions=("bf16", "fp8"), width="deep64", roi=512)
+    res = lowprec_accuracy(_dev(), n_images=48, size=2048, precisions=("bf16", "fp8"), width="deep64", roi=512)
     assert res["trained_net"]["channels"] == [64, 128, 256, 512, 1024] and res["trained_net"]["window"] == 512
-    assert res["trained_net"]["cells_found_fp32"] > 12000 and res["trained_net"]["f1_vs_truth_fp32"] > 0.6, res["trained_net"]
+    assert res["trained_net"]["cells_found_fp32"] > 36000 and res["trained_net"]["f1_vs_truth_fp32"] > 0.6, res["trained_net"]
     for prec in ("bf16", "fp8"):
         assert res[prec]["f1_vs_fp32"] >= 0.995 and res[prec]["pixel_agreement"] >= 0.998, (prec, res[prec])
-        assert abs(res[prec]["delta_f1_vs_truth"]) <= 1e-3, (prec, res[prec])
+        assert abs(res[prec]["delta_f1_mean"]) + 2 * res[prec]["delta_f1_se"] <= 1e-3, (prec, res[prec])
 
 
 def test_predict_cli_accepts_fp8(tmp_path):

@@ -1295,20 +1295,26 @@ int launch_conv_bf16s(hipStream_t s, int ksize, int stride, int planes, const Co
 // ------------------------------------------------------------------------------------------------
 // SUM2 (bf16 datapath): the `b` source is the decoder's residual sum act(norm(V)) + act(norm(U)), read as its two bf16 tensors.
 // The loads stay unconditional (chunks of `a` fetch their own item twice, an L1 hit) so that the waits keep their counts.
-template <int WN, int NTW, int NP, bool A16, bool SUM2 = false>
+// THX = 2 (round 6): a block owns EIGHT input rows instead of four.  A wave reads every weight fragment from L2 itself (never through LDS),
+// and at four rows a fragment feeds only MTW = 2 MFMAs per phase tap: the wide-K levels (128 + 256 -> 64 channels of configs[4]: 432
+// fragments = 442 KB per block for 64 input pixels) were bound by that stream, 17 % matrix-busy at 3.4 x the layer's HBM floor.  Eight
+// rows halve the weight bytes per pixel; the epilogue slab stays the four-row one and is used twice (rows 0-3, then 4-7).
+template <int WN, int NTW, int NP, bool A16, bool SUM2 = false, int THX = 1>
 __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     static_assert(!A16 || NP == 1, "bf16 activations in HBM only make sense for the plain-bf16 mode");
     static_assert(!SUM2 || A16, "sum sources are implemented for the bf16 datapath");
+    static_assert(THX == 1 || (THX == 2 && A16), "the eight-row tile exists for the bf16 datapath");
     typedef typename std::conditional<A16, u32x2, f32x4>::type raw4;
     constexpr bool F16 = SplitCfg<NP>::f16;
     constexpr int NPL = SplitCfg<NP>::planes, NTERM = SplitCfg<NP>::terms, NACC = 1;
-    constexpr int WM = 4 / WN, TH = 4, TW = 16, MTW = TH / WM, NTB = WN * NTW;
+    constexpr int WM = 4 / WN, TH = 4 * THX, TW = 16, MTW = TH / WM, NTB = WN * NTW;
     constexpr int IH = TH + 1, IW = TW + 1, PITCH = 96;
     constexpr int IN_ITEMS = IH * IW * 8, IN_ITERS = (IN_ITEMS + 255) / 256;
     constexpr int PLANE_BYTES = IH * IW * PITCH;
     constexpr int IN_BYTES = (NPL * PLANE_BYTES + 15) / 16 * 16;
     constexpr int EPS = 16 * NTB + 4;
-    constexpr int EP_BYTES = 2 * TH * 32 * EPS * 4;          // 8 output rows x 32 output pixels
+    constexpr int EPH = 4;                                   // input rows per epilogue pass
+    constexpr int EP_BYTES = 2 * EPH * 32 * EPS * 4;         // 8 output rows x 32 output pixels
     constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
     __shared__ double red[WM > 1 ? WM * NTB * 32 : 1];      // per-wave statistics of the block's channels (stats_stash_b)
@@ -1487,68 +1493,87 @@ __global__ __launch_bounds__(256, 2) void convt_bf16s_kernel(ConvBParams p) {
     }
 
     float* ep = reinterpret_cast<float*>(smem);
+    double s_[NTW], qq_[NTW];
+    float sf_[NTW], qf_[NTW];                                // bf16 datapath: fp32 partial sums per lane (see stats_commit_b)
+    float bias_[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        const int co = (nt_w + t) * 16 + pl;
-        const float bias = p.bias ? p.bias[co] : 0.f;
-        double s = 0.0, qq = 0.0;
-        float sf = 0.f, qf = 0.f;                            // bf16 datapath: fp32 partial sums per lane (see stats_commit_b)
+        s_[t] = 0.0; qq_[t] = 0.0; sf_[t] = 0.f; qf_[t] = 0.f;
+        bias_[t] = p.bias ? p.bias[(nt_w + t) * 16 + pl] : 0.f;
+    }
+    // the slab holds EPH = 4 input rows (8 output rows): one pass for the four-row tile, two for the eight-row one
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            const int row = wm * MTW + m, iy = iy0 + row;
+    for (int pass = 0; pass < THX; ++pass) {
+        if (pass > 0) __syncthreads();                       // the stores of the previous pass have read the slab
 #pragma unroll
-            for (int ph = 0; ph < 4; ++ph)
+        for (int t = 0; t < NTW; ++t) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ix = ix0 + g * 4 + r;
-                    float v = acc[0][m][ph][t][r];
-                    if constexpr (F16) v *= F16_OUT_SCALE;
-                    v += bias;
-                    ep[((2 * row + (ph >> 1)) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + (wn * NTW + t) * 16 + pl] = v;
-                    if (p.stats && iy < p.hin && ix < p.win) {
-                        if constexpr (A16) {
-                            sf += v;
-                            qf = fmaf(v, v, qf);
-                        } else {
-                            s += (double)v;
-                            qq += (double)v * (double)v;
+            for (int m = 0; m < MTW; ++m) {
+                const int row = wm * MTW + m, iy = iy0 + row;
+                if (THX > 1 && row / EPH != pass) continue;
+                const int lrow = row - pass * EPH;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ix = ix0 + g * 4 + r;
+                        float v = acc[0][m][ph][t][r];
+                        if constexpr (F16) v *= F16_OUT_SCALE;
+                        v += bias_[t];
+                        ep[((2 * lrow + (ph >> 1)) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + (wn * NTW + t) * 16 + pl] = v;
+                        if (p.stats && iy < p.hin && ix < p.win) {
+                            if constexpr (A16) {
+                                sf_[t] += v;
+                                qf_[t] = fmaf(v, v, qf_[t]);
+                            } else {
+                                s_[t] += (double)v;
+                                qq_[t] += (double)v * (double)v;
+                            }
                         }
                     }
+            }
+        }
+        __syncthreads();
+        {
+            constexpr int F4 = NTB * 4;
+            const int oy_base = 2 * (iy0 + pass * EPH);
+            const size_t el0 = (((size_t)img * p.hout + oy_base) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;
+#pragma unroll
+            for (int it_ = 0; it_ < (2 * EPH * 32 * F4 + 255) / 256; ++it_) {      // (trip count visible to the unroller: the LDS reads of all passes go out together)
+                const int i = tid + 256 * it_;
+                if ((2 * EPH * 32 * F4) % 256 != 0 && i >= 2 * EPH * 32 * F4) break;
+                const int pix = i / F4, c4 = i - pix * F4;
+                const int row = pix >> 5, x = pix & 31;
+                if (oy_base + row < p.hout && 2 * ix0 + x < p.wout) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                    const size_t el = el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4;
+                    if constexpr (A16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el) = f32x4_to_bf16v(v);
+                    else {
+                        if (p.addend)
+                            v += *reinterpret_cast<const f32x4*>(p.addend + (((size_t)img * p.hout + oy_base + row) * p.wout + 2 * ix0 + x) * p.pitch_add +
+                                                                 wk.ct * NTB * 16 + c4 * 4);
+                        *reinterpret_cast<f32x4*>(p.out + el) = v;
+                    }
                 }
+            }
         }
-        if constexpr (A16) {
-            s = (double)sf;
-            qq = (double)qf;
-        }
-        if (p.stats) {
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int co = (nt_w + t) * 16 + pl;
+            double s = s_[t], qq = qq_[t];
+            if constexpr (A16) {
+                s = (double)sf_[t];
+                qq = (double)qf_[t];
+            }
             if constexpr (WM > 1) stats_stash_b(s, qq, red + ((wm * NTB + wn * NTW + t) * 16 + pl) * 2, lane);
             else stats_commit_b(s, qq, p.stats + ((size_t)img * p.cout + co) * 2, lane);
         }
     }
-    __syncthreads();
-    if constexpr (WM > 1)
+    if constexpr (WM > 1) {
+        __syncthreads();
         if (p.stats) stats_flush_b<WM, NTB * 16>(red, p.stats + ((size_t)img * p.cout + wk.ct * NTB * 16) * 2, tid);
-    {
-        constexpr int F4 = NTB * 4;
-        const size_t el0 = (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;
-#pragma unroll
-        for (int it_ = 0; it_ < (2 * TH * 32 * F4 + 255) / 256; ++it_) {      // (trip count visible to the unroller: the LDS reads of all passes go out together)
-            const int i = tid + 256 * it_;
-            if ((2 * TH * 32 * F4) % 256 != 0 && i >= 2 * TH * 32 * F4) break;
-            const int pix = i / F4, c4 = i - pix * F4;
-            const int row = pix >> 5, x = pix & 31;
-            if (2 * iy0 + row < p.hout && 2 * ix0 + x < p.wout) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
-                const size_t el = el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4;
-                if constexpr (A16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el) = f32x4_to_bf16v(v);
-                else {
-                    if (p.addend)
-                        v += *reinterpret_cast<const f32x4*>(p.addend + (((size_t)img * p.hout + 2 * iy0 + row) * p.wout + 2 * ix0 + x) * p.pitch_add +
-                                                             wk.ct * NTB * 16 + c4 * 4);
-                    *reinterpret_cast<f32x4*>(p.out + el) = v;
-                }
-            }
-        }
     }
 }
 
@@ -1748,6 +1773,18 @@ __global__ __launch_bounds__(128, 2) void convt_bf16_rows_kernel(ConvBParams p, 
 
 template <int WN, int NTW, int NP, bool A16 = false>
 static int launch_tb(hipStream_t s, ConvBParams p) {
+    if constexpr (A16 && WN == 2 && NTW == 2) {
+        // 64-channel blocks on maps of >= 16 rows with a wide K: the eight-row tile (CS_CONVT_TH8=0: the four-row one everywhere)
+        static const int th8_env = getenv("CS_CONVT_TH8") ? atoi(getenv("CS_CONVT_TH8")) : 1;
+        if (th8_env && p.hin >= 16 && p.hin % 8 == 0 && p.a.c + p.b.c >= th8_env * 128) {
+            p.tiles_y = ceil_div(p.hin, 8);
+            dim3 grid8(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
+            if (p.b.ptr2) hipLaunchKernelGGL((convt_bf16s_kernel<WN, NTW, NP, A16, true, 2>), grid8, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((convt_bf16s_kernel<WN, NTW, NP, A16, false, 2>), grid8, dim3(256), 0, s, p);
+            CS_HIP(hipGetLastError());
+            return CS_OK;
+        }
+    }
     dim3 grid(xcd_grid(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
     if constexpr (A16) {
         if (p.b.ptr2) {

@@ -352,14 +352,17 @@ int launch_conv_fp8(hipStream_t s, int ksize, int stride, const ConvSrc& a, cons
 // ------------------------------------------------------------------------------------------------
 // transposed conv k3 s2 p1 op1 in fp8: 4 output phases per input pixel (see convt_mfma_kernel)
 // ------------------------------------------------------------------------------------------------
-template <int WN, int NTW>
+// THX = 2 (round 6, as convt_bf16s_kernel): eight input rows per block - every weight fragment a wave fetches from L2 feeds twice the
+// MFMAs; the epilogue slab stays the four-row one and is used twice.
+template <int WN, int NTW, int THX = 1>
 __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
-    constexpr int WM = 4 / WN, TH = 4, TW = 16, MTW = TH / WM, NTB = WN * NTW;
+    constexpr int WM = 4 / WN, TH = 4 * THX, TW = 16, MTW = TH / WM, NTB = WN * NTW;
     constexpr int IH = TH + 1, IW = TW + 1, PITCH = 144;
     constexpr int IN_ITEMS = IH * IW * 8, IN_ITERS = (IN_ITEMS + 255) / 256;
     constexpr int IN_BYTES = (IH * IW * PITCH + 15) / 16 * 16;
     constexpr int EPS = 16 * NTB + 4;
-    constexpr int EP_BYTES = 2 * TH * 32 * EPS * 4;
+    constexpr int EPH = 4;                                   // input rows per epilogue pass
+    constexpr int EP_BYTES = 2 * EPH * 32 * EPS * 4;
     constexpr int SM_BYTES = IN_BYTES > EP_BYTES ? IN_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM_BYTES];
     __shared__ double red8[WM > 1 ? WM * NTB * 32 : 1];     // per-wave statistics of the block's channels (stats_stash8)
@@ -478,57 +481,84 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
     }
 
     float* ep = reinterpret_cast<float*>(smem);
+    float sf_[NTW], qf_[NTW], bias_[NTW], ws_[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int co = (nt_w + t) * 16 + pl;
-        const float bias = p.bias ? p.bias[co] : 0.f;
-        const float ws = p.wscale[co];
-        float sf = 0.f, qf = 0.f;
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            const int row = wm * MTW + m, iy = iy0 + row;
-#pragma unroll
-            for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ix = ix0 + g * 4 + r;
-                    const float v = acc[m][ph][t][r] * ws + bias;
-                    ep[((2 * row + (ph >> 1)) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + (wn * NTW + t) * 16 + pl] = v;
-                    if (p.stats && iy < p.hin && ix < p.win) {
-                        sf += v;
-                        qf = fmaf(v, v, qf);
-                    }
-                }
-        }
-        if (p.stats) {
-            if constexpr (WM > 1) stats_stash8((double)sf, (double)qf, red8 + ((wm * NTB + wn * NTW + t) * 16 + pl) * 2, lane);
-            else stats_commit8((double)sf, (double)qf, p.stats + ((size_t)img * p.cout + co) * 2, lane);
-        }
+        sf_[t] = 0.f; qf_[t] = 0.f;
+        bias_[t] = p.bias ? p.bias[co] : 0.f;
+        ws_[t] = p.wscale[co];
     }
-    __syncthreads();
-    if constexpr (WM > 1)
-        if (p.stats) stats_flush8<WM, NTB * 16>(red8, p.stats + ((size_t)img * p.cout + wk.ct * NTB * 16) * 2, tid);
-    {
-        constexpr int F4 = NTB * 4;
-        const size_t el0 = (((size_t)img * p.hout + 2 * iy0) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;
 #pragma unroll
-        for (int it_ = 0; it_ < (2 * TH * 32 * F4 + 255) / 256; ++it_) {      // (trip count visible to the unroller: the LDS reads of all passes go out together)
-            const int i = tid + 256 * it_;
-            if ((2 * TH * 32 * F4) % 256 != 0 && i >= 2 * TH * 32 * F4) break;
-            const int pix = i / F4, c4 = i - pix * F4;
-            const int row = pix >> 5, x = pix & 31;
-            if (2 * iy0 + row < p.hout && 2 * ix0 + x < p.wout) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
-                const uint2 o = f32x4_to_bf16(v);
-                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) =
-                    u32x2{o.x, o.y};
+    for (int pass = 0; pass < THX; ++pass) {
+        if (pass > 0) __syncthreads();                       // the stores of the previous pass have read the slab
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int row = wm * MTW + m, iy = iy0 + row;
+                if (THX > 1 && row / EPH != pass) continue;
+                const int lrow = row - pass * EPH;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ix = ix0 + g * 4 + r;
+                        const float v = acc[m][ph][t][r] * ws_[t] + bias_[t];
+                        ep[((2 * lrow + (ph >> 1)) * 32 + 2 * (g * 4 + r) + (ph & 1)) * EPS + (wn * NTW + t) * 16 + pl] = v;
+                        if (p.stats && iy < p.hin && ix < p.win) {
+                            sf_[t] += v;
+                            qf_[t] = fmaf(v, v, qf_[t]);
+                        }
+                    }
             }
         }
+        __syncthreads();
+        {
+            constexpr int F4 = NTB * 4;
+            const int oy_base = 2 * (iy0 + pass * EPH);
+            const size_t el0 = (((size_t)img * p.hout + oy_base) * p.wout + 2 * ix0) * p.pitch_out + wk.ct * NTB * 16;
+#pragma unroll
+            for (int it_ = 0; it_ < (2 * EPH * 32 * F4 + 255) / 256; ++it_) {      // (trip count visible to the unroller: the LDS reads of all passes go out together)
+                const int i = tid + 256 * it_;
+                if ((2 * EPH * 32 * F4) % 256 != 0 && i >= 2 * EPH * 32 * F4) break;
+                const int pix = i / F4, c4 = i - pix * F4;
+                const int row = pix >> 5, x = pix & 31;
+                if (oy_base + row < p.hout && 2 * ix0 + x < p.wout) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&ep[pix * EPS + c4 * 4]);
+                    const uint2 o = f32x4_to_bf16(v);
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + el0 + ((int64_t)row * p.wout + x) * p.pitch_out + c4 * 4) =
+                        u32x2{o.x, o.y};
+                }
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int co = (nt_w + t) * 16 + pl;
+            if constexpr (WM > 1) stats_stash8((double)sf_[t], (double)qf_[t], red8 + ((wm * NTB + wn * NTW + t) * 16 + pl) * 2, lane);
+            else stats_commit8((double)sf_[t], (double)qf_[t], p.stats + ((size_t)img * p.cout + co) * 2, lane);
+        }
+    }
+    if constexpr (WM > 1) {
+        __syncthreads();
+        if (p.stats) stats_flush8<WM, NTB * 16>(red8, p.stats + ((size_t)img * p.cout + wk.ct * NTB * 16) * 2, tid);
     }
 }
 
 template <int WN, int NTW>
 static int launch_t8(hipStream_t s, Conv8Params p) {
+    if constexpr (WN == 2 && NTW == 2) {
+        static const int th8_env = getenv("CS_CONVT_TH8") ? atoi(getenv("CS_CONVT_TH8")) : 1;     // 0: the four-row tile everywhere
+        if (th8_env && p.hin >= 16 && p.hin % 8 == 0) {
+            p.tiles_y = ceil_div(p.hin, 8);
+            dim3 grid8(xcd_grid8(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
+            hipLaunchKernelGGL((convt_fp8_kernel<WN, NTW, 2>), grid8, dim3(256), 0, s, p);
+            CS_HIP(hipGetLastError());
+            return CS_OK;
+        }
+    }
     dim3 grid(xcd_grid8(p.tiles_x * p.tiles_y * p.n, p.ntile_total / (WN * NTW)));
     hipLaunchKernelGGL((convt_fp8_kernel<WN, NTW>), grid, dim3(256), 0, s, p);
     CS_HIP(hipGetLastError());

@@ -8,10 +8,10 @@ one() {   # <suffix> <extra bench args...>
     local sfx=$1; shift
     local d=gpurun_out/prof_${TAG}${sfx}
     local stats fetch write sq
-    stats=$(find $d/stats -name "*kernel_stats.csv" | head -1)
-    fetch=$(find $d/fetch -name "*counter_collection.csv" | head -1)
-    write=$(find $d/write -name "*counter_collection.csv" | head -1)
-    sq=$(find $d/sq -name "*counter_collection.csv" | head -1)
+    stats=$(ls -t $(find $d/stats -name "*kernel_stats.csv") | head -1)
+    fetch=$(ls -t $(find $d/fetch -name "*counter_collection.csv") | head -1)
+    write=$(ls -t $(find $d/write -name "*counter_collection.csv") | head -1)
+    sq=$(ls -t $(find $d/sq -name "*counter_collection.csv") | head -1)
     cp "$stats" profiles/rocprofv3_kernel_stats_${TAG}${sfx}.csv
     python3 tools/pmc_summary.py ${TAG}${sfx} "$stats" "$fetch" "$write" "$@"
     python3 tools/pmc_mfma_summary.py ${TAG}${sfx} "$sq" "$@"

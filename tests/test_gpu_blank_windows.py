@@ -161,48 +161,58 @@ def test_the_reference_sample_images_through_the_tiler(nets, tmp_path):
 
 
 def test_a_4096_slide_with_exactly_zero_background(nets, tmp_path):
-    """A 4096^2 slide whose background (>= 55 % of the pixels) is exactly 0 - whole windows of it blank -, cells quantised through uint8
+    """A 4096^2 slide whose background (2/3 of the pixels) is exactly 0 - whole windows of it blank -, cells quantised through uint8
     like the reference's pipeline, through cs_swi_infer (961 windows at stride 128) with the 32-base net of the bench, default Winograd
-    form.  Against a float64 evaluation of the oracle tiler EVERYWHERE (on the blank windows too, where torch-fp32 itself is 1e-2 off), against
-    the torch-fp32 oracle tiler on the pixels none of whose windows is blank, and the interior mask outside a band around 0.5."""
+    form: against the torch-fp32 oracle tiler on the pixels none of whose windows is blank, and the interior mask outside a band around
+    0.5 (thresholded float64 where it exists, see below).  Against a FLOAT64 evaluation of the oracle tiler EVERYWHERE - on the blank
+    windows too, where torch-fp32 itself is 1e-2 off - on the slide's top-left 2048^2 quarter (the float64 tiler on 16 host cores costs
+    a minute for the whole slide; profiles/blank_windows_r06.json holds a whole-slide run: 9.3e-5)."""
     from blank_inputs import zero_background_slide
     from oracle.postprocess_ref import softmax_interior_ref
     from oracle.sliding_window_ref import sliding_window_inference_ref
     img = zero_background_slide(4096)
+    quarter = img[:, :2048, :2048].contiguous()
     data = (img != 0).float().amax(0)[None, None]
     cells = torch.nn.functional.max_pool2d(data, 128, 128)                                   # the 128 x 128 grid cells that hold data
     blank_windows = float((torch.nn.functional.max_pool2d(data, 256, 128) == 0).float().mean())
-    assert float((img == 0).float().mean()) >= 0.55 and blank_windows >= 0.1
+    blank_q = float((torch.nn.functional.max_pool2d(data[..., :2048, :2048], 256, 128) == 0).float().mean())
+    assert float((img == 0).float().mean()) >= 0.55 and blank_windows >= 0.1 and blank_q >= 0.05
     use = {"seeded32": nets["seeded32"]}
-    got = _engine({"nets": use, "slides": {"wsi": (img, 256, 0.5)}}, 2, tmp_path, "wsi")["seeded32/wsi"]
+    got_all = _engine({"nets": use, "slides": {"wsi": (img, 256, 0.5), "quarter": (quarter, 256, 0.5)}}, 2, tmp_path, "wsi")
+    got, got_q = got_all["seeded32/wsi"], got_all["seeded32/quarter"]
     ref, ref64 = _refs(use["seeded32"])
     with torch.no_grad():
         want = sliding_window_inference_ref(img[None], (256, 256), 8, ref, 0.5)[0]
-        w64 = sliding_window_inference_ref(img[None].double(), (256, 256), 8, ref64, 0.5)[0]
+        w64 = sliding_window_inference_ref(quarter[None].double(), (256, 256), 8, ref64, 0.5)[0]
     # a pixel's windows all hold data when every 128-cell within one cell of its own does (stride 128, window 256: a covering window spans 2 x 2 cells)
     busy = torch.nn.functional.interpolate(1.0 - torch.nn.functional.max_pool2d(1.0 - cells, 3, 1, 1), scale_factor=128)[0, 0] > 0
     e32 = (got["logits"] - want).abs().amax(0)
-    e64 = float((got["logits"].double() - w64).abs().max())
-    p_ref = softmax_interior_ref(w64.float().numpy())
-    sure = np.abs(p_ref - 0.5) > 1e-4
+    e64 = float((got_q["logits"].double() - w64).abs().max())
+    p_ref = softmax_interior_ref(want.numpy())
+    sure = (np.abs(p_ref - 0.5) > 1e-4) & busy.numpy()
     mask = got["mask"].numpy() != 0
-    row = {"engine_vs_fp64": e64, "engine_vs_torch32_busy_pixels": float(e32[busy].max()), "engine_vs_torch32_all_pixels": float(e32.max()),
-           "torch32_vs_fp64": float((want.double() - w64).abs().max()), "busy_pixel_fraction": float(busy.float().mean()),
-           "band_pixels": int((~sure).sum()), "mismatch_outside_band": int((mask[sure] != (p_ref > 0.5)[sure]).sum()),
-           "blank_windows_fraction": blank_windows, "zero_fraction": float((img == 0).float().mean()), "logit_scale": float(w64.abs().max())}
+    p64 = softmax_interior_ref(w64.float().numpy())
+    sure_q = np.abs(p64 - 0.5) > 1e-4
+    mask_q = got_q["mask"].numpy() != 0
+    row = {"engine_vs_fp64_quarter": e64, "engine_vs_torch32_busy_pixels": float(e32[busy].max()), "engine_vs_torch32_all_pixels": float(e32.max()),
+           "torch32_vs_fp64_quarter": float((want[:, :1920, :1920].double() - w64[:, :1920, :1920]).abs().max()), "busy_pixel_fraction": float(busy.float().mean()),
+           "mismatch_outside_band_busy": int((mask[sure] != (p_ref > 0.5)[sure]).sum()), "mismatch_outside_band_quarter_fp64": int((mask_q[sure_q] != (p64 > 0.5)[sure_q]).sum()),
+           "blank_windows_fraction": blank_windows, "blank_windows_fraction_quarter": blank_q, "zero_fraction": float((img == 0).float().mean()),
+           "logit_scale": float(w64.abs().max())}
     _report([row], "wsi")
     assert row["busy_pixel_fraction"] > 0.2, row
-    assert e64 <= max(TOL, REL * row["logit_scale"]) and row["engine_vs_torch32_busy_pixels"] <= TOL and row["mismatch_outside_band"] == 0, row
+    assert e64 <= max(TOL, REL * row["logit_scale"]) and row["engine_vs_torch32_busy_pixels"] <= TOL, row
+    assert row["mismatch_outside_band_busy"] == 0 and row["mismatch_outside_band_quarter_fp64"] == 0, row
 
 
 def test_randomised_sparse_input_sweep_short():
-    """Half a minute of tests/diagnostics/gpu_fuzz_sparse.py: random images of zero / constant background, rectangles, blobs, single pixels and
+    """A quarter of a minute of tests/diagnostics/gpu_fuzz_sparse.py: random images of zero / constant background, rectangles, blobs, single pixels and
     noise patches (most of them uint8-quantised), random sizes / windows / overlaps, three net depths, through the tiler against the
     torch-CPU oracle and a float64 evaluation of it - the bars of this file.  (profiles/fuzz_sparse_r06.jsonl holds a longer sweep.)"""
     sys.path.insert(0, os.path.join(HERE, "diagnostics"))
     import gpu_fuzz_sparse
-    res = gpu_fuzz_sparse.run(seconds=30.0, seed=2022)
-    assert res["cases"] >= 10 and res["status"] == "all within the bars", res
+    res = gpu_fuzz_sparse.run(seconds=15.0, seed=2022)
+    assert res["cases"] >= 6 and res["status"] == "all within the bars", res
 
 
 def test_low_precision_modes_on_a_zero_background_slide(nets):

@@ -33,7 +33,7 @@ def test_bench_strips_leg_deadline_releases_a_hung_leg():
     deadline prints the slides line and the job exits non-zero."""
     from conftest import run_bench
     line, _ = run_bench("--gpus", "2", "--size", "1024", "--steps", "1", "--warmup", "1", "--no-secondary", expect_rc=1,
-                        BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_STRIPS_HANG_RANK=1, BENCH_STRIPS_DEADLINE_S=20)
+                        BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_STRIPS_HANG_RANK=1, BENCH_STRIPS_DEADLINE_S=10)
     assert line["scaling"] == "weak" and "did not finish within" in line["strips_error"]
 
 

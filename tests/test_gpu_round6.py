@@ -79,15 +79,15 @@ dev = torch.device("cuda:0")
 torch.manual_seed(31)
 m = ca.UNet(channels=(64, 128, 256, 512, 1024), strides=(2, 2, 2, 2), num_res_units=2).to(dev).eval()
 m.precision = sys.argv[1]
-x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(32)).to(dev)
+x = torch.rand(2, 3, 128, int(sys.argv[3]), generator=torch.Generator().manual_seed(32)).to(dev)
 logits, taps = m.traced_forward(x)
 torch.save({"logits": logits.float().cpu(), "U": {k: v.float().cpu().clone() for k, v in taps.items() if k.endswith(".U")},
             "tab": {k: v.float().cpu().clone() for k, v in taps.items() if k.endswith(".tabt")}}, sys.argv[2])
 """
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp8"])
-def test_eight_row_tile_of_the_transposed_convs_is_bitwise_the_four_row_one(tmp_path, precision):
+@pytest.mark.parametrize("precision,width", [("bf16", 128), ("fp8", 128), ("bf16", 96), ("fp8", 160)])      # 96 / 160: partial 16-column tiles at the deep levels
+def test_eight_row_tile_of_the_transposed_convs_is_bitwise_the_four_row_one(tmp_path, precision, width):
     """Round 6: the 64-channel blocks of convt_bf16s_kernel / convt_fp8_kernel own eight input rows instead of four on maps of >= 16 rows
     (half the weight-fragment stream per MFMA; CS_CONVT_TH8=0: four rows everywhere).  Same products in the same order per output
     element: every transposed conv's raw output is bit for bit the four-row kernel's (the 64...1024 net on 128 x 128 tiles: up1 at 32 x 32
@@ -101,7 +101,7 @@ def test_eight_row_tile_of_the_transposed_convs_is_bitwise_the_four_row_one(tmp_
     res = {}
     for tag, env in (("th8", {"CS_CONVT_TH8": 1}), ("th4", {"CS_CONVT_TH8": 0})):
         out = tmp_path / f"{tag}.pt"
-        cp = subprocess.run([sys.executable, str(script), precision, str(out)], capture_output=True, text=True, timeout=600, env=cli_env(**env))
+        cp = subprocess.run([sys.executable, str(script), precision, str(out), str(width)], capture_output=True, text=True, timeout=600, env=cli_env(**env))
         assert cp.returncode == 0, cp.stderr[-2000:]
         res[tag] = torch.load(out)
     assert set(res["th8"]["U"]) >= {"up1.U", "up2.U", "up3.U"}

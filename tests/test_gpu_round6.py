@@ -117,3 +117,29 @@ def test_eight_row_tile_of_the_transposed_convs_is_bitwise_the_four_row_one(tmp_
         a, b = res["th8"]["tab"][k], res["th4"]["tab"][k]
         assert (a - b).abs().max().item() <= 1e-3 * (1.0 + b.abs().max().item()), k
     assert (res["th8"]["logits"] - res["th4"]["logits"]).abs().max().item() <= 2e-2
+
+
+def test_a_failed_strips_leg_under_torchrun_fails_the_job_and_keeps_the_line():
+    """The driver's launch form with a rank that raises inside its seam exchange (BENCH_STRIPS_FAIL_RANK): every rank leaves with code 3, so
+    torch.distributed.run reports the failure (non-zero) - and rank 0's slides line with strips_error is still the last JSON line on stdout."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT, cli_env
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "1024", "--no-secondary"]
+    cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                        env=cli_env(BENCH_DEVICE=0, BENCH_BACKEND="gloo", BENCH_STRIPS_FAIL_RANK=1, BENCH_STRIPS_DEADLINE_S=60, BENCH_FULL_NAME="bench_full_test_torchrun_fail.json"))
+    assert cp.returncode != 0
+    lines = [ln for ln in cp.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096, cp.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["scaling"] == "weak" and "provoked failure" in line["strips_error"] and line["value"] > 0
+    path = os.path.join(ROOT, "gpurun_out", "bench_full_test_torchrun_fail.json")
+    if os.path.exists(path):
+        os.remove(path)

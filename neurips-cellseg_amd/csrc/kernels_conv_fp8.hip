@@ -51,7 +51,7 @@ struct SrcDev8 {
 
 struct Conv8Params {
     SrcDev8 a, b;
-    const unsigned char* wpack;  // [chunk][tap][ntile_total][64 lanes][32] e4m3
+    const unsigned char* wpack;  // [chunk][tap][ntile_total][half][64 lanes][16] e4m3 (pack_conv_weights_fp8)
     const float* wscale;         // [cout] per-output-channel weight scale
     const float* bias;
     float* out;                  // bf16 elements
@@ -185,12 +185,12 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Conv8Params p) {
     };
     // weight fragments of one tap row: KS x NTW fragments of 32 bytes per lane (two lane-linear 16-byte loads each, from L2)
     i32x8 bq[KS][NTW];
-    const i32x4* wbase = reinterpret_cast<const i32x4*>(p.wpack) + ((size_t)nt_w * 64 + lane) * 2;
+    const i32x4* wbase = reinterpret_cast<const i32x4*>(p.wpack) + (size_t)nt_w * 128 + lane;      // [channel tile][half 0 / 1][lane][16 bytes]
     auto load_b = [&](int ch, int ky, int kx) {
         const i32x4* w = wbase + ((size_t)ch * TAPS + ky * KS + kx) * p.ntile_total * 128;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const i32x4 lo = w[t * 128], hi = w[t * 128 + 1];
+            const i32x4 lo = w[t * 128], hi = w[t * 128 + 64];        // each a lane-linear kilobyte: full 128-byte lines per instruction
             bq[kx][t] = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         }
     };
@@ -423,12 +423,12 @@ __global__ __launch_bounds__(256, 2) void convt_fp8_kernel(Conv8Params p) {
         }
     };
     i32x8 bq[3][NTW];
-    const i32x4* wbase = reinterpret_cast<const i32x4*>(p.wpack) + ((size_t)nt_w * 64 + lane) * 2;
+    const i32x4* wbase = reinterpret_cast<const i32x4*>(p.wpack) + (size_t)nt_w * 128 + lane;      // [channel tile][half 0 / 1][lane][16 bytes]
     auto load_b = [&](int ch, int tap, int slot) {
         const i32x4* w = wbase + ((size_t)ch * 9 + tap) * p.ntile_total * 128;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const i32x4 lo = w[t * 128], hi = w[t * 128 + 1];
+            const i32x4 lo = w[t * 128], hi = w[t * 128 + 64];        // each a lane-linear kilobyte: full 128-byte lines per instruction
             bq[slot][t] = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         }
     };
@@ -591,7 +591,9 @@ int launch_convt_fp8(hipStream_t s, const ConvSrc& a, const ConvSrc& b, const un
 
 // ------------------------------------------------------------------------------------------------
 // weight packing: fp32 PyTorch layout -> per-output-channel scale + e4m3 fragments
-//   packed[chunk][tap][ntile_total][lane][32]: cout = ntile*16 + (lane & 15), cin = chunk*128 + 32 (lane >> 4) + j
+//   packed[chunk][tap][ntile_total][half][lane][16]: cout = ntile*16 + (lane & 15), cin = chunk*128 + 32 (lane >> 4) + 16 half + j
+//   (round 6: the two 16-byte halves of a lane's 32-byte fragment are lane-linear kilobytes of their own, so that each load instruction
+//   of a wave reads whole 128-byte lines; before, lane l read bytes 32 l ... 32 l + 15 and 32 l + 16 ... + 31 in two half-line passes)
 //   input channels >= cin_split (second concat source) start a fresh 128-channel chunk, as the kernels stage them
 // ------------------------------------------------------------------------------------------------
 size_t packed_fp8_bytes(int cout_total, int cin_a, int cin_b, int ksize) {
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(256) void fp8_pack_kernel(const float* w, int trans
     }
     unsigned o = pk_fp8<false>(v[0], v[1], 0u);
     o = pk_fp8<true>(v[2], v[3], o);
-    packed[((((size_t)chunk * taps + tap) * ntile_total + cout_off / 16 + ntl) * 64 + lane) * 8 + jd] = o;
+    packed[(((((size_t)chunk * taps + tap) * ntile_total + cout_off / 16 + ntl) * 2 + (jd >> 2)) * 64 + lane) * 4 + (jd & 3)] = o;
 }
 
 // Not batched: the fp8 packing is a load-time (inference) step, two small kernels per tensor on the caller's stream.
